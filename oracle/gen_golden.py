@@ -1,0 +1,402 @@
+"""Generate tests/golden/*.npz by running the REAL reference (container only).
+
+Usage (from the repo root, in the build container where /root/reference exists):
+    python -m oracle.gen_golden
+
+Each .npz stores the inputs AND the reference's outputs for one scenario family, so the parity
+tests need neither the reference nor this script at run time.  Scenario list = SURVEY.md App. B
+(re-stated here on seeded inputs; the reference's unittest files themselves cannot run without
+ddt/qiskit).  Results that involve a non-diagonal rotating frame are stored OUT of the frame
+basis (`in_frame_basis=False`), which is invariant under the eigenvector gauge of `eigh`.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle.ref_shim import load_reference  # noqa: E402
+
+load_reference()
+
+from qiskit_dynamics.models import GeneratorModel, HamiltonianModel, LindbladModel  # noqa: E402
+from qiskit_dynamics.models import RotatingFrame  # noqa: E402
+from qiskit_dynamics.models.operator_collections import OperatorCollection  # noqa: E402
+from qiskit_dynamics.signals import DiscreteSignal, Signal, SignalList  # noqa: E402
+from qiskit_dynamics.solvers.fixed_step_solvers import (  # noqa: E402
+    RK4_solver, get_fixed_step_sizes, scipy_expm_solver)
+from qiskit_dynamics.solvers.solver_classes import Solver  # noqa: E402
+from qiskit_dynamics.solvers.solver_functions import solve_lmde  # noqa: E402
+
+from qiskit_dynamics_amd import workloads  # noqa: E402  (pure-numpy input builders)
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def crand(rng, *shape):
+    return rng.uniform(-1, 1, shape) + 1j * rng.uniform(-1, 1, shape)
+
+
+def herm(rng, n):
+    a = crand(rng, n, n)
+    return a + a.conj().T
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_collection():
+    """a1/a2: OperatorCollection.evaluate / evaluate_rhs (test_operator_collections.py:60-94)."""
+    rng = np.random.default_rng(342)
+    n, k, m = 16, 6, 3
+    ops = crand(rng, k, n, n)
+    static = crand(rng, n, n)
+    coeffs = rng.uniform(-1, 1, (5, k))
+    y1 = crand(rng, n)
+    ym = crand(rng, n, m)
+    out = {}
+    for tag, st, op in (("full", static, ops), ("nostatic", None, ops)):
+        coll = OperatorCollection(static_operator=st, operators=op)
+        out[f"{tag}_eval"] = np.array([coll.evaluate(c) for c in coeffs])
+        out[f"{tag}_rhs1"] = np.array([coll.evaluate_rhs(c, y1) for c in coeffs])
+        out[f"{tag}_rhsm"] = np.array([coll.evaluate_rhs(c, ym) for c in coeffs])
+    coll = OperatorCollection(static_operator=static, operators=None)
+    out["staticonly_eval"] = coll.evaluate(None)
+    out["staticonly_rhs1"] = coll.evaluate_rhs(None, y1)
+    # Pauli KAT, test/dynamics/arraylias/test_alias.py:92-102
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    coll = OperatorCollection(operators=np.array([x, 1j * z]))
+    out["pauli_eval"] = coll.evaluate(np.array([1.0, 2.0]))
+    save("collection", ops=ops, static=static, coeffs=coeffs, y1=y1, ym=ym, **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_signals():
+    """a8: Signal / DiscreteSignal / SignalSum / SignalList values (test_signals.py:386-430)."""
+    t = np.linspace(-0.7, 2.3, 41)
+    out = {"t": t}
+    s_const = Signal(0.37, carrier_freq=1.3, phase=0.4)
+    out["const"] = s_const(t)
+    amp, t0, sig, nu, phi = 0.8, 0.9, 0.35, 4.75, -1.1
+    s_gauss = Signal(lambda tt: amp * np.exp(-((tt - t0) ** 2) / (2 * sig**2)), nu, phi)
+    out["gauss_params"] = np.array([amp, t0, sig, nu, phi])
+    out["gauss"] = s_gauss(t)
+    samples = np.array([1.0 + 2.0j, 2.0 + 1.0j, 3.0 + 0.0j, -0.5j])
+    d = DiscreteSignal(dt=0.5, samples=samples, start_time=0.25, carrier_freq=0.9, phase=0.2)
+    out["disc_samples"] = samples
+    out["disc_params"] = np.array([0.5, 0.25, 0.9, 0.2])
+    out["disc"] = d(t)
+    out["disc_env"] = d.envelope(t)
+    # exact bin edges
+    edges = np.array([0.25, 0.75, 1.25, 1.75, 2.25, 0.2499999, 2.2499999])
+    out["disc_edges_t"] = edges
+    out["disc_edges"] = d(edges)
+    ssum = s_const + s_gauss
+    out["sum"] = ssum(t)
+    sl = SignalList([s_const, s_gauss, d, ssum, 1.5])
+    out["list"] = sl(t)  # (T, 5)
+    out["list_scalar_t"] = sl(0.613)
+    save("signals", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def _gm_cases():
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    y = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    return x, y, z
+
+
+def gen_generator_model():
+    """a3-a7: GeneratorModel / HamiltonianModel evaluate + evaluate_rhs
+    (test_generator_model.py:171-221,267-347,370-397,495-505,615-674;
+    test_hamiltonian_model.py:99-139,201-287)."""
+    x, y, z = _gm_cases()
+    out = {}
+    # analytic 2x2 KAT
+    gm = GeneratorModel(operators=[-1j * x / 2 * 2, -1j * z / 2], static_operator=None,
+                        signals=[Signal(1.0, 1.0 / 3), Signal(1.0, 2.0 / 3)])
+    out["kat_ops"] = np.array([-1j * x, -1j * z / 2])
+    out["kat_carrier"] = np.array([1.0 / 3, 2.0 / 3])
+    out["kat_eval_t2"] = gm.evaluate(2.0)
+    out["kat_rhs_t2"] = gm.evaluate_rhs(2.0, np.array([0.2, 0.5]))
+
+    for tag, seed, n, k in (("r5", 30493, 5, 3), ("r10", 94818, 10, 5)):
+        rng = np.random.default_rng(seed)
+        ops = crand(rng, k, n, n)
+        static = crand(rng, n, n)
+        fr = crand(rng, n, n)
+        frame_op = fr - fr.conj().T  # anti-Hermitian
+        carr = rng.uniform(0.2, 2.0, k)
+        phases = rng.uniform(-np.pi, np.pi, k)
+        amps = rng.uniform(-1, 1, k)
+        sigs = [Signal(a, c, p) for a, c, p in zip(amps, carr, phases)]
+        times = np.array([0.0, 1.0, 1.123, np.pi])
+        y1 = crand(rng, n)
+        ym = crand(rng, n, 2)
+        out[f"{tag}_ops"], out[f"{tag}_static"], out[f"{tag}_frame"] = ops, static, frame_op
+        out[f"{tag}_carrier"], out[f"{tag}_phase"], out[f"{tag}_amp"] = carr, phases, amps
+        out[f"{tag}_times"], out[f"{tag}_y1"], out[f"{tag}_ym"] = times, y1, ym
+        for ftag, frame in (("fr", frame_op), ("diag", np.diag(frame_op).copy()), ("nofr", None)):
+            for stag, st in (("st", static), ("nost", None)):
+                m = GeneratorModel(static_operator=st, operators=ops, signals=sigs,
+                                   rotating_frame=frame)
+                key = f"{tag}_{ftag}_{stag}"
+                out[key + "_coeffs"] = np.array([m.signals(t) for t in times])
+                out[key + "_eval"] = np.array([m.evaluate(t) for t in times])
+                out[key + "_rhs1"] = np.array([m.evaluate_rhs(t, y1) for t in times])
+                out[key + "_rhsm"] = np.array([m.evaluate_rhs(t, ym) for t in times])
+                if ftag == "diag":
+                    m.in_frame_basis = True
+                    out[key + "_eval_fb"] = np.array([m.evaluate(t) for t in times])
+                    out[key + "_rhs1_fb"] = np.array([m.evaluate_rhs(t, y1) for t in times])
+        # Hamiltonian model, Hermitian frame R + R^dagger (test_hamiltonian_model.py:201-287)
+        hops = np.array([herm(rng, n) for _ in range(k)])
+        hstatic = herm(rng, n)
+        hframe = herm(rng, n)
+        out[f"{tag}_hops"], out[f"{tag}_hstatic"], out[f"{tag}_hframe"] = hops, hstatic, hframe
+        hm = HamiltonianModel(static_operator=hstatic, operators=hops, signals=sigs,
+                              rotating_frame=hframe)
+        out[f"{tag}_ham_eval"] = np.array([hm.evaluate(t) for t in times])
+        out[f"{tag}_ham_rhs1"] = np.array([hm.evaluate_rhs(t, y1) for t in times])
+        out[f"{tag}_ham_rhsm"] = np.array([hm.evaluate_rhs(t, ym) for t in times])
+        out[f"{tag}_ham_static_getter"] = hm.static_operator
+        out[f"{tag}_ham_ops_getter"] = hm.operators
+        hm2 = HamiltonianModel(static_operator=hstatic, operators=hops, signals=sigs,
+                               rotating_frame=hstatic)
+        out[f"{tag}_ham_selfframe_eval"] = np.array([hm2.evaluate(t) for t in times])
+        out[f"{tag}_ham_selfframe_rhs1"] = np.array([hm2.evaluate_rhs(t, y1) for t in times])
+    save("generator_model", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_fixed_step():
+    """a9-a11: step-size rule, RK4, scipy_expm m=1,2,3 (test_fixed_step_solvers.py:56-389)."""
+    out = {}
+    cases = [
+        ([0.0, 1.0], None, 0.1), ([0.0, 1.0], None, 0.3), ([0.0, 1.0], [0.0, 0.25, 0.9, 1.0], 0.1),
+        ([1.0, 0.0], None, 0.1), ([1.0, 0.0], [0.75, 0.3], 0.07), ([0.0, 0.05], None, 0.1),
+        ([0.0, 5.0], None, 0.005), ([0.0, 10.0], None, 0.01), ([0.0, 1.5], [0.5, 0.5, 1.0], 0.5),
+        ([0.0, 0.3], None, 0.1), ([0.0, 0.7], None, 0.1),
+    ]
+    for i, (ts, te, mdt) in enumerate(cases):
+        tl, hl, nl = get_fixed_step_sizes(ts, te, mdt)
+        out[f"sizes{i}_tspan"] = np.array(ts)
+        out[f"sizes{i}_teval"] = np.array([] if te is None else te)
+        out[f"sizes{i}_has_teval"] = np.array(te is not None)
+        out[f"sizes{i}_maxdt"] = np.array(mdt)
+        out[f"sizes{i}_t"], out[f"sizes{i}_h"], out[f"sizes{i}_n"] = tl, hl, nl
+    out["n_sizes"] = np.array(len(cases))
+
+    rng = np.random.default_rng(5213)
+    n = 5
+    a = crand(rng, n, n)
+    g0 = a - a.conj().T
+    b = crand(rng, n, n)
+    g1 = b - b.conj().T
+    y0 = crand(rng, n)
+    ym = np.eye(n, dtype=complex)
+    out["g0"], out["g1"], out["y0"] = g0, g1, y0
+
+    def gen(t):
+        return g0 + np.cos(1.3 * t) * g1
+
+    def rhs(t, y):
+        return gen(t) @ y
+
+    for tag, ts, te, mdt in (("fw", [0.0, 1.0], None, 0.1),
+                             ("te", [0.0, 1.0], [0.0, 0.33, 0.71, 1.0], 0.05),
+                             ("bw", [1.0, 0.0], [0.8, 0.2], 0.1)):
+        r = RK4_solver(rhs, ts, y0, max_dt=mdt, t_eval=te)
+        out[f"rk4_{tag}_t"], out[f"rk4_{tag}_y"] = np.asarray(r.t), np.asarray(r.y)
+        r = RK4_solver(rhs, ts, ym, max_dt=mdt, t_eval=te)
+        out[f"rk4m_{tag}_y"] = np.asarray(r.y)
+        for mo in (1, 2, 3):
+            r = scipy_expm_solver(gen, ts, y0, max_dt=mdt, t_eval=te, magnus_order=mo)
+            out[f"expm{mo}_{tag}_t"], out[f"expm{mo}_{tag}_y"] = np.asarray(r.t), np.asarray(r.y)
+            r = scipy_expm_solver(gen, ts, ym, max_dt=mdt, t_eval=te, magnus_order=mo)
+            out[f"expm{mo}m_{tag}_y"] = np.asarray(r.y)
+    save("fixed_step", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_solve_lmde():
+    """a12 + cfg 1 + down-scaled cfg 2: solve_lmde end to end
+    (test_solver_functions.py:46-217,247-356; test_solver_functions_interface.py:164-395)."""
+    out = {}
+    # cfg 1 in full (n=4, 1000 RK4 steps) -- BASELINE.json configs[0]
+    c1 = workloads.config1()
+    sigs = [Signal(1.0, 5.0), Signal(lambda t: np.exp(-((t - 5.0) ** 2) / 8.0), 5.0)]
+    hm = HamiltonianModel(static_operator=c1["h_d"], operators=c1["ops"], signals=sigs,
+                          rotating_frame=c1["h_d"])
+    r = solve_lmde(hm, c1["t_span"], c1["y0"], method="RK4", max_dt=c1["max_dt"],
+                   t_eval=[0.0, 2.5, 5.0, 7.5, 10.0])
+    out["cfg1_t"], out["cfg1_y"] = np.asarray(r.t), np.asarray(r.y)
+    for mo in (1, 2):
+        r = solve_lmde(hm, c1["t_span"], c1["y0"], method="scipy_expm", max_dt=0.05,
+                       magnus_order=mo)
+        out[f"cfg1_expm{mo}_y"] = np.asarray(r.y)
+
+    # random 7x7 framed model with a DiscreteSignal (test_solver_functions.py:76-115)
+    rng = np.random.default_rng(3093)
+    n, k = 7, 3
+    hops = np.array([herm(rng, n) for _ in range(k)])
+    hstatic = herm(rng, n)
+    hframe = herm(rng, n)
+    samples = crand(rng, 5)
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    sigs = [Signal(0.5, 1.0, 0.3), DiscreteSignal(dt=0.1, samples=samples, carrier_freq=1.0),
+            Signal(lambda t: 0.3 * np.cos(t) + 0 * 1j, 0.0)]
+    out["r7_hops"], out["r7_hstatic"], out["r7_hframe"] = hops, hstatic, hframe
+    out["r7_samples"], out["r7_y0"] = samples, y0
+    hm = HamiltonianModel(static_operator=hstatic, operators=hops, signals=sigs,
+                          rotating_frame=hframe)
+    r = solve_lmde(hm, [0.0, 0.5], y0, method="RK4", max_dt=1e-3, t_eval=[0.1, 0.3, 0.5])
+    out["r7_rk4_t"], out["r7_rk4_y"] = np.asarray(r.t), np.asarray(r.y)
+    r = solve_lmde(hm, [0.0, 0.5], np.eye(n, dtype=complex), method="RK4", max_dt=1e-3)
+    out["r7_rk4_unitary"] = np.asarray(r.y)
+    for mo in (1, 2, 3):
+        r = solve_lmde(hm, [0.0, 0.5], y0, method="scipy_expm", max_dt=1e-2, magnus_order=mo,
+                       t_eval=[0.1, 0.3, 0.5])
+        out[f"r7_expm{mo}_y"] = np.asarray(r.y)
+    r = solve_lmde(hm, [0.5, 0.0], y0, method="RK4", max_dt=1e-3)
+    out["r7_rk4_backwards"] = np.asarray(r.y)
+    hm.in_frame_basis = True
+    r = solve_lmde(hm, [0.0, 0.5], y0, method="RK4", max_dt=1e-3)
+    out["r7_rk4_in_fb"] = np.asarray(r.y)  # gauge dependent: informational only
+    save("solve_lmde", **out)
+
+    # down-scaled cfg 2/3: 6 qubits (n=64), k=6, RK4 + sweep of 4 instances through Solver
+    cfg = workloads.schrodinger_config(n_qubits=6, n_drives=6, t_final=1.0, max_dt=0.01)
+    out = {}
+    solver = Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                    rotating_frame=cfg["h_d"])
+    sig_lists = []
+    for b in range(4):
+        amps, phases = workloads.sweep_parameters(b, 6)
+        sig_lists.append([
+            Signal(lambda t, a=a: a * np.exp(-((t - cfg["t_final"] / 2) ** 2) / (2 * 1.0**2)),
+                   nu, ph) for a, nu, ph in zip(amps, cfg["carrier"], phases)])
+    res = solver.solve(t_span=cfg["t_span"], y0=cfg["y0"], signals=sig_lists, method="RK4",
+                       max_dt=cfg["max_dt"])
+    out["sweep_y_final"] = np.array([r.y[-1] for r in res])
+    tt = np.linspace(0, 1, 7)
+    out["sweep_tt"] = tt
+    out["sweep_coeffs"] = np.array([SignalList(s)(tt) for s in sig_lists])
+    # single RHS evaluations of instance 0 on the in-frame-basis model (diagonal-frame twin is
+    # gauge free: use frame = diag(H_d) for the per-eval golden)
+    hm = HamiltonianModel(static_operator=cfg["h_d"], operators=cfg["ops"], signals=sig_lists[0],
+                          rotating_frame=np.diag(cfg["h_d"]).real.copy())
+    rng = np.random.default_rng(64)
+    yv = crand(rng, 64)
+    out["diag_yv"] = yv
+    out["diag_rhs"] = np.array([hm.evaluate_rhs(t, yv) for t in (0.0, 0.37, 1.0)])
+    out["diag_eval_t037"] = hm.evaluate(0.37)
+    save("cfg2_small", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_lindblad():
+    """a13/a14: vectorised LindbladModel (test_lindblad_model.py:281-425,461-523;
+    test_operator_collections.py:550-706; test_rotating_frame.py:440-488)."""
+    rng = np.random.default_rng(9848)
+    n = 4
+    hops = np.array([herm(rng, n) for _ in range(2)])
+    hstatic = herm(rng, n)
+    nstat = crand(rng, 2, n, n)
+    lops = crand(rng, 2, n, n)
+    hframe = herm(rng, n)
+    hsig = [Signal(0.7, 1.1, 0.2), Signal(lambda t: 0.4 * np.sin(2 * t) + 0j, 0.6)]
+    dsig = [Signal(0.3, 0.0), Signal(lambda t: 0.2 + 0.1 * np.cos(t) + 0j, 0.0)]
+    rho = crand(rng, n, n)
+    rho = rho @ rho.conj().T
+    rho /= np.trace(rho)
+    times = np.array([0.0, 0.4, 1.7])
+    out = dict(hops=hops, hstatic=hstatic, nstat=nstat, lops=lops, hframe=hframe, rho=rho,
+               times=times)
+    for ftag, frame in (("fr", hframe), ("diag", np.diag(hframe).real.copy()), ("nofr", None)):
+        for vec in (True, False):
+            m = LindbladModel(static_hamiltonian=hstatic, hamiltonian_operators=hops,
+                              hamiltonian_signals=hsig, static_dissipators=nstat,
+                              dissipator_operators=lops, dissipator_signals=dsig,
+                              rotating_frame=frame, vectorized=vec)
+            key = f"{ftag}_{'vec' if vec else 'mat'}"
+            yin = rho.flatten(order="F") if vec else rho
+            out[key + "_rhs"] = np.array([m.evaluate_rhs(t, yin) for t in times])
+            if vec:
+                out[key + "_eval"] = np.array([m.evaluate(t) for t in times])
+                out[key + "_hcoeffs"] = np.array([m.signals[0](t) for t in times])
+                out[key + "_dcoeffs"] = np.array([m.signals[1](t) for t in times])
+                r = solve_lmde(m, [0.0, 0.6], yin, method="scipy_expm", max_dt=0.02,
+                               t_eval=[0.2, 0.6])
+                out[key + "_expm_y"] = np.asarray(r.y)
+                r = solve_lmde(m, [0.0, 0.6], yin, method="RK4", max_dt=0.002)
+                out[key + "_rk4_y"] = np.asarray(r.y)
+    # subsets of operator groups (presence patterns)
+    m = LindbladModel(hamiltonian_operators=hops, hamiltonian_signals=hsig,
+                      static_dissipators=nstat, vectorized=True)
+    out["pat_hs_eval"] = m.evaluate(0.4)
+    m = LindbladModel(static_hamiltonian=hstatic, dissipator_operators=lops,
+                      dissipator_signals=dsig, vectorized=True, rotating_frame=hframe)
+    out["pat_sd_fr_eval"] = m.evaluate(0.4)
+    out["pat_sd_fr_rhs"] = m.evaluate_rhs(0.4, rho.flatten(order="F"))
+
+    # down-scaled cfg 4: 3 qubits, N=64, 3 drives, 2 static sigma^- dissipators
+    cfg = workloads.lindblad_config(n_qubits=3, n_drives=3, n_diss=2, gamma=1e-2, t_final=1.0,
+                                    max_dt=0.05)
+    amps, phases = workloads.sweep_parameters(0, 3)
+    sigs = [Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    for ftag, frame in (("nofr", None), ("diag", np.diag(cfg["h_d"]).real.copy())):
+        s = Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                   static_dissipators=cfg["static_dissipators"], rotating_frame=frame,
+                   vectorized=True)
+        r = s.solve(t_span=cfg["t_span"], y0=cfg["rho0"].flatten(order="F"), signals=sigs,
+                    method="scipy_expm", max_dt=cfg["max_dt"])
+        out[f"cfg4s_{ftag}_y"] = np.asarray(r.y)
+    save("lindblad", **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_solver_list():
+    """a15: Solver list mode == individual solves (test_solver_classes.py:1389-1599)."""
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    out = {}
+    s = Solver(hamiltonian_operators=[x], static_hamiltonian=5 * z, rotating_frame=5 * z)
+    y0 = np.array([0.0, 1.0], dtype=complex)
+    res = s.solve(t_span=[0.0, 0.4232], y0=y0, signals=[[Signal(1.0, 5.0)], [Signal(0.5, 5.0)]],
+                  method="RK4", max_dt=0.001)
+    out["ham_list_y"] = np.array([r.y for r in res])
+    res = s.solve(t_span=[[0.0, 0.4232], [0.0, 1.23]], y0=y0, signals=[Signal(1.0, 5.0)],
+                  method="RK4", max_dt=0.001)
+    out["ham_tspan_list_y_final"] = np.array([r.y[-1] for r in res])
+    res = s.solve(t_span=[0.0, 0.4232], y0=[y0, np.array([1.0, 0.0], dtype=complex)],
+                  signals=[Signal(1.0, 5.0)], method="scipy_expm", max_dt=0.01)
+    out["ham_y0_list_expm_y"] = np.array([r.y for r in res])
+    sl = Solver(hamiltonian_operators=[x], static_hamiltonian=5 * z, rotating_frame=5 * z,
+                static_dissipators=[0.01 * x], vectorized=True)
+    rho0 = np.array([[0.0, 0.0], [0.0, 1.0]], dtype=complex)
+    res = sl.solve(t_span=[0.0, 0.4232], y0=rho0.flatten(order="F"),
+                   signals=[[Signal(1.0, 5.0)], [Signal(0.5, 5.0)]], method="scipy_expm",
+                   max_dt=0.01)
+    out["lind_list_y"] = np.array([r.y for r in res])
+    save("solver_list", **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_collection()
+    gen_signals()
+    gen_generator_model()
+    gen_fixed_step()
+    gen_solve_lmde()
+    gen_lindblad()
+    gen_solver_list()

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+        return cache[name]
+
+    return load
+
+
+def assert_close(a, b, tol=1e-12):
+    """max|a-b| <= tol * (1 + max|b|)  -- the parity criterion of SURVEY.md 8(d)."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, f"shape {a.shape} != {b.shape}"
+    err = float(np.max(np.abs(a - b))) if a.size else 0.0
+    scale = 1.0 + (float(np.max(np.abs(b))) if b.size else 0.0)
+    assert err <= tol * scale, f"max|diff|={err:.3e} > {tol:.1e}*(1+{scale - 1:.3e})"
