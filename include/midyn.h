@@ -1,0 +1,135 @@
+/*
+ * midyn.h -- C-ABI of libmidyn.so, the MI355X (gfx950) implementation of the qiskit-dynamics
+ * ODE-RHS hot path.
+ *
+ * The reference (qiskit-community/qiskit-dynamics, pure Python) has NO FFI for this path; its
+ * seams are:
+ *   - arraylias function registration          qiskit_dynamics/arraylias/alias.py:44-128
+ *   - `array_library=` -> collection factory   qiskit_dynamics/models/generator_model.py:368-397
+ *                                              qiskit_dynamics/models/lindblad_model.py:541-597
+ *   - `method=` -> solver function             qiskit_dynamics/solvers/solver_functions.py:53-65,198-207,349-364
+ *   - `Solver.solve` list mode                 qiskit_dynamics/solvers/solver_classes.py:384-676
+ * Each entry point below names the reference function whose arithmetic it replaces.  The binding a
+ * qiskit-dynamics maintainer would add is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - All arrays are caller-owned HOST buffers unless a parameter is called `dev_*`.
+ *   - Complex numbers are C99 `double _Complex` (interleaved re,im), matrices C-order (row major).
+ *   - Operator stack `ops` is [k][n][n]; static operator [n][n] or NULL; the rotating-frame
+ *     diagonal d (purely imaginary) is passed as its imaginary part `frame_im[n]` or NULL.
+ *   - A state is [n][m] with the m states as COLUMNS (generator_model tests :615-643); a batch of
+ *     B instances is [B][n][m].  Vectorised density matrices are column stacked (caller's job).
+ *   - Every function returns 0 on success, non-zero on failure; `midyn_last_error` gives the text.
+ *   - A ctx owns one HIP stream and is single threaded.  One ctx per device / per process rank.
+ *   - Handles are opaque; the library never keeps a host pointer after a call returns.
+ */
+#ifndef MIDYN_H
+#define MIDYN_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+typedef struct { double re, im; } midyn_complex;
+#else
+#include <complex.h>
+typedef double _Complex midyn_complex;
+#endif
+
+typedef struct midyn_ctx midyn_ctx;
+typedef struct midyn_stack midyn_stack;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int midyn_ctx_create(int device, midyn_ctx** out);
+int midyn_ctx_destroy(midyn_ctx* ctx);
+int midyn_ctx_synchronize(midyn_ctx* ctx);
+/* Text of the last error on this ctx (or of the last ctx-less failure when ctx == NULL). */
+const char* midyn_last_error(midyn_ctx* ctx);
+/* 0: skip exact-zero real/imaginary planes of operators in the MFMA contraction (default 1). */
+int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long value);
+
+/* ---- operator stack ----------------------------------------------------------------------
+ * Replaces OperatorCollection.__init__ (models/operator_collections.py:54-81): the device-resident
+ * (k,n,n) stack + static operator (+ frame diagonal of models/rotating_frame.py:59-112).
+ * `midyn_stack_packed_bytes` gives the size of the single packed device buffer; when `dev_buffer`
+ * is non-NULL the stack is built inside that caller-owned device allocation (e.g. a torch uint8
+ * tensor, so that rank 0 can RCCL-broadcast it); `midyn_stack_adopt` wraps an already packed
+ * (broadcast) buffer on the receiving ranks. */
+int midyn_stack_packed_bytes(int n, int k, int has_static, size_t* bytes);
+int midyn_stack_create(midyn_ctx* ctx, int n, int k, const midyn_complex* ops,
+                       const midyn_complex* static_op, const double* frame_im, void* dev_buffer,
+                       midyn_stack** out);
+int midyn_stack_adopt(midyn_ctx* ctx, int n, int k, int has_static, int has_frame,
+                      void* dev_buffer, midyn_stack** out);
+int midyn_stack_destroy(midyn_stack* stack);
+/* info[0..7] = n, n_pad, k, has_static, has_frame, n_segments, n_active_segments, packed_bytes>>20 */
+int midyn_stack_info(midyn_stack* stack, long long* info);
+
+/* ---- single evaluations --------------------------------------------------------------------
+ * midyn_eval_generator: GeneratorModel.evaluate in the frame basis
+ *   (models/generator_model.py:256-279 -> OperatorCollection.evaluate operator_collections.py:101-122
+ *    -> RotatingFrame._conjugate_and_add rotating_frame.py:286-370):
+ *      G = Delta(t) o (G_d + sum_j c_j G_j),  Delta_ab = conj(e_a) e_b,  e = exp(d t).
+ * midyn_eval_rhs: GeneratorModel.evaluate_rhs in the frame basis (generator_model.py:281-316):
+ *      out = exp(-d t) o ( (G_d + sum_j c_j G_j) (exp(d t) o y) ),   y is [n][m]. */
+int midyn_eval_generator(midyn_stack* stack, const double* coeffs, double t, midyn_complex* G_out);
+int midyn_eval_rhs(midyn_stack* stack, const double* coeffs, double t, const midyn_complex* y,
+                   int m, midyn_complex* out);
+
+/* ---- fixed-step RK4 (solvers/fixed_step_solvers.py:43-77 inside the template :406-459) --------
+ * B independent instances advance together (the loop of solvers/solver_classes.py:556-590 turned
+ * into one batched contraction).  The caller evaluates the signals on the host into the table
+ * S[B][R][k] (signals/signals.py:792-803) at the R distinct times `times[R]`; step s uses table
+ * rows step_rows[s][0..2] = (t, t+h/2, t+h) and step size step_h[s]; after step s the state is
+ * stored in output slot step_save[s] when that is >= 0.  Slot 0 always receives y0.
+ * y0 is [B][n][m], or [n][m] when y0_shared != 0; Y_out is [B][P][n][m]. */
+int midyn_rk4_solve(midyn_stack* stack, int B, int m, int R, const double* times, const double* S,
+                    int nsteps, const int* step_rows, const double* step_h, const int* step_save,
+                    int P, const midyn_complex* y0, int y0_shared, midyn_complex* Y_out);
+
+/* ---- matrix exponential (scipy.linalg.expm as called at solvers/fixed_step_solvers.py:22,104) --
+ * E_out[b] = expm(A[b]) for `batch` n x n matrices.  Algorithm: scaling and squaring of a
+ * degree-16 Taylor polynomial evaluated with Paterson-Stockmeyer (matrix products only, all on
+ * the fp64 MFMA zgemm); see DESIGN.md for the parity statement. info (optional, [batch][2]):
+ * squarings s and the 1-norm (as a truncated integer *1e6). */
+int midyn_expm(midyn_ctx* ctx, int n, int batch, const midyn_complex* A, midyn_complex* E_out,
+               long long* info);
+
+/* ---- fixed-step Magnus/expm solver (solvers/fixed_step_solvers.py:80-108,321-403) ----------------
+ * y <- expm(Omega_m) y per step; the generator evaluations use table rows step_rows[s][0..m-1]
+ * (m = magnus_order Gauss points, in the order of fixed_step_solvers.py:345-377).
+ * Instances are processed one after the other (each expm fills the device). */
+int midyn_expm_solve(midyn_stack* stack, int B, int m, int R, const double* times, const double* S,
+                     int nsteps, const int* step_rows, const double* step_h, const int* step_save,
+                     int P, int magnus_order, const midyn_complex* y0, int y0_shared,
+                     midyn_complex* Y_out);
+
+/* ---- plain complex GEMM on the same MFMA kernel (yardstick + tests) --------------------------- */
+int midyn_zgemm(midyn_ctx* ctx, int M, int N, int K, const midyn_complex* A, const midyn_complex* B,
+                midyn_complex* C);
+
+/* ---- bench hooks: work on DEVICE-RESIDENT data so the timed region excludes PCIe ---------------
+ * midyn_rk4_plan_create uploads everything midyn_rk4_solve needs and returns a plan;
+ * midyn_rk4_plan_run executes steps [step_begin, step_end) asynchronously on the ctx stream
+ * (state continues from the previous call); midyn_rk4_plan_fetch copies the current state out as
+ * [B][n][m]. */
+typedef struct midyn_rk4_plan midyn_rk4_plan;
+int midyn_rk4_plan_create(midyn_stack* stack, int B, int m, int R, const double* times,
+                          const double* S, int nsteps, const int* step_rows, const double* step_h,
+                          const midyn_complex* y0, int y0_shared, midyn_rk4_plan** out);
+int midyn_rk4_plan_run(midyn_rk4_plan* plan, int step_begin, int step_end);
+int midyn_rk4_plan_fetch(midyn_rk4_plan* plan, midyn_complex* Y_out);
+int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
+
+/* ---- counters ----------------------------------------------------------------------------------
+ * Kernel-time accounting measured with HIP events on the ctx stream.
+ * names: "rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise".
+ * out[0] = launches, out[1] = total ms (events are only recorded when profiling is enabled with
+ * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch). */
+int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);
+int midyn_reset_counters(midyn_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIDYN_H */

@@ -1,0 +1,330 @@
+"""ctypes binding of libmidyn.so (C-ABI declared in include/midyn.h).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is visible when a
+context is requested, this module raises -- it never routes work to NumPy.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmidyn.so")
+
+# every symbol include/midyn.h declares (tests/test_abi.py checks the .so exports all of them)
+ABI_SYMBOLS = [
+    "midyn_ctx_create", "midyn_ctx_destroy", "midyn_ctx_synchronize", "midyn_last_error",
+    "midyn_ctx_set_option", "midyn_stack_packed_bytes", "midyn_stack_create", "midyn_stack_adopt",
+    "midyn_stack_destroy", "midyn_stack_info", "midyn_eval_generator", "midyn_eval_rhs",
+    "midyn_rk4_solve", "midyn_expm", "midyn_expm_solve", "midyn_zgemm", "midyn_rk4_plan_create",
+    "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_get_counters",
+    "midyn_reset_counters",
+]
+
+
+class DynamicsError(Exception):
+    """Raised where the reference raises ``QiskitError``."""
+
+
+class HipLibraryError(RuntimeError):
+    """libmidyn.so missing / failed / no GPU: the HIP path cannot run (and nothing else will)."""
+
+
+_lib = None
+_lock = threading.Lock()
+
+_vp = ctypes.c_void_p
+_ci = ctypes.c_int
+_cd = ctypes.c_double
+_cll = ctypes.c_longlong
+
+
+def load():
+    """Load libmidyn.so (once) and set the prototypes."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). qiskit_dynamics_amd has no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        P = ctypes.POINTER
+        lib.midyn_last_error.restype = ctypes.c_char_p
+        lib.midyn_last_error.argtypes = [_vp]
+        lib.midyn_ctx_create.argtypes = [_ci, P(_vp)]
+        lib.midyn_ctx_destroy.argtypes = [_vp]
+        lib.midyn_ctx_synchronize.argtypes = [_vp]
+        lib.midyn_ctx_set_option.argtypes = [_vp, ctypes.c_char_p, _cll]
+        lib.midyn_stack_packed_bytes.argtypes = [_ci, _ci, _ci, P(ctypes.c_size_t)]
+        lib.midyn_stack_create.argtypes = [_vp, _ci, _ci, _vp, _vp, _vp, _vp, P(_vp)]
+        lib.midyn_stack_adopt.argtypes = [_vp, _ci, _ci, _ci, _ci, _vp, P(_vp)]
+        lib.midyn_stack_destroy.argtypes = [_vp]
+        lib.midyn_stack_info.argtypes = [_vp, P(_cll)]
+        lib.midyn_eval_generator.argtypes = [_vp, _vp, _cd, _vp]
+        lib.midyn_eval_rhs.argtypes = [_vp, _vp, _cd, _vp, _ci, _vp]
+        lib.midyn_rk4_solve.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _vp,
+                                        _ci, _vp]
+        lib.midyn_expm.argtypes = [_vp, _ci, _ci, _vp, _vp, _vp]
+        lib.midyn_expm_solve.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _ci,
+                                         _vp, _ci, _vp]
+        lib.midyn_zgemm.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp]
+        lib.midyn_rk4_plan_create.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci,
+                                              P(_vp)]
+        lib.midyn_rk4_plan_run.argtypes = [_vp, _ci, _ci]
+        lib.midyn_rk4_plan_fetch.argtypes = [_vp, _vp]
+        lib.midyn_rk4_plan_destroy.argtypes = [_vp]
+        lib.midyn_get_counters.argtypes = [_vp, ctypes.c_char_p, P(_cd)]
+        lib.midyn_reset_counters.argtypes = [_vp]
+        for name in ABI_SYMBOLS:
+            if name != "midyn_last_error":
+                getattr(lib, name).restype = _ci
+        _lib = lib
+        return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def c128(a):
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Context:
+    """One HIP stream on one device (``midyn_ctx``)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = _vp()
+        st = self.lib.midyn_ctx_create(int(device), ctypes.byref(h))
+        if st != 0:
+            raise HipLibraryError(self.lib.midyn_last_error(None).decode())
+        self.handle = h
+        self.device = int(device)
+
+    def check(self, status):
+        if status != 0:
+            raise DynamicsError(self.lib.midyn_last_error(self.handle).decode())
+
+    def set_option(self, name: str, value: int):
+        self.check(self.lib.midyn_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def synchronize(self):
+        self.check(self.lib.midyn_ctx_synchronize(self.handle))
+
+    def counters(self, name: str):
+        out = (ctypes.c_double * 2)()
+        self.check(self.lib.midyn_get_counters(self.handle, name.encode(), out))
+        return {"launches": out[0], "ms": out[1]}
+
+    def reset_counters(self):
+        self.check(self.lib.midyn_reset_counters(self.handle))
+
+    def zgemm(self, a, b):
+        a, b = c128(a), c128(b)
+        m, k = a.shape
+        k2, n = b.shape
+        if k != k2:
+            raise DynamicsError("zgemm: inner dimensions differ")
+        c = np.empty((m, n), dtype=np.complex128)
+        self.check(self.lib.midyn_zgemm(self.handle, m, n, k, _ptr(a), _ptr(b), _ptr(c)))
+        return c
+
+    def expm(self, a, return_info=False):
+        a = c128(a)
+        single = a.ndim == 2
+        if single:
+            a = a[None]
+        batch, n, n2 = a.shape
+        if n != n2:
+            raise DynamicsError("expm: matrices must be square")
+        out = np.empty_like(a)
+        info = np.zeros((batch, 2), dtype=np.int64)
+        self.check(self.lib.midyn_expm(self.handle, n, batch, _ptr(a), _ptr(out), _ptr(info)))
+        out = out[0] if single else out
+        return (out, info) if return_info else out
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.midyn_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None) -> Context:
+    """Process-wide context for `device` (default: LOCAL_RANK, else 0)."""
+    if device is None:
+        device = int(os.environ.get("MIDYN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class Stack:
+    """Device-resident operator stack (``midyn_stack``).
+
+    ops (k,n,n) | None, static (n,n) | None, frame_im (n,) | None -- all in the frame basis.
+    """
+
+    def __init__(self, ctx: Context, ops, static, frame_im, dev_buffer_ptr=None, _adopt=None):
+        self.ctx = ctx
+        lib = ctx.lib
+        h = _vp()
+        if _adopt is not None:
+            n, k, has_static, has_frame = _adopt
+            ctx.check(lib.midyn_stack_adopt(ctx.handle, n, k, has_static, has_frame,
+                                            _vp(dev_buffer_ptr), ctypes.byref(h)))
+        else:
+            ops_a = None if ops is None else c128(ops)
+            st_a = None if static is None else c128(static)
+            fr_a = None if frame_im is None else f64(frame_im)
+            if ops_a is not None and ops_a.ndim != 3:
+                raise DynamicsError("operators must be a (k,n,n) array")
+            n = st_a.shape[-1] if st_a is not None else ops_a.shape[-1]
+            k = 0 if ops_a is None else ops_a.shape[0]
+            ctx.check(lib.midyn_stack_create(ctx.handle, n, k, _ptr(ops_a), _ptr(st_a), _ptr(fr_a),
+                                             _vp(dev_buffer_ptr) if dev_buffer_ptr else None,
+                                             ctypes.byref(h)))
+        self.handle = h
+        info = (ctypes.c_longlong * 8)()
+        ctx.check(lib.midyn_stack_info(h, info))
+        (self.n, self.n_pad, self.k, self.has_static, self.has_frame, self.n_segments,
+         self.n_active_segments, self.packed_mib) = [int(x) for x in info]
+
+    @staticmethod
+    def packed_bytes(n, k, has_static):
+        lib = load()
+        b = ctypes.c_size_t()
+        if lib.midyn_stack_packed_bytes(int(n), int(k), int(bool(has_static)), ctypes.byref(b)):
+            raise DynamicsError(lib.midyn_last_error(None).decode())
+        return int(b.value)
+
+    # -- single evaluations -----------------------------------------------------------------
+    def eval_generator(self, coeffs, t):
+        out = np.empty((self.n, self.n), dtype=np.complex128)
+        c = None if self.k == 0 else f64(coeffs)
+        if c is not None and c.shape != (self.k,):
+            raise DynamicsError("coefficient vector has the wrong length")
+        self.ctx.check(self.ctx.lib.midyn_eval_generator(self.handle, _ptr(c), float(t), _ptr(out)))
+        return out
+
+    def eval_rhs(self, coeffs, t, y):
+        y = c128(y)
+        if y.shape[0] != self.n or y.ndim > 2:
+            raise DynamicsError("state has the wrong shape")
+        m = 1 if y.ndim == 1 else y.shape[1]
+        out = np.empty_like(y)
+        c = None if self.k == 0 else f64(coeffs)
+        if c is not None and c.shape != (self.k,):
+            raise DynamicsError("coefficient vector has the wrong length")
+        self.ctx.check(self.ctx.lib.midyn_eval_rhs(self.handle, _ptr(c), float(t), _ptr(y), m, _ptr(out)))
+        return out
+
+    # -- solves -----------------------------------------------------------------------------
+    def _solve_args(self, times, table, step_rows, step_h, step_save, y0, batch):
+        times = f64(times)
+        r = times.shape[0]
+        if self.k > 0:
+            table = f64(table)
+            if table.shape != (batch, r, self.k):
+                raise DynamicsError(f"coefficient table must be (B,R,k)={(batch, r, self.k)}, got {table.shape}")
+        else:
+            table = None
+        step_rows = i32(step_rows).reshape(-1, 3)
+        step_h = f64(step_h)
+        step_save = i32(step_save)
+        nsteps = step_rows.shape[0]
+        y0 = c128(y0)
+        return times, r, table, step_rows, step_h, step_save, nsteps, y0
+
+    def rk4_solve(self, times, table, step_rows, step_h, step_save, n_save, y0, batch, y0_shared):
+        """y0: (n,m) if y0_shared else (B,n,m).  Returns (B, P, n, m)."""
+        times, r, table, step_rows, step_h, step_save, nsteps, y0 = self._solve_args(
+            times, table, step_rows, step_h, step_save, y0, batch)
+        m = y0.shape[-1]
+        out = np.empty((batch, n_save, self.n, m), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.midyn_rk4_solve(
+            self.handle, batch, m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows), _ptr(step_h),
+            _ptr(step_save), n_save, _ptr(y0), int(bool(y0_shared)), _ptr(out)))
+        return out
+
+    def expm_solve(self, times, table, step_rows, step_h, step_save, n_save, magnus_order, y0, batch,
+                   y0_shared):
+        times, r, table, step_rows, step_h, step_save, nsteps, y0 = self._solve_args(
+            times, table, step_rows, step_h, step_save, y0, batch)
+        m = y0.shape[-1]
+        out = np.empty((batch, n_save, self.n, m), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.midyn_expm_solve(
+            self.handle, batch, m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows), _ptr(step_h),
+            _ptr(step_save), n_save, int(magnus_order), _ptr(y0), int(bool(y0_shared)), _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:
+            self.ctx.lib.midyn_stack_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+class Rk4Plan:
+    """Device-resident RK4 state for benchmarking (inputs stay in HBM between timed runs)."""
+
+    def __init__(self, stack: Stack, times, table, step_rows, step_h, y0, batch, y0_shared):
+        self.stack = stack
+        ctx = stack.ctx
+        times, r, table, step_rows, step_h, _, nsteps, y0 = stack._solve_args(
+            times, table, step_rows, step_h, np.zeros(0, dtype=np.int32), y0, batch)
+        self.m = y0.shape[-1]
+        self.batch = batch
+        self.nsteps = nsteps
+        h = _vp()
+        ctx.check(ctx.lib.midyn_rk4_plan_create(
+            stack.handle, batch, self.m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows),
+            _ptr(step_h), _ptr(y0), int(bool(y0_shared)), ctypes.byref(h)))
+        self.handle = h
+
+    def run(self, step_begin, step_end):
+        self.stack.ctx.check(self.stack.ctx.lib.midyn_rk4_plan_run(self.handle, int(step_begin), int(step_end)))
+
+    def fetch(self):
+        out = np.empty((self.batch, self.stack.n, self.m), dtype=np.complex128)
+        self.stack.ctx.check(self.stack.ctx.lib.midyn_rk4_plan_fetch(self.handle, _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.stack.ctx.lib.midyn_rk4_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass

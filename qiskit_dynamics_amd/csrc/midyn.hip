@@ -1,0 +1,1089 @@
+// midyn.hip -- host side of libmidyn.so: the C-ABI of include/midyn.h on top of the gfx950 kernels
+// in midyn_kernels.h.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC midyn.hip
+//
+// No CPU fallback exists in this library: every entry point needs a HIP device and fails with a
+// non-zero status (text via midyn_last_error) when there is none.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/midyn.h"
+#include "midyn_kernels.h"
+
+using namespace midyn;
+
+// -------------------------------------------------------------------------------------------------
+// context, errors, profiling
+// -------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+enum KClass { KC_STREAM = 0, KC_RHS_GEMM, KC_ZGEMM, KC_GEN, KC_ELEM, KC_COUNT };
+static const char* kclass_names[KC_COUNT] = {"rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise"};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int cls;
+};
+
+struct midyn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool skip_zero_planes = true;
+    bool profile = false;
+    int force_tile = 0;  // 0 auto, 64, 128
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> pool;
+    double cls_ms[KC_COUNT] = {0};
+    double cls_n[KC_COUNT] = {0};
+    int* d_one_seg = nullptr;  // device int {0}: single full segment list for plain zgemm
+    int num_cu = 256;
+};
+
+static int fail(midyn_ctx* ctx, const std::string& msg) {
+    g_last_error = msg;
+    if (ctx) ctx->err = msg;
+    return 1;
+}
+
+#define HIPCHK(ctx, expr)                                                                   \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return fail((ctx), std::string(#expr) + ": " + hipGetErrorString(_e) + " at " + \
+                                   __FILE__ + ":" + std::to_string(__LINE__));              \
+    } while (0)
+
+#define CHK(expr)                  \
+    do {                           \
+        int _s = (expr);           \
+        if (_s != 0) return _s;    \
+    } while (0)
+
+struct ProfScope {
+    midyn_ctx* ctx;
+    EventPair ep;
+    bool on;
+    ProfScope(midyn_ctx* c, int cls) : ctx(c), on(c->profile) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!ctx->pool.empty()) {
+                e = ctx->pool.back();
+                ctx->pool.pop_back();
+            } else {
+                hipEventCreate(&e);
+            }
+            return e;
+        };
+        ep.a = get();
+        ep.b = get();
+        ep.cls = cls;
+        hipEventRecord(ep.a, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(ep.b, ctx->stream);
+        ctx->pending.push_back(ep);
+    }
+};
+
+static void drain_events(midyn_ctx* ctx) {
+    if (ctx->pending.empty()) return;
+    hipStreamSynchronize(ctx->stream);
+    for (auto& ep : ctx->pending) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ep.a, ep.b);
+        ctx->cls_ms[ep.cls] += ms;
+        ctx->cls_n[ep.cls] += 1;
+        ctx->pool.push_back(ep.a);
+        ctx->pool.push_back(ep.b);
+    }
+    ctx->pending.clear();
+}
+
+extern "C" const char* midyn_last_error(midyn_ctx* ctx) {
+    return ctx ? ctx->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" int midyn_ctx_create(int device, midyn_ctx** out) {
+    if (!out) return fail(nullptr, "midyn_ctx_create: out is NULL");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, std::string("midyn_ctx_create: no HIP device available (") +
+                                 hipGetErrorString(e) + "); libmidyn has no CPU fallback");
+    if (device < 0 || device >= count)
+        return fail(nullptr, "midyn_ctx_create: device index out of range");
+    midyn_ctx* ctx = new midyn_ctx();
+    ctx->device = device;
+    HIPCHK(ctx, hipSetDevice(device));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
+    ctx->num_cu = prop.multiProcessorCount;
+    HIPCHK(ctx, hipMalloc(&ctx->d_one_seg, sizeof(int)));
+    int zero = 0;
+    HIPCHK(ctx, hipMemcpy(ctx->d_one_seg, &zero, sizeof(int), hipMemcpyHostToDevice));
+    *out = ctx;
+    return 0;
+}
+
+extern "C" int midyn_ctx_destroy(midyn_ctx* ctx) {
+    if (!ctx) return 0;
+    hipSetDevice(ctx->device);
+    drain_events(ctx);
+    for (auto e : ctx->pool) hipEventDestroy(e);
+    if (ctx->d_one_seg) hipFree(ctx->d_one_seg);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+extern "C" int midyn_ctx_synchronize(midyn_ctx* ctx) {
+    if (!ctx) return fail(nullptr, "NULL ctx");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long value) {
+    if (!ctx || !name) return fail(ctx, "midyn_ctx_set_option: NULL argument");
+    std::string n(name);
+    if (n == "skip_zero_planes") ctx->skip_zero_planes = value != 0;
+    else if (n == "profile") {
+        if (!value) drain_events(ctx);
+        ctx->profile = value != 0;
+    } else if (n == "force_tile") ctx->force_tile = (int)value;
+    else return fail(ctx, "midyn_ctx_set_option: unknown option " + n);
+    return 0;
+}
+
+extern "C" int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out) {
+    if (!ctx || !name || !out) return fail(ctx, "midyn_get_counters: NULL argument");
+    drain_events(ctx);
+    for (int i = 0; i < KC_COUNT; ++i)
+        if (std::string(name) == kclass_names[i]) {
+            out[0] = ctx->cls_n[i];
+            out[1] = ctx->cls_ms[i];
+            return 0;
+        }
+    return fail(ctx, std::string("midyn_get_counters: unknown counter ") + name);
+}
+
+extern "C" int midyn_reset_counters(midyn_ctx* ctx) {
+    if (!ctx) return fail(nullptr, "NULL ctx");
+    drain_events(ctx);
+    for (int i = 0; i < KC_COUNT; ++i) ctx->cls_ms[i] = ctx->cls_n[i] = 0;
+    return 0;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int grid_for(size_t total, int cap = 4096) {
+    size_t b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > (size_t)cap) b = cap;
+    return (int)b;
+}
+
+// -------------------------------------------------------------------------------------------------
+// operator stack
+// -------------------------------------------------------------------------------------------------
+struct midyn_stack {
+    midyn_ctx* ctx = nullptr;
+    int n = 0, n_pad = 0, k = 0, has_static = 0, has_frame = 0, nseg = 0;
+    char* buf = nullptr;  // packed device buffer
+    bool owns = false;
+    size_t bytes = 0;
+    double2* ops = nullptr;     // [nseg][n_pad][n_pad]
+    double* frame_im = nullptr; // [n_pad]
+    int* flags = nullptr;       // [2*nseg] plane non-zero flags (device)
+    int* seg_all = nullptr;     // [nseg] every segment, mode 0 (device)
+    int* seg_act = nullptr;     // [nseg] active list with plane modes (device)
+    int n_act = 0;
+    std::vector<int> h_flags;
+};
+
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct PackLayout {
+    size_t off_ops, off_frame, off_flags, off_all, off_act, total;
+};
+static PackLayout pack_layout(int n_pad, int nseg) {
+    PackLayout L;
+    size_t o = 0;
+    L.off_ops = o;
+    o = align256(o + (size_t)nseg * n_pad * n_pad * sizeof(double2));
+    L.off_frame = o;
+    o = align256(o + (size_t)n_pad * sizeof(double));
+    L.off_flags = o;
+    o = align256(o + (size_t)2 * std::max(nseg, 1) * sizeof(int));
+    L.off_all = o;
+    o = align256(o + (size_t)std::max(nseg, 1) * sizeof(int));
+    L.off_act = o;
+    o = align256(o + (size_t)std::max(nseg, 1) * sizeof(int));
+    L.total = o;
+    return L;
+}
+
+extern "C" int midyn_stack_packed_bytes(int n, int k, int has_static, size_t* bytes) {
+    if (!bytes || n <= 0 || k < 0) return fail(nullptr, "midyn_stack_packed_bytes: bad argument");
+    *bytes = pack_layout(round_up(n, 64), k + (has_static ? 1 : 0)).total;
+    return 0;
+}
+
+static void stack_bind(midyn_stack* s) {
+    PackLayout L = pack_layout(s->n_pad, s->nseg);
+    s->bytes = L.total;
+    s->ops = reinterpret_cast<double2*>(s->buf + L.off_ops);
+    s->frame_im = reinterpret_cast<double*>(s->buf + L.off_frame);
+    s->flags = reinterpret_cast<int*>(s->buf + L.off_flags);
+    s->seg_all = reinterpret_cast<int*>(s->buf + L.off_all);
+    s->seg_act = reinterpret_cast<int*>(s->buf + L.off_act);
+}
+
+// derive the active segment list from the plane flags (host copy) and upload both lists
+static int stack_finish_lists(midyn_stack* s) {
+    midyn_ctx* ctx = s->ctx;
+    s->h_flags.assign(2 * std::max(s->nseg, 1), 0);
+    if (s->nseg > 0)
+        HIPCHK(ctx, hipMemcpy(s->h_flags.data(), s->flags, 2 * s->nseg * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> all(std::max(s->nseg, 1), 0), act(std::max(s->nseg, 1), 0);
+    s->n_act = 0;
+    for (int seg = 0; seg < s->nseg; ++seg) {
+        all[seg] = seg << 2;
+        const int fr = s->h_flags[2 * seg], fi = s->h_flags[2 * seg + 1];
+        if (!fr && !fi) continue;            // exactly zero operator: contributes nothing
+        int mode = 0;
+        if (fr && !fi) mode = 1;             // real only
+        if (!fr && fi) mode = 2;             // imaginary only
+        act[s->n_act++] = (seg << 2) | mode;
+    }
+    HIPCHK(ctx, hipMemcpy(s->seg_all, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(s->seg_act, act.data(), act.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int midyn_stack_create(midyn_ctx* ctx, int n, int k, const midyn_complex* ops,
+                                  const midyn_complex* static_op, const double* frame_im,
+                                  void* dev_buffer, midyn_stack** out) {
+    if (!ctx || !out) return fail(ctx, "midyn_stack_create: NULL ctx/out");
+    if (n <= 0 || k < 0) return fail(ctx, "midyn_stack_create: n must be > 0 and k >= 0");
+    if (k > 0 && !ops) return fail(ctx, "midyn_stack_create: k > 0 but ops is NULL");
+    if (k == 0 && !static_op)
+        return fail(ctx, "midyn_stack_create: neither static operator nor operators given");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    midyn_stack* s = new midyn_stack();
+    s->ctx = ctx;
+    s->n = n;
+    s->n_pad = round_up(n, 64);
+    s->k = k;
+    s->has_static = static_op ? 1 : 0;
+    s->has_frame = frame_im ? 1 : 0;
+    s->nseg = k + s->has_static;
+    PackLayout L = pack_layout(s->n_pad, s->nseg);
+    if (dev_buffer) {
+        s->buf = static_cast<char*>(dev_buffer);
+        s->owns = false;
+    } else {
+        HIPCHK(ctx, hipMalloc(&s->buf, L.total));
+        s->owns = true;
+    }
+    stack_bind(s);
+    HIPCHK(ctx, hipMemsetAsync(s->buf, 0, L.total, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t plane = (size_t)s->n_pad * s->n_pad;
+    int seg = 0;
+    if (static_op) {
+        HIPCHK(ctx, hipMemcpy2D(s->ops, (size_t)s->n_pad * sizeof(double2), static_op,
+                                (size_t)n * sizeof(double2), (size_t)n * sizeof(double2), n,
+                                hipMemcpyHostToDevice));
+        seg = 1;
+    }
+    for (int j = 0; j < k; ++j, ++seg) {
+        const char* src = reinterpret_cast<const char*>(ops) + (size_t)j * n * n * sizeof(double2);
+        HIPCHK(ctx, hipMemcpy2D(s->ops + seg * plane, (size_t)s->n_pad * sizeof(double2), src,
+                                (size_t)n * sizeof(double2), (size_t)n * sizeof(double2), n,
+                                hipMemcpyHostToDevice));
+    }
+    if (frame_im)
+        HIPCHK(ctx, hipMemcpy(s->frame_im, frame_im, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    if (s->nseg > 0) {
+        hipLaunchKernelGGL(plane_flags_kernel, dim3(grid_for(plane * s->nseg)), dim3(256), 0, ctx->stream,
+                           s->ops, plane, s->nseg, s->flags);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    CHK(stack_finish_lists(s));
+    *out = s;
+    return 0;
+}
+
+extern "C" int midyn_stack_adopt(midyn_ctx* ctx, int n, int k, int has_static, int has_frame,
+                                 void* dev_buffer, midyn_stack** out) {
+    if (!ctx || !out || !dev_buffer) return fail(ctx, "midyn_stack_adopt: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    midyn_stack* s = new midyn_stack();
+    s->ctx = ctx;
+    s->n = n;
+    s->n_pad = round_up(n, 64);
+    s->k = k;
+    s->has_static = has_static ? 1 : 0;
+    s->has_frame = has_frame ? 1 : 0;
+    s->nseg = k + s->has_static;
+    s->buf = static_cast<char*>(dev_buffer);
+    s->owns = false;
+    stack_bind(s);
+    CHK(stack_finish_lists(s));
+    *out = s;
+    return 0;
+}
+
+extern "C" int midyn_stack_destroy(midyn_stack* s) {
+    if (!s) return 0;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    if (s->owns && s->buf) hipFree(s->buf);
+    delete s;
+    return 0;
+}
+
+extern "C" int midyn_stack_info(midyn_stack* s, long long* info) {
+    if (!s || !info) return fail(nullptr, "midyn_stack_info: NULL argument");
+    info[0] = s->n;
+    info[1] = s->n_pad;
+    info[2] = s->k;
+    info[3] = s->has_static;
+    info[4] = s->has_frame;
+    info[5] = s->nseg;
+    info[6] = s->n_act;
+    info[7] = (long long)(s->bytes >> 20);
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// kernel launch helpers
+// -------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm_cfg(midyn_ctx* ctx, const GemmArgs& g) {
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr size_t SMEM = (size_t)2 * GEMM_BK * (BM + BN) * sizeof(double2);
+    static bool attr_set[16] = {false};
+    auto kern = zgemm_seg_kernel<BM, BN, WM, WN>;
+    if (!attr_set[ctx->device & 15]) {
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_set[ctx->device & 15] = true;
+    }
+    const int blocks = (g.M / BM) * (g.N / BN);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(THREADS), SMEM, ctx->stream, g);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// tile choice: 128x128 (8 waves) when that still gives >= 1 block per CU, else 64x64 (4 waves)
+static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g, int cls) {
+    if (g.M % 64 || g.N % 64 || g.K % GEMM_BK)
+        return fail(ctx, "launch_gemm: dimensions must be padded to 64/64/16");
+    ProfScope ps(ctx, cls);
+    bool big = (g.M % 128 == 0) && (g.N % 128 == 0) &&
+               ((long long)(g.M / 128) * (g.N / 128) >= (long long)ctx->num_cu);
+    if (ctx->force_tile == 64) big = false;
+    if (ctx->force_tile == 128 && g.M % 128 == 0 && g.N % 128 == 0) big = true;
+    if (big) return launch_gemm_cfg<128, 128, 2, 4>(ctx, g);
+    return launch_gemm_cfg<64, 64, 2, 2>(ctx, g);
+}
+
+static int launch_stream(midyn_ctx* ctx, const StreamArgs& a) {
+    ProfScope ps(ctx, KC_STREAM);
+    if (a.n_pad >= 1024)
+        hipLaunchKernelGGL(rhs_stream_kernel<4>, dim3(a.n_pad), dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(rhs_stream_kernel<1>, dim3(a.n_pad), dim3(256), 0, ctx->stream, a);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// plain zgemm on device buffers: C = alpha * A.B + beta * Z   (all [n][n], ld n, n % 64 == 0)
+static int dev_zgemm(midyn_ctx* ctx, int M, int N, int K, const double2* A, int lda, const double2* B,
+                     int ldb, double2* C, int ldc, double alpha, double beta, const double2* Z) {
+    GemmArgs g{};
+    g.A = A;
+    g.a_seg_stride = 0;
+    g.lda = lda;
+    g.B = B;
+    g.ldb = ldb;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.seg_list = ctx->d_one_seg;
+    g.n_act = 1;
+    g.has_static = 0;
+    g.coeff = nullptr;
+    g.inst_stride = 0;
+    g.m_cols = 1;
+    g.n_inst = N;
+    g.epi.mode = EPI_PLAIN;
+    g.epi.ld = ldc;
+    g.epi.alpha = alpha;
+    g.epi.beta = beta;
+    g.epi.out = C;
+    g.epi.z = Z;
+    return launch_gemm(ctx, g, KC_ZGEMM);
+}
+
+static int dev_lincomb(midyn_ctx* ctx, int n, double2* out, int nterms, const double2* const* xs,
+                       const double* alphas, double gamma) {
+    LinArgs a{};
+    a.nterms = nterms;
+    for (int i = 0; i < nterms; ++i) {
+        a.x[i] = xs[i];
+        a.alpha[i] = alphas[i];
+    }
+    a.gamma = gamma;
+    a.n = n;
+    a.out = out;
+    ProfScope ps(ctx, KC_ELEM);
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for((size_t)n * n)), dim3(256), 0, ctx->stream, a);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// simple device buffer holder
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() {
+        if (p) hipFree(p);
+    }
+    int alloc(midyn_ctx* ctx, size_t b) {
+        if (p) hipFree(p);
+        p = nullptr;
+        bytes = b;
+        if (b == 0) return 0;
+        HIPCHK(ctx, hipMalloc(&p, b));
+        return 0;
+    }
+    template <class T>
+    T* as() { return static_cast<T*>(p); }
+};
+
+// -------------------------------------------------------------------------------------------------
+// single evaluations
+// -------------------------------------------------------------------------------------------------
+static const int* stack_seg_list(midyn_stack* s, int* n_act) {
+    if (s->ctx->skip_zero_planes) {
+        *n_act = s->n_act;
+        return s->seg_act;
+    }
+    *n_act = s->nseg;
+    return s->seg_all;
+}
+
+static int launch_gen_eval(midyn_stack* s, const double* d_coeff, const double2* d_e, double scale,
+                           double2* d_out) {
+    midyn_ctx* ctx = s->ctx;
+    GenArgs a{};
+    a.ops = s->ops;
+    a.seg_list = stack_seg_list(s, &a.n_act);
+    a.n_pad = s->n_pad;
+    a.has_static = s->has_static;
+    a.coeff = d_coeff;
+    a.e = d_e;
+    a.scale = scale;
+    a.out = d_out;
+    ProfScope ps(ctx, KC_GEN);
+    hipLaunchKernelGGL(gen_eval_kernel, dim3(grid_for((size_t)s->n_pad * s->n_pad, 8192)), dim3(256), 0,
+                       ctx->stream, a);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+static int make_phase_rows(midyn_stack* s, const double* h_times, int rows, DevBuf& d_times, DevBuf& d_E) {
+    midyn_ctx* ctx = s->ctx;
+    if (!s->has_frame) return 0;
+    CHK(d_times.alloc(ctx, (size_t)rows * sizeof(double)));
+    CHK(d_E.alloc(ctx, (size_t)rows * s->n_pad * sizeof(double2)));
+    HIPCHK(ctx, hipMemcpyAsync(d_times.p, h_times, (size_t)rows * sizeof(double), hipMemcpyHostToDevice,
+                               ctx->stream));
+    hipLaunchKernelGGL(phase_table_kernel, dim3(grid_for((size_t)rows * s->n_pad)), dim3(256), 0,
+                       ctx->stream, s->frame_im, d_times.as<double>(), s->n_pad, rows, d_E.as<double2>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // h_times may be a stack temporary
+    return 0;
+}
+
+extern "C" int midyn_eval_generator(midyn_stack* s, const double* coeffs, double t, midyn_complex* G_out) {
+    if (!s || !G_out) return fail(s ? s->ctx : nullptr, "midyn_eval_generator: NULL argument");
+    midyn_ctx* ctx = s->ctx;
+    if (s->k > 0 && !coeffs) return fail(ctx, "midyn_eval_generator: coeffs is NULL but the stack has operators");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf d_coeff, d_times, d_E, d_G;
+    CHK(d_coeff.alloc(ctx, std::max(1, s->k) * sizeof(double)));
+    if (s->k > 0)
+        HIPCHK(ctx, hipMemcpy(d_coeff.p, coeffs, s->k * sizeof(double), hipMemcpyHostToDevice));
+    CHK(make_phase_rows(s, &t, 1, d_times, d_E));
+    CHK(d_G.alloc(ctx, (size_t)s->n_pad * s->n_pad * sizeof(double2)));
+    CHK(launch_gen_eval(s, d_coeff.as<double>(), s->has_frame ? d_E.as<double2>() : nullptr, 1.0,
+                        d_G.as<double2>()));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy2D(G_out, (size_t)s->n * sizeof(double2), d_G.p, (size_t)s->n_pad * sizeof(double2),
+                            (size_t)s->n * sizeof(double2), s->n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// RK4 plan: all device state of a batched fixed-step RK4 solve
+// -------------------------------------------------------------------------------------------------
+struct midyn_rk4_plan {
+    midyn_stack* stack = nullptr;
+    int B = 0, m = 0, ncol = 0, ld = 0, R = 0, nsteps = 0, P = 0;
+    bool stream_path = false;
+    DevBuf d_S, d_times, d_E, d_y, d_acc, d_yin[2], d_out, d_tmp;
+    std::vector<int> rows;     // [nsteps][3]
+    std::vector<double> hs;    // [nsteps]
+    std::vector<int> save;     // [nsteps] or empty
+    int cur_yin = 0;           // which yin buffer holds the input of the next stage-1
+    int next_step = 0;         // next step expected (state continuity)
+};
+
+static const double2* plan_E(midyn_rk4_plan* p, int row) {
+    if (!p->stack->has_frame) return nullptr;
+    return p->d_E.as<double2>() + (size_t)row * p->stack->n_pad;
+}
+
+static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, const double2* yin) {
+    midyn_stack* s = p->stack;
+    midyn_ctx* ctx = s->ctx;
+    if (p->stream_path) {
+        StreamArgs a{};
+        a.ops = s->ops;
+        a.seg_list = stack_seg_list(s, &a.n_act);
+        a.n_pad = s->n_pad;
+        a.has_static = s->has_static;
+        a.coeff = s->k > 0 ? p->d_S.as<double>() + (size_t)row * s->k : nullptr;
+        a.yin = yin;
+        a.epi = epi;
+        return launch_stream(ctx, a);
+    }
+    GemmArgs g{};
+    g.A = s->ops;
+    g.a_seg_stride = (long long)s->n_pad * s->n_pad;
+    g.lda = s->n_pad;
+    g.B = yin;
+    g.ldb = p->ld;
+    g.M = s->n_pad;
+    g.N = p->ld;
+    g.K = s->n_pad;
+    g.seg_list = stack_seg_list(s, &g.n_act);
+    g.has_static = s->has_static;
+    g.coeff = s->k > 0 ? p->d_S.as<double>() + (size_t)row * s->k : nullptr;
+    g.inst_stride = (long long)p->R * s->k;
+    g.m_cols = p->m;
+    g.n_inst = p->B;
+    g.epi = epi;
+    return launch_gemm(ctx, g, KC_RHS_GEMM);
+}
+
+extern "C" int midyn_rk4_plan_destroy(midyn_rk4_plan* p) {
+    if (!p) return 0;
+    hipSetDevice(p->stack->ctx->device);
+    hipStreamSynchronize(p->stack->ctx->stream);
+    delete p;
+    return 0;
+}
+
+static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* times, const double* S,
+                            int nsteps, const int* step_rows, const double* step_h, const int* step_save,
+                            int P, const midyn_complex* y0, int y0_shared, midyn_rk4_plan** out) {
+    midyn_ctx* ctx = s->ctx;
+    if (B <= 0 || m <= 0 || R <= 0 || nsteps < 0) return fail(ctx, "rk4 plan: bad sizes");
+    if (!times || !step_rows || !step_h || !y0 || (s->k > 0 && !S)) return fail(ctx, "rk4 plan: NULL argument");
+    for (int i = 0; i < 3 * nsteps; ++i)
+        if (step_rows[i] < 0 || step_rows[i] >= R) return fail(ctx, "rk4 plan: step_rows out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    midyn_rk4_plan* p = new midyn_rk4_plan();
+    p->stack = s;
+    p->B = B;
+    p->m = m;
+    p->ncol = B * m;
+    p->stream_path = (p->ncol == 1);
+    p->ld = p->stream_path ? 1 : round_up(p->ncol, 64);
+    p->R = R;
+    p->nsteps = nsteps;
+    p->P = P;
+    p->rows.assign(step_rows, step_rows + 3 * nsteps);
+    p->hs.assign(step_h, step_h + nsteps);
+    if (step_save) p->save.assign(step_save, step_save + nsteps);
+    const size_t state_bytes = (size_t)s->n_pad * p->ld * sizeof(double2);
+    int st = 0;
+    auto guard = [&](int r) { if (r && !st) st = r; };
+    guard(p->d_y.alloc(ctx, state_bytes));
+    guard(p->d_acc.alloc(ctx, state_bytes));
+    guard(p->d_yin[0].alloc(ctx, state_bytes));
+    guard(p->d_yin[1].alloc(ctx, state_bytes));
+    if (s->k > 0) guard(p->d_S.alloc(ctx, (size_t)B * R * s->k * sizeof(double)));
+    const size_t y0_elems = (size_t)(y0_shared ? 1 : B) * s->n * m;
+    guard(p->d_tmp.alloc(ctx, y0_elems * sizeof(double2)));
+    if (P > 0) guard(p->d_out.alloc(ctx, (size_t)B * P * s->n * m * sizeof(double2)));
+    if (st) {
+        delete p;
+        return st;
+    }
+    auto bail = [&](int r) {
+        delete p;
+        return r;
+    };
+    if (s->k > 0) {
+        hipError_t e = hipMemcpy(p->d_S.p, S, (size_t)B * R * s->k * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bail(fail(ctx, std::string("upload S: ") + hipGetErrorString(e)));
+    }
+    if (int r = make_phase_rows(s, times, R, p->d_times, p->d_E)) return bail(r);
+    hipMemsetAsync(p->d_y.p, 0, state_bytes, ctx->stream);
+    hipMemsetAsync(p->d_acc.p, 0, state_bytes, ctx->stream);
+    hipMemsetAsync(p->d_yin[0].p, 0, state_bytes, ctx->stream);
+    hipMemsetAsync(p->d_yin[1].p, 0, state_bytes, ctx->stream);
+    {
+        hipError_t e = hipMemcpyAsync(p->d_tmp.p, y0, y0_elems * sizeof(double2), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return bail(fail(ctx, std::string("upload y0: ") + hipGetErrorString(e)));
+    }
+    const int row0 = nsteps > 0 ? p->rows[0] : 0;
+    hipLaunchKernelGGL(scatter_state_kernel, dim3(grid_for((size_t)B * s->n * m)), dim3(256), 0, ctx->stream,
+                       p->d_tmp.as<double2>(), y0_shared ? 1 : 0, B, s->n, m, p->ld, plan_E(p, row0),
+                       p->d_y.as<double2>(), p->d_yin[0].as<double2>());
+    if (P > 0)
+        hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for((size_t)B * s->n * m)), dim3(256), 0, ctx->stream,
+                           p->d_y.as<double2>(), B, s->n, m, p->ld, P, 0, p->d_out.as<double2>());
+    {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) return bail(fail(ctx, std::string("rk4 plan init: ") + hipGetErrorString(e)));
+    }
+    p->cur_yin = 0;
+    p->next_step = 0;
+    *out = p;
+    return 0;
+}
+
+extern "C" int midyn_rk4_plan_create(midyn_stack* s, int B, int m, int R, const double* times,
+                                     const double* S, int nsteps, const int* step_rows, const double* step_h,
+                                     const midyn_complex* y0, int y0_shared, midyn_rk4_plan** out) {
+    if (!s || !out) return fail(s ? s->ctx : nullptr, "midyn_rk4_plan_create: NULL argument");
+    return plan_create_impl(s, B, m, R, times, S, nsteps, step_rows, step_h, nullptr, 0, y0, y0_shared, out);
+}
+
+extern "C" int midyn_rk4_plan_run(midyn_rk4_plan* p, int step_begin, int step_end) {
+    if (!p) return fail(nullptr, "midyn_rk4_plan_run: NULL plan");
+    midyn_stack* s = p->stack;
+    midyn_ctx* ctx = s->ctx;
+    if (step_begin < 0 || step_end > p->nsteps || step_begin > step_end)
+        return fail(ctx, "midyn_rk4_plan_run: step range out of bounds");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int st = step_begin; st < step_end; ++st) {
+        const int r0 = p->rows[3 * st], r1 = p->rows[3 * st + 1], r2 = p->rows[3 * st + 2];
+        if (st != p->next_step) {
+            // non-contiguous call: rebuild the pre-phased input from y at this step's start time
+            hipLaunchKernelGGL(rephase_kernel, dim3(grid_for((size_t)s->n_pad * p->ld)), dim3(256), 0,
+                               ctx->stream, p->d_y.as<double2>(), plan_E(p, r0), s->n_pad, p->ld,
+                               p->d_yin[p->cur_yin].as<double2>());
+            HIPCHK(ctx, hipGetLastError());
+        }
+        // the time at which the NEXT stage-1 input must be phased
+        const int rnext = (st + 1 < p->nsteps) ? p->rows[3 * (st + 1)] : r2;
+        Epilogue e{};
+        e.ld = p->ld;
+        e.h = p->hs[st];
+        e.y = p->d_y.as<double2>();
+        e.acc = p->d_acc.as<double2>();
+        const int stage_row[4] = {r0, r1, r1, r2};
+        const int next_row[4] = {r1, r1, r2, rnext};
+        for (int sg = 0; sg < 4; ++sg) {
+            e.mode = EPI_RK1 + sg;
+            e.e_cur = plan_E(p, stage_row[sg]);
+            e.e_next = plan_E(p, next_row[sg]);
+            const double2* yin = p->d_yin[p->cur_yin].as<double2>();
+            e.yin_next = p->d_yin[p->cur_yin ^ 1].as<double2>();
+            CHK(plan_rhs_launch(p, stage_row[sg], e, yin));
+            p->cur_yin ^= 1;
+        }
+        p->next_step = st + 1;
+        if (!p->save.empty() && p->save[st] >= 0 && p->P > 0) {
+            if (p->save[st] >= p->P) return fail(ctx, "midyn_rk4_plan_run: save slot out of range");
+            hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for((size_t)p->B * s->n * p->m)), dim3(256), 0,
+                               ctx->stream, p->d_y.as<double2>(), p->B, s->n, p->m, p->ld, p->P, p->save[st],
+                               p->d_out.as<double2>());
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+extern "C" int midyn_rk4_plan_fetch(midyn_rk4_plan* p, midyn_complex* Y_out) {
+    if (!p || !Y_out) return fail(nullptr, "midyn_rk4_plan_fetch: NULL argument");
+    midyn_stack* s = p->stack;
+    midyn_ctx* ctx = s->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf tmp;
+    const size_t elems = (size_t)p->B * s->n * p->m;
+    CHK(tmp.alloc(ctx, elems * sizeof(double2)));
+    hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(elems)), dim3(256), 0, ctx->stream,
+                       p->d_y.as<double2>(), p->B, s->n, p->m, p->ld, 1, 0, tmp.as<double2>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(Y_out, tmp.p, elems * sizeof(double2), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int midyn_rk4_solve(midyn_stack* s, int B, int m, int R, const double* times, const double* S,
+                               int nsteps, const int* step_rows, const double* step_h, const int* step_save,
+                               int P, const midyn_complex* y0, int y0_shared, midyn_complex* Y_out) {
+    if (!s || !Y_out) return fail(s ? s->ctx : nullptr, "midyn_rk4_solve: NULL argument");
+    if (P < 1) return fail(s->ctx, "midyn_rk4_solve: P must be >= 1 (slot 0 holds y0)");
+    midyn_rk4_plan* p = nullptr;
+    CHK(plan_create_impl(s, B, m, R, times, S, nsteps, step_rows, step_h, step_save, P, y0, y0_shared, &p));
+    int st = midyn_rk4_plan_run(p, 0, nsteps);
+    if (!st) {
+        hipError_t e = hipStreamSynchronize(s->ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpy(Y_out, p->d_out.p, (size_t)B * P * s->n * m * sizeof(double2), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(s->ctx, std::string("midyn_rk4_solve: ") + hipGetErrorString(e));
+    }
+    midyn_rk4_plan_destroy(p);
+    return st;
+}
+
+extern "C" int midyn_eval_rhs(midyn_stack* s, const double* coeffs, double t, const midyn_complex* y, int m,
+                              midyn_complex* out) {
+    if (!s || !y || !out) return fail(s ? s->ctx : nullptr, "midyn_eval_rhs: NULL argument");
+    midyn_ctx* ctx = s->ctx;
+    if (m <= 0) return fail(ctx, "midyn_eval_rhs: m must be positive");
+    if (s->k > 0 && !coeffs) return fail(ctx, "midyn_eval_rhs: coeffs is NULL but the stack has operators");
+    // one instance, m columns, one table row; reuse the plan machinery with a zero-step plan
+    midyn_rk4_plan* p = nullptr;
+    int rows3[3] = {0, 0, 0};
+    double h0 = 0.0;
+    // nsteps = 1 only so that rows[0] exists for the initial phasing; no step is run
+    CHK(plan_create_impl(s, 1, m, 1, &t, coeffs, 1, rows3, &h0, nullptr, 0, y, 1, &p));
+    DevBuf d_out;
+    int st = d_out.alloc(ctx, (size_t)s->n_pad * p->ld * sizeof(double2));
+    if (!st) {
+        Epilogue e{};
+        e.mode = EPI_RHS;
+        e.ld = p->ld;
+        e.e_cur = plan_E(p, 0);
+        e.out = d_out.as<double2>();
+        st = plan_rhs_launch(p, 0, e, p->d_yin[0].as<double2>());
+    }
+    DevBuf tmp;
+    const size_t elems = (size_t)s->n * m;
+    if (!st) st = tmp.alloc(ctx, elems * sizeof(double2));
+    if (!st) {
+        hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(elems)), dim3(256), 0, ctx->stream,
+                           d_out.as<double2>(), 1, s->n, m, p->ld, 1, 0, tmp.as<double2>());
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, tmp.p, elems * sizeof(double2), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(ctx, std::string("midyn_eval_rhs: ") + hipGetErrorString(e));
+    }
+    midyn_rk4_plan_destroy(p);
+    return st;
+}
+
+// -------------------------------------------------------------------------------------------------
+// zgemm (host buffers) and expm
+// -------------------------------------------------------------------------------------------------
+static int upload_padded(midyn_ctx* ctx, const midyn_complex* h, int rows, int cols, double2* d, int ld) {
+    HIPCHK(ctx, hipMemcpy2D(d, (size_t)ld * sizeof(double2), h, (size_t)cols * sizeof(double2),
+                            (size_t)cols * sizeof(double2), rows, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int midyn_zgemm(midyn_ctx* ctx, int M, int N, int K, const midyn_complex* A, const midyn_complex* B,
+                           midyn_complex* C) {
+    if (!ctx || !A || !B || !C || M <= 0 || N <= 0 || K <= 0) return fail(ctx, "midyn_zgemm: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int Mp = round_up(M, 64), Np = round_up(N, 64), Kp = round_up(K, 64);
+    DevBuf dA, dB, dC;
+    CHK(dA.alloc(ctx, (size_t)Mp * Kp * sizeof(double2)));
+    CHK(dB.alloc(ctx, (size_t)Kp * Np * sizeof(double2)));
+    CHK(dC.alloc(ctx, (size_t)Mp * Np * sizeof(double2)));
+    HIPCHK(ctx, hipMemset(dA.p, 0, dA.bytes));
+    HIPCHK(ctx, hipMemset(dB.p, 0, dB.bytes));
+    CHK(upload_padded(ctx, A, M, K, dA.as<double2>(), Kp));
+    CHK(upload_padded(ctx, B, K, N, dB.as<double2>(), Np));
+    CHK(dev_zgemm(ctx, Mp, Np, Kp, dA.as<double2>(), Kp, dB.as<double2>(), Np, dC.as<double2>(), Np, 1.0, 0.0, nullptr));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy2D(C, (size_t)N * sizeof(double2), dC.p, (size_t)Np * sizeof(double2),
+                            (size_t)N * sizeof(double2), M, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// expm workspace: X (input/output), powers, temporaries; all [np][np]
+struct ExpmWork {
+    int np = 0;
+    DevBuf A2, A3, A4, T0, T1, colsum;
+    int ensure(midyn_ctx* ctx, int n_pad) {
+        if (np == n_pad) return 0;
+        const size_t b = (size_t)n_pad * n_pad * sizeof(double2);
+        CHK(A2.alloc(ctx, b));
+        CHK(A3.alloc(ctx, b));
+        CHK(A4.alloc(ctx, b));
+        CHK(T0.alloc(ctx, b));
+        CHK(T1.alloc(ctx, b));
+        CHK(colsum.alloc(ctx, (size_t)n_pad * sizeof(double)));
+        np = n_pad;
+        return 0;
+    }
+};
+
+static const double EXPM_THETA16 = 0.5;  // conservative: ||A/2^s||_1 <= 0.5 for the degree-16 Taylor
+
+// In place: X <- expm(X).  X is [np][np] on the device (padding rows/cols zero; the padded block of
+// the result becomes the identity, which is harmless).  Degree-16 Taylor polynomial evaluated with
+// Paterson-Stockmeyer (powers A^2,A^3,A^4 + Horner in A^4: 6 zgemm) and s squarings.
+static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int* s_out, double* norm_out) {
+    CHK(w.ensure(ctx, np));
+    hipLaunchKernelGGL(colsum_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, X, np,
+                       w.colsum.as<double>());
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<double> cs(np);
+    HIPCHK(ctx, hipMemcpyAsync(cs.data(), w.colsum.p, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double norm1 = 0.0;
+    for (double v : cs) norm1 = std::max(norm1, v);
+    if (!std::isfinite(norm1)) return fail(ctx, "midyn_expm: matrix has non-finite entries");
+    int s = 0;
+    if (norm1 > EXPM_THETA16) s = std::max(0, (int)std::ceil(std::log2(norm1 / EXPM_THETA16)));
+    if (s_out) *s_out = s;
+    if (norm_out) *norm_out = norm1;
+    const double scale = std::ldexp(1.0, -s);
+    double c[17];
+    c[0] = 1.0;
+    for (int i = 1; i <= 16; ++i) c[i] = c[i - 1] / i;
+    double2* A = X;
+    double2* A2 = w.A2.as<double2>();
+    double2* A3 = w.A3.as<double2>();
+    double2* A4 = w.A4.as<double2>();
+    double2* T0 = w.T0.as<double2>();
+    double2* T1 = w.T1.as<double2>();
+    if (s > 0) {
+        const double2* xs[1] = {A};
+        double al[1] = {scale};
+        CHK(dev_lincomb(ctx, np, A, 1, xs, al, 0.0));
+    }
+    CHK(dev_zgemm(ctx, np, np, np, A, np, A, np, A2, np, 1.0, 0.0, nullptr));
+    CHK(dev_zgemm(ctx, np, np, np, A2, np, A, np, A3, np, 1.0, 0.0, nullptr));
+    CHK(dev_zgemm(ctx, np, np, np, A2, np, A2, np, A4, np, 1.0, 0.0, nullptr));
+    // B_j = c[4j] I + c[4j+1] A + c[4j+2] A2 + c[4j+3] A3 ;  P3 = B3 + c16 A4
+    {
+        const double2* xs[4] = {A, A2, A3, A4};
+        double al[4] = {c[13], c[14], c[15], c[16]};
+        CHK(dev_lincomb(ctx, np, T0, 4, xs, al, c[12]));  // T0 = P3
+    }
+    double2* P = T0;
+    double2* Q = T1;
+    for (int j = 2; j >= 0; --j) {
+        // Q = B_j + A4 . P
+        const double2* xs[3] = {A, A2, A3};
+        double al[3] = {c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]};
+        if (j > 0) {
+            CHK(dev_lincomb(ctx, np, Q, 3, xs, al, c[4 * j]));
+            CHK(dev_zgemm(ctx, np, np, np, A4, np, P, np, Q, np, 1.0, 1.0, Q));
+            std::swap(P, Q);
+        } else {
+            // final result goes back into X (= A); build B_0 in Q first because A is an input of B_0
+            CHK(dev_lincomb(ctx, np, Q, 3, xs, al, c[0]));
+            CHK(dev_zgemm(ctx, np, np, np, A4, np, P, np, X, np, 1.0, 1.0, Q));
+        }
+    }
+    // squarings: X <- X.X, ping-pong through T0
+    double2* cur = X;
+    double2* oth = T0;
+    for (int i = 0; i < s; ++i) {
+        CHK(dev_zgemm(ctx, np, np, np, cur, np, cur, np, oth, np, 1.0, 0.0, nullptr));
+        std::swap(cur, oth);
+    }
+    if (cur != X)
+        HIPCHK(ctx, hipMemcpyAsync(X, cur, (size_t)np * np * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+extern "C" int midyn_expm(midyn_ctx* ctx, int n, int batch, const midyn_complex* A, midyn_complex* E_out,
+                          long long* info) {
+    if (!ctx || !A || !E_out || n <= 0 || batch <= 0) return fail(ctx, "midyn_expm: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int np = round_up(n, 64);
+    ExpmWork w;
+    DevBuf X;
+    CHK(X.alloc(ctx, (size_t)np * np * sizeof(double2)));
+    for (int b = 0; b < batch; ++b) {
+        HIPCHK(ctx, hipMemset(X.p, 0, X.bytes));
+        CHK(upload_padded(ctx, A + (size_t)b * n * n, n, n, X.as<double2>(), np));
+        int s = 0;
+        double nrm = 0;
+        CHK(dev_expm_inplace(ctx, w, X.as<double2>(), np, &s, &nrm));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy2D(E_out + (size_t)b * n * n, (size_t)n * sizeof(double2), X.p,
+                                (size_t)np * sizeof(double2), (size_t)n * sizeof(double2), n, hipMemcpyDeviceToHost));
+        if (info) {
+            info[2 * b] = s;
+            info[2 * b + 1] = (long long)(nrm * 1e6);
+        }
+    }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Magnus / expm fixed-step solver
+// -------------------------------------------------------------------------------------------------
+static int commutator(midyn_ctx* ctx, int np, const double2* a, const double2* b, double2* out, double2* tmp) {
+    // out = a.b - b.a
+    CHK(dev_zgemm(ctx, np, np, np, b, np, a, np, tmp, np, 1.0, 0.0, nullptr));
+    CHK(dev_zgemm(ctx, np, np, np, a, np, b, np, out, np, 1.0, -1.0, tmp));
+    return 0;
+}
+
+extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const double* times, const double* S,
+                                int nsteps, const int* step_rows, const double* step_h, const int* step_save,
+                                int P, int magnus_order, const midyn_complex* y0, int y0_shared,
+                                midyn_complex* Y_out) {
+    if (!s || !Y_out || !y0 || !times || !step_rows || !step_h)
+        return fail(s ? s->ctx : nullptr, "midyn_expm_solve: NULL argument");
+    midyn_ctx* ctx = s->ctx;
+    if (magnus_order < 1 || magnus_order > 3) return fail(ctx, "Only magnus_order 1, 2, and 3 are supported.");
+    if (B <= 0 || m <= 0 || R <= 0 || P < 1) return fail(ctx, "midyn_expm_solve: bad sizes");
+    if (s->k > 0 && !S) return fail(ctx, "midyn_expm_solve: S is NULL but the stack has operators");
+    for (int i = 0; i < 3 * nsteps; ++i)
+        if (step_rows[i] < 0 || step_rows[i] >= R) return fail(ctx, "midyn_expm_solve: step_rows out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int np = s->n_pad;
+    const int ld = round_up(m, 64);
+    const size_t mat = (size_t)np * np * sizeof(double2);
+    const size_t stb = (size_t)np * ld * sizeof(double2);
+    DevBuf d_S, d_times, d_E, d_y[2], d_tmp, d_out, G[3], W[4], Om;
+    ExpmWork w;
+    if (s->k > 0) {
+        CHK(d_S.alloc(ctx, (size_t)B * R * s->k * sizeof(double)));
+        HIPCHK(ctx, hipMemcpy(d_S.p, S, d_S.bytes, hipMemcpyHostToDevice));
+    }
+    CHK(make_phase_rows(s, times, R, d_times, d_E));
+    CHK(d_y[0].alloc(ctx, stb));
+    CHK(d_y[1].alloc(ctx, stb));
+    CHK(d_tmp.alloc(ctx, (size_t)s->n * m * sizeof(double2)));
+    CHK(d_out.alloc(ctx, (size_t)P * s->n * m * sizeof(double2)));
+    CHK(Om.alloc(ctx, mat));
+    for (int i = 0; i < magnus_order; ++i) CHK(G[i].alloc(ctx, mat));
+    if (magnus_order >= 2)
+        for (int i = 0; i < (magnus_order == 2 ? 2 : 4); ++i) CHK(W[i].alloc(ctx, mat));
+    auto Erow = [&](int row) -> const double2* {
+        return s->has_frame ? d_E.as<double2>() + (size_t)row * np : nullptr;
+    };
+    const size_t inst_elems = (size_t)s->n * m;
+    for (int b = 0; b < B; ++b) {
+        const midyn_complex* y0b = y0 + (y0_shared ? 0 : (size_t)b * inst_elems);
+        HIPCHK(ctx, hipMemsetAsync(d_y[0].p, 0, stb, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_y[1].p, 0, stb, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_tmp.p, y0b, inst_elems * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(scatter_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                           d_tmp.as<double2>(), 1, 1, s->n, m, ld, (const double2*)nullptr, d_y[0].as<double2>(),
+                           (double2*)nullptr);
+        hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                           d_y[0].as<double2>(), 1, s->n, m, ld, P, 0, d_out.as<double2>());
+        HIPCHK(ctx, hipGetLastError());
+        int cur = 0;
+        const double* coeff_b = s->k > 0 ? d_S.as<double>() + (size_t)b * R * s->k : nullptr;
+        for (int st = 0; st < nsteps; ++st) {
+            const double h = step_h[st];
+            const int* rr = step_rows + 3 * st;
+            auto cf = [&](int row) { return coeff_b ? coeff_b + (size_t)row * s->k : nullptr; };
+            double2* Omega = Om.as<double2>();
+            if (magnus_order == 1) {
+                CHK(launch_gen_eval(s, cf(rr[0]), Erow(rr[0]), h, Omega));
+            } else if (magnus_order == 2) {
+                // fixed_step_solvers.py:348-363
+                CHK(launch_gen_eval(s, cf(rr[0]), Erow(rr[0]), 1.0, G[0].as<double2>()));
+                CHK(launch_gen_eval(s, cf(rr[1]), Erow(rr[1]), 1.0, G[1].as<double2>()));
+                CHK(commutator(ctx, np, G[1].as<double2>(), G[0].as<double2>(), W[0].as<double2>(), W[1].as<double2>()));
+                const double p2 = std::sqrt(3.0) / 12;
+                const double2* xs[3] = {G[0].as<double2>(), G[1].as<double2>(), W[0].as<double2>()};
+                double al[3] = {h / 2, h / 2, p2 * (h * h)};
+                CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0));
+            } else {
+                // fixed_step_solvers.py:365-392
+                const double c0 = std::sqrt(15.0) / 3, c1 = 10.0 / 3;
+                CHK(launch_gen_eval(s, cf(rr[0]), Erow(rr[0]), 1.0, G[0].as<double2>()));
+                CHK(launch_gen_eval(s, cf(rr[1]), Erow(rr[1]), 1.0, G[1].as<double2>()));
+                CHK(launch_gen_eval(s, cf(rr[2]), Erow(rr[2]), 1.0, G[2].as<double2>()));
+                double2 *g1 = G[0].as<double2>(), *g2 = G[1].as<double2>(), *g3 = G[2].as<double2>();
+                double2 *w0 = W[0].as<double2>(), *w1 = W[1].as<double2>(), *w2 = W[2].as<double2>(),
+                        *w3 = W[3].as<double2>();
+                // a1 -> g2 (in place), a2 -> w0, a3 -> w1
+                {
+                    const double2* xs[2] = {g3, g1};
+                    double al[2] = {c0 * h, -c0 * h};
+                    CHK(dev_lincomb(ctx, np, w0, 2, xs, al, 0.0));
+                }
+                {
+                    const double2* xs[3] = {g3, g2, g1};
+                    double al[3] = {c1 * h, -2 * c1 * h, c1 * h};
+                    CHK(dev_lincomb(ctx, np, w1, 3, xs, al, 0.0));
+                }
+                {
+                    const double2* xs[1] = {g2};
+                    double al[1] = {h};
+                    CHK(dev_lincomb(ctx, np, g2, 1, xs, al, 0.0));
+                }
+                double2 *a1 = g2, *a2 = w0, *a3 = w1;
+                // comm1 = [a1, a2] -> w2 (tmp g1)
+                CHK(commutator(ctx, np, a1, a2, w2, g1));
+                double2* comm1 = w2;
+                // X = 2 a3 + comm1 -> g3 ; comm2 = [X, a1]/60 -> w3 (tmp g1)
+                {
+                    const double2* xs[2] = {a3, comm1};
+                    double al[2] = {2.0, 1.0};
+                    CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0));
+                }
+                CHK(commutator(ctx, np, g3, a1, w3, g1));
+                // Y2 = a2 + comm2/60 -> g3 ; Y1 = -20 a1 - a3 + comm1 -> g1
+                {
+                    const double2* xs[2] = {a2, w3};
+                    double al[2] = {1.0, 1.0 / 60};
+                    CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0));
+                }
+                {
+                    const double2* xs[3] = {a1, a3, comm1};
+                    double al[3] = {-20.0, -1.0, 1.0};
+                    CHK(dev_lincomb(ctx, np, g1, 3, xs, al, 0.0));
+                }
+                // comm3 = [Y1, Y2] -> w3 (tmp w2: comm1 no longer needed)
+                CHK(commutator(ctx, np, g1, g3, w3, w2));
+                {
+                    const double2* xs[3] = {a1, a3, w3};
+                    double al[3] = {1.0, 1.0 / 12, 1.0 / 240};
+                    CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0));
+                }
+            }
+            CHK(dev_expm_inplace(ctx, w, Omega, np, nullptr, nullptr));
+            // y <- expm(Omega) y
+            CHK(dev_zgemm(ctx, np, ld, np, Omega, np, d_y[cur].as<double2>(), ld, d_y[cur ^ 1].as<double2>(), ld,
+                          1.0, 0.0, nullptr));
+            cur ^= 1;
+            if (step_save && step_save[st] >= 0) {
+                if (step_save[st] >= P) return fail(ctx, "midyn_expm_solve: save slot out of range");
+                hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                                   d_y[cur].as<double2>(), 1, s->n, m, ld, P, step_save[st], d_out.as<double2>());
+                HIPCHK(ctx, hipGetLastError());
+            }
+        }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b * P * inst_elems, d_out.p, (size_t)P * inst_elems * sizeof(double2),
+                              hipMemcpyDeviceToHost));
+    }
+    return 0;
+}

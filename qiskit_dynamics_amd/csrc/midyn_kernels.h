@@ -1,0 +1,568 @@
+// midyn_kernels.h -- gfx950 (CDNA4) device kernels of libmidyn.
+//
+// Data layout in HBM (everything complex128 interleaved, row major, leading dims padded):
+//   operator stack   ops[seg][n_pad][n_pad]   seg 0 = static operator when present, then the k
+//                                             time dependent operators; zero padded to n_pad
+//   state block      Y[n_pad][ncol_pad]       one COLUMN per (instance, state column); the column
+//                                             index is the fastest axis so that MFMA B-operand
+//                                             tiles and C tiles are contiguous 256-B row pieces
+//   phases           E[row][n_pad]            exp(d * t_row), one row per distinct time
+//   coefficients     S[B][R][k] float64       host layout kept (read once per segment per wave)
+//
+// Kernels
+//   rhs_stream_kernel   single column: HBM-bound fused  sum_j c_j A_j[row,:] . y'  (+ RK4 epilogue)
+//   zgemm_seg_kernel    many columns: fp64 MFMA 16x16x4 complex GEMM over the K = nseg*n axis with
+//                       the real signal coefficient applied to the B fragment (+ RK4 epilogue);
+//                       also the plain zgemm of the expm pipeline
+//   gen_eval_kernel     G = scale * Delta(t) o (A_d + sum c_j A_j)
+//   small elementwise kernels (lincomb, phase table, transposes, norms)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace midyn {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cmul_conj_a(double2 a, double2 b) {  // conj(a) * b
+    return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ double2 cfma_r(double s, double2 a, double2 c) {  // c + s*a, s real
+    return make_double2(fma(s, a.x, c.x), fma(s, a.y, c.y));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by the stream and the MFMA kernels.
+//   EPI_RHS    out = conj(Ecur[row]) * C                         (GeneratorModel.evaluate_rhs)
+//   EPI_RK1..4 classic RK4 stages, fixed_step_solvers.py:62-73, fused:
+//              k = conj(Ecur) * C
+//              1: acc = y + h/6 k         ; yin_next = Enext * (y + h/2 k)
+//              2: acc += h/3 k            ; yin_next = Enext * (y + h/2 k)
+//              3: acc += h/3 k            ; yin_next = Enext * (y + h k)
+//              4: y = acc + h/6 k         ; yin_next = Enext * y
+//   EPI_PLAIN  out = alpha * C + beta * Z                          (expm pipeline zgemm)
+// The stage input is kept PRE-PHASED (yin = exp(d t_stage) o y_stage) so the contraction kernels
+// never touch the frame; yin ping-pongs between two buffers because other workgroups still read
+// the current one while this one already writes the next.
+// ------------------------------------------------------------------------------------------------
+enum { EPI_RHS = 0, EPI_RK1 = 1, EPI_RK2 = 2, EPI_RK3 = 3, EPI_RK4 = 4, EPI_PLAIN = 5 };
+
+struct Epilogue {
+    int mode;
+    int ld;                  // leading dimension (columns) of y/acc/yin_next/out/Z
+    double h;                // step size (RK modes)
+    double alpha, beta;      // EPI_PLAIN
+    const double2* e_cur;    // [n_pad] or nullptr (no frame)
+    const double2* e_next;   // [n_pad] or nullptr
+    double2* y;              // RK: current state
+    double2* acc;            // RK: accumulator
+    double2* yin_next;       // RK: next pre-phased stage input
+    double2* out;            // EPI_RHS / EPI_PLAIN destination
+    const double2* z;        // EPI_PLAIN addend or nullptr
+};
+
+__device__ __forceinline__ void apply_epilogue(const Epilogue& e, int row, int col, double2 c) {
+    const size_t idx = (size_t)row * e.ld + col;
+    if (e.mode == EPI_PLAIN) {
+        double2 r = make_double2(e.alpha * c.x, e.alpha * c.y);
+        if (e.z) {
+            const double2 z = e.z[idx];
+            r.x = fma(e.beta, z.x, r.x);
+            r.y = fma(e.beta, z.y, r.y);
+        }
+        e.out[idx] = r;
+        return;
+    }
+    double2 k = c;
+    if (e.e_cur) k = cmul_conj_a(e.e_cur[row], c);
+    if (e.mode == EPI_RHS) {
+        e.out[idx] = k;
+        return;
+    }
+    const double2 en = e.e_next ? e.e_next[row] : make_double2(1.0, 0.0);
+    const double h = e.h;
+    if (e.mode == EPI_RK1) {
+        const double2 y = e.y[idx];
+        e.acc[idx] = cfma_r(h * (1.0 / 6), k, y);
+        e.yin_next[idx] = cmul(en, cfma_r(0.5 * h, k, y));
+    } else if (e.mode == EPI_RK2) {
+        const double2 y = e.y[idx];
+        e.acc[idx] = cfma_r(h * (1.0 / 3), k, e.acc[idx]);
+        e.yin_next[idx] = cmul(en, cfma_r(0.5 * h, k, y));
+    } else if (e.mode == EPI_RK3) {
+        const double2 y = e.y[idx];
+        e.acc[idx] = cfma_r(h * (1.0 / 3), k, e.acc[idx]);
+        e.yin_next[idx] = cmul(en, cfma_r(h, k, y));
+    } else {  // EPI_RK4
+        const double2 yn = cfma_r(h * (1.0 / 6), k, e.acc[idx]);
+        e.y[idx] = yn;
+        e.yin_next[idx] = cmul(en, yn);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rhs_stream_kernel: one state column.  One workgroup (256 threads = 4 waves) per output row; every
+// lane streams 16-B complex elements of the (nseg) operator rows with fully coalesced 1-KiB wave
+// loads, forms g = sum_seg c_seg A_seg[row][col] in registers (2 FMA per operator) and accumulates
+// g * y'[col] (4 FMA); wave shuffle + LDS reduction; lane 0 runs the epilogue.
+// Algorithmic traffic per launch: 16*nseg*n^2 + 32 n bytes; arithmetic intensity
+// 0.29 F/B -> HBM bound.
+// ------------------------------------------------------------------------------------------------
+struct StreamArgs {
+    const double2* ops;      // [nseg][n_pad][n_pad]
+    const int* seg_list;     // active segment list: (seg<<2)|mode, n_act entries
+    int n_act;
+    int n_pad;
+    int has_static;
+    const double* coeff;     // [k] coefficients of this evaluation (device) or nullptr
+    const double2* yin;      // [n_pad * ld] pre-phased input, column 0 used
+    Epilogue epi;
+};
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void rhs_stream_kernel(StreamArgs a) {
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = a.n_pad;
+    const size_t plane = (size_t)n * n;
+    const int ld = a.epi.ld;
+    double2 acc = make_double2(0.0, 0.0);
+    // columns handled by this thread: tid, tid+256, ...
+    for (int c0 = tid; c0 < n; c0 += 256 * UNROLL) {
+        double2 g[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) g[u] = make_double2(0.0, 0.0);
+        for (int s = 0; s < a.n_act; ++s) {
+            const int seg = a.seg_list[s] >> 2;
+            const double cf = (a.has_static && seg == 0) ? 1.0 : a.coeff[seg - a.has_static];
+            const double2* p = a.ops + seg * plane + (size_t)row * n;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int c = c0 + u * 256;
+                if (c < n) {
+                    const double2 v = p[c];
+                    g[u].x = fma(cf, v.x, g[u].x);
+                    g[u].y = fma(cf, v.y, g[u].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int c = c0 + u * 256;
+            if (c < n) {
+                const double2 yv = a.yin[(size_t)c * ld];
+                acc.x = fma(g[u].x, yv.x, acc.x);
+                acc.x = fma(-g[u].y, yv.y, acc.x);
+                acc.y = fma(g[u].x, yv.y, acc.y);
+                acc.y = fma(g[u].y, yv.x, acc.y);
+            }
+        }
+    }
+    // wave reduction (64 lanes)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        acc.x += __shfl_down(acc.x, off, 64);
+        acc.y += __shfl_down(acc.y, off, 64);
+    }
+    __shared__ double2 part[4];
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double2 c = part[0];
+        c.x += part[1].x + part[2].x + part[3].x;
+        c.y += part[1].y + part[2].y + part[3].y;
+        apply_epilogue(a.epi, row, 0, c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// zgemm_seg_kernel:  C[M][N] = sum_{seg in active} A_seg[M][K] . ( B[K][N] o s_seg[col] )
+// fp64 MFMA v_mfma_f64_16x16x4_f64; complex product = 4 real MFMAs on (re,im) of the fragments
+// (2 when a plane of A_seg is exactly zero).  Fragment maps (one f64 per lane):
+//     A[i = lane & 15][k = lane >> 4]     B[k = lane >> 4][j = lane & 15]
+//     D[row = (lane >> 4) + 4 * reg][col = lane & 15]
+// LDS tiles are k-major ([BK][BM] / [BK][BN] complex) so that a fragment read is one conflict-free
+// ds_read_b128 per lane (the 16-lane service groups of ds_read_b128 cover 16 distinct 16-B slots).
+// The A tile is transposed on its way into LDS (register staged, lane -> (m = l & 7, k = l >> 3),
+// 128-B global row pieces, conflict-free ds_write_b128); the B tile is a straight row copy.
+// Double-buffered LDS, one barrier per K tile; one MFMA is 64 cycles on a SIMD so each 16-deep K
+// tile is >= 8192 MFMA cycles per wave against ~1.5k cycles of staging work: MFMA bound.
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const double2* A;        // segment 0 base
+    long long a_seg_stride;  // elements between segments
+    int lda;
+    const double2* B;
+    int ldb;
+    int M, N, K;             // multiples of BM / BN / BK
+    const int* seg_list;     // (seg<<2)|mode ; mode 0 full, 1 re only, 2 im only
+    int n_act;
+    int has_static;
+    const double* coeff;     // nullptr -> all ones;  else coeff[inst*inst_stride + (seg-has_static)]
+    long long inst_stride;
+    int m_cols;              // columns per instance
+    int n_inst;              // number of instances (columns beyond are padding)
+    Epilogue epi;
+};
+
+constexpr int GEMM_BK = 16;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void zgemm_seg_kernel(GemmArgs g) {
+    constexpr int BK = GEMM_BK;
+    constexpr int THREADS = 64 * WM * WN;
+    constexpr int NWAVE = WM * WN;
+    constexpr int TM = BM / WM;  // wave tile
+    constexpr int TN = BN / WN;
+    constexpr int MT = TM / 16;
+    constexpr int NT = TN / 16;
+    constexpr int A_PER_T = BM * BK / THREADS;
+    constexpr int B_PER_T = BN * BK / THREADS;
+    static_assert(A_PER_T * THREADS == BM * BK && B_PER_T * THREADS == BN * BK, "tile/threads");
+    static_assert((BM / 8) * (BK / 8) == NWAVE * A_PER_T, "A staging map");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double2* As = reinterpret_cast<double2*>(smem_raw);             // [2][BK][BM]
+    double2* Bs = As + 2 * BK * BM;                                 // [2][BK][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    // M-fastest block order: blocks that share an A row panel land on the same XCD (id % 8).
+    const int grid_m = g.M / BM;
+    const int bm = blockIdx.x % grid_m;
+    const int bn = blockIdx.x / grid_m;
+    const int m0 = bm * BM;
+    const int n0 = bn * BN;
+
+    const int KT = g.K / BK;
+    const int total = g.n_act * KT;
+
+    // per-lane column bookkeeping for the coefficient scaling
+    const int lcol = lane & 15;
+    const int lk = lane >> 4;
+    int inst[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int col = n0 + wn * TN + nt * 16 + lcol;
+        int in = col / g.m_cols;
+        inst[nt] = in < g.n_inst ? in : g.n_inst - 1;
+    }
+
+    d4 cre[MT][NT], cim[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            cre[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+            cim[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+
+    double2 ra[A_PER_T], rb[B_PER_T];
+
+    auto load_tiles = [&](int it) {
+        const int s = it / KT;
+        const int kt = it - s * KT;
+        const int seg = g.seg_list[s] >> 2;
+        const double2* Ab = g.A + seg * g.a_seg_stride + (size_t)m0 * g.lda + kt * BK;
+#pragma unroll
+        for (int p = 0; p < A_PER_T; ++p) {
+            const int sub = wave + NWAVE * p;
+            const int sub_m = sub / (BK / 8);
+            const int sub_k = sub % (BK / 8);
+            const int m = sub_m * 8 + (lane & 7);
+            const int k = sub_k * 8 + (lane >> 3);
+            ra[p] = Ab[(size_t)m * g.lda + k];
+        }
+        const double2* Bb = g.B + (size_t)(kt * BK) * g.ldb + n0;
+#pragma unroll
+        for (int p = 0; p < B_PER_T; ++p) {
+            const int idx = tid + THREADS * p;
+            const int k = idx / BN;
+            const int n = idx % BN;
+            rb[p] = Bb[(size_t)k * g.ldb + n];
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        double2* Ad = As + buf * BK * BM;
+#pragma unroll
+        for (int p = 0; p < A_PER_T; ++p) {
+            const int sub = wave + NWAVE * p;
+            const int sub_m = sub / (BK / 8);
+            const int sub_k = sub % (BK / 8);
+            const int m = sub_m * 8 + (lane & 7);
+            const int k = sub_k * 8 + (lane >> 3);
+            Ad[k * BM + m] = ra[p];
+        }
+        double2* Bd = Bs + buf * BK * BN;
+#pragma unroll
+        for (int p = 0; p < B_PER_T; ++p) {
+            const int idx = tid + THREADS * p;
+            Bd[idx] = rb[p];  // idx == k*BN + n
+        }
+    };
+
+    if (total > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    double sc[NT];
+    int cur_s = -1;
+    int mode = 0;
+    for (int it = 0; it < total; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < total) load_tiles(it + 1);
+        const int s = it / KT;
+        if (s != cur_s) {
+            cur_s = s;
+            const int packed = g.seg_list[s];
+            const int seg = packed >> 2;
+            mode = packed & 3;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (g.coeff == nullptr || (g.has_static && seg == 0)) sc[nt] = 1.0;
+                else sc[nt] = g.coeff[inst[nt] * g.inst_stride + (seg - g.has_static)];
+            }
+        }
+        const double2* Ab = As + buf * BK * BM + wm * TM + lcol;
+        const double2* Bb = Bs + buf * BK * BN + wn * TN + lcol;
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            double2 a[MT], b[NT];
+            const int krow = ks * 4 + lk;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = Ab[krow * BM + mt * 16];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                double2 v = Bb[krow * BN + nt * 16];
+                b[nt] = make_double2(v.x * sc[nt], v.y * sc[nt]);
+            }
+            if (mode != 2) {  // real plane of A present
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].x, b[nt].x, cre[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].x, b[nt].y, cim[mt][nt], 0, 0, 0);
+            }
+            if (mode != 1) {  // imaginary plane of A present
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].y, -b[nt].y, cre[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].y, b[nt].x, cim[mt][nt], 0, 0, 0);
+            }
+        }
+        if (it + 1 < total) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[row = (lane>>4) + 4*reg][col = lane & 15]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * TM + mt * 16 + lk + 4 * r;
+                const int col = n0 + wn * TN + nt * 16 + lcol;
+                apply_epilogue(g.epi, row, col, make_double2(cre[mt][nt][r], cim[mt][nt][r]));
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gen_eval_kernel:  G[r][c] = scale * conj(E[r]) * E[c] * (sum_seg cf_seg A_seg[r][c])
+// (RotatingFrame._conjugate_and_add, rotating_frame.py:350-353, fused with the linear combination
+// of operator_collections.py:113-114).  HBM bound: reads 16*nseg B, writes 16 B per element.
+// ------------------------------------------------------------------------------------------------
+struct GenArgs {
+    const double2* ops;
+    const int* seg_list;
+    int n_act;
+    int n_pad;
+    int has_static;
+    const double* coeff;
+    const double2* e;  // [n_pad] phases or nullptr
+    double scale;
+    double2* out;      // [n_pad][n_pad]
+};
+
+__global__ __launch_bounds__(256) void gen_eval_kernel(GenArgs a) {
+    const int n = a.n_pad;
+    const size_t plane = (size_t)n * n;
+    const size_t total = plane;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        double2 gsum = make_double2(0.0, 0.0);
+        for (int s = 0; s < a.n_act; ++s) {
+            const int seg = a.seg_list[s] >> 2;
+            const double cf = (a.has_static && seg == 0) ? 1.0 : a.coeff[seg - a.has_static];
+            const double2 v = a.ops[seg * plane + idx];
+            gsum.x = fma(cf, v.x, gsum.x);
+            gsum.y = fma(cf, v.y, gsum.y);
+        }
+        if (a.e) {
+            const int r = (int)(idx / n);
+            const int c = (int)(idx - (size_t)r * n);
+            const double2 ph = cmul_conj_a(a.e[r], a.e[c]);
+            gsum = cmul(ph, gsum);
+        }
+        a.out[idx] = make_double2(a.scale * gsum.x, a.scale * gsum.y);
+    }
+}
+
+// out = sum_i alpha_i X_i + gamma * I   (real alpha; up to 4 terms) on [n][n] with leading dim n
+struct LinArgs {
+    const double2* x[4];
+    double alpha[4];
+    int nterms;
+    double gamma;
+    int n;
+    double2* out;
+};
+
+__global__ __launch_bounds__(256) void lincomb_kernel(LinArgs a) {
+    const size_t total = (size_t)a.n * a.n;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        double2 r = make_double2(0.0, 0.0);
+        for (int i = 0; i < a.nterms; ++i) {
+            const double2 v = a.x[i][idx];
+            r.x = fma(a.alpha[i], v.x, r.x);
+            r.y = fma(a.alpha[i], v.y, r.y);
+        }
+        if (a.gamma != 0.0) {
+            const size_t rr = idx / a.n;
+            if (idx - rr * a.n == rr) r.x += a.gamma;
+        }
+        a.out[idx] = r;
+    }
+}
+
+// E[r][i] = exp(i * frame_im[i] * times[r])  (rotating_frame.py:255,350: exp(frame_diag * t))
+__global__ __launch_bounds__(256) void phase_table_kernel(const double* frame_im, const double* times,
+                                                          int n_pad, int rows, double2* E) {
+    const size_t total = (size_t)rows * n_pad;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / n_pad);
+        const int i = (int)(idx - (size_t)r * n_pad);
+        double s, c;
+        sincos(frame_im[i] * times[r], &s, &c);
+        E[idx] = make_double2(c, s);
+    }
+}
+
+// Host batch layout [B][n][m] (or shared [n][m]) -> device column block [n_pad][ld]; also writes the
+// pre-phased copy yin = E o y.  Padding rows/cols are zeroed by the caller (memset).
+__global__ __launch_bounds__(256) void scatter_state_kernel(const double2* src, int shared, int B, int n,
+                                                            int m, int ld, const double2* e,
+                                                            double2* y, double2* yin) {
+    const size_t total = (size_t)B * n * m;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int b = (int)(idx / ((size_t)n * m));
+        const size_t rem = idx - (size_t)b * n * m;
+        const int i = (int)(rem / m);
+        const int j = (int)(rem - (size_t)i * m);
+        const double2 v = shared ? src[rem] : src[idx];
+        const size_t dst = (size_t)i * ld + (size_t)b * m + j;
+        if (y) y[dst] = v;
+        if (yin) yin[dst] = e ? cmul(e[i], v) : v;
+    }
+}
+
+// device column block [n_pad][ld] -> out[b][slot][i][j] with out laid out [B][P][n][m]
+__global__ __launch_bounds__(256) void gather_state_kernel(const double2* y, int B, int n, int m, int ld,
+                                                           int P, int slot, double2* out) {
+    const size_t total = (size_t)B * n * m;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int b = (int)(idx / ((size_t)n * m));
+        const size_t rem = idx - (size_t)b * n * m;
+        const int i = (int)(rem / m);
+        const int j = (int)(rem - (size_t)i * m);
+        out[((size_t)b * P + slot) * n * m + rem] = y[(size_t)i * ld + (size_t)b * m + j];
+    }
+}
+
+// yin = E o y  (re-phasing when a step starts from a time that is not the previous step's end)
+__global__ __launch_bounds__(256) void rephase_kernel(const double2* y, const double2* e, int n_pad, int ld,
+                                                      double2* yin) {
+    const size_t total = (size_t)n_pad * ld;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int i = (int)(idx / ld);
+        yin[idx] = e ? cmul(e[i], y[idx]) : y[idx];
+    }
+}
+
+// flags[2*seg + 0/1] = 1 if any real / imaginary part of segment seg is non zero
+__global__ __launch_bounds__(256) void plane_flags_kernel(const double2* ops, size_t plane, int nseg,
+                                                          int* flags) {
+    const size_t total = plane * nseg;
+    int fr = 0, fi = 0;
+    int seg_of = -1;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int seg = (int)(idx / plane);
+        if (seg != seg_of) {
+            if (seg_of >= 0) {
+                if (fr) flags[2 * seg_of] = 1;
+                if (fi) flags[2 * seg_of + 1] = 1;
+            }
+            seg_of = seg;
+            fr = fi = 0;
+        }
+        const double2 v = ops[idx];
+        fr |= (v.x != 0.0);
+        fi |= (v.y != 0.0);
+    }
+    if (seg_of >= 0) {
+        if (fr) flags[2 * seg_of] = 1;
+        if (fi) flags[2 * seg_of + 1] = 1;
+    }
+}
+
+// column abs sums of an [n][n] matrix (ld n): sums[c] = sum_r |A[r][c]|   (1-norm = max_c)
+__global__ __launch_bounds__(256) void colsum_kernel(const double2* A, int n, double* sums) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    double s = 0.0;
+    for (int r = 0; r < n; ++r) {
+        const double2 v = A[(size_t)r * n + c];
+        s += hypot(v.x, v.y);
+    }
+    sums[c] = s;
+}
+
+// pad copy: src [rows][cols] (ld src_ld) -> dst (ld dst_ld), both complex
+__global__ __launch_bounds__(256) void copy2d_kernel(const double2* src, int src_ld, double2* dst, int dst_ld,
+                                                     int rows, int cols) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / cols);
+        const int c = (int)(idx - (size_t)r * cols);
+        dst[(size_t)r * dst_ld + c] = src[(size_t)r * src_ld + c];
+    }
+}
+
+}  // namespace midyn

@@ -1,0 +1,96 @@
+"""Multi-GPU sweep sharding: one process per GPU, trajectories are independent.
+
+The reference loops sweep instances sequentially in one process (solvers/solver_classes.py:568-586);
+there is no communication in its path.  Here the B instances are split into contiguous shards, one
+per rank; the ONLY collective is a single RCCL broadcast of the packed operator stack from rank 0
+over xGMI at setup (`broadcast_stack`), after which every rank integrates its shard with zero
+per-step traffic.  torch.distributed is used purely as the RCCL / rendezvous plumbing
+(backend "nccl" is RCCL on ROCm; "gloo" for the CPU tests).
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import numpy as np
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of `n_items` owned by `rank` (sizes differ by at most one)."""
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError("bad rank/world")
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def init_process_group_from_env(backend: str = "nccl"):
+    """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (as torchrun sets them)."""
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def broadcast_stack(ctx, ops, static, frame_im, n, k, src: int = 0):
+    """Build the packed device stack on `src`, RCCL-broadcast it, adopt it on the other ranks.
+
+    `ops`/`static`/`frame_im` are only read on rank `src` (may be None elsewhere); n, k and the
+    presence flags must be known on every rank.  Returns (Stack, torch tensor that owns the memory).
+    """
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+
+    rank = dist.get_rank()
+    meta = torch.zeros(2, dtype=torch.int64)
+    if rank == src:
+        meta[0] = 1 if static is not None else 0
+        meta[1] = 1 if frame_im is not None else 0
+    dev = torch.device("cuda", ctx.device)
+    meta = meta.to(dev)
+    dist.broadcast(meta, src=src)
+    has_static, has_frame = int(meta[0].item()), int(meta[1].item())
+    nbytes = _lib.Stack.packed_bytes(n, k, has_static)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    stack = None
+    if rank == src:
+        stack = _lib.Stack(ctx, ops, static, frame_im, dev_buffer_ptr=buf.data_ptr())
+        ctx.synchronize()
+    torch.cuda.synchronize(dev)
+    dist.broadcast(buf, src=src)
+    torch.cuda.synchronize(dev)
+    if rank != src:
+        stack = _lib.Stack(ctx, None, None, None, dev_buffer_ptr=buf.data_ptr(),
+                           _adopt=(n, k, has_static, has_frame))
+    return stack, buf
+
+
+def gather_sweep_results(local: np.ndarray, n_total: int):
+    """All-gather per-rank result blocks (shape (b_loc, ...)) into the full (n_total, ...) array on
+    every rank.  Not on the timed path; used by tests and for returning sweep results."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    backend = dist.get_backend()
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    sizes = [shard_bounds(n_total, r, world) for r in range(world)]
+    max_b = max(hi - lo for lo, hi in sizes)
+    pad = np.zeros((max_b,) + local.shape[1:], dtype=np.complex128)
+    pad[: local.shape[0]] = local
+    t = torch.view_as_real(torch.from_numpy(pad)).contiguous().to(dev)
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    full = np.concatenate([
+        torch.view_as_complex(o.cpu().contiguous()).numpy()[: hi - lo] for o, (lo, hi) in zip(outs, sizes)
+    ])
+    return full

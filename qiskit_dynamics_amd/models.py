@@ -1,0 +1,483 @@
+"""Model classes whose evaluation runs on the MI355X through libmidyn.
+
+Drop-in surface for the reference's ``GeneratorModel`` (models/generator_model.py:108-316),
+``HamiltonianModel`` (models/hamiltonian_model.py:31-150) and ``LindbladModel``
+(models/lindblad_model.py:38-538): same constructor keywords, ``evaluate(t)``, ``evaluate_rhs(t,
+y)``, ``__call__``, ``signals`` setter, ``in_frame_basis``, ``dim``, ``rotating_frame`` and
+operator getters.  ``array_library`` accepts ``None`` or ``"hip"``; this package has exactly one
+compute path (the HIP library) and raises if it is unavailable.
+
+Build time (host, once): -iH, frame diagonalisation, U^dagger . U of the operator stack, Kronecker
+superoperators for the vectorised Lindblad model; the resulting frame-basis stack is uploaded once
+and stays resident in HBM (``_lib.Stack``).  Per evaluation (device): the signal-weighted operator
+sum, the frame phases and the contraction.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import DynamicsError
+from .rotating_frame import RotatingFrame
+from .signals import Signal, SignalList
+
+_ACCEPTED_LIBS = (None, "hip")
+
+
+def _check_library(array_library):
+    if array_library not in _ACCEPTED_LIBS:
+        raise DynamicsError(
+            f"array_library={array_library!r} is not available in qiskit_dynamics_amd; the only "
+            "compute path is array_library='hip' (libmidyn on MI355X).")
+
+
+def is_hermitian(operator, tol: float = 1e-10) -> bool:
+    operator = np.asarray(operator)
+    return bool(np.linalg.norm(operator.conj().T - operator) < tol)
+
+
+def _as_signal_list(signals, n_ops, what="Signals"):
+    if isinstance(signals, list):
+        signals = SignalList(signals)
+    if not isinstance(signals, SignalList):
+        raise DynamicsError(f"{what} specified in unaccepted format.")
+    if len(signals) != n_ops:
+        raise DynamicsError(f"{what} needs to have the same length as operators.")
+    return signals
+
+
+def vec_commutator(a):
+    """-i (I (x) A - A^T (x) I): column-stacking matrix of X -> -i[A, X]."""
+    a = np.asarray(a)
+    iden = np.eye(a.shape[-1])
+    return -1j * (np.kron(iden, a) - np.kron(np.swapaxes(a, -1, -2), iden))
+
+
+def vec_dissipator(l):
+    """conj(L) (x) L - (I (x) L^+L + (L^+L)^T (x) I)/2: column-stacking Lindblad dissipator."""
+    l = np.asarray(l)
+    iden = np.eye(l.shape[-1])
+    lc = l.conj()
+    ldl = np.swapaxes(lc, -1, -2) @ l
+    return np.kron(lc, iden) @ np.kron(iden, l) - 0.5 * (
+        np.kron(iden, ldl) + np.kron(np.swapaxes(ldl, -1, -2), iden))
+
+
+class BaseGeneratorModel:
+    """``model(t)`` -> generator matrix, ``model(t, y)`` -> RHS."""
+
+    array_library = "hip"
+
+    def __call__(self, time: float, y=None):
+        return self.evaluate(time) if y is None else self.evaluate_rhs(time, y)
+
+
+class GeneratorModel(BaseGeneratorModel):
+    r"""LMDE generator :math:`G(t) = G_d + \sum_j s_j(t) G_j` evaluated on the device."""
+
+    def __init__(self, static_operator=None, operators=None, signals=None, rotating_frame=None,
+                 in_frame_basis: bool = False, array_library: Optional[str] = None, context=None):
+        _check_library(array_library)
+        if static_operator is None and operators is None:
+            raise DynamicsError(
+                f"{type(self).__name__} requires at least one of static_operator or operators to "
+                "be specified at construction.")
+        self._rotating_frame = RotatingFrame(rotating_frame)
+        self._in_frame_basis = in_frame_basis
+        frame = self._rotating_frame
+        # operators into the frame basis; frame subtracted from the static part
+        if static_operator is None:
+            static_fb = None if frame.frame_diag is None else np.diag(-frame.frame_diag)
+        else:
+            static_fb = np.asarray(static_operator, dtype=complex)
+            if static_fb.ndim != 2 or static_fb.shape[0] != static_fb.shape[1]:
+                raise DynamicsError("static_operator must be a square matrix")
+            if frame.frame_diag is not None:
+                static_fb = frame.operator_into_frame_basis(static_fb) - np.diag(frame.frame_diag)
+        ops_fb = None
+        if operators is not None:
+            ops_fb = np.asarray(operators, dtype=complex)
+            if ops_fb.ndim != 3 or ops_fb.shape[1] != ops_fb.shape[2]:
+                raise DynamicsError("operators must be a (k, n, n) array or list of square matrices")
+            ops_fb = frame.operator_into_frame_basis(ops_fb)
+        self._static_fb = static_fb
+        self._ops_fb = ops_fb
+        self._dim = static_fb.shape[-1] if static_fb is not None else ops_fb.shape[-1]
+        if frame.dim is not None and frame.dim != self._dim:
+            raise DynamicsError("rotating frame dimension does not match the operators")
+        self._ctx = context or _lib.default_context()
+        self._stack = _lib.Stack(self._ctx, ops_fb, static_fb, self._frame_diag_imag())
+        self._signals = None
+        self.signals = signals
+
+    # frame diagonal seen by the device (overridden by the vectorised Lindblad model)
+    def _frame_diag_imag(self):
+        return self._rotating_frame.frame_diag_imag
+
+    # -- properties -----------------------------------------------------------------------------
+    @property
+    def dim(self) -> int:
+        return self._dim
+
+    @property
+    def rotating_frame(self) -> RotatingFrame:
+        return self._rotating_frame
+
+    @property
+    def in_frame_basis(self) -> bool:
+        return self._in_frame_basis
+
+    @in_frame_basis.setter
+    def in_frame_basis(self, value: bool):
+        self._in_frame_basis = value
+
+    @property
+    def stack(self) -> "_lib.Stack":
+        """The device-resident operator stack (frame basis)."""
+        return self._stack
+
+    @property
+    def static_operator(self):
+        if self._static_fb is None:
+            return None
+        if self._in_frame_basis:
+            return self._static_fb
+        return self._rotating_frame.operator_out_of_frame_basis(self._static_fb)
+
+    @property
+    def operators(self):
+        if self._ops_fb is None:
+            return None
+        if self._in_frame_basis:
+            return self._ops_fb
+        return self._rotating_frame.operator_out_of_frame_basis(self._ops_fb)
+
+    @property
+    def signals(self) -> Optional[SignalList]:
+        return self._signals
+
+    @signals.setter
+    def signals(self, signals):
+        if signals is None:
+            self._signals = None
+        elif self._ops_fb is None:
+            raise DynamicsError("Signals must be None if operators is None.")
+        else:
+            self._signals = _as_signal_list(signals, self._ops_fb.shape[0])
+
+    # -- evaluation -----------------------------------------------------------------------------
+    def _coefficients(self, time):
+        if self._signals is None:
+            if self._ops_fb is not None:
+                raise DynamicsError(
+                    f"{type(self).__name__} with non-empty operators must be evaluated signals.")
+            return None
+        return np.asarray(self._signals(time), dtype=float)
+
+    def _basis(self):
+        return self._rotating_frame.frame_basis
+
+    def evaluate(self, time: float):
+        """Generator matrix at ``time`` (in the rotating frame)."""
+        g = self._stack.eval_generator(self._coefficients(time), time)
+        basis = self._basis()
+        if not self._in_frame_basis and basis is not None:
+            g = self._ctx.zgemm(self._ctx.zgemm(basis, g), basis.conj().T)
+        return g
+
+    def evaluate_rhs(self, time: float, y):
+        """``G(t) @ y`` for ``y`` of shape ``(n,)`` or ``(n, m)`` (states as columns)."""
+        y = np.asarray(y, dtype=complex)
+        basis = self._basis()
+        rotate = (not self._in_frame_basis) and basis is not None
+        if rotate:
+            y = basis.conj().T @ y
+        out = self._stack.eval_rhs(self._coefficients(time), time, y)
+        if rotate:
+            out = basis @ out
+        return out
+
+
+class HamiltonianModel(GeneratorModel):
+    r"""Hamiltonian :math:`H(t) = H_d + \sum_j s_j(t) H_j`; evaluates the generator ``-i H`` in the
+    rotating frame exactly like the reference (``model(t)`` returns ``-i e^{-tF}(H(t)-H_F)e^{tF}``)."""
+
+    def __init__(self, static_operator=None, operators=None, signals=None, rotating_frame=None,
+                 in_frame_basis: bool = False, array_library: Optional[str] = None,
+                 validate: bool = True, context=None):
+        if static_operator is not None:
+            if validate and not is_hermitian(static_operator):
+                raise DynamicsError("HamiltonianModel static_operator must be Hermitian.")
+            static_operator = -1j * np.asarray(static_operator, dtype=complex)
+        if operators is not None:
+            if validate and any(not is_hermitian(op) for op in operators):
+                raise DynamicsError("HamiltonianModel operators must be Hermitian.")
+            operators = -1j * np.asarray(operators, dtype=complex)
+        super().__init__(static_operator=static_operator, operators=operators, signals=signals,
+                         rotating_frame=rotating_frame, in_frame_basis=in_frame_basis,
+                         array_library=array_library, context=context)
+
+    @property
+    def static_operator(self):
+        if self._static_fb is None:
+            return None
+        if self._in_frame_basis:
+            return self._static_fb
+        return 1j * self._rotating_frame.operator_out_of_frame_basis(self._static_fb)
+
+    @property
+    def operators(self):
+        if self._ops_fb is None:
+            return None
+        if self._in_frame_basis:
+            return 1j * self._ops_fb
+        return 1j * self._rotating_frame.operator_out_of_frame_basis(self._ops_fb)
+
+
+class LindbladModel(BaseGeneratorModel):
+    """Lindblad master equation.  ``vectorized=True`` (needed by the LMDE/expm methods, as in the
+    reference) turns it into a dim^2 generator model handled by the same device kernels; the
+    non-vectorised ``evaluate_rhs`` is served through the same superoperator (small systems only --
+    the dedicated n x n kernel is the 'next' row f2 of SURVEY.md section 8)."""
+
+    _MAX_UNVECTORIZED_DIM = 64
+
+    def __init__(self, static_hamiltonian=None, hamiltonian_operators=None, hamiltonian_signals=None,
+                 static_dissipators=None, dissipator_operators=None, dissipator_signals=None,
+                 rotating_frame=None, in_frame_basis: bool = False,
+                 array_library: Optional[str] = None, vectorized: bool = False,
+                 validate: bool = True, context=None):
+        _check_library(array_library)
+        if (static_hamiltonian is None and hamiltonian_operators is None
+                and static_dissipators is None and dissipator_operators is None):
+            raise DynamicsError(
+                f"{type(self).__name__} requires at least one of static_hamiltonian "
+                "hamiltonian_operators, static_dissipators, or dissipator_operators "
+                "to be specified at construction.")
+        if validate:
+            if static_hamiltonian is not None and not is_hermitian(static_hamiltonian):
+                raise DynamicsError("LinbladModel static_hamiltonian must be Hermitian.")
+            if hamiltonian_operators is not None and any(
+                    not is_hermitian(op) for op in hamiltonian_operators):
+                raise DynamicsError("LindbladModel hamiltonian_operators must be Hermitian.")
+        self._vectorized = vectorized
+        self._rotating_frame = RotatingFrame(rotating_frame)
+        self._in_frame_basis = in_frame_basis
+        frame = self._rotating_frame
+
+        def fb(x):
+            if x is None:
+                return None
+            x = np.asarray(x, dtype=complex)
+            if x.ndim == 2:
+                x = x[None]
+            return frame.operator_into_frame_basis(x)
+
+        if static_hamiltonian is not None:
+            g = -1j * np.asarray(static_hamiltonian, dtype=complex)
+            if frame.frame_diag is not None:
+                g = frame.operator_into_frame_basis(g) - np.diag(frame.frame_diag)
+            h_d = 1j * g
+        elif frame.frame_diag is not None:
+            h_d = 1j * np.diag(-frame.frame_diag)
+        else:
+            h_d = None
+        self._h_d = h_d
+        self._h_ops = fb(hamiltonian_operators)
+        self._n_static = fb(static_dissipators)
+        self._l_ops = fb(dissipator_operators)
+        for x in (self._h_d, self._h_ops, self._n_static, self._l_ops):
+            if x is not None:
+                self._dim = x.shape[-1]
+                break
+        if not vectorized and self._dim > self._MAX_UNVECTORIZED_DIM:
+            raise DynamicsError(
+                "non-vectorised LindbladModel beyond dim "
+                f"{self._MAX_UNVECTORIZED_DIM} is not on the HIP path yet; use vectorized=True.")
+        # superoperator stack (column stacking): static = vec_comm(H_d) + sum vec_diss(N_j),
+        # operators = [vec_comm(H_j) ; vec_diss(L_j)]
+        s_d = None
+        if self._h_d is not None:
+            s_d = vec_commutator(self._h_d)
+        if self._n_static is not None:
+            nd = np.sum(vec_dissipator(self._n_static), axis=0)
+            s_d = nd if s_d is None else s_d + nd
+        parts = []
+        if self._h_ops is not None:
+            parts.append(vec_commutator(self._h_ops))
+        if self._l_ops is not None:
+            parts.append(vec_dissipator(self._l_ops))
+        s_ops = None
+        if parts:
+            s_ops = parts[0] if len(parts) == 1 else np.append(parts[0], parts[1], axis=0)
+        self._ctx = context or _lib.default_context()
+        self._stack = _lib.Stack(self._ctx, s_ops, s_d, frame.vectorized_frame_diag_imag())
+        self._hamiltonian_signals = None
+        self._dissipator_signals = None
+        self.signals = (hamiltonian_signals, dissipator_signals)
+
+    # -- properties -----------------------------------------------------------------------------
+    @property
+    def dim(self) -> int:
+        return self._dim
+
+    @property
+    def vectorized(self) -> bool:
+        return self._vectorized
+
+    @property
+    def rotating_frame(self) -> RotatingFrame:
+        return self._rotating_frame
+
+    @property
+    def in_frame_basis(self) -> bool:
+        return self._in_frame_basis
+
+    @in_frame_basis.setter
+    def in_frame_basis(self, value: bool):
+        self._in_frame_basis = value
+
+    @property
+    def stack(self):
+        return self._stack
+
+    def _out(self, x):
+        if x is None or self._in_frame_basis:
+            return x
+        return self._rotating_frame.operator_out_of_frame_basis(x)
+
+    @property
+    def static_hamiltonian(self):
+        return self._out(self._h_d)
+
+    @property
+    def hamiltonian_operators(self):
+        return self._out(self._h_ops)
+
+    @property
+    def static_dissipators(self):
+        return self._out(self._n_static)
+
+    @property
+    def dissipator_operators(self):
+        return self._out(self._l_ops)
+
+    @property
+    def signals(self) -> Tuple[Optional[SignalList], Optional[SignalList]]:
+        return (self._hamiltonian_signals, self._dissipator_signals)
+
+    @signals.setter
+    def signals(self, new_signals):
+        ham, dis = new_signals
+        if ham is None:
+            self._hamiltonian_signals = None
+        elif self._h_ops is None:
+            raise DynamicsError("Hamiltonian signals must be None if hamiltonian_operators is None.")
+        else:
+            self._hamiltonian_signals = _as_signal_list(ham, self._h_ops.shape[0],
+                                                        "Hamiltonian signals")
+        if dis is None:
+            self._dissipator_signals = None
+        elif self._l_ops is None:
+            raise DynamicsError("Dissipator signals must be None if dissipator_operators is None.")
+        else:
+            self._dissipator_signals = _as_signal_list(dis, self._l_ops.shape[0],
+                                                       "Dissipator signals")
+
+    @classmethod
+    def from_hamiltonian(cls, hamiltonian: HamiltonianModel, static_dissipators=None,
+                         dissipator_operators=None, dissipator_signals=None,
+                         array_library: Optional[str] = None, vectorized: bool = False):
+        saved = hamiltonian.in_frame_basis
+        hamiltonian.in_frame_basis = False
+        h_static, h_ops = hamiltonian.static_operator, hamiltonian.operators
+        hamiltonian.in_frame_basis = saved
+        return cls(static_hamiltonian=h_static, hamiltonian_operators=h_ops,
+                   hamiltonian_signals=hamiltonian.signals, static_dissipators=static_dissipators,
+                   dissipator_operators=dissipator_operators, dissipator_signals=dissipator_signals,
+                   rotating_frame=hamiltonian.rotating_frame, in_frame_basis=saved,
+                   array_library=array_library, vectorized=vectorized)
+
+    # -- evaluation -----------------------------------------------------------------------------
+    def _coefficients(self, time):
+        """Concatenated (ham, diss) coefficient vector, as _concatenate_coefficients does."""
+        parts = []
+        if self._hamiltonian_signals is not None:
+            parts.append(np.asarray(self._hamiltonian_signals(time), dtype=float))
+        elif self._h_ops is not None:
+            raise DynamicsError(
+                f"{type(self).__name__} with non-empty hamiltonian operators cannot be evaluated "
+                "without hamiltonian signals.")
+        if self._dissipator_signals is not None:
+            parts.append(np.asarray(self._dissipator_signals(time), dtype=float))
+        elif self._l_ops is not None:
+            raise DynamicsError(
+                f"{type(self).__name__} with non-empty dissipator operators cannot be evaluated "
+                "without dissipator signals.")
+        if not parts:
+            return None
+        return np.concatenate(parts, axis=-1)
+
+    def _signal_table(self, times):
+        """(R, k_h + k_d) table for an array of times (used by the solvers)."""
+        parts = []
+        if self._hamiltonian_signals is not None:
+            parts.append(self._hamiltonian_signals.table(times))
+        if self._dissipator_signals is not None:
+            parts.append(self._dissipator_signals.table(times))
+        self._coefficients(times[0] if len(times) else 0.0)  # raises if signals are missing
+        if not parts:
+            return np.zeros((len(times), 0))
+        return np.ascontiguousarray(np.concatenate(parts, axis=-1))
+
+    def evaluate_hamiltonian(self, time: float):
+        sig = None if self._hamiltonian_signals is None else self._hamiltonian_signals(time)
+        if self._h_ops is not None and self._h_d is not None:
+            ham = np.tensordot(sig, self._h_ops, axes=1) + self._h_d
+        elif self._h_ops is not None:
+            ham = np.tensordot(sig, self._h_ops, axes=1)
+        elif self._h_d is not None:
+            ham = self._h_d
+        else:
+            raise DynamicsError("LindbladModel has no Hamiltonian terms.")
+        if self._rotating_frame.frame_diag is not None:
+            ham = self._rotating_frame.operator_into_frame(
+                time, ham, operator_in_frame_basis=True, return_in_frame_basis=self._in_frame_basis)
+        return ham
+
+    def evaluate(self, time: float):
+        if not self._vectorized:
+            raise NotImplementedError(
+                "Non-vectorized Lindblad models cannot be represented without a given state.")
+        g = self._stack.eval_generator(self._coefficients(time), time)
+        vb = self._rotating_frame.vectorized_frame_basis
+        if not self._in_frame_basis and vb is not None:
+            g = self._ctx.zgemm(self._ctx.zgemm(vb, g), vb.conj().T)
+        return g
+
+    def evaluate_rhs(self, time: float, y):
+        y = np.asarray(y, dtype=complex)
+        coeffs = self._coefficients(time)
+        basis = self._rotating_frame.frame_basis
+        rotate = (not self._in_frame_basis) and basis is not None
+        n = self._dim
+        if self._vectorized:
+            if rotate:
+                y = self._rotating_frame.vectorized_frame_basis_adjoint @ y
+            out = self._stack.eval_rhs(coeffs, time, y)
+            if rotate:
+                out = self._rotating_frame.vectorized_frame_basis @ out
+            return out
+        # non-vectorised: (n,n) or (l,n,n) density matrices through the superoperator
+        single = y.ndim == 2
+        rho = y[None] if single else y
+        if rotate:
+            rho = basis.conj().T @ rho @ basis
+        cols = np.stack([r.flatten(order="F") for r in rho], axis=1)  # (n^2, l)
+        out = self._stack.eval_rhs(coeffs, time, cols)
+        res = np.stack([out[:, i].reshape(n, n, order="F") for i in range(out.shape[1])])
+        if rotate:
+            res = basis @ res @ basis.conj().T
+        return res[0] if single else res

@@ -1,0 +1,162 @@
+"""Rotating frame bookkeeping (host side, build time only).
+
+Everything here runs ONCE per model (diagonalisation, basis changes of the operator stack) or once
+per solve (y0 / results basis change) -- SURVEY.md rows a3/a4/a12.  The per-evaluation frame work
+(``exp(+-d t)`` phases, the Delta(t) Hadamard mask) is done on the device from ``frame_diag``;
+inside a solve the model is always in the frame basis, so no ``U . U^dagger`` is ever in the loop.
+
+Conventions follow the reference ``models/rotating_frame.py``: the frame operator F is
+anti-Hermitian, a Hermitian input H means F = -iH (:585-660); a 1-D input is the diagonal (:87-95);
+``frame_diag = -1j * eigh(1j F).evals`` and ``frame_basis = U`` (:102-107); vectorised frame basis
+``kron(conj(U), U)`` (:518).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import DynamicsError
+
+
+def _to_anti_hermitian(mat, atol=1e-10, rtol=1e-10):
+    mat = np.asarray(mat)
+    if mat.ndim == 1:
+        if np.allclose(mat.imag, 0.0, atol=atol, rtol=0) and np.allclose(mat, mat.conj(), atol=atol, rtol=rtol):
+            return -1j * mat
+        if np.allclose(mat, -mat.conj(), atol=atol, rtol=rtol):
+            return mat
+    elif mat.ndim == 2 and mat.shape[0] == mat.shape[1]:
+        if np.allclose(mat, mat.conj().T, atol=atol, rtol=rtol):
+            return -1j * mat
+        if np.allclose(mat, -mat.conj().T, atol=atol, rtol=rtol):
+            return mat
+    raise DynamicsError("frame_operator must be either a Hermitian or anti-Hermitian matrix.")
+
+
+class RotatingFrame:
+    """Frame operator F (anti-Hermitian) with its eigen-decomposition ``F = U diag(d) U^dagger``."""
+
+    def __init__(self, frame_operator, atol: float = 1e-10, rtol: float = 1e-10):
+        if isinstance(frame_operator, RotatingFrame):
+            frame_operator = frame_operator.frame_operator
+        self._frame_operator = frame_operator
+        self._vec_basis = None
+        if frame_operator is None:
+            self._dim = None
+            self._frame_diag = None
+            self._frame_basis = None
+            return
+        f = _to_anti_hermitian(np.asarray(frame_operator), atol=atol, rtol=rtol)
+        if f.ndim == 1:
+            self._frame_diag = f
+            self._frame_basis = None
+        else:
+            evals, basis = np.linalg.eigh(1j * f)
+            self._frame_diag = -1j * evals
+            self._frame_basis = basis
+        self._dim = len(self._frame_diag)
+
+    # -- properties ---------------------------------------------------------------------------
+    @property
+    def dim(self):
+        return self._dim
+
+    @property
+    def frame_operator(self):
+        return self._frame_operator
+
+    @property
+    def frame_diag(self):
+        return self._frame_diag
+
+    @property
+    def frame_basis(self):
+        return self._frame_basis
+
+    @property
+    def frame_basis_adjoint(self):
+        return None if self._frame_basis is None else self._frame_basis.conj().T
+
+    @property
+    def frame_diag_imag(self):
+        """Im(d): what the device needs (d is purely imaginary)."""
+        return None if self._frame_diag is None else np.ascontiguousarray(self._frame_diag.imag)
+
+    @property
+    def vectorized_frame_basis(self):
+        if self._frame_basis is None:
+            return None
+        if self._vec_basis is None:
+            self._vec_basis = np.kron(self._frame_basis.conj(), self._frame_basis)
+        return self._vec_basis
+
+    @property
+    def vectorized_frame_basis_adjoint(self):
+        vb = self.vectorized_frame_basis
+        return None if vb is None else vb.conj().T
+
+    def vectorized_frame_diag_imag(self):
+        """Im of D with vec(e^{-tF} X e^{tF}) = exp(-D t) o vec(X) (column stacking):
+        D[r + n c] = d_r - d_c.  Lets the vectorised Lindblad model reuse the generator kernels."""
+        if self._frame_diag is None:
+            return None
+        d = self._frame_diag.imag
+        return np.ascontiguousarray((d.reshape(-1, 1) - d.reshape(1, -1)).flatten(order="F"))
+
+    # -- basis changes (host, O(n^3) once) --------------------------------------------------------
+    def state_into_frame_basis(self, y):
+        y = np.asarray(y)
+        return y if self._frame_basis is None else self._frame_basis.conj().T @ y
+
+    def state_out_of_frame_basis(self, y):
+        y = np.asarray(y)
+        return y if self._frame_basis is None else self._frame_basis @ y
+
+    def operator_into_frame_basis(self, op):
+        if op is None or self._frame_basis is None:
+            return None if op is None else np.asarray(op)
+        return self._frame_basis.conj().T @ (np.asarray(op) @ self._frame_basis)
+
+    def operator_out_of_frame_basis(self, op):
+        if op is None or self._frame_basis is None:
+            return None if op is None else np.asarray(op)
+        return self._frame_basis @ (np.asarray(op) @ self._frame_basis.conj().T)
+
+    # -- elementwise frame maps (host versions, used for results post-processing / tests) --------
+    def state_into_frame(self, t, y, y_in_frame_basis=False, return_in_frame_basis=False):
+        """exp(-tF) y."""
+        y = np.asarray(y)
+        if self._frame_operator is None:
+            return y
+        out = y if y_in_frame_basis else self.state_into_frame_basis(y)
+        out = (np.exp(self._frame_diag * (-t)) * out.T).T
+        return out if return_in_frame_basis else self.state_out_of_frame_basis(out)
+
+    def state_out_of_frame(self, t, y, y_in_frame_basis=False, return_in_frame_basis=False):
+        """exp(tF) y."""
+        return self.state_into_frame(-t, y, y_in_frame_basis, return_in_frame_basis)
+
+    def operator_into_frame(self, t, operator, operator_in_frame_basis=False,
+                            return_in_frame_basis=False):
+        """exp(-tF) A exp(tF)."""
+        operator = np.asarray(operator)
+        if self._frame_operator is None:
+            return operator
+        out = operator if operator_in_frame_basis else self.operator_into_frame_basis(operator)
+        e = np.exp(self._frame_diag * t)
+        out = out * (e.conj().reshape(self.dim, 1) * e)
+        return out if return_in_frame_basis else self.operator_out_of_frame_basis(out)
+
+    def operator_out_of_frame(self, t, operator, operator_in_frame_basis=False,
+                              return_in_frame_basis=False):
+        return self.operator_into_frame(-t, operator, operator_in_frame_basis, return_in_frame_basis)
+
+    def generator_into_frame(self, t, operator, operator_in_frame_basis=False,
+                             return_in_frame_basis=False):
+        """exp(-tF) G exp(tF) - F."""
+        operator = np.asarray(operator)
+        if self._frame_operator is None:
+            return operator
+        out = operator if operator_in_frame_basis else self.operator_into_frame_basis(operator)
+        e = np.exp(self._frame_diag * t)
+        out = out * (e.conj().reshape(self.dim, 1) * e) - np.diag(self._frame_diag)
+        return out if return_in_frame_basis else self.operator_out_of_frame_basis(out)

@@ -1,0 +1,224 @@
+"""Host-side signal objects: they only PRODUCE the real coefficient table ``S[B][R][k]`` that is
+shipped to the device; no device code here.
+
+Mirrors the evaluation surface of the reference's ``signals/signals.py`` (``Signal`` :34-155,
+``DiscreteSignal`` :257-311, ``SignalSum`` :505-577, ``SignalList`` :780-803): a signal is
+``Re[f(t) exp(i(2 pi nu t + phi))]`` with an array-vectorised complex envelope ``f``.  The
+arithmetic ORDER of the reference is kept (complex carrier argument, one ``exp``, sum over terms,
+real part) so that tables are bit-identical to ``SignalList(...)(t)`` of the reference.
+Signal algebra beyond ``+`` (products, RWA, transfer functions) is out of scope for this path.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+
+from ._lib import DynamicsError
+
+
+class Signal:
+    """``Re[f(t) e^{i(2 pi nu t + phi)}]`` with envelope ``f`` (callable or constant)."""
+
+    def __init__(self, envelope: Union[Callable, complex, float], carrier_freq=0.0, phase=0.0,
+                 name: Optional[str] = None):
+        self._name = name
+        self._is_constant = False
+        if not callable(envelope):
+            const = np.asarray(envelope)
+            if np.ndim(carrier_freq) == 0 and carrier_freq == 0.0:
+                self._is_constant = True
+            self._envelope = lambda t: const * np.ones_like(t)
+        else:
+            self._envelope = envelope
+        self.carrier_freq = carrier_freq
+        self.phase = phase
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def is_constant(self) -> bool:
+        return self._is_constant
+
+    @property
+    def carrier_freq(self):
+        return self._carrier_freq
+
+    @carrier_freq.setter
+    def carrier_freq(self, value):
+        self._carrier_freq = np.asarray(value)
+        self._carrier_arg = 1j * 2 * np.pi * self._carrier_freq
+
+    @property
+    def phase(self):
+        return self._phase
+
+    @phase.setter
+    def phase(self, value):
+        self._phase = np.asarray(value)
+        self._phase_arg = 1j * self._phase
+
+    def envelope(self, t):
+        return self._envelope(t)
+
+    def complex_value(self, t):
+        return self.envelope(t) * np.exp(self._carrier_arg * t + self._phase_arg)
+
+    def __call__(self, t):
+        return np.real(self.complex_value(t))
+
+    def __add__(self, other):
+        return SignalSum(self, other)
+
+    def __radd__(self, other):
+        return SignalSum(other, self)
+
+    def __str__(self):
+        if self._name is not None:
+            return str(self._name)
+        if self._is_constant:
+            return f"Constant({self(0.0)})"
+        return f"Signal(carrier_freq={self.carrier_freq}, phase={self.phase})"
+
+
+class DiscreteSignal(Signal):
+    """Piecewise-constant envelope ``samples[floor((t - t0)/dt)]``, zero outside the sample window
+    (the clipped indices -1 and len hit a zero pad)."""
+
+    def __init__(self, dt: float, samples, start_time: float = 0.0, carrier_freq=0.0, phase=0.0,
+                 name: Optional[str] = None):
+        self._dt = dt
+        samples = np.asarray(samples)
+        if len(samples) == 0:
+            pad = np.asarray([0])
+        else:
+            pad = np.expand_dims(np.zeros_like(samples[0]), 0)
+        self._padded_samples = np.append(samples, pad, axis=0)
+        self._start_time = start_time
+
+        def envelope(t):
+            t = np.asarray(t)
+            idx = np.clip(np.array((t - self._start_time) // self._dt, dtype=int), -1,
+                          len(self.samples))
+            return self._padded_samples[idx]
+
+        super().__init__(envelope=envelope, carrier_freq=carrier_freq, phase=phase, name=name)
+
+    @property
+    def dt(self):
+        return self._dt
+
+    @property
+    def samples(self):
+        return self._padded_samples[:-1]
+
+    @property
+    def start_time(self):
+        return self._start_time
+
+    @property
+    def duration(self):
+        return len(self.samples)
+
+
+class SignalSum(Signal):
+    """Sum of signals; ``complex_value`` sums the complex values of the terms."""
+
+    def __init__(self, *signals, name: Optional[str] = None):
+        components: List[Signal] = []
+        for sig in signals:
+            if isinstance(sig, list):
+                sig = SignalSum(*sig)
+            if isinstance(sig, SignalSum):
+                components += sig.components
+            elif isinstance(sig, Signal):
+                components.append(sig)
+            elif np.asarray(sig).ndim == 0 and np.asarray(sig).dtype.kind in "iufc":
+                components.append(Signal(sig))
+            else:
+                raise DynamicsError(
+                    "Components of a SignalSum must be instances of a Signal subclass or a scalar.")
+        self._components = components
+
+        def envelope(t):
+            return np.moveaxis(np.asarray([s.envelope(t) for s in self._components]), 0, -1)
+
+        super().__init__(envelope=envelope,
+                         carrier_freq=[s.carrier_freq for s in components],
+                         phase=[s.phase for s in components], name=name)
+
+    @property
+    def components(self):
+        return self._components
+
+    def __len__(self):
+        return len(self._components)
+
+    def __getitem__(self, idx):
+        return self._components[idx]
+
+    def __iter__(self):
+        return iter(self._components)
+
+    def complex_value(self, t):
+        exp_phases = np.exp(np.expand_dims(t, -1) * self._carrier_arg + self._phase_arg)
+        return np.sum(self.envelope(t) * exp_phases, axis=-1)
+
+
+def to_SignalSum(sig) -> SignalSum:
+    """Anything signal-like -> SignalSum (numbers become constant signals)."""
+    if isinstance(sig, SignalSum):
+        return sig
+    if isinstance(sig, Signal):
+        return SignalSum(sig)
+    if np.asarray(sig).ndim == 0 and np.asarray(sig).dtype.kind in "iufc":
+        return SignalSum(Signal(sig))
+    raise DynamicsError("Input type incompatible with SignalSum.")
+
+
+class SignalList:
+    """List of signals evaluated together: ``SignalList(sigs)(t)`` has shape ``(*t.shape, k)``."""
+
+    def __init__(self, signal_list):
+        self._components = [to_SignalSum(s) for s in signal_list]
+
+    @property
+    def components(self):
+        return self._components
+
+    def __len__(self):
+        return len(self._components)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            return SignalList(self._components[idx])
+        return self._components[idx]
+
+    def __iter__(self):
+        return iter(self._components)
+
+    def complex_value(self, t):
+        return np.moveaxis(np.asarray([s.complex_value(t) for s in self._components]), 0, -1)
+
+    def __call__(self, t):
+        return np.moveaxis(np.asarray([s(t) for s in self._components]), 0, -1)
+
+    @property
+    def drift(self):
+        out = []
+        for comp in self._components:
+            val = 0.0
+            for term in comp:
+                if term.is_constant:
+                    val += term(0.0)
+            out.append(val)
+        return np.asarray(out)
+
+    def table(self, times) -> np.ndarray:
+        """Real coefficient table (R, k) float64 at the 1-D array of times (vectorised over t)."""
+        times = np.asarray(times, dtype=float)
+        if len(self._components) == 0:
+            return np.zeros((times.size, 0))
+        return np.ascontiguousarray(self(times), dtype=np.float64)

@@ -1,0 +1,393 @@
+"""Fixed-step solvers on the device: ``solve_lmde`` / ``solve_ode`` dispatch and the ``Solver`` class.
+
+Drop-in surface for the reference's ``solvers/solver_functions.py`` (``solve_lmde`` :220-373,
+``solve_ode`` :129-217) and ``solvers/solver_classes.py`` (``Solver`` :177-377, ``solve`` :384-554,
+list mode :556-590) restricted to the fixed-step methods of the hot path:
+
+    method "RK4"  / "hip_RK4"        classic RK4          (fixed_step_solvers.py:43-77)
+    method "scipy_expm" / "hip_expm" Magnus-1/2/3 + expm  (fixed_step_solvers.py:80-108,321-403)
+
+Both spellings run the HIP kernels (there is no NumPy path in this package): user code written for
+the reference keeps its method strings.  The time loop of ``fixed_step_solver_template`` (:406-459)
+runs on the device; the host only (a) applies the step-count rule of ``get_fixed_step_sizes``
+(:616-653), (b) evaluates every signal ONCE, array-vectorised over all evaluation times, into the
+coefficient table S[B][R][k] (every time a fixed-step method touches is known up front), and
+(c) changes basis of y0 / results (solver_functions.py:376-450).
+
+A sweep (``Solver.solve`` with lists) whose instances share ``t_span``/``t_eval`` and the y0 shape is
+ONE batched device solve: the reference's sequential loop over instances (solver_classes.py:568-586)
+becomes the N dimension of the MFMA contraction.  The batched path is functional: it never mutates
+the model's signals (the reference's ``_set_new_signals`` is not reentrant).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+from scipy.integrate._ivp.ivp import OdeResult
+
+from ._lib import DynamicsError
+from .models import BaseGeneratorModel, GeneratorModel, HamiltonianModel, LindbladModel
+from .signals import Signal, SignalList
+
+RK4_METHODS = ("RK4", "hip_RK4")
+EXPM_METHODS = ("scipy_expm", "hip_expm")
+ODE_METHODS = list(RK4_METHODS)
+LMDE_METHODS = list(EXPM_METHODS)
+
+
+# -------------------------------------------------------------------------------------------------
+# time grid (host)
+# -------------------------------------------------------------------------------------------------
+def merge_t_args(t_span, t_eval=None) -> np.ndarray:
+    """``t_span`` with ``t_eval`` spliced in; same validation as the reference."""
+    if t_eval is None:
+        return np.asarray(t_span, dtype=float)
+    t_span = np.array(t_span, dtype=float)
+    t_eval = np.array(t_eval, dtype=float)
+    if t_eval.ndim > 1:
+        raise ValueError("t_eval must be 1 dimensional.")
+    if np.min(t_eval) < np.min(t_span) or np.max(t_eval) > np.max(t_span):
+        raise ValueError("t_eval entries must lie in t_span.")
+    direction = np.sign(t_span[1] - t_span[0])
+    if np.any(direction * np.diff(t_eval) < 0.0):
+        raise ValueError("t_eval must be ordered according to the direction of integration.")
+    return np.append(np.append(t_span[0], t_eval), t_span[1])
+
+
+def get_fixed_step_sizes(t_span, t_eval, max_dt) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(t_list, h_list, n_steps_list): fewest equal sub-steps per interval with |h| <= max_dt."""
+    t_list = np.array(merge_t_args(t_span, t_eval))
+    max_dt = np.array(max_dt)
+    delta = np.diff(t_list)
+    n_steps = np.abs(delta / max_dt).astype(int)
+    for i, (dt_i, n_i) in enumerate(zip(delta, n_steps)):
+        if n_i == 0:
+            n_steps[i] = 1
+        elif np.abs(dt_i / n_i) / max_dt > 1 + 1e-15:
+            n_steps[i] = n_i + 1
+    return t_list, np.array(delta / n_steps), n_steps
+
+
+class FixedStepSchedule:
+    """Everything the device loop needs about time: the distinct evaluation times, which table rows
+    each step reads, step sizes and save slots.  ``points`` yields, for a step starting at t with
+    size h, the times the method evaluates the model at (in the reference's floating-point order)."""
+
+    def __init__(self, t_span, t_eval, max_dt, points):
+        self.t_list, h_list, n_list = get_fixed_step_sizes(t_span, t_eval, max_dt)
+        self.has_t_eval = t_eval is not None
+        index = {}
+        times: List[float] = []
+        rows: List[List[int]] = []
+        hs: List[float] = []
+        save: List[int] = []
+
+        def row_of(t):
+            key = float(t)
+            if key not in index:
+                index[key] = len(times)
+                times.append(key)
+            return index[key]
+
+        for i, (t0, h, n) in enumerate(zip(self.t_list[:-1], h_list, n_list)):
+            t = t0
+            for s in range(int(n)):
+                pts = [row_of(p) for p in points(t, h)]
+                rows.append((pts + [pts[-1]] * 3)[:3])
+                hs.append(float(h))
+                save.append(i + 1 if s == int(n) - 1 else -1)
+                t = t + h
+        if not times:
+            times.append(float(self.t_list[0]))
+        self.times = np.array(times, dtype=float)
+        self.step_rows = np.array(rows, dtype=np.int32).reshape(-1, 3)
+        self.step_h = np.array(hs, dtype=float)
+        self.step_save = np.array(save, dtype=np.int32)
+        self.n_save = len(self.t_list)
+
+    def trim(self, y):
+        """``trim_t_results``: with ``t_eval`` only the interior points are returned."""
+        if self.has_t_eval:
+            return self.t_list[1:-1], y[1:-1]
+        return self.t_list, y
+
+
+def _rk4_points(t, h):
+    h2 = 0.5 * h
+    return [t, t + h2, t + h]
+
+
+def _magnus_points(order):
+    if order == 1:
+        return lambda t, h: [t + (h / 2)]
+    if order == 2:
+        c1 = 0.5 - np.sqrt(3) / 6
+        c2 = 0.5 + np.sqrt(3) / 6
+        return lambda t, h: [t + c1 * h, t + c2 * h]
+    if order == 3:
+        d1 = 0.5 - np.sqrt(15) / 10
+        d3 = 0.5 + np.sqrt(15) / 10
+        return lambda t, h: [t + d1 * h, t + 0.5 * h, t + d3 * h]
+    raise DynamicsError("Only magnus_order 1, 2, and 3 are supported.")
+
+
+# -------------------------------------------------------------------------------------------------
+# model plumbing
+# -------------------------------------------------------------------------------------------------
+def _model_kind(model) -> str:
+    if isinstance(model, LindbladModel):
+        return "lindblad_vec" if model.vectorized else "lindblad"
+    if isinstance(model, GeneratorModel):
+        return "generator"
+    raise DynamicsError(
+        "The HIP solvers need a GeneratorModel / HamiltonianModel / LindbladModel instance; "
+        "arbitrary Python callables cannot run on the device.")
+
+
+def _signal_table(model, signals, times) -> np.ndarray:
+    """(R, k) float64 table of ``signals`` (model's own signals when None) at ``times``."""
+    if isinstance(model, LindbladModel):
+        if signals is not None:
+            saved = model.signals
+            try:
+                model.signals = signals if isinstance(signals, tuple) else (signals, None)
+                return model._signal_table(times)
+            finally:
+                model.signals = saved
+        return model._signal_table(times)
+    n_ops = 0 if model._ops_fb is None else model._ops_fb.shape[0]
+    sl = model.signals if signals is None else signals
+    if sl is None:
+        if n_ops:
+            raise DynamicsError(
+                f"{type(model).__name__} with non-empty operators must be evaluated signals.")
+        return np.zeros((len(times), 0))
+    if isinstance(sl, list):
+        sl = SignalList(sl)
+    if len(sl) != n_ops:
+        raise DynamicsError("Signals needs to have the same length as operators.")
+    return sl.table(times)
+
+
+def _prepare_y0(model, kind, y0):
+    """y0 -> frame basis, as a (rows, m) matrix for the device; returns (matrix, restore)."""
+    y0 = np.asarray(y0, dtype=complex)
+    frame = model.rotating_frame
+    n = model.dim
+    if kind == "lindblad":
+        if y0.shape[-2:] != (n, n) or y0.ndim != 2:
+            raise DynamicsError("Shape mismatch for initial state y0 and LindbladModel.")
+        if not model.in_frame_basis:
+            y0 = frame.operator_into_frame_basis(y0)
+        return y0.flatten(order="F").reshape(-1, 1), "lindblad"
+    rows = n * n if kind == "lindblad_vec" else n
+    if y0.ndim not in (1, 2) or y0.shape[0] != rows:
+        if kind == "lindblad_vec":
+            raise DynamicsError("Shape mismatch for initial state y0 and LindbladModel in vectorized "
+                                "evaluation mode.")
+        raise DynamicsError("Shape mismatch for initial state y0 and HamiltonianModel.")
+    if not model.in_frame_basis:
+        if kind == "lindblad_vec":
+            if frame.frame_basis is not None:
+                y0 = frame.vectorized_frame_basis_adjoint @ y0
+        else:
+            y0 = frame.state_into_frame_basis(y0)
+    if y0.ndim == 1:
+        return y0.reshape(-1, 1), "vector"
+    return y0, "matrix"
+
+
+def _restore_y(model, kind, shape_tag, ys):
+    """(P, rows, m) device result -> user layout, out of the frame basis when required."""
+    frame = model.rotating_frame
+    n = model.dim
+    if shape_tag == "lindblad":
+        out = np.stack([y[:, 0].reshape(n, n, order="F") for y in ys])
+        if not model.in_frame_basis:
+            out = frame.operator_out_of_frame_basis(out)
+        return out
+    if not model.in_frame_basis:
+        if kind == "lindblad_vec":
+            if frame.frame_basis is not None:
+                ys = frame.vectorized_frame_basis @ ys
+        elif frame.frame_basis is not None:
+            ys = frame.frame_basis @ ys
+    if shape_tag == "vector":
+        return ys[:, :, 0]
+    return ys
+
+
+def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_dt=None,
+                 magnus_order=1, **unknown):
+    """Solve ``len(y0_list)`` instances that share t_span/t_eval in one device call."""
+    if unknown:
+        raise DynamicsError(f"Unsupported solver options for the HIP fixed-step methods: {sorted(unknown)}")
+    if max_dt is None:
+        raise DynamicsError("max_dt must be specified for fixed-step methods.")
+    kind = _model_kind(model)
+    if method in EXPM_METHODS:
+        if kind == "lindblad":
+            raise DynamicsError(
+                "LMDE-specific methods with LindbladModel requires setting a vectorized=True.")
+        sched = FixedStepSchedule(t_span, t_eval, max_dt, _magnus_points(magnus_order))
+    elif method in RK4_METHODS:
+        sched = FixedStepSchedule(t_span, t_eval, max_dt, _rk4_points)
+    else:
+        raise DynamicsError(f"Method {method} not supported by solve_lmde.")
+    batch = len(y0_list)
+    prepared = [_prepare_y0(model, kind, y0) for y0 in y0_list]
+    tags = {p[1] for p in prepared}
+    shapes = {p[0].shape for p in prepared}
+    if len(tags) != 1 or len(shapes) != 1:
+        raise DynamicsError("internal: batched instances must share the y0 shape")
+    tag = prepared[0][1]
+    shared_y0 = all(y is y0_list[0] for y in y0_list)
+    y0_dev = prepared[0][0] if shared_y0 else np.stack([p[0] for p in prepared])
+    shared_sig = all(s is signals_list[0] for s in signals_list)
+    if shared_sig:
+        one = _signal_table(model, signals_list[0], sched.times)
+        table = np.broadcast_to(one, (batch,) + one.shape)
+    else:
+        table = np.stack([_signal_table(model, s, sched.times) for s in signals_list])
+    stack = model.stack
+    if method in RK4_METHODS:
+        ys = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                             sched.n_save, y0_dev, batch, shared_y0)
+    else:
+        ys = stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                              sched.n_save, magnus_order, y0_dev, batch, shared_y0)
+    results = []
+    for b in range(batch):
+        t_out, y_out = sched.trim(_restore_y(model, kind, tag, ys[b]))
+        results.append(OdeResult(t=t_out, y=y_out))
+    return results
+
+
+def solve_lmde(generator, t_span, y0, method: str = "RK4", t_eval=None, **kwargs) -> OdeResult:
+    """Solve ``y' = G(t) y`` for a model instance with a fixed-step HIP method."""
+    if not isinstance(generator, BaseGeneratorModel):
+        raise DynamicsError(
+            "solve_lmde on the HIP path requires a model instance (GeneratorModel, HamiltonianModel "
+            "or LindbladModel); Python callables cannot be evaluated on the device.")
+    if method not in RK4_METHODS + EXPM_METHODS:
+        raise DynamicsError(f"Method {method} not supported by solve_lmde.")
+    return _solve_batch(generator, t_span, [y0], [None], method, t_eval=t_eval, **kwargs)[0]
+
+
+def solve_ode(rhs, t_span, y0, method: str = "RK4", t_eval=None, **kwargs) -> OdeResult:
+    """ODE-method entry point; only the fixed-step RK4 of the hot path is available."""
+    if method not in RK4_METHODS:
+        raise DynamicsError(f"Method {method} not supported by solve_ode.")
+    return solve_lmde(rhs, t_span, y0, method=method, t_eval=t_eval, **kwargs)
+
+
+# -------------------------------------------------------------------------------------------------
+# Solver
+# -------------------------------------------------------------------------------------------------
+def _nested_ndim(x) -> int:
+    if isinstance(x, (list, tuple)):
+        return 1 + _nested_ndim(x[0])
+    if hasattr(x, "ndim"):
+        return x.ndim
+    return 0
+
+
+def _t_span_to_list(t_span):
+    nd = _nested_ndim(t_span)
+    if nd > 2:
+        raise DynamicsError("t_span must be either 1d or 2d.")
+    if nd == 1:
+        return [t_span], False
+    return list(t_span), True
+
+
+def _y0_to_list(y0):
+    if isinstance(y0, list):
+        return y0, True
+    return [y0], False
+
+
+def _signals_to_list(signals):
+    if signals is None or isinstance(signals, tuple):
+        return [signals], False
+    if isinstance(signals, list) and len(signals) and isinstance(signals[0], (tuple, list, SignalList)):
+        return signals, True
+    if isinstance(signals, SignalList) or isinstance(signals, list):
+        return [signals], False
+    raise DynamicsError("Signals specified in invalid format.")
+
+
+def _setup_args_lists(t_span, y0, signals):
+    names = ["t_span", "y0", "signals"]
+    lists, was_list = [], False
+    for arg, fn in zip((t_span, y0, signals), (_t_span_to_list, _y0_to_list, _signals_to_list)):
+        as_list, flag = fn(arg)
+        lists.append(as_list)
+        was_list = was_list or flag
+    lens = [len(x) for x in lists]
+    max_len = max(lens)
+    for name, ln in zip(names, lens):
+        if ln not in (1, max_len):
+            big = names[lens.index(max_len)]
+            raise DynamicsError(
+                f"If one of t_span, y0, and signals is given as a list of valid inputs, then the "
+                f"others must specify only a single input, or a list of the same length. {big} "
+                f"specifies {max_len} inputs, but {name} is of length {ln}, which is incompatible.")
+    lists = [x * max_len if ln == 1 else x for x, ln in zip(lists, lens)]
+    return lists, was_list
+
+
+class Solver:
+    """Builds a :class:`HamiltonianModel` or :class:`LindbladModel` and solves it, including sweeps:
+    each of ``t_span``, ``y0``, ``signals`` may be a single specification or a list (one common
+    length); a list comes back iff any input was a list."""
+
+    def __init__(self, static_hamiltonian=None, hamiltonian_operators=None, static_dissipators=None,
+                 dissipator_operators=None, rotating_frame=None, in_frame_basis: bool = False,
+                 array_library: Optional[str] = None, vectorized: Optional[bool] = None,
+                 validate: bool = True, context=None):
+        if static_dissipators is None and dissipator_operators is None:
+            self._model = HamiltonianModel(
+                static_operator=static_hamiltonian, operators=hamiltonian_operators,
+                rotating_frame=rotating_frame, in_frame_basis=in_frame_basis,
+                array_library=array_library, validate=validate, context=context)
+        else:
+            self._model = LindbladModel(
+                static_hamiltonian=static_hamiltonian, hamiltonian_operators=hamiltonian_operators,
+                static_dissipators=static_dissipators, dissipator_operators=dissipator_operators,
+                rotating_frame=rotating_frame, in_frame_basis=in_frame_basis,
+                array_library=array_library, vectorized=bool(vectorized), validate=validate,
+                context=context)
+
+    @property
+    def model(self) -> Union[HamiltonianModel, LindbladModel]:
+        return self._model
+
+    def _normalize_signals(self, signals):
+        if signals is None:
+            return None
+        if isinstance(self._model, LindbladModel) and isinstance(signals, (list, SignalList)):
+            return (signals, None)
+        return signals
+
+    def solve(self, t_span, y0, signals=None, **kwargs):
+        (t_spans, y0s, sigs), multiple = _setup_args_lists(t_span, y0, signals)
+        method = kwargs.pop("method", "RK4")
+        t_eval = kwargs.get("t_eval", None)
+        sigs = [self._normalize_signals(s) for s in sigs]
+        n = len(t_spans)
+        results: List[Optional[OdeResult]] = [None] * n
+        # group instances that can share one device solve: same t_span and same y0 shape
+        groups = {}
+        for i in range(n):
+            key = (tuple(np.asarray(t_spans[i], dtype=float).tolist()), np.asarray(y0s[i]).shape)
+            groups.setdefault(key, []).append(i)
+        for (_tkey, _shape), idxs in groups.items():
+            if t_eval is not None and _nested_ndim(t_eval) > 1:
+                raise DynamicsError("t_eval must be 1 dimensional.")
+            out = _solve_batch(self._model, t_spans[idxs[0]], [y0s[i] for i in idxs],
+                               [sigs[i] for i in idxs], method, **kwargs)
+            for i, r in zip(idxs, out):
+                results[i] = r
+        return results if multiple else results[0]

@@ -1,0 +1,536 @@
+"""Parity of the HIP path (through the C-ABI of libmidyn.so) against
+  (1) golden vectors captured from the real reference (tests/golden/*.npz) and
+  (2) the CPU oracle (oracle/dynamics_oracle.py) on seeded inputs, up to BASELINE.json sizes.
+
+Tolerances (fp64): single evaluations max|d| <= 1e-12 (1 + max|ref|); fixed-step
+solves <= 1e-9; expm ||E - E_ref||_1 / ||E_ref||_1 <= 1e-12 and unitarity <= 1e-12 * n.
+All tests need a real MI355X: run with `pytest -m gpu`.
+"""
+import numpy as np
+import pytest
+import scipy.linalg
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+EVAL_TOL = 1e-12
+SOLVE_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def qd():
+    import qiskit_dynamics_amd as q
+
+    q.default_context()  # raises loudly when libmidyn / the GPU is missing
+    return q
+
+
+def crand(rng, *shape):
+    return rng.uniform(-1, 1, shape) + 1j * rng.uniform(-1, 1, shape)
+
+
+# ------------------------------------------------------------------------------------------------
+# MFMA zgemm: layout, transposition, padding, both tile configurations
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [0, 64, 128])
+@pytest.mark.parametrize("shape", [(5, 7, 3), (64, 64, 64), (130, 70, 200), (256, 384, 128),
+                                   (1, 1, 1), (16, 300, 17)])
+def test_zgemm(qd, shape, tile):
+    m, n, k = shape
+    rng = np.random.default_rng(m * 1000 + n * 10 + k)
+    a = crand(rng, m, k)
+    b = crand(rng, k, n)  # asymmetric on purpose (catches row/col swaps)
+    ctx = qd.default_context()
+    ctx.set_option("force_tile", tile)
+    try:
+        c = ctx.zgemm(a, b)
+    finally:
+        ctx.set_option("force_tile", 0)
+    assert_close(c, a @ b, 1e-13)
+
+
+def test_zgemm_identity_asymmetric(qd):
+    """A = I with an asymmetric B: detects an output transpose (guide rule: A=I check)."""
+    n = 96
+    b = np.arange(n * n, dtype=float).reshape(n, n) + 1j * np.arange(n * n, dtype=float).reshape(n, n)[::-1]
+    c = qd.default_context().zgemm(np.eye(n, dtype=complex), b)
+    assert_close(c, b, 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# a1/a2 operator collection
+# ------------------------------------------------------------------------------------------------
+def test_collection_golden(qd, golden):
+    g = golden("collection")
+    ctx = qd.default_context()
+    for tag, st in (("full", g["static"]), ("nostatic", None)):
+        stack = qd.Stack(ctx, g["ops"], st, None)
+        for i, c in enumerate(g["coeffs"]):
+            assert_close(stack.eval_generator(c, 0.0), g[f"{tag}_eval"][i], EVAL_TOL)
+            assert_close(stack.eval_rhs(c, 0.0, g["y1"]), g[f"{tag}_rhs1"][i], EVAL_TOL)
+            assert_close(stack.eval_rhs(c, 0.0, g["ym"]), g[f"{tag}_rhsm"][i], EVAL_TOL)
+    stack = qd.Stack(ctx, None, g["static"], None)
+    assert_close(stack.eval_generator(None, 0.0), g["staticonly_eval"], 0)
+    assert_close(stack.eval_rhs(None, 0.0, g["y1"]), g["staticonly_rhs1"], EVAL_TOL)
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    stack = qd.Stack(ctx, np.array([x, 1j * z]), None, None)
+    assert_close(stack.eval_generator(np.array([1.0, 2.0]), 0.0), g["pauli_eval"], 0)
+
+
+def test_zero_plane_skipping_is_exact(qd):
+    """Purely real / purely imaginary / zero operators take the reduced MFMA paths; results must
+    match the dense path."""
+    rng = np.random.default_rng(7)
+    n, k, m = 48, 4, 5
+    ops = np.zeros((k, n, n), dtype=complex)
+    ops[0] = rng.normal(size=(n, n))              # real only
+    ops[1] = 1j * rng.normal(size=(n, n))         # imaginary only
+    ops[2] = 0.0                                  # exactly zero
+    ops[3] = crand(rng, n, n)
+    static = 1j * rng.normal(size=(n, n))
+    c = rng.uniform(-1, 1, k)
+    y = crand(rng, n, m)
+    ref = (np.tensordot(c, ops, axes=1) + static) @ y
+    ctx = qd.default_context()
+    stack = qd.Stack(ctx, ops, static, None)
+    assert stack.n_active_segments == 4
+    for skip in (1, 0):
+        ctx.set_option("skip_zero_planes", skip)
+        try:
+            assert_close(stack.eval_rhs(c, 0.3, y), ref, EVAL_TOL)
+            assert_close(stack.eval_rhs(c, 0.3, y[:, 0]), ref[:, 0], EVAL_TOL)
+        finally:
+            ctx.set_option("skip_zero_planes", 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# a3-a7 generator / Hamiltonian model
+# ------------------------------------------------------------------------------------------------
+def _sigs(qd, g, tag):
+    return [qd.Signal(a, c, p) for a, c, p in zip(g[f"{tag}_amp"], g[f"{tag}_carrier"], g[f"{tag}_phase"])]
+
+
+@pytest.mark.parametrize("tag", ["r5", "r10"])
+def test_generator_model_golden(qd, golden, tag):
+    g = golden("generator_model")
+    ops, static, frame = g[f"{tag}_ops"], g[f"{tag}_static"], g[f"{tag}_frame"]
+    times, y1, ym = g[f"{tag}_times"], g[f"{tag}_y1"], g[f"{tag}_ym"]
+    sigs = _sigs(qd, g, tag)
+    for ftag, fr in (("fr", frame), ("diag", np.diag(frame).copy()), ("nofr", None)):
+        for stag, st in (("st", static), ("nost", None)):
+            key = f"{tag}_{ftag}_{stag}"
+            m = qd.GeneratorModel(static_operator=st, operators=ops, signals=sigs, rotating_frame=fr)
+            for i, t in enumerate(times):
+                assert_close(m.signals(t), g[key + "_coeffs"][i], 1e-15)
+                assert_close(m.evaluate(t), g[key + "_eval"][i], EVAL_TOL)
+                assert_close(m(t), g[key + "_eval"][i], EVAL_TOL)
+                assert_close(m.evaluate_rhs(t, y1), g[key + "_rhs1"][i], EVAL_TOL)
+                assert_close(m(t, ym), g[key + "_rhsm"][i], EVAL_TOL)
+            if ftag == "diag":
+                m.in_frame_basis = True
+                for i, t in enumerate(times):
+                    assert_close(m.evaluate(t), g[key + "_eval_fb"][i], EVAL_TOL)
+                    assert_close(m.evaluate_rhs(t, y1), g[key + "_rhs1_fb"][i], EVAL_TOL)
+    hm = qd.HamiltonianModel(static_operator=g[f"{tag}_hstatic"], operators=g[f"{tag}_hops"],
+                             signals=sigs, rotating_frame=g[f"{tag}_hframe"])
+    for i, t in enumerate(times):
+        assert_close(hm.evaluate(t), g[f"{tag}_ham_eval"][i], EVAL_TOL)
+        assert_close(hm.evaluate_rhs(t, y1), g[f"{tag}_ham_rhs1"][i], EVAL_TOL)
+        assert_close(hm.evaluate_rhs(t, ym), g[f"{tag}_ham_rhsm"][i], EVAL_TOL)
+    assert_close(hm.static_operator, g[f"{tag}_ham_static_getter"], 1e-12)
+    assert_close(hm.operators, g[f"{tag}_ham_ops_getter"], 1e-12)
+    hm2 = qd.HamiltonianModel(static_operator=g[f"{tag}_hstatic"], operators=g[f"{tag}_hops"],
+                              signals=sigs, rotating_frame=g[f"{tag}_hstatic"])
+    for i, t in enumerate(times):
+        assert_close(hm2.evaluate(t), g[f"{tag}_ham_selfframe_eval"][i], EVAL_TOL)
+        assert_close(hm2.evaluate_rhs(t, y1), g[f"{tag}_ham_selfframe_rhs1"][i], EVAL_TOL)
+
+
+def test_generator_kat(qd, golden):
+    g = golden("generator_model")
+    m = qd.GeneratorModel(operators=g["kat_ops"],
+                          signals=[qd.Signal(1.0, f) for f in g["kat_carrier"]])
+    assert_close(m.evaluate(2.0), g["kat_eval_t2"], 1e-15)
+    assert_close(m.evaluate_rhs(2.0, np.array([0.2, 0.5])), g["kat_rhs_t2"], 1e-15)
+
+
+def test_model_errors(qd):
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    with pytest.raises(qd.DynamicsError):
+        qd.GeneratorModel()
+    with pytest.raises(qd.DynamicsError):
+        qd.HamiltonianModel(operators=[x + 1j * np.triu(np.ones((2, 2)), 1)])
+    m = qd.HamiltonianModel(operators=[x])
+    with pytest.raises(qd.DynamicsError):
+        m.evaluate(0.1)  # no signals
+    with pytest.raises(qd.DynamicsError):
+        m.signals = [qd.Signal(1.0), qd.Signal(1.0)]
+    with pytest.raises(qd.DynamicsError):
+        qd.GeneratorModel(operators=[x], array_library="jax")
+    with pytest.raises(qd.DynamicsError):
+        qd.RotatingFrame(np.array([[0, 1], [0, 0]], dtype=complex))
+
+
+# ------------------------------------------------------------------------------------------------
+# a9-a11 fixed-step solvers on a time-dependent 5x5 generator
+# ------------------------------------------------------------------------------------------------
+CASES = {"fw": ([0.0, 1.0], None, 0.1), "te": ([0.0, 1.0], [0.0, 0.33, 0.71, 1.0], 0.05),
+         "bw": ([1.0, 0.0], [0.8, 0.2], 0.1)}
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_fixed_step_golden(qd, golden, tag):
+    g = golden("fixed_step")
+    ts, te, mdt = CASES[tag]
+    m = qd.GeneratorModel(static_operator=g["g0"], operators=[g["g1"]],
+                          signals=[qd.Signal(lambda t: np.cos(1.3 * t) + 0j)])
+    r = qd.solve_lmde(m, ts, g["y0"], method="RK4", max_dt=mdt, t_eval=te)
+    assert_close(r.t, g[f"rk4_{tag}_t"], 0)
+    assert_close(r.y, g[f"rk4_{tag}_y"], SOLVE_TOL)
+    r = qd.solve_lmde(m, ts, np.eye(5, dtype=complex), method="hip_RK4", max_dt=mdt, t_eval=te)
+    assert_close(r.y, g[f"rk4m_{tag}_y"], SOLVE_TOL)
+    for mo in (1, 2, 3):
+        r = qd.solve_lmde(m, ts, g["y0"], method="scipy_expm", max_dt=mdt, t_eval=te, magnus_order=mo)
+        assert_close(r.t, g[f"expm{mo}_{tag}_t"], 0)
+        assert_close(r.y, g[f"expm{mo}_{tag}_y"], SOLVE_TOL)
+        r = qd.solve_lmde(m, ts, np.eye(5, dtype=complex), method="hip_expm", max_dt=mdt, t_eval=te,
+                          magnus_order=mo)
+        assert_close(r.y, g[f"expm{mo}m_{tag}_y"], SOLVE_TOL)
+
+
+def test_solver_error_surface(qd):
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    m = qd.HamiltonianModel(operators=[x], signals=[qd.Signal(1.0)])
+    y0 = np.array([1.0, 0.0], dtype=complex)
+    with pytest.raises(qd.DynamicsError):
+        qd.solve_lmde(m, [0, 1], y0, method="DOP853", max_dt=0.1)
+    with pytest.raises(qd.DynamicsError):
+        qd.solve_lmde(m, [0, 1], y0, method="scipy_expm", max_dt=0.1, magnus_order=4)
+    with pytest.raises(qd.DynamicsError):
+        qd.solve_lmde(lambda t: x, [0, 1], y0, method="RK4", max_dt=0.1)
+    lm = qd.LindbladModel(hamiltonian_operators=[x], hamiltonian_signals=[qd.Signal(1.0)],
+                          static_dissipators=[0.1 * x], vectorized=False)
+    with pytest.raises(qd.DynamicsError):
+        qd.solve_lmde(lm, [0, 1], np.eye(2, dtype=complex) / 2, method="scipy_expm", max_dt=0.1)
+    with pytest.raises(qd.DynamicsError):
+        qd.solve_lmde(m, [0, 1], np.ones(3, dtype=complex), method="RK4", max_dt=0.1)
+    with pytest.raises(ValueError):
+        qd.solve_lmde(m, [0, 1], y0, method="RK4", max_dt=0.1, t_eval=[0.5, 1.5])
+
+
+# ------------------------------------------------------------------------------------------------
+# a12 solve_lmde end to end
+# ------------------------------------------------------------------------------------------------
+def test_cfg1_golden(qd, golden):
+    """BASELINE.json configs[0] shape (2 qubits, 3 ops, RK4) -- in full, 1000 steps."""
+    from qiskit_dynamics_amd import workloads
+
+    g = golden("solve_lmde")
+    c1 = workloads.config1()
+    sigs = [qd.Signal(1.0, 5.0), qd.Signal(lambda t: np.exp(-((t - 5.0) ** 2) / 8.0), 5.0)]
+    hm = qd.HamiltonianModel(static_operator=c1["h_d"], operators=c1["ops"], signals=sigs,
+                             rotating_frame=c1["h_d"])
+    r = qd.solve_lmde(hm, c1["t_span"], c1["y0"], method="RK4", max_dt=c1["max_dt"],
+                      t_eval=[0.0, 2.5, 5.0, 7.5, 10.0])
+    assert_close(r.t, g["cfg1_t"], 0)
+    assert_close(r.y, g["cfg1_y"], SOLVE_TOL)
+    for mo in (1, 2):
+        r = qd.solve_lmde(hm, c1["t_span"], c1["y0"], method="scipy_expm", max_dt=0.05, magnus_order=mo)
+        assert_close(r.y, g[f"cfg1_expm{mo}_y"], SOLVE_TOL)
+
+
+def test_random_framed_model_golden(qd, golden):
+    g = golden("solve_lmde")
+    sigs = [qd.Signal(0.5, 1.0, 0.3), qd.DiscreteSignal(dt=0.1, samples=g["r7_samples"], carrier_freq=1.0),
+            qd.Signal(lambda t: 0.3 * np.cos(t) + 0 * 1j, 0.0)]
+    hm = qd.HamiltonianModel(static_operator=g["r7_hstatic"], operators=g["r7_hops"], signals=sigs,
+                             rotating_frame=g["r7_hframe"])
+    r = qd.solve_lmde(hm, [0.0, 0.5], g["r7_y0"], method="RK4", max_dt=1e-3, t_eval=[0.1, 0.3, 0.5])
+    assert_close(r.t, g["r7_rk4_t"], 0)
+    assert_close(r.y, g["r7_rk4_y"], SOLVE_TOL)
+    r = qd.solve_lmde(hm, [0.0, 0.5], np.eye(7, dtype=complex), method="RK4", max_dt=1e-3)
+    assert_close(r.y, g["r7_rk4_unitary"], SOLVE_TOL)
+    for mo in (1, 2, 3):
+        r = qd.solve_lmde(hm, [0.0, 0.5], g["r7_y0"], method="scipy_expm", max_dt=1e-2,
+                          magnus_order=mo, t_eval=[0.1, 0.3, 0.5])
+        assert_close(r.y, g[f"r7_expm{mo}_y"], SOLVE_TOL)
+    r = qd.solve_lmde(hm, [0.5, 0.0], g["r7_y0"], method="RK4", max_dt=1e-3)
+    assert_close(r.y, g["r7_rk4_backwards"], SOLVE_TOL)
+    assert hm.in_frame_basis is False  # solve does not leave the model mutated
+
+
+def _sweep_signals(qd, cfg, b, k, t_final):
+    from qiskit_dynamics_amd import workloads
+
+    amps, phases = workloads.sweep_parameters(b, k)
+    return [qd.Signal(lambda t, a=a: a * np.exp(-((t - t_final / 2) ** 2) / (2 * 1.0**2)), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+
+
+def test_cfg2_small_golden(qd, golden):
+    """Down-scaled cfg 2/3 (6 qubits, n=64, k=6): Solver sweep of 4 instances, one batched solve."""
+    from qiskit_dynamics_amd import workloads
+
+    g = golden("cfg2_small")
+    cfg = workloads.schrodinger_config(n_qubits=6, n_drives=6, t_final=1.0, max_dt=0.01)
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       rotating_frame=cfg["h_d"])
+    sig_lists = [_sweep_signals(qd, cfg, b, 6, 1.0) for b in range(4)]
+    assert_close(np.array([qd.SignalList(s)(g["sweep_tt"]) for s in sig_lists]), g["sweep_coeffs"], 0)
+    res = solver.solve(t_span=cfg["t_span"], y0=cfg["y0"], signals=sig_lists, method="RK4",
+                       max_dt=cfg["max_dt"])
+    assert isinstance(res, list) and len(res) == 4
+    assert_close(np.array([r.y[-1] for r in res]), g["sweep_y_final"], SOLVE_TOL)
+    # list result == individual solves (Solver list-mode contract)
+    one = solver.solve(t_span=cfg["t_span"], y0=cfg["y0"], signals=sig_lists[2], method="RK4",
+                       max_dt=cfg["max_dt"])
+    assert_close(one.y[-1], res[2].y[-1], 1e-12)
+    hm = qd.HamiltonianModel(static_operator=cfg["h_d"], operators=cfg["ops"], signals=sig_lists[0],
+                             rotating_frame=np.diag(cfg["h_d"]).real.copy())
+    for i, t in enumerate((0.0, 0.37, 1.0)):
+        assert_close(hm.evaluate_rhs(t, g["diag_yv"]), g["diag_rhs"][i], EVAL_TOL)
+    assert_close(hm.evaluate(0.37), g["diag_eval_t037"], EVAL_TOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# a13/a14 vectorised Lindblad
+# ------------------------------------------------------------------------------------------------
+def _lind_signals(qd):
+    hsig = [qd.Signal(0.7, 1.1, 0.2), qd.Signal(lambda t: 0.4 * np.sin(2 * t) + 0j, 0.6)]
+    dsig = [qd.Signal(0.3, 0.0), qd.Signal(lambda t: 0.2 + 0.1 * np.cos(t) + 0j, 0.0)]
+    return hsig, dsig
+
+
+@pytest.mark.parametrize("ftag", ["fr", "diag", "nofr"])
+def test_lindblad_golden(qd, golden, ftag):
+    g = golden("lindblad")
+    frame = {"fr": g["hframe"], "diag": np.diag(g["hframe"]).real.copy(), "nofr": None}[ftag]
+    hsig, dsig = _lind_signals(qd)
+    rho = g["rho"]
+    for vec in (True, False):
+        m = qd.LindbladModel(static_hamiltonian=g["hstatic"], hamiltonian_operators=g["hops"],
+                             hamiltonian_signals=hsig, static_dissipators=g["nstat"],
+                             dissipator_operators=g["lops"], dissipator_signals=dsig,
+                             rotating_frame=frame, vectorized=vec)
+        key = f"{ftag}_{'vec' if vec else 'mat'}"
+        yin = rho.flatten(order="F") if vec else rho
+        for i, t in enumerate(g["times"]):
+            assert_close(m.evaluate_rhs(t, yin), g[key + "_rhs"][i], EVAL_TOL)
+            if vec:
+                assert_close(m.evaluate(t), g[key + "_eval"][i], EVAL_TOL)
+        if vec:
+            r = qd.solve_lmde(m, [0.0, 0.6], yin, method="scipy_expm", max_dt=0.02, t_eval=[0.2, 0.6])
+            assert_close(r.y, g[key + "_expm_y"], SOLVE_TOL)
+            r = qd.solve_lmde(m, [0.0, 0.6], yin, method="RK4", max_dt=0.002)
+            assert_close(r.y, g[key + "_rk4_y"], SOLVE_TOL)
+        else:
+            with pytest.raises(NotImplementedError):
+                m.evaluate(0.1)
+            r = qd.solve_lmde(m, [0.0, 0.6], yin, method="RK4", max_dt=0.002)
+            assert_close(r.y[-1], g[f"{ftag}_vec_rk4_y"][-1].reshape(4, 4, order="F"), SOLVE_TOL)
+
+
+def test_lindblad_patterns_and_cfg4_small(qd, golden):
+    from qiskit_dynamics_amd import workloads
+
+    g = golden("lindblad")
+    hsig, dsig = _lind_signals(qd)
+    m = qd.LindbladModel(hamiltonian_operators=g["hops"], hamiltonian_signals=hsig,
+                         static_dissipators=g["nstat"], vectorized=True)
+    assert_close(m.evaluate(0.4), g["pat_hs_eval"], EVAL_TOL)
+    m = qd.LindbladModel(static_hamiltonian=g["hstatic"], dissipator_operators=g["lops"],
+                         dissipator_signals=dsig, vectorized=True, rotating_frame=g["hframe"])
+    assert_close(m.evaluate(0.4), g["pat_sd_fr_eval"], EVAL_TOL)
+    assert_close(m.evaluate_rhs(0.4, g["rho"].flatten(order="F")), g["pat_sd_fr_rhs"], EVAL_TOL)
+    cfg = workloads.lindblad_config(n_qubits=3, n_drives=3, n_diss=2, gamma=1e-2, t_final=1.0, max_dt=0.05)
+    amps, phases = workloads.sweep_parameters(0, 3)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    for ftag, frame in (("nofr", None), ("diag", np.diag(cfg["h_d"]).real.copy())):
+        s = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                      static_dissipators=cfg["static_dissipators"], rotating_frame=frame, vectorized=True)
+        r = s.solve(t_span=cfg["t_span"], y0=cfg["rho0"].flatten(order="F"), signals=sigs,
+                    method="scipy_expm", max_dt=cfg["max_dt"])
+        assert_close(r.y, g[f"cfg4s_{ftag}_y"], SOLVE_TOL)
+        rho_t = r.y[-1].reshape(8, 8, order="F")
+        assert abs(np.trace(rho_t) - 1.0) < 1e-10  # trace preservation
+
+
+# ------------------------------------------------------------------------------------------------
+# a15 Solver list mode
+# ------------------------------------------------------------------------------------------------
+def test_solver_list_golden(qd, golden):
+    g = golden("solver_list")
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    s = qd.Solver(hamiltonian_operators=[x], static_hamiltonian=5 * z, rotating_frame=5 * z)
+    y0 = np.array([0.0, 1.0], dtype=complex)
+    res = s.solve(t_span=[0.0, 0.4232], y0=y0, signals=[[qd.Signal(1.0, 5.0)], [qd.Signal(0.5, 5.0)]],
+                  method="RK4", max_dt=0.001)
+    assert_close(np.array([r.y for r in res]), g["ham_list_y"], SOLVE_TOL)
+    res = s.solve(t_span=[[0.0, 0.4232], [0.0, 1.23]], y0=y0, signals=[qd.Signal(1.0, 5.0)],
+                  method="RK4", max_dt=0.001)
+    assert_close(np.array([r.y[-1] for r in res]), g["ham_tspan_list_y_final"], SOLVE_TOL)
+    res = s.solve(t_span=[0.0, 0.4232], y0=[y0, np.array([1.0, 0.0], dtype=complex)],
+                  signals=[qd.Signal(1.0, 5.0)], method="scipy_expm", max_dt=0.01)
+    assert_close(np.array([r.y for r in res]), g["ham_y0_list_expm_y"], SOLVE_TOL)
+    sl = qd.Solver(hamiltonian_operators=[x], static_hamiltonian=5 * z, rotating_frame=5 * z,
+                   static_dissipators=[0.01 * x], vectorized=True)
+    rho0 = np.array([[0.0, 0.0], [0.0, 1.0]], dtype=complex)
+    res = sl.solve(t_span=[0.0, 0.4232], y0=rho0.flatten(order="F"),
+                   signals=[[qd.Signal(1.0, 5.0)], [qd.Signal(0.5, 5.0)]], method="scipy_expm", max_dt=0.01)
+    assert_close(np.array([r.y for r in res]), g["lind_list_y"], SOLVE_TOL)
+    single = s.solve(t_span=[0.0, 0.4232], y0=y0, signals=[qd.Signal(1.0, 5.0)], method="RK4", max_dt=0.001)
+    assert not isinstance(single, list)
+    with pytest.raises(qd.DynamicsError):
+        s.solve(t_span=[[0, 1], [0, 1], [0, 1]], y0=[y0, y0], signals=[qd.Signal(1.0, 5.0)],
+                method="RK4", max_dt=0.1)
+
+
+# ------------------------------------------------------------------------------------------------
+# a11 expm against scipy (the dependency the reference calls) + invariants
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,scale", [(3, 1e-3), (8, 0.1), (16, 0.7), (40, 1.9), (64, 6.0), (100, 60.0),
+                                     (256, 3.0)])
+def test_expm_vs_scipy(qd, n, scale):
+    rng = np.random.default_rng(n)
+    a = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    a = (a - a.conj().T)
+    a *= scale / np.linalg.norm(a, 1)
+    e, info = qd.default_context().expm(a, return_info=True)
+    ref = scipy.linalg.expm(a)
+    assert np.linalg.norm(e - ref, 1) / np.linalg.norm(ref, 1) < 1e-12
+    assert np.linalg.norm(e.conj().T @ e - np.eye(n)) < 1e-12 * n
+    einv = qd.default_context().expm(-a)
+    assert np.linalg.norm(e @ einv - np.eye(n)) < 1e-12 * n
+
+
+def test_expm_general_and_batch(qd):
+    rng = np.random.default_rng(5)
+    a = rng.normal(size=(3, 20, 20)) * 0.3 + 1j * rng.normal(size=(3, 20, 20)) * 0.1
+    e = qd.default_context().expm(a)
+    for i in range(3):
+        ref = scipy.linalg.expm(a[i])
+        assert np.linalg.norm(e[i] - ref, 1) / np.linalg.norm(ref, 1) < 1e-12
+    z = np.zeros((4, 4), dtype=complex)
+    assert_close(qd.default_context().expm(z), np.eye(4), 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json sizes: cfg 2 (n=1024, k=8) against the oracle, cfg 3 through invariants
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cfg2(qd):
+    from qiskit_dynamics_amd import workloads
+    from oracle import dynamics_oracle as orc
+
+    cfg = workloads.schrodinger_config()  # 10 qubits, n=1024, k=8
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], cfg["h_d"])
+    stack = qd.Stack(qd.default_context(), a, a_d, np.ascontiguousarray(d.imag))
+    return cfg, (a_d, a, d, basis), stack
+
+
+def test_cfg2_full_size_rhs_and_generator(qd, cfg2):
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+
+    cfg, (a_d, a, d, basis), stack = cfg2
+    rng = np.random.default_rng(1024)
+    y = crand(rng, 1024)
+    amps, phases = workloads.sweep_parameters(0, 8)
+    for t in (0.0, 1.234, 5.0):
+        c = workloads.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], 5.0)[0]
+        assert_close(stack.eval_rhs(c, t, y), orc.generator_rhs(a_d, a, c, d, None, t, y), EVAL_TOL)
+    c = workloads.gaussian_coefficient_table(np.array([2.5]), amps, phases, cfg["carrier"], 5.0)[0]
+    assert_close(stack.eval_generator(c, 2.5), orc.generator_evaluate(a_d, a, c, d, None, 2.5), EVAL_TOL)
+    ym = crand(rng, 1024, 96)
+    assert_close(stack.eval_rhs(c, 2.5, ym), orc.generator_rhs(a_d, a, c, d, None, 2.5, ym), EVAL_TOL)
+
+
+def _table_for(cfg, instances, times, k=8):
+    from qiskit_dynamics_amd import workloads
+
+    amps = np.array([workloads.sweep_parameters(b, k)[0] for b in instances])
+    phs = np.array([workloads.sweep_parameters(b, k)[1] for b in instances])
+    return workloads.gaussian_coefficient_table(times, amps, phs, cfg["carrier"], cfg["t_final"]), amps, phs
+
+
+def test_cfg2_single_trajectory_rk4_vs_oracle(qd, cfg2):
+    """cfg 2: one trajectory, streaming kernel, 40 RK4 steps against the oracle."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    cfg, (a_d, a, d, basis), stack = cfg2
+    t_span = [2.4, 2.6]
+    sched = FixedStepSchedule(t_span, None, cfg["max_dt"], _rk4_points)
+    table, amps, phs = _table_for(cfg, [0], sched.times)
+    y0 = np.zeros((1024, 1), dtype=complex)
+    y0[3, 0] = 1.0
+    ys = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                         sched.n_save, y0, 1, True)
+
+    def rhs(t, y):
+        c = workloads.gaussian_coefficient_table(np.array([t]), amps[0], phs[0], cfg["carrier"], 5.0)[0]
+        return orc.generator_rhs(a_d, a, c, d, None, t, y)
+
+    _, yref = orc.rk4_solve(rhs, t_span, y0[:, 0], cfg["max_dt"])
+    assert_close(ys[0, -1, :, 0], yref[-1], SOLVE_TOL)
+
+
+def test_cfg3_batched_sweep_vs_oracle_and_invariants(qd, cfg2):
+    """cfg 3 shape: 256 instances (2 x 128-column MFMA tiles on the full 9216-deep K loop),
+    20 RK4 steps; three instances checked against the oracle, all of them for norm conservation,
+    and the batched result must equal the single-trajectory (streaming-kernel) result."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    cfg, (a_d, a, d, basis), stack = cfg2
+    B = 256
+    t_span = [2.45, 2.55]
+    sched = FixedStepSchedule(t_span, None, cfg["max_dt"], _rk4_points)
+    table, amps, phs = _table_for(cfg, range(B), sched.times)
+    y0 = np.zeros((1024, 1), dtype=complex)
+    y0[0, 0] = 1.0
+    ys = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                         sched.n_save, y0, B, True)
+    final = ys[:, -1, :, 0]
+    norms = np.linalg.norm(final, axis=1)
+    assert np.max(np.abs(norms - 1.0)) < 1e-9  # RK4 on anti-Hermitian generator, tiny steps
+    for b in (0, 101, 255):
+        def rhs(t, y, b=b):
+            c = workloads.gaussian_coefficient_table(np.array([t]), amps[b], phs[b], cfg["carrier"], 5.0)[0]
+            return orc.generator_rhs(a_d, a, c, d, None, t, y)
+
+        _, yref = orc.rk4_solve(rhs, t_span, y0[:, 0], cfg["max_dt"])
+        assert_close(final[b], yref[-1], SOLVE_TOL)
+    one = stack.rk4_solve(sched.times, table[7:8], sched.step_rows, sched.step_h, sched.step_save,
+                          sched.n_save, y0, 1, True)
+    assert_close(one[0, -1, :, 0], final[7], 1e-12)
+    # linearity in y0: solve(a*y0) == a*solve(y0)
+    ys2 = stack.rk4_solve(sched.times, table[:64], sched.step_rows, sched.step_h, sched.step_save,
+                          sched.n_save, (0.3 - 0.4j) * y0, 64, True)
+    assert_close(ys2[:, -1, :, 0], (0.3 - 0.4j) * final[:64], 1e-12)
+
+
+def test_rk4_plan_matches_solve(qd, cfg2):
+    """The bench hook (device-resident plan, chunked runs) gives the same states as rk4_solve."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    cfg, _, stack = cfg2
+    B = 128
+    sched = FixedStepSchedule([0.0, 0.05], None, cfg["max_dt"], _rk4_points)
+    table, _, _ = _table_for(cfg, range(B), sched.times)
+    y0 = np.zeros((1024, 1), dtype=complex)
+    y0[0, 0] = 1.0
+    ref = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                          sched.n_save, y0, B, True)[:, -1]
+    plan = qd.Rk4Plan(stack, sched.times, table, sched.step_rows, sched.step_h, y0, B, True)
+    plan.run(0, 4)
+    plan.run(4, plan.nsteps)
+    stack.ctx.synchronize()
+    assert_close(plan.fetch(), ref, 1e-13)
+    plan.close()

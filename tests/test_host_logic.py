@@ -1,0 +1,197 @@
+"""CPU-only tests of the host side of the product package: signals -> coefficient tables, the
+fixed-step schedule (step-count rule, table rows, save slots), rotating-frame bookkeeping, list-mode
+argument handling, and that the C-ABI library loads and exports every symbol of include/midyn.h.
+No GPU compute is invoked here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_close
+
+import qiskit_dynamics_amd as qd
+from qiskit_dynamics_amd import _lib, solvers, workloads
+from qiskit_dynamics_amd.distributed import shard_bounds
+
+
+def test_signals_match_reference_golden(golden):
+    g = golden("signals")
+    t = g["t"]
+    s_const = qd.Signal(0.37, carrier_freq=1.3, phase=0.4)
+    assert_close(s_const(t), g["const"], 0)
+    amp, t0, sig, nu, phi = g["gauss_params"]
+    s_gauss = qd.Signal(lambda tt: amp * np.exp(-((tt - t0) ** 2) / (2 * sig**2)), nu, phi)
+    assert_close(s_gauss(t), g["gauss"], 0)
+    dt, st, cf, ph = g["disc_params"]
+    d = qd.DiscreteSignal(dt=dt, samples=g["disc_samples"], start_time=st, carrier_freq=cf, phase=ph)
+    assert_close(d.envelope(t), g["disc_env"], 0)
+    assert_close(d(t), g["disc"], 0)
+    assert_close(d(g["disc_edges_t"]), g["disc_edges"], 0)
+    ssum = s_const + s_gauss
+    assert_close(ssum(t), g["sum"], 0)
+    sl = qd.SignalList([s_const, s_gauss, d, ssum, 1.5])
+    assert_close(sl(t), g["list"], 0)          # bit-identical table
+    assert_close(sl(0.613), g["list_scalar_t"], 0)
+    assert_close(sl.table(t), g["list"], 0)
+    assert sl.table(t).dtype == np.float64 and sl.table(t).flags.c_contiguous
+    assert len(sl) == 5 and s_const.is_constant is False and qd.Signal(2.0).is_constant
+    assert_close(qd.SignalList([qd.Signal(2.0), s_gauss]).drift, np.array([2.0, 0.0]), 0)
+    with pytest.raises(qd.DynamicsError):
+        qd.SignalList(["not a signal"])
+
+
+def test_fixed_step_sizes_golden(golden):
+    g = golden("fixed_step")
+    for i in range(int(g["n_sizes"])):
+        te = g[f"sizes{i}_teval"] if bool(g[f"sizes{i}_has_teval"]) else None
+        t, h, n = solvers.get_fixed_step_sizes(g[f"sizes{i}_tspan"], te, float(g[f"sizes{i}_maxdt"]))
+        assert_close(t, g[f"sizes{i}_t"], 0)
+        assert_close(h, g[f"sizes{i}_h"], 0)
+        assert np.array_equal(n, g[f"sizes{i}_n"])
+
+
+def test_schedule_rows_follow_reference_time_arithmetic():
+    sched = solvers.FixedStepSchedule([0.0, 1.0], [0.25, 0.9], 0.1, solvers._rk4_points)
+    # replay the template loop (fixed_step_solvers.py:448-454) and check every table row
+    t_list, h_list, n_list = solvers.get_fixed_step_sizes([0.0, 1.0], [0.25, 0.9], 0.1)
+    s = 0
+    for i, (t0, h, n) in enumerate(zip(t_list[:-1], h_list, n_list)):
+        t = t0
+        for j in range(int(n)):
+            r = sched.step_rows[s]
+            assert sched.times[r[0]] == t and sched.times[r[1]] == t + 0.5 * h and sched.times[r[2]] == t + h
+            assert sched.step_h[s] == h
+            assert sched.step_save[s] == (i + 1 if j == n - 1 else -1)
+            t = t + h
+            s += 1
+    assert s == len(sched.step_h) == int(np.sum(n_list))
+    assert sched.n_save == len(t_list)
+    assert len(set(sched.times.tolist())) == len(sched.times)  # rows are distinct times
+    # consecutive steps inside an interval share the boundary row (t+h of step s == t of step s+1)
+    assert sched.step_rows[0][2] == sched.step_rows[1][0]
+    t_out, y_out = sched.trim(np.arange(sched.n_save))
+    assert_close(t_out, np.array([0.25, 0.9]), 0) and list(y_out) == [1, 2]
+    # backwards, zero-length interval, Magnus points
+    sb = solvers.FixedStepSchedule([1.0, 0.0], None, 0.3, solvers._magnus_points(2))
+    assert np.all(sb.step_h < 0) and sb.step_rows.shape == (4, 3)
+    c1 = 0.5 - np.sqrt(3) / 6
+    assert sb.times[sb.step_rows[0][0]] == 1.0 + c1 * sb.step_h[0]
+    s3 = solvers.FixedStepSchedule([0.0, 0.2], None, 0.1, solvers._magnus_points(3))
+    assert s3.times[s3.step_rows[1][1]] == (0.0 + s3.step_h[0]) + 0.5 * s3.step_h[1]
+    with pytest.raises(qd.DynamicsError):
+        solvers._magnus_points(4)
+    with pytest.raises(ValueError):
+        solvers.FixedStepSchedule([0.0, 1.0], [1.5], 0.1, solvers._rk4_points)
+    with pytest.raises(ValueError):
+        solvers.FixedStepSchedule([0.0, 1.0], [0.5, 0.2], 0.1, solvers._rk4_points)
+
+
+def test_rotating_frame_host():
+    rng = np.random.default_rng(34233)
+    n = 5
+    a = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    h = a + a.conj().T
+    rf = qd.RotatingFrame(h)
+    u, d = rf.frame_basis, rf.frame_diag
+    assert_close(u @ np.diag(d) @ u.conj().T, -1j * h, 1e-12)   # F = -iH = U diag(d) U^+
+    assert np.allclose(d.real, 0)
+    rf2 = qd.RotatingFrame(-1j * h)                                # anti-Hermitian input kept
+    assert_close(rf2.frame_diag, d, 1e-12)
+    op = rng.normal(size=(n, n)) + 0j
+    assert_close(rf.operator_out_of_frame_basis(rf.operator_into_frame_basis(op)), op, 1e-12)
+    y = rng.normal(size=n) + 0j
+    assert_close(rf.state_out_of_frame(0.7, rf.state_into_frame(0.7, y)), y, 1e-12)
+    import scipy.linalg as sla
+    f = -1j * h
+    assert_close(rf.state_into_frame(0.7, y), sla.expm(-0.7 * f) @ y, 1e-12)
+    assert_close(rf.operator_into_frame(0.3, op), sla.expm(-0.3 * f) @ op @ sla.expm(0.3 * f), 1e-11)
+    assert_close(rf.generator_into_frame(0.3, op), sla.expm(-0.3 * f) @ op @ sla.expm(0.3 * f) - f, 1e-11)
+    rd = qd.RotatingFrame(np.array([1.0, 2.0, -0.5]))             # 1-D Hermitian diagonal
+    assert rd.frame_basis is None
+    assert_close(rd.frame_diag, -1j * np.array([1.0, 2.0, -0.5]), 0)
+    dv = rd.vectorized_frame_diag_imag()
+    dd = rd.frame_diag.imag
+    for r in range(3):
+        for c in range(3):
+            assert dv[r + 3 * c] == dd[r] - dd[c]
+    assert qd.RotatingFrame(None).frame_diag is None
+    assert_close(rf.vectorized_frame_basis, np.kron(u.conj(), u), 0)
+    with pytest.raises(qd.DynamicsError):
+        qd.RotatingFrame(a)
+
+
+def test_list_mode_argument_handling():
+    sig = qd.Signal(1.0, 5.0)
+    (ts, ys, ss), multi = solvers._setup_args_lists([0, 1], np.zeros(2), [sig])
+    assert not multi and len(ts) == len(ys) == len(ss) == 1
+    (ts, ys, ss), multi = solvers._setup_args_lists([0, 1], np.zeros(2), [[sig], [sig], [sig]])
+    assert multi and len(ts) == len(ys) == len(ss) == 3 and ys[0] is ys[2]
+    (ts, ys, ss), multi = solvers._setup_args_lists([[0, 1], [0, 2]], [np.zeros(2), np.ones(2)], None)
+    assert multi and ss == [None, None]
+    (ts, ys, ss), multi = solvers._setup_args_lists([0, 1], np.zeros(2), ([sig], None))
+    assert not multi and isinstance(ss[0], tuple)
+    (ts, ys, ss), multi = solvers._setup_args_lists([0, 1], np.zeros(2), [([sig], None), ([sig], None)])
+    assert multi and len(ss) == 2
+    with pytest.raises(qd.DynamicsError):
+        solvers._setup_args_lists([[0, 1], [0, 2], [0, 3]], [np.zeros(2), np.ones(2)], None)
+    with pytest.raises(qd.DynamicsError):
+        solvers._setup_args_lists([[[0, 1]]], np.zeros(2), None)
+
+
+def test_workload_tables_are_bit_identical_to_signal_objects():
+    cfg = workloads.schrodinger_config(n_qubits=3, n_drives=3, t_final=5.0)
+    times = np.linspace(0, 5, 23)
+    amps, phases = workloads.sweep_parameters(17, 3)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / (2 * 1.0**2)), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    tab = workloads.gaussian_coefficient_table(times, amps, phases, cfg["carrier"], 5.0)
+    assert_close(tab, qd.SignalList(sigs).table(times), 0)
+    both = workloads.gaussian_coefficient_table(times, np.stack([amps, amps]), np.stack([phases, phases]),
+                                                cfg["carrier"], 5.0)
+    assert both.shape == (2, 23, 3) and np.array_equal(both[0], tab)
+    h_d, ops, nu = workloads.chain_hamiltonian(3, 2)
+    assert np.allclose(h_d, h_d.conj().T) and ops.shape == (2, 8, 8)
+
+
+def test_shard_bounds():
+    for n, w in ((4096, 8), (10, 3), (5, 8), (0, 2), (1024, 1)):
+        cover = []
+        for r in range(w):
+            lo, hi = shard_bounds(n, r, w)
+            assert 0 <= lo <= hi <= n
+            cover += list(range(lo, hi))
+        assert cover == list(range(n))
+        sizes = [shard_bounds(n, r, w)[1] - shard_bounds(n, r, w)[0] for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def test_abi_library_loads_and_exports_every_header_symbol():
+    header = open(os.path.join(ROOT, "include", "midyn.h")).read()
+    declared = sorted(set(re.findall(r"\b(midyn_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations parsed from include/midyn.h"
+    assert sorted(_lib.ABI_SYMBOLS) == declared, "python binding and header disagree"
+    assert os.path.exists(_lib.LIB_PATH), "libmidyn.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported by libmidyn.so"
+    assert _lib.load() is not None
+    nbytes = _lib.Stack.packed_bytes(1024, 8, 1)   # pure host arithmetic, no device needed
+    assert nbytes >= 9 * 1024 * 1024 * 16
+    assert _lib.Stack.packed_bytes(4, 2, 0) >= 2 * 64 * 64 * 16  # n padded to 64
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device the product must fail loudly, not compute on the CPU."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(qd.HipLibraryError):
+        _lib.Context(0)
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    with pytest.raises(qd.HipLibraryError):
+        qd.HamiltonianModel(operators=[x], signals=[qd.Signal(1.0)])
