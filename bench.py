@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py -- RHS evals/s of the 10-qubit (dim 1024) Schrodinger sweep on N MI355X.
+
+Workload (BASELINE.json metric / configs[2], SURVEY.md 8(d) cfg 3): chain Hamiltonian, n = 1024,
+k = 8 drive operators + static operator, rotating frame = H_d (dense frame-basis operators), RK4 with
+max_dt = 0.005 on t in [0, 5] (1000 steps, 4 RHS evaluations each), 4096 signal instances per GPU
+(weak scaling: every rank integrates its own 4096-instance shard; the only collective is one RCCL
+broadcast of the packed operator stack at setup).  A "step" is one RK4 step of the whole per-GPU
+batch = 4 batched RHS evaluations = 4 * 4096 instance-evaluations.
+
+Timed region: inputs (operator stack, coefficient table, states) are resident in HBM; K steps are
+enqueued on the library's HIP stream and bracketed by barrier + device synchronisation; the max over
+ranks is taken.  One JSON line is printed by rank 0.
+
+Extra objects on the same line: `roofline` (dominant kernel = the fp64-MFMA batched RHS contraction;
+average launch duration measured with HIP events on the stream the kernel runs on),
+`roofline_single_trajectory` (cfg 2: the HBM-bound streaming kernel, measured the same way) and
+`cpu_baseline` (the NumPy oracle on the host cores, rank 0, N=1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_QUBITS = 10
+N_DRIVES = 8
+T_FINAL = 5.0
+MAX_DT = 0.005
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor FP64 matrix peak (SURVEY.md 8(d) / BASELINE.md 3)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def build_frame_basis_stack(cfg):
+    """Host model build (a3/a4): -iH, eigh of the frame, U^dagger . U.  Uses the product classes'
+    own code path (RotatingFrame) so the stack is exactly what HamiltonianModel uploads."""
+    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
+
+    frame = RotatingFrame(cfg["h_d"])
+    static = frame.operator_into_frame_basis(-1j * cfg["h_d"]) - np.diag(frame.frame_diag)
+    ops = frame.operator_into_frame_basis(-1j * cfg["ops"])
+    return ops, static, frame.frame_diag_imag
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=4096, help="sweep instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the cfg-2 single-trajectory leg")
+    ap.add_argument("--dense", action="store_true",
+                    help="disable exact-zero plane skipping (time the general dense-complex path)")
+    args = ap.parse_args()
+
+    import qiskit_dynamics_amd as qd
+    from qiskit_dynamics_amd import workloads
+    from qiskit_dynamics_amd.distributed import broadcast_stack, init_process_group_from_env
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        init_process_group_from_env(backend="nccl")
+    ctx = qd.default_context(local_rank)
+    if args.dense:
+        ctx.set_option("skip_zero_planes", 0)
+
+    cfg = workloads.schrodinger_config(N_QUBITS, N_DRIVES, T_FINAL, MAX_DT)
+    n = 2**N_QUBITS
+    k = N_DRIVES
+    t_setup = time.time()
+    if world > 1:
+        ops = static = frame_im = None
+        if rank == 0:
+            ops, static, frame_im = build_frame_basis_stack(cfg)
+        stack, _keep = broadcast_stack(ctx, ops, static, frame_im, n, k, src=0)
+    else:
+        ops, static, frame_im = build_frame_basis_stack(cfg)
+        stack = qd.Stack(ctx, ops, static, frame_im)
+    setup_s = time.time() - t_setup
+
+    # schedule of the real 1000-step solve; the bench runs its first (warmup + steps) steps
+    sched = FixedStepSchedule(cfg["t_span"], None, MAX_DT, _rk4_points)
+    total = args.warmup + args.steps
+    if total > len(sched.step_h):
+        raise SystemExit(f"warmup+steps must be <= {len(sched.step_h)}")
+    rows = sched.step_rows[:total]
+    n_rows = int(rows.max()) + 1
+    times = sched.times[:n_rows]
+    b_loc = args.batch
+    inst0 = rank * b_loc
+    amps = np.empty((b_loc, k))
+    phs = np.empty((b_loc, k))
+    for b in range(b_loc):
+        amps[b], phs[b] = workloads.sweep_parameters(inst0 + b, k)
+    table = workloads.gaussian_coefficient_table(times, amps, phs, cfg["carrier"], T_FINAL)
+    y0 = cfg["y0"].reshape(-1, 1)
+    plan = qd.Rk4Plan(stack, times, table, rows, sched.step_h[:total], y0, b_loc, True)
+
+    def sync_all():
+        ctx.synchronize()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    plan.run(0, args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    plan.run(args.warmup, total)
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        torch.cuda.synchronize()
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final = plan.fetch()[:, :, 0]
+    norm_dev = float(np.max(np.abs(np.linalg.norm(final, axis=1) - 1.0)))
+
+    evals = world * b_loc * 4 * args.steps
+    value = evals / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel: HIP-event timing of every launch on the ctx stream ----
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    prof_steps = min(args.steps, 10)
+    plan.run(total - prof_steps, total)   # re-runs the last steps (state is re-phased automatically)
+    ctx.synchronize()
+    cnt = ctx.counters("rhs_gemm")
+    ctx.set_option("profile", 0)
+    roofline = None
+    if cnt["launches"] > 0:
+        avg_ms = cnt["ms"] / cnt["launches"]
+        flops_per_launch = (4 * k + 10) * n * n * b_loc          # useful flops, SURVEY 8(d) cfg 3
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        n_act = stack.n_active_segments
+        roofline = {
+            "kernel": "zgemm_seg_kernel (batched RHS, fp64 MFMA 16x16x4)", "bound": "mfma",
+            "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "avg_launch_ms": round(avg_ms, 4), "launches_timed": int(cnt["launches"]),
+            "algorithmic_flops_per_launch": flops_per_launch,
+            "executed_mfma_flops_per_launch": None,
+            "active_segments": n_act, "zero_plane_skipping": not args.dense,
+        }
+    plan.close()
+
+    out = {
+        "metric": "RHS evals/sec, 10-qubit Schrodinger (dim 1024), 4096-param batch", "value": round(value, 1),
+        "unit": "RHS evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
+        "config": {"workload": "cfg3: 10-qubit chain, n=1024, k=8 drives + static, rotating frame H_d, "
+                               "RK4 max_dt=0.005, sweep of %d instances per GPU" % b_loc,
+                   "instances_per_gpu": b_loc, "global_instances": b_loc * world,
+                   "rhs_evals_per_step": 4 * b_loc * world, "parallelism": f"sweep-shard x{world}"},
+        "solve_wall_clock_s": round(ms_per_step * len(sched.step_h) / 1e3, 3),
+        "solve_wall_clock_note": "1000 RK4 steps = 1000 x ms_per_step (fixed step, identical work per step)",
+        "setup_s": round(setup_s, 2), "max_norm_deviation": norm_dev,
+    }
+    if roofline:
+        out["roofline"] = roofline
+
+    # ---- cfg 2: single trajectory, HBM-bound streaming kernel (rank 0 only) ---------------------
+    if rank == 0 and not args.no_single:
+        s_total = 64
+        rows1 = sched.step_rows[:s_total]
+        nr1 = int(rows1.max()) + 1
+        table1 = workloads.gaussian_coefficient_table(sched.times[:nr1], amps[:1], phs[:1], cfg["carrier"], T_FINAL)
+        p1 = qd.Rk4Plan(stack, sched.times[:nr1], table1, rows1, sched.step_h[:s_total], y0, 1, True)
+        p1.run(0, 8)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        p1.run(8, s_total)
+        ctx.synchronize()
+        el1 = time.perf_counter() - t0
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        p1.run(8, s_total)
+        ctx.synchronize()
+        c1 = ctx.counters("rhs_stream")
+        ctx.set_option("profile", 0)
+        p1.close()
+        nseg = stack.n_segments
+        bytes_per_launch = 16 * nseg * n * n + 32 * n                 # SURVEY 8(d) cfg 2: 151.03 MB
+        avg_ms1 = c1["ms"] / max(c1["launches"], 1)
+        gbs = bytes_per_launch / (avg_ms1 * 1e-3) / 1e9
+        out["single_trajectory"] = {
+            "workload": "cfg2: same model, 1 trajectory, RK4", "rhs_evals_per_s": round(4 * (s_total - 8) / el1, 1),
+            "ms_per_step": round(el1 / (s_total - 8) * 1e3, 4)}
+        out["roofline_single_trajectory"] = {
+            "kernel": "rhs_stream_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_ms": round(avg_ms1, 5), "launches_timed": int(c1["launches"]),
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "note": "stack (151 MB) fits the 256 MB Infinity Cache: effective rate may exceed HBM"}
+
+    # ---- CPU baseline: the NumPy oracle on this host, bounded sample (rank 0, N=1 only) ---------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import dynamics_oracle as orc
+
+        a_d, a = static, ops
+        d = 1j * frame_im
+        n_inst, n_steps = 2, 40
+        t0c = time.perf_counter()
+        for b in range(n_inst):
+            def rhs(t, y, b=b):
+                c = workloads.gaussian_coefficient_table(np.array([t]), amps[b], phs[b], cfg["carrier"], T_FINAL)[0]
+                return orc.generator_rhs(a_d, a, c, d, None, t, y)
+
+            orc.rk4_solve(rhs, [0.0, n_steps * MAX_DT], cfg["y0"], MAX_DT)
+        cpu_s = time.perf_counter() - t0c
+        out["cpu_baseline"] = {
+            "value": round(n_inst * n_steps * 4 / cpu_s, 1), "unit": "RHS evals/s", "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"{n_inst} instances x {n_steps} RK4 steps ({n_inst * n_steps * 4} RHS evals) of the same "
+                      f"model, NumPy oracle (tensordot + matvec, BLAS threads = all {os.cpu_count()} cores), "
+                      f"{cpu_s:.1f} s"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

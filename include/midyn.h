@@ -64,6 +64,10 @@ int midyn_stack_adopt(midyn_ctx* ctx, int n, int k, int has_static, int has_fram
 int midyn_stack_destroy(midyn_stack* stack);
 /* info[0..7] = n, n_pad, k, has_static, has_frame, n_segments, n_active_segments, packed_bytes>>20 */
 int midyn_stack_info(midyn_stack* stack, long long* info);
+/* modes[seg] for seg < n_segments: 0 dense complex, 1 real only, 2 imaginary only, 3 exactly zero
+ * (exact-zero planes are detected once on the device; they let the MFMA contraction skip the
+ * corresponding real products without changing any result bit). */
+int midyn_stack_segment_modes(midyn_stack* stack, int* modes);
 
 /* ---- single evaluations --------------------------------------------------------------------
  * midyn_eval_generator: GeneratorModel.evaluate in the frame basis
@@ -128,6 +132,10 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch). */
 int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);
 int midyn_reset_counters(midyn_ctx* ctx);
+/* Measured ceilings: "mfma_f64" -> out[0] = TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64;
+ * "hbm_read" -> GB/s streaming a 4 GiB buffer; "mall_read" -> GB/s re-reading 144 MiB (the size of
+ * the cfg-2 operator stack, which fits the 256 MiB Infinity Cache). */
+int midyn_microbench(midyn_ctx* ctx, const char* name, double* out);
 
 #ifdef __cplusplus
 }

@@ -18,10 +18,10 @@ LIB_PATH = os.path.join(_HERE, "libmidyn.so")
 ABI_SYMBOLS = [
     "midyn_ctx_create", "midyn_ctx_destroy", "midyn_ctx_synchronize", "midyn_last_error",
     "midyn_ctx_set_option", "midyn_stack_packed_bytes", "midyn_stack_create", "midyn_stack_adopt",
-    "midyn_stack_destroy", "midyn_stack_info", "midyn_eval_generator", "midyn_eval_rhs",
+    "midyn_stack_destroy", "midyn_stack_info", "midyn_stack_segment_modes", "midyn_eval_generator", "midyn_eval_rhs",
     "midyn_rk4_solve", "midyn_expm", "midyn_expm_solve", "midyn_zgemm", "midyn_rk4_plan_create",
     "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_get_counters",
-    "midyn_reset_counters",
+    "midyn_reset_counters", "midyn_microbench",
 ]
 
 
@@ -66,6 +66,7 @@ def load():
         lib.midyn_stack_adopt.argtypes = [_vp, _ci, _ci, _ci, _ci, _vp, P(_vp)]
         lib.midyn_stack_destroy.argtypes = [_vp]
         lib.midyn_stack_info.argtypes = [_vp, P(_cll)]
+        lib.midyn_stack_segment_modes.argtypes = [_vp, P(_ci)]
         lib.midyn_eval_generator.argtypes = [_vp, _vp, _cd, _vp]
         lib.midyn_eval_rhs.argtypes = [_vp, _vp, _cd, _vp, _ci, _vp]
         lib.midyn_rk4_solve.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _vp,
@@ -81,6 +82,7 @@ def load():
         lib.midyn_rk4_plan_destroy.argtypes = [_vp]
         lib.midyn_get_counters.argtypes = [_vp, ctypes.c_char_p, P(_cd)]
         lib.midyn_reset_counters.argtypes = [_vp]
+        lib.midyn_microbench.argtypes = [_vp, ctypes.c_char_p, P(_cd)]
         for name in ABI_SYMBOLS:
             if name != "midyn_last_error":
                 getattr(lib, name).restype = _ci
@@ -130,6 +132,11 @@ class Context:
         out = (ctypes.c_double * 2)()
         self.check(self.lib.midyn_get_counters(self.handle, name.encode(), out))
         return {"launches": out[0], "ms": out[1]}
+
+    def microbench(self, name: str) -> float:
+        out = (ctypes.c_double * 2)()
+        self.check(self.lib.midyn_microbench(self.handle, name.encode(), out))
+        return float(out[0])
 
     def reset_counters(self):
         self.check(self.lib.midyn_reset_counters(self.handle))
@@ -212,6 +219,9 @@ class Stack:
         ctx.check(lib.midyn_stack_info(h, info))
         (self.n, self.n_pad, self.k, self.has_static, self.has_frame, self.n_segments,
          self.n_active_segments, self.packed_mib) = [int(x) for x in info]
+        modes = (ctypes.c_int * max(self.n_segments, 1))()
+        ctx.check(lib.midyn_stack_segment_modes(h, modes))
+        self.segment_modes = [int(modes[i]) for i in range(self.n_segments)]
 
     @staticmethod
     def packed_bytes(n, k, has_static):

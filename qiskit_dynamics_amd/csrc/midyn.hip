@@ -207,7 +207,9 @@ struct midyn_stack {
     int* seg_all = nullptr;     // [nseg] every segment, mode 0 (device)
     int* seg_act = nullptr;     // [nseg] active list with plane modes (device)
     int n_act = 0;
+    int uniform_mode = 3;       // plane mode shared by all active segments, or 3 (mixed)
     std::vector<int> h_flags;
+    std::vector<int> h_modes;   // per segment: 0 full, 1 real only, 2 imaginary only, 3 zero
 };
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -256,6 +258,8 @@ static int stack_finish_lists(midyn_stack* s) {
         HIPCHK(ctx, hipMemcpy(s->h_flags.data(), s->flags, 2 * s->nseg * sizeof(int), hipMemcpyDeviceToHost));
     std::vector<int> all(std::max(s->nseg, 1), 0), act(std::max(s->nseg, 1), 0);
     s->n_act = 0;
+    s->h_modes.assign(std::max(s->nseg, 1), 3);
+    int um = -1;
     for (int seg = 0; seg < s->nseg; ++seg) {
         all[seg] = seg << 2;
         const int fr = s->h_flags[2 * seg], fi = s->h_flags[2 * seg + 1];
@@ -263,8 +267,11 @@ static int stack_finish_lists(midyn_stack* s) {
         int mode = 0;
         if (fr && !fi) mode = 1;             // real only
         if (!fr && fi) mode = 2;             // imaginary only
+        s->h_modes[seg] = mode;
+        um = (um == -1 || um == mode) ? mode : 3;
         act[s->n_act++] = (seg << 2) | mode;
     }
+    s->uniform_mode = um < 0 ? 0 : um;
     HIPCHK(ctx, hipMemcpy(s->seg_all, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(s->seg_act, act.data(), act.size() * sizeof(int), hipMemcpyHostToDevice));
     return 0;
@@ -367,15 +374,21 @@ extern "C" int midyn_stack_info(midyn_stack* s, long long* info) {
     return 0;
 }
 
+extern "C" int midyn_stack_segment_modes(midyn_stack* s, int* modes) {
+    if (!s || !modes) return fail(nullptr, "midyn_stack_segment_modes: NULL argument");
+    for (int i = 0; i < s->nseg; ++i) modes[i] = s->h_modes[i];
+    return 0;
+}
+
 // -------------------------------------------------------------------------------------------------
 // kernel launch helpers
 // -------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
-static int launch_gemm_cfg(midyn_ctx* ctx, const GemmArgs& g) {
+template <int BM, int BN, int WM, int WN, int MODE>
+static int launch_gemm_mode(midyn_ctx* ctx, const GemmArgs& g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr size_t SMEM = (size_t)2 * GEMM_BK * (BM + BN) * sizeof(double2);
     static bool attr_set[16] = {false};
-    auto kern = zgemm_seg_kernel<BM, BN, WM, WN>;
+    auto kern = zgemm_seg_kernel<BM, BN, WM, WN, MODE>;
     if (!attr_set[ctx->device & 15]) {
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
@@ -387,8 +400,20 @@ static int launch_gemm_cfg(midyn_ctx* ctx, const GemmArgs& g) {
     return 0;
 }
 
+// uniform_mode: 0/1/2 when every active segment has that plane mode (straight-line specialised
+// kernel), 3 when the stack is mixed (per-segment run-time flags)
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm_cfg(midyn_ctx* ctx, const GemmArgs& g, int uniform_mode) {
+    switch (uniform_mode) {
+        case 0: return launch_gemm_mode<BM, BN, WM, WN, 0>(ctx, g);
+        case 1: return launch_gemm_mode<BM, BN, WM, WN, 1>(ctx, g);
+        case 2: return launch_gemm_mode<BM, BN, WM, WN, 2>(ctx, g);
+        default: return launch_gemm_mode<BM, BN, WM, WN, 3>(ctx, g);
+    }
+}
+
 // tile choice: 128x128 (8 waves) when that still gives >= 1 block per CU, else 64x64 (4 waves)
-static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g, int cls) {
+static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g, int cls, int uniform_mode = 0) {
     if (g.M % 64 || g.N % 64 || g.K % GEMM_BK)
         return fail(ctx, "launch_gemm: dimensions must be padded to 64/64/16");
     ProfScope ps(ctx, cls);
@@ -396,8 +421,8 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g, int cls) {
                ((long long)(g.M / 128) * (g.N / 128) >= (long long)ctx->num_cu);
     if (ctx->force_tile == 64) big = false;
     if (ctx->force_tile == 128 && g.M % 128 == 0 && g.N % 128 == 0) big = true;
-    if (big) return launch_gemm_cfg<128, 128, 2, 4>(ctx, g);
-    return launch_gemm_cfg<64, 64, 2, 2>(ctx, g);
+    if (big) return launch_gemm_cfg<128, 128, 2, 4>(ctx, g, uniform_mode);
+    return launch_gemm_cfg<64, 64, 2, 2>(ctx, g, uniform_mode);
 }
 
 static int launch_stream(midyn_ctx* ctx, const StreamArgs& a) {
@@ -588,7 +613,7 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
     g.m_cols = p->m;
     g.n_inst = p->B;
     g.epi = epi;
-    return launch_gemm(ctx, g, KC_RHS_GEMM);
+    return launch_gemm(ctx, g, KC_RHS_GEMM, ctx->skip_zero_planes ? s->uniform_mode : 0);
 }
 
 extern "C" int midyn_rk4_plan_destroy(midyn_rk4_plan* p) {
@@ -1085,5 +1110,56 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
         HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b * P * inst_elems, d_out.p, (size_t)P * inst_elems * sizeof(double2),
                               hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// micro-benchmarks (measured ceilings printed next to the vendor peaks)
+// -------------------------------------------------------------------------------------------------
+extern "C" int midyn_microbench(midyn_ctx* ctx, const char* name, double* out) {
+    if (!ctx || !name || !out) return fail(ctx, "midyn_microbench: NULL argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::string n(name);
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    DevBuf sink;
+    CHK(sink.alloc(ctx, 64));
+    float ms = 0.f;
+    if (n == "mfma_f64") {
+        // one 256-thread block per SIMD-pair: 8 blocks/CU worth of waves keeps every matrix pipe busy
+        const int blocks = ctx->num_cu * 4, iters = 4000;
+        hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink.as<double>(), 100);
+        HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink.as<double>(), iters);
+        HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+        HIPCHK(ctx, hipEventSynchronize(e1));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+        const double flops = (double)blocks * 4 /*waves*/ * iters * 16 * 2048.0;
+        out[0] = flops / (ms * 1e-3) / 1e12;  // TFLOP/s
+    } else if (n == "hbm_read" || n == "mall_read") {
+        const size_t bytes = (n == "hbm_read") ? ((size_t)4 << 30) : ((size_t)144 << 20);
+        DevBuf buf;
+        CHK(buf.alloc(ctx, bytes));
+        HIPCHK(ctx, hipMemsetAsync(buf.p, 1, bytes, ctx->stream));
+        const int reps = (n == "hbm_read") ? 4 : 40;
+        hipLaunchKernelGGL(stream_read_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream,
+                           buf.as<double2>(), bytes / 16, sink.as<double>());
+        HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+        for (int r = 0; r < reps; ++r)
+            hipLaunchKernelGGL(stream_read_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream,
+                               buf.as<double2>(), bytes / 16, sink.as<double>());
+        HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+        HIPCHK(ctx, hipEventSynchronize(e1));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+        out[0] = (double)bytes * reps / (ms * 1e-3) / 1e9;  // GB/s
+    } else {
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        return fail(ctx, "midyn_microbench: unknown benchmark " + n);
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    HIPCHK(ctx, hipGetLastError());
     return 0;
 }

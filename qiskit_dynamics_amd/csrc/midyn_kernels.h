@@ -210,7 +210,68 @@ struct GemmArgs {
 
 constexpr int GEMM_BK = 16;
 
-template <int BM, int BN, int WM, int WN>
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// One K tile (BK = 16 -> 4 MFMA k-steps) of the wave's TM x TN complex tile.  MODE: 0 = A complex,
+// 1 = A real only, 2 = A imaginary only (the other plane of the operator is exactly zero, so the two
+// MFMAs that would multiply it are skipped).
+//   A tile in LDS: [m][16 slots] complex, element (m,k) at slot k ^ (m & 15)  (XOR swizzle: a
+//   fragment read -- 16 rows x 4 k per wave -- touches 16 distinct 16-B slots in every ds_read_b128
+//   lane group, i.e. it is bank-conflict free without padding, which LDS-DMA could not write).
+//   B tile in LDS: [k][BN] complex, straight.
+template <int MODE, int BN, int MT, int NT>
+__device__ __forceinline__ void mfma_tile(const double2* __restrict__ Ab, const double2* __restrict__ Bb,
+                                          int lk, int li, int rt_mode, const double (&sc)[NT],
+                                          d4 (&cre)[MT][NT], d4 (&cim)[MT][NT]) {
+    constexpr int KS = GEMM_BK / 4;
+    // MODE 3 = decided at run time per segment (mixed stacks); 0/1/2 = compile-time specialisation
+    const bool do_re = MODE == 3 ? (rt_mode != 2) : (MODE != 2);
+    const bool do_im = MODE == 3 ? (rt_mode != 1) : (MODE != 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        double2 a[MT], b[NT];
+        const int k = ks * 4 + lk;
+        const int slot = k ^ li;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = Ab[mt * 16 * GEMM_BK + slot];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = Bb[k * BN + nt * 16];
+        double br[NT], bi[NT], bin[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            br[nt] = b[nt].x * sc[nt];
+            bi[nt] = b[nt].y * sc[nt];
+            bin[nt] = -bi[nt];
+        }
+        if (do_re) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].x, br[nt], cre[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].x, bi[nt], cim[mt][nt], 0, 0, 0);
+        }
+        if (do_im) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].y, bin[nt], cre[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].y, br[nt], cim[mt][nt], 0, 0, 0);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) void zgemm_seg_kernel(GemmArgs g) {
     constexpr int BK = GEMM_BK;
     constexpr int THREADS = 64 * WM * WN;
@@ -219,13 +280,16 @@ __global__ __launch_bounds__(64 * WM * WN) void zgemm_seg_kernel(GemmArgs g) {
     constexpr int TN = BN / WN;
     constexpr int MT = TM / 16;
     constexpr int NT = TN / 16;
-    constexpr int A_PER_T = BM * BK / THREADS;
-    constexpr int B_PER_T = BN * BK / THREADS;
-    static_assert(A_PER_T * THREADS == BM * BK && B_PER_T * THREADS == BN * BK, "tile/threads");
-    static_assert((BM / 8) * (BK / 8) == NWAVE * A_PER_T, "A staging map");
+    constexpr int A_CHUNKS = BM / 4;             // 1-KiB DMA pieces (4 rows x 256 B) of the A tile
+    constexpr int B_PER_ROW = BN / 64;           // 1-KiB DMA pieces per B tile row
+    constexpr int B_CHUNKS = BK * B_PER_ROW;
+    constexpr int A_PER_W = A_CHUNKS / NWAVE;
+    constexpr int B_PER_W = B_CHUNKS / NWAVE;
+    static_assert(A_PER_W * NWAVE == A_CHUNKS && B_PER_W * NWAVE == B_CHUNKS, "DMA split");
+    static_assert(BK == 16, "swizzle assumes 16 slots per A row");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double2* As = reinterpret_cast<double2*>(smem_raw);             // [2][BK][BM]
+    double2* As = reinterpret_cast<double2*>(smem_raw);             // [2][BM][16]
     double2* Bs = As + 2 * BK * BM;                                 // [2][BK][BN]
 
     const int tid = threadIdx.x;
@@ -264,114 +328,69 @@ __global__ __launch_bounds__(64 * WM * WN) void zgemm_seg_kernel(GemmArgs g) {
             cim[i][j] = d4{0.0, 0.0, 0.0, 0.0};
         }
 
-    double2 ra[A_PER_T], rb[B_PER_T];
+    // LDS-DMA source offsets (per lane, fixed): lane l of chunk c fetches A row m = 4c + l/16,
+    // k = (l % 16) ^ (m & 15), and lands at LDS slot l of the chunk (= row m, slot l % 16).
+    int a_src[A_PER_W];
+#pragma unroll
+    for (int p = 0; p < A_PER_W; ++p) {
+        const int m = (wave + NWAVE * p) * 4 + (lane >> 4);
+        const int k = (lane & 15) ^ (m & 15);
+        a_src[p] = m * g.lda + k;
+    }
+    int b_src[B_PER_W];
+#pragma unroll
+    for (int p = 0; p < B_PER_W; ++p) {
+        const int c = wave + NWAVE * p;
+        b_src[p] = (c / B_PER_ROW) * g.ldb + (c % B_PER_ROW) * 64 + lane;
+    }
+    const double2* Abase = g.A + (size_t)m0 * g.lda;
+    const double2* Bbase = g.B + n0;
 
-    auto load_tiles = [&](int it) {
+    // global -> LDS direct (no VGPR staging, no ds_write): tile `it_raw` (clamped) into buffer buf
+    auto dma_tiles = [&](int it_raw, int buf) {
+        const int it = it_raw < total ? it_raw : total - 1;
         const int s = it / KT;
         const int kt = it - s * KT;
         const int seg = g.seg_list[s] >> 2;
-        const double2* Ab = g.A + seg * g.a_seg_stride + (size_t)m0 * g.lda + kt * BK;
-#pragma unroll
-        for (int p = 0; p < A_PER_T; ++p) {
-            const int sub = wave + NWAVE * p;
-            const int sub_m = sub / (BK / 8);
-            const int sub_k = sub % (BK / 8);
-            const int m = sub_m * 8 + (lane & 7);
-            const int k = sub_k * 8 + (lane >> 3);
-            ra[p] = Ab[(size_t)m * g.lda + k];
-        }
-        const double2* Bb = g.B + (size_t)(kt * BK) * g.ldb + n0;
-#pragma unroll
-        for (int p = 0; p < B_PER_T; ++p) {
-            const int idx = tid + THREADS * p;
-            const int k = idx / BN;
-            const int n = idx % BN;
-            rb[p] = Bb[(size_t)k * g.ldb + n];
-        }
-    };
-    auto store_tiles = [&](int buf) {
+        const double2* Ab = Abase + seg * g.a_seg_stride + kt * BK;
         double2* Ad = As + buf * BK * BM;
 #pragma unroll
-        for (int p = 0; p < A_PER_T; ++p) {
-            const int sub = wave + NWAVE * p;
-            const int sub_m = sub / (BK / 8);
-            const int sub_k = sub % (BK / 8);
-            const int m = sub_m * 8 + (lane & 7);
-            const int k = sub_k * 8 + (lane >> 3);
-            Ad[k * BM + m] = ra[p];
-        }
+        for (int p = 0; p < A_PER_W; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + a_src[p]),
+                                             (lds_void_t*)(Ad + (wave + NWAVE * p) * 64), 16, 0, 0);
+        const double2* Bb = Bbase + (size_t)(kt * BK) * g.ldb;
         double2* Bd = Bs + buf * BK * BN;
 #pragma unroll
-        for (int p = 0; p < B_PER_T; ++p) {
-            const int idx = tid + THREADS * p;
-            Bd[idx] = rb[p];  // idx == k*BN + n
-        }
+        for (int p = 0; p < B_PER_W; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bb + b_src[p]),
+                                             (lds_void_t*)(Bd + (wave + NWAVE * p) * 64), 16, 0, 0);
     };
 
-    if (total > 0) {
-        load_tiles(0);
-        store_tiles(0);
-    }
+    if (total > 0) dma_tiles(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    double sc[NT];
-    int cur_s = -1;
-    int mode = 0;
-    for (int it = 0; it < total; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < total) load_tiles(it + 1);
-        const int s = it / KT;
-        if (s != cur_s) {
-            cur_s = s;
-            const int packed = g.seg_list[s];
-            const int seg = packed >> 2;
-            mode = packed & 3;
+    int it = 0;
+    for (int s = 0; s < g.n_act; ++s) {
+        const int packed = g.seg_list[s];
+        const int seg = packed >> 2;
+        const int mode = packed & 3;
+        double sc[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (g.coeff == nullptr || (g.has_static && seg == 0)) sc[nt] = 1.0;
-                else sc[nt] = g.coeff[inst[nt] * g.inst_stride + (seg - g.has_static)];
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            if (g.coeff == nullptr || (g.has_static && seg == 0)) sc[nt] = 1.0;
+            else sc[nt] = g.coeff[inst[nt] * g.inst_stride + (seg - g.has_static)];
         }
-        const double2* Ab = As + buf * BK * BM + wm * TM + lcol;
-        const double2* Bb = Bs + buf * BK * BN + wn * TN + lcol;
-#pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            double2 a[MT], b[NT];
-            const int krow = ks * 4 + lk;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = Ab[krow * BM + mt * 16];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                double2 v = Bb[krow * BN + nt * 16];
-                b[nt] = make_double2(v.x * sc[nt], v.y * sc[nt]);
-            }
-            if (mode != 2) {  // real plane of A present
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].x, b[nt].x, cre[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].x, b[nt].y, cim[mt][nt], 0, 0, 0);
-            }
-            if (mode != 1) {  // imaginary plane of A present
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].y, -b[nt].y, cre[mt][nt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].y, b[nt].x, cim[mt][nt], 0, 0, 0);
-            }
+        for (int kt = 0; kt < KT; ++kt, ++it) {
+            const int buf = it & 1;
+            dma_tiles(it + 1, buf ^ 1);
+            const double2* Ab = As + buf * BK * BM + (wm * TM + lcol) * BK;
+            const double2* Bb = Bs + buf * BK * BN + wn * TN + lcol;
+            mfma_tile<MODE, BN, MT, NT>(Ab, Bb, lk, lcol, mode, sc, cre, cim);
+            __builtin_amdgcn_sched_barrier(0);  // keep every MFMA of this tile ahead of the barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        if (it + 1 < total) store_tiles(buf ^ 1);
-        __syncthreads();
     }
 
     // epilogue: D[row = (lane>>4) + 4*reg][col = lane & 15]
@@ -563,6 +582,42 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const double2* src, int src
         const int c = (int)(idx - (size_t)r * cols);
         dst[(size_t)r * dst_ld + c] = src[(size_t)r * src_ld + c];
     }
+}
+
+// ---- micro-benchmarks: the ceilings the roofline fractions are quoted against -------------------
+// 16 independent fp64 MFMA accumulators per wave, `iters` rounds: pure matrix-pipe throughput.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters) {
+    d4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double a[16], b = 0.5 - threadIdx.x * 1e-9;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = 1.0 + (threadIdx.x + 64 * i) * 1e-9;  // distinct: no CSE of chains
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456) sink[0] = s;
+}
+
+// streaming read of `n16` 16-byte elements (grid-stride, 4 independent loads per thread per round)
+__global__ __launch_bounds__(256) void stream_read_kernel(const double2* src, size_t n16, double* sink) {
+    double2 acc = make_double2(0.0, 0.0);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const double2 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+        acc.x += v0.x + v1.x + v2.x + v3.x;
+        acc.y += v0.y + v1.y + v2.y + v3.y;
+    }
+    for (; i < n16; i += stride) {
+        acc.x += src[i].x;
+        acc.y += src[i].y;
+    }
+    if (acc.x == 123.456 && acc.y == 654.321) sink[0] = acc.x;
 }
 
 }  // namespace midyn

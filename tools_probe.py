@@ -1,0 +1,6 @@
+import sys, numpy as np
+sys.path.insert(0, '.')
+import qiskit_dynamics_amd as qd
+ctx = qd.default_context()
+for name in ("mfma_f64", "hbm_read", "mall_read"):
+    print(name, round(ctx.microbench(name), 1))
