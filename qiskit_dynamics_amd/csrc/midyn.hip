@@ -416,6 +416,8 @@ static int launch_gemm_cfg(midyn_ctx* ctx, const GemmArgs& g, int uniform_mode) 
 static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g, int cls, int uniform_mode = 0) {
     if (g.M % 64 || g.N % 64 || g.K % GEMM_BK)
         return fail(ctx, "launch_gemm: dimensions must be padded to 64/64/16");
+    if (g.n_act > 64)
+        return fail(ctx, "more than 64 non-zero operator segments are not supported by the MFMA contraction yet");
     ProfScope ps(ctx, cls);
     bool big = (g.M % 128 == 0) && (g.N % 128 == 0) &&
                ((long long)(g.M / 128) * (g.N / 128) >= (long long)ctx->num_cu);

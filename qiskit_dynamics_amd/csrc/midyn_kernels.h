@@ -346,51 +346,71 @@ __global__ __launch_bounds__(64 * WM * WN) void zgemm_seg_kernel(GemmArgs g) {
     const double2* Abase = g.A + (size_t)m0 * g.lda;
     const double2* Bbase = g.B + n0;
 
-    // global -> LDS direct (no VGPR staging, no ds_write): tile `it_raw` (clamped) into buffer buf
-    auto dma_tiles = [&](int it_raw, int buf) {
-        const int it = it_raw < total ? it_raw : total - 1;
-        const int s = it / KT;
-        const int kt = it - s * KT;
-        const int seg = g.seg_list[s] >> 2;
-        const double2* Ab = Abase + seg * g.a_seg_stride + kt * BK;
+    // Loop order: K tile outer, operator segment inner -- the B (state) tile is staged ONCE per K
+    // tile and reused by all n_act operator tiles, so per launch the state block is read once per
+    // M-block instead of n_act times (memory-side traffic / n_act).
+    // The (<= 64 entry) segment table lives in one VGPR (lane s holds entry s) and is read with
+    // v_readlane: no scalar-memory load sits between the barrier and the first ds_read of a tile.
+    const int seg_vec = lane < g.n_act ? g.seg_list[lane] : 0;
+    // global -> LDS direct (no VGPR staging, no ds_write).
+    auto dma_a = [&](int kt_, int seg, int buf) {
+        const double2* Ab = Abase + seg * g.a_seg_stride + kt_ * BK;
         double2* Ad = As + buf * BK * BM;
 #pragma unroll
         for (int p = 0; p < A_PER_W; ++p)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + a_src[p]),
                                              (lds_void_t*)(Ad + (wave + NWAVE * p) * 64), 16, 0, 0);
-        const double2* Bb = Bbase + (size_t)(kt * BK) * g.ldb;
+    };
+    auto dma_b = [&](int kt_, int buf) {
+        const double2* Bb = Bbase + (size_t)(kt_ * BK) * g.ldb;
         double2* Bd = Bs + buf * BK * BN;
 #pragma unroll
         for (int p = 0; p < B_PER_W; ++p)
             __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bb + b_src[p]),
                                              (lds_void_t*)(Bd + (wave + NWAVE * p) * 64), 16, 0, 0);
     };
+    auto load_sc = [&](int seg, double (&scv)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (g.coeff == nullptr || (g.has_static && seg == 0)) scv[nt] = 1.0;
+            else scv[nt] = g.coeff[inst[nt] * g.inst_stride + (seg - g.has_static)];
+        }
+    };
 
-    if (total > 0) dma_tiles(0, 0);
+    double sc[NT], sc_next[NT];
+    int packed = __builtin_amdgcn_readlane(seg_vec, 0);
+    if (total > 0) {
+        dma_a(0, packed >> 2, 0);
+        dma_b(0, 0);
+        load_sc(packed >> 2, sc);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int it = 0;
-    for (int s = 0; s < g.n_act; ++s) {
-        const int packed = g.seg_list[s];
-        const int seg = packed >> 2;
-        const int mode = packed & 3;
-        double sc[NT];
+    int kt = 0, s = 0;
+    for (int it = 0; it < total; ++it) {
+        int s_n = s + 1, kt_n = kt;
+        if (s_n == g.n_act) {
+            s_n = 0;
+            kt_n = kt + 1;
+        }
+        const int packed_n = __builtin_amdgcn_readlane(seg_vec, s_n);
+        if (it + 1 < total) {
+            dma_a(kt_n, packed_n >> 2, (it + 1) & 1);
+            if (s_n == 0) dma_b(kt_n, kt_n & 1);
+        }
+        load_sc(packed_n >> 2, sc_next);
+        const double2* Ab = As + (it & 1) * BK * BM + (wm * TM + lcol) * BK;
+        const double2* Bb = Bs + (kt & 1) * BK * BN + wn * TN + lcol;
+        mfma_tile<MODE, BN, MT, NT>(Ab, Bb, lk, lcol, packed & 3, sc, cre, cim);
+        __builtin_amdgcn_sched_barrier(0);  // keep every MFMA of this tile ahead of the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (g.coeff == nullptr || (g.has_static && seg == 0)) sc[nt] = 1.0;
-            else sc[nt] = g.coeff[inst[nt] * g.inst_stride + (seg - g.has_static)];
-        }
-        for (int kt = 0; kt < KT; ++kt, ++it) {
-            const int buf = it & 1;
-            dma_tiles(it + 1, buf ^ 1);
-            const double2* Ab = As + buf * BK * BM + (wm * TM + lcol) * BK;
-            const double2* Bb = Bs + buf * BK * BN + wn * TN + lcol;
-            mfma_tile<MODE, BN, MT, NT>(Ab, Bb, lk, lcol, mode, sc, cre, cim);
-            __builtin_amdgcn_sched_barrier(0);  // keep every MFMA of this tile ahead of the barrier
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        for (int nt = 0; nt < NT; ++nt) sc[nt] = sc_next[nt];
+        s = s_n;
+        kt = kt_n;
+        packed = packed_n;
     }
 
     // epilogue: D[row = (lane>>4) + 4*reg][col = lane & 15]
@@ -585,21 +605,26 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const double2* src, int src
 }
 
 // ---- micro-benchmarks: the ceilings the roofline fractions are quoted against -------------------
-// 16 independent fp64 MFMA accumulators per wave, `iters` rounds: pure matrix-pipe throughput.
+// 8 independent fp64 MFMA accumulators per wave (all in VGPRs), `iters` rounds, 4 waves per SIMD:
+// pure matrix-pipe throughput.
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters) {
-    d4 acc[16];
+    d4 acc[8];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
-    double a[16], b = 0.5 - threadIdx.x * 1e-9;
+    for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double a[8], b = 0.5 - threadIdx.x * 1e-9;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = 1.0 + (threadIdx.x + 64 * i) * 1e-9;  // distinct: no CSE of chains
+    for (int i = 0; i < 8; ++i) a[i] = 1.0 + (threadIdx.x + 64 * i) * 1e-9;  // distinct: no CSE of chains
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(b), "v"(a[i]));
     }
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 123.456) sink[0] = s;
 }
 

@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Turn rocprofv3 (rocpd sqlite) outputs into the text summaries committed under profiles/.
+
+usage: python tools/summarize_rocprof.py <dir with stats/ pmc_*/ sub-dirs> <out.md> [title]
+Reads <dir>/stats/*.db (--kernel-trace --stats run) and every <dir>/pmc_*/*.db (--pmc runs, one
+counter set per run as MI355X_MICROARCH.md prescribes).  FETCH_SIZE is reported raw (KiB) AND
+corrected x2 (gfx950: 128-B requests are tallied as 64 B for wide coalesced reads).
+"""
+import glob
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.split("(")[0]
+    for a, b in (("midyn::", ""), ("void ", "")):
+        name = name.replace(a, b)
+    return name[:90]
+
+
+def kernel_stats(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+                       "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
+                       "max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
+    con.close()
+    return rows
+
+
+def pmc_stats(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, counter_name, count(*), avg(counter_value), sum(counter_value) "
+                       "from pmc_events group by name, counter_name").fetchall()
+    con.close()
+    return rows
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    title = sys.argv[3] if len(sys.argv) > 3 else os.path.basename(root)
+    lines = [f"# rocprofv3 summary: {title}", ""]
+    for db in sorted(glob.glob(os.path.join(root, "stats", "*.db"))):
+        rows = kernel_stats(db)
+        total = sum(r[2] for r in rows) or 1
+        lines += ["## kernel trace (`rocprofv3 --kernel-trace --stats`)", "",
+                  "| kernel | calls | total ms | avg us | min us | max us | % | vgpr | agpr | sgpr | lds B | scratch | grid | wg |",
+                  "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+        for r in rows:
+            lines.append(f"| `{short(r[0])}` | {r[1]} | {r[2] / 1e6:.3f} | {r[3] / 1e3:.2f} | {r[4] / 1e3:.2f} | "
+                         f"{r[5] / 1e3:.2f} | {100 * r[2] / total:.1f} | {r[6]} | {r[7]} | {r[8]} | {r[9]} | {r[10]} | "
+                         f"{r[11]} | {r[12]} |")
+        lines.append("")
+    for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+        for db in sorted(glob.glob(os.path.join(d, "*.db"))):
+            rows = pmc_stats(db)
+            if not rows:
+                continue
+            lines += [f"## counters ({os.path.basename(d)}; separate `rocprofv3 --pmc` pass)", "",
+                      "| kernel | counter | dispatches | avg per dispatch | note |", "|---|---|---|---|---|"]
+            by_kernel = defaultdict(dict)
+            for name, cname, n, avg, tot in rows:
+                by_kernel[name][cname] = avg
+                note = ""
+                if cname == "FETCH_SIZE":
+                    note = f"KiB; x2 gfx950 correction -> {2 * avg * 1024 / 1e6:.1f} MB/dispatch"
+                if cname == "WRITE_SIZE":
+                    note = f"KiB -> {avg * 1024 / 1e6:.1f} MB/dispatch (uncalibrated)"
+                lines.append(f"| `{short(name)}` | {cname} | {n} | {avg:.4g} | {note} |")
+            for name, c in by_kernel.items():
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"]:
+                    lines.append(f"| `{short(name)}` | MFMA busy / SQ busy | | "
+                                 f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.3f} | ratio of summed counters |")
+            lines.append("")
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    with open(out, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
