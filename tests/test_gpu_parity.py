@@ -534,3 +534,36 @@ def test_rk4_plan_matches_solve(qd, cfg2):
     stack.ctx.synchronize()
     assert_close(plan.fetch(), ref, 1e-13)
     plan.close()
+
+
+def test_stack_adopt_roundtrip(qd):
+    """Multi-GPU plumbing on one GPU: build the packed stack inside a torch buffer (as rank 0 does),
+    copy the bytes (what the RCCL broadcast does) and adopt the copy (as the other ranks do)."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    n, k = 20, 3
+    ops = crand(rng, k, n, n)
+    ops[1] = 1j * rng.normal(size=(n, n))      # single-plane operator: flags must travel too
+    static = crand(rng, n, n)
+    frame_im = rng.normal(size=n)
+    ctx = qd.default_context()
+    dev = torch.device("cuda", ctx.device)
+    nbytes = qd.Stack.packed_bytes(n, k, True)
+    buf0 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    s0 = qd.Stack(ctx, ops, static, frame_im, dev_buffer_ptr=buf0.data_ptr())
+    ctx.synchronize()
+    torch.cuda.synchronize(dev)
+    buf1 = buf0.clone()
+    torch.cuda.synchronize(dev)
+    s1 = qd.Stack(ctx, None, None, None, dev_buffer_ptr=buf1.data_ptr(), _adopt=(n, k, 1, 1))
+    assert s1.segment_modes == s0.segment_modes == [0, 0, 2, 0]
+    c = rng.uniform(-1, 1, k)
+    y = crand(rng, n, 3)
+    assert_close(s1.eval_rhs(c, 0.4, y), s0.eval_rhs(c, 0.4, y), 0)
+    assert_close(s1.eval_generator(c, 0.4), s0.eval_generator(c, 0.4), 0)
+    e = np.exp(1j * frame_im * 0.4)
+    ref = (np.tensordot(c, ops, axes=1) + static) * (e.conj()[:, None] * e[None, :])
+    assert_close(s1.eval_generator(c, 0.4), ref, EVAL_TOL)
+    s1.close()
+    s0.close()
