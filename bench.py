@@ -71,8 +71,9 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
-        import torch
+    use_dist = world > 1 or bool(os.environ.get("MIDYN_BENCH_FORCE_DIST"))  # the latter: 1-GPU test of the RCCL path
+    if use_dist:
+        import torch  # BEFORE the first libmidyn call: the library then binds to torch's HIP runtime
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
@@ -85,7 +86,7 @@ def main():
     n = 2**N_QUBITS
     k = N_DRIVES
     t_setup = time.time()
-    if world > 1:
+    if use_dist:
         ops = static = frame_im = None
         if rank == 0:
             ops, static, frame_im = build_frame_basis_stack(cfg)

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -42,6 +43,37 @@ _cd = ctypes.c_double
 _cll = ctypes.c_longlong
 
 
+HIP_RUNTIME = None  # path of the HIP runtime libmidyn's hip* symbols were bound to
+
+
+def _preload_hip_runtime():
+    """libmidyn.so has no DT_NEEDED on libamdhip64: exactly ONE HIP runtime must serve the process.
+    If torch is already imported (torchrun / RCCL plumbing) use the runtime bundled with torch, else
+    the system ROCm one.  Override with MIDYN_HIP_RUNTIME=torch|system|/path/to/libamdhip64.so."""
+    global HIP_RUNTIME
+    choice = os.environ.get("MIDYN_HIP_RUNTIME", "auto")
+    cands = []
+    if choice == "torch" or (choice == "auto" and "torch" in sys.modules):
+        import torch
+
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    elif choice not in ("auto", "system"):
+        cands.append(choice)
+    cands += ["/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so", "libamdhip64.so.7",
+              "libamdhip64.so"]
+    errors = []
+    for c in cands:
+        if os.path.sep in c and not os.path.exists(c):
+            continue
+        try:
+            ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            HIP_RUNTIME = c
+            return
+        except OSError as e:  # pragma: no cover
+            errors.append(f"{c}: {e}")
+    raise HipLibraryError("no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errors))
+
+
 def load():
     """Load libmidyn.so (once) and set the prototypes."""
     global _lib
@@ -53,6 +85,7 @@ def load():
                 f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). qiskit_dynamics_amd has no CPU fallback."
             )
+        _preload_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         P = ctypes.POINTER
         lib.midyn_last_error.restype = ctypes.c_char_p

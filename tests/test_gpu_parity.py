@@ -536,34 +536,64 @@ def test_rk4_plan_matches_solve(qd, cfg2):
     plan.close()
 
 
-def test_stack_adopt_roundtrip(qd):
-    """Multi-GPU plumbing on one GPU: build the packed stack inside a torch buffer (as rank 0 does),
-    copy the bytes (what the RCCL broadcast does) and adopt the copy (as the other ranks do)."""
-    import torch
+ADOPT_SCRIPT = r"""
+import sys
+import numpy as np
+import torch                      # imported FIRST: libmidyn then binds to torch's HIP runtime
+sys.path.insert(0, sys.argv[1])
+import qiskit_dynamics_amd as qd
+from qiskit_dynamics_amd import _lib
 
-    rng = np.random.default_rng(3)
-    n, k = 20, 3
-    ops = crand(rng, k, n, n)
-    ops[1] = 1j * rng.normal(size=(n, n))      # single-plane operator: flags must travel too
-    static = crand(rng, n, n)
-    frame_im = rng.normal(size=n)
-    ctx = qd.default_context()
-    dev = torch.device("cuda", ctx.device)
-    nbytes = qd.Stack.packed_bytes(n, k, True)
-    buf0 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    s0 = qd.Stack(ctx, ops, static, frame_im, dev_buffer_ptr=buf0.data_ptr())
-    ctx.synchronize()
-    torch.cuda.synchronize(dev)
-    buf1 = buf0.clone()
-    torch.cuda.synchronize(dev)
-    s1 = qd.Stack(ctx, None, None, None, dev_buffer_ptr=buf1.data_ptr(), _adopt=(n, k, 1, 1))
-    assert s1.segment_modes == s0.segment_modes == [0, 0, 2, 0]
-    c = rng.uniform(-1, 1, k)
-    y = crand(rng, n, 3)
-    assert_close(s1.eval_rhs(c, 0.4, y), s0.eval_rhs(c, 0.4, y), 0)
-    assert_close(s1.eval_generator(c, 0.4), s0.eval_generator(c, 0.4), 0)
-    e = np.exp(1j * frame_im * 0.4)
-    ref = (np.tensordot(c, ops, axes=1) + static) * (e.conj()[:, None] * e[None, :])
-    assert_close(s1.eval_generator(c, 0.4), ref, EVAL_TOL)
-    s1.close()
-    s0.close()
+def crand(rng, *shape):
+    return rng.uniform(-1, 1, shape) + 1j * rng.uniform(-1, 1, shape)
+
+rng = np.random.default_rng(3)
+n, k = 20, 3
+ops = crand(rng, k, n, n)
+ops[1] = 1j * rng.normal(size=(n, n))      # single-plane operator: flags must travel too
+static = crand(rng, n, n)
+frame_im = rng.normal(size=n)
+ctx = qd.default_context()
+assert "torch" in _lib.HIP_RUNTIME, _lib.HIP_RUNTIME
+dev = torch.device("cuda", ctx.device)
+nbytes = qd.Stack.packed_bytes(n, k, True)
+buf0 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+s0 = qd.Stack(ctx, ops, static, frame_im, dev_buffer_ptr=buf0.data_ptr())
+ctx.synchronize()
+torch.cuda.synchronize(dev)
+buf1 = buf0.clone()
+torch.cuda.synchronize(dev)
+s1 = qd.Stack(ctx, None, None, None, dev_buffer_ptr=buf1.data_ptr(), _adopt=(n, k, 1, 1))
+assert s1.segment_modes == s0.segment_modes == [0, 0, 2, 0], (s0.segment_modes, s1.segment_modes)
+c = rng.uniform(-1, 1, k)
+y = crand(rng, n, 3)
+assert np.array_equal(s1.eval_rhs(c, 0.4, y), s0.eval_rhs(c, 0.4, y))
+assert np.array_equal(s1.eval_generator(c, 0.4), s0.eval_generator(c, 0.4))
+e = np.exp(1j * frame_im * 0.4)
+ref = (np.tensordot(c, ops, axes=1) + static) * (e.conj()[:, None] * e[None, :])
+assert np.max(np.abs(s1.eval_generator(c, 0.4) - ref)) < 1e-12
+# a world-size-1 NCCL (= RCCL) broadcast of the packed buffer through torch.distributed
+import os, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+dist.init_process_group("nccl", rank=0, world_size=1)
+from qiskit_dynamics_amd.distributed import broadcast_stack
+s2, keep = broadcast_stack(ctx, ops, static, frame_im, n, k, src=0)
+assert np.array_equal(s2.eval_rhs(c, 0.4, y), s0.eval_rhs(c, 0.4, y))
+dist.destroy_process_group()
+print("ADOPT_OK")
+"""
+
+
+def test_stack_adopt_roundtrip(tmp_path):
+    """Multi-GPU plumbing on one GPU, in a fresh process that imports torch first (as under
+    torchrun): build the packed stack inside a torch buffer (rank 0), copy the bytes (what the RCCL
+    broadcast does), adopt the copy (other ranks), and run a world-size-1 NCCL broadcast."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    script = tmp_path / "adopt.py"
+    script.write_text(ADOPT_SCRIPT)
+    p = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ADOPT_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]

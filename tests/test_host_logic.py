@@ -175,10 +175,11 @@ def test_abi_library_loads_and_exports_every_header_symbol():
     assert declared, "no declarations parsed from include/midyn.h"
     assert sorted(_lib.ABI_SYMBOLS) == declared, "python binding and header disagree"
     assert os.path.exists(_lib.LIB_PATH), "libmidyn.so not built: run __graft_entry__.build()"
-    lib = ctypes.CDLL(_lib.LIB_PATH)
+    assert _lib.load() is not None      # pre-loads ONE HIP runtime, then dlopens libmidyn.so
+    assert _lib.HIP_RUNTIME is not None
+    lib = ctypes.CDLL(_lib.LIB_PATH)    # a second handle on the same object: check the raw exports
     for name in declared:
         assert hasattr(lib, name), f"{name} not exported by libmidyn.so"
-    assert _lib.load() is not None
     nbytes = _lib.Stack.packed_bytes(1024, 8, 1)   # pure host arithmetic, no device needed
     assert nbytes >= 9 * 1024 * 1024 * 16
     assert _lib.Stack.packed_bytes(4, 2, 0) >= 2 * 64 * 64 * 16  # n padded to 64

@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Secondary measurements for BASELINE.json configs 2, 4, 5 and the expm kernel alone.
+Prints one JSON object per line.  (bench.py is the contract benchmark; this feeds profiles/.)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import qiskit_dynamics_amd as qd  # noqa: E402
+from qiskit_dynamics_amd import workloads  # noqa: E402
+
+ctx = qd.default_context()
+which = sys.argv[1:] or ["expm", "cfg4", "cfg5"]
+
+
+def timed(fn):
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    ctx.synchronize()
+    return out, time.perf_counter() - t0
+
+
+if "expm" in which:
+    for n in (1024, 2048, 4096):
+        rng = np.random.default_rng(n)
+        a = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+        a = a - a.conj().T
+        a *= 2.0 / np.linalg.norm(a, 1)
+        ctx.expm(a[:64, :64])  # warm
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        (e, info), dt = timed(lambda: ctx.expm(a, return_info=True))
+        c = ctx.counters("zgemm")
+        ctx.set_option("profile", 0)
+        s = int(info[0, 0])
+        flops = 8.0 * n**3 * (6 + s)
+        unit = float(np.linalg.norm(e.conj().T @ e - np.eye(n)) / n) if n <= 2048 else None
+        print(json.dumps({"what": "expm", "n": n, "norm1": 2.0, "squarings": s, "wall_s_incl_pcie": round(dt, 4),
+                          "zgemm_launches": c["launches"], "zgemm_ms": round(c["ms"], 3),
+                          "tflops_in_zgemm": round(flops / (c["ms"] * 1e-3) / 1e12, 2),
+                          "unitarity_per_n": unit}), flush=True)
+
+if "cfg4" in which:
+    t0 = time.time()
+    cfg = workloads.lindblad_config()  # 6 qubits, N = 4096
+    amps, phases = workloads.sweep_parameters(0, 6)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       static_dissipators=cfg["static_dissipators"], vectorized=True)
+    build_s = time.time() - t0
+    nsteps = 5
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    r, dt = timed(lambda: solver.solve(t_span=[0.0, nsteps * cfg["max_dt"]], y0=cfg["rho0"].flatten(order="F"),
+                                       signals=sigs, method="scipy_expm", max_dt=cfg["max_dt"]))
+    cz, cg = ctx.counters("zgemm"), ctx.counters("gen_eval")
+    ctx.set_option("profile", 0)
+    rho = r.y[-1].reshape(64, 64, order="F")
+    print(json.dumps({"what": "cfg4 (6-qubit vectorised Lindblad, N=4096, scipy_expm m=1, no frame)",
+                      "steps": nsteps, "model_build_s": round(build_s, 1), "wall_s": round(dt, 3),
+                      "ms_per_step_device": round((cz["ms"] + cg["ms"]) / nsteps, 2),
+                      "zgemm_launches_per_step": cz["launches"] / nsteps, "zgemm_ms_per_step": round(cz["ms"] / nsteps, 2),
+                      "gen_eval_ms_per_step": round(cg["ms"] / nsteps, 3),
+                      "trace": float(abs(np.trace(rho))), "hermiticity": float(np.linalg.norm(rho - rho.conj().T))}),
+          flush=True)
+    del solver
+
+if "cfg5" in which:
+    t0 = time.time()
+    cfg = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
+    frame = np.diag(cfg["h_d"]).real.copy()
+    amps, phases = workloads.sweep_parameters(0, 8)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    hm = qd.HamiltonianModel(static_operator=cfg["h_d"], operators=cfg["ops"], signals=sigs, rotating_frame=frame)
+    build_s = time.time() - t0
+    nsteps = 2
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    r, dt = timed(lambda: qd.solve_lmde(hm, [0.0, nsteps * 0.25], cfg["y0"], method="scipy_expm", max_dt=0.25,
+                                        magnus_order=2))
+    cz, cg = ctx.counters("zgemm"), ctx.counters("gen_eval")
+    ctx.set_option("profile", 0)
+    print(json.dumps({"what": "cfg5 (12-qubit Schrodinger n=4096, diagonal frame, Magnus-2 expm), 1 instance",
+                      "steps": nsteps, "model_build_s": round(build_s, 1), "wall_s": round(dt, 3),
+                      "ms_per_instance_step_device": round((cz["ms"] + cg["ms"]) / nsteps, 2),
+                      "zgemm_launches_per_step": cz["launches"] / nsteps,
+                      "tflops_8n3_per_zgemm": round(8 * 4096.0**3 * cz["launches"] / (cz["ms"] * 1e-3) / 1e12, 2),
+                      "norm": float(np.linalg.norm(r.y[-1])), "segment_modes": hm.stack.segment_modes}), flush=True)
