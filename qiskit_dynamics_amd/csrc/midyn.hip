@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -37,7 +38,14 @@ struct midyn_ctx {
     std::string err;
     bool skip_zero_planes = true;
     bool profile = false;
-    int force_tile = 0;  // 0 auto, 64, 128
+    int force_tile = 0;  // 0 auto, 64, 128, 12864
+    bool prefer_duo = false;
+    int ablate = 0;
+    int stream_variant = 0;
+    bool split_k = true;
+    int force_splits = 0;
+    void* splitk_ws = nullptr;
+    size_t splitk_bytes = 0;
     std::vector<EventPair> pending;
     std::vector<hipEvent_t> pool;
     double cls_ms[KC_COUNT] = {0};
@@ -141,6 +149,7 @@ extern "C" int midyn_ctx_destroy(midyn_ctx* ctx) {
     drain_events(ctx);
     for (auto e : ctx->pool) hipEventDestroy(e);
     if (ctx->d_one_seg) hipFree(ctx->d_one_seg);
+    if (ctx->splitk_ws) hipFree(ctx->splitk_ws);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -161,6 +170,11 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
         if (!value) drain_events(ctx);
         ctx->profile = value != 0;
     } else if (n == "force_tile") ctx->force_tile = (int)value;
+    else if (n == "prefer_duo") ctx->prefer_duo = value != 0;
+    else if (n == "ablate") ctx->ablate = (int)value;
+    else if (n == "stream_variant") ctx->stream_variant = (int)value;
+    else if (n == "split_k") ctx->split_k = value != 0;
+    else if (n == "force_splits") ctx->force_splits = (int)value;
     else return fail(ctx, "midyn_ctx_set_option: unknown option " + n);
     return 0;
 }
@@ -383,18 +397,18 @@ extern "C" int midyn_stack_segment_modes(midyn_stack* s, int* modes) {
 // -------------------------------------------------------------------------------------------------
 // kernel launch helpers
 // -------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE>
 static int launch_gemm_mode(midyn_ctx* ctx, const GemmArgs& g) {
     constexpr int THREADS = 64 * WM * WN;
-    constexpr size_t SMEM = (size_t)2 * GEMM_BK * (BM + BN) * sizeof(double2);
+    constexpr size_t SMEM = (size_t)2 * BK * (BM + BN) * sizeof(double2);
     static bool attr_set[16] = {false};
-    auto kern = zgemm_seg_kernel<BM, BN, WM, WN, MODE>;
+    auto kern = zgemm_seg_kernel<BM, BN, WM, WN, BK, MODE>;
     if (!attr_set[ctx->device & 15]) {
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
         attr_set[ctx->device & 15] = true;
     }
-    const int blocks = (g.M / BM) * (g.N / BN);
+    const int blocks = (g.M / BM) * (g.N / BN) * g.splits;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(THREADS), SMEM, ctx->stream, g);
     HIPCHK(ctx, hipGetLastError());
     return 0;
@@ -402,37 +416,106 @@ static int launch_gemm_mode(midyn_ctx* ctx, const GemmArgs& g) {
 
 // uniform_mode: 0/1/2 when every active segment has that plane mode (straight-line specialised
 // kernel), 3 when the stack is mixed (per-segment run-time flags)
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK>
 static int launch_gemm_cfg(midyn_ctx* ctx, const GemmArgs& g, int uniform_mode) {
     switch (uniform_mode) {
-        case 0: return launch_gemm_mode<BM, BN, WM, WN, 0>(ctx, g);
-        case 1: return launch_gemm_mode<BM, BN, WM, WN, 1>(ctx, g);
-        case 2: return launch_gemm_mode<BM, BN, WM, WN, 2>(ctx, g);
-        default: return launch_gemm_mode<BM, BN, WM, WN, 3>(ctx, g);
+        case 0: return launch_gemm_mode<BM, BN, WM, WN, BK, 0>(ctx, g);
+        case 1: return launch_gemm_mode<BM, BN, WM, WN, BK, 1>(ctx, g);
+        case 2: return launch_gemm_mode<BM, BN, WM, WN, BK, 2>(ctx, g);
+        default: return launch_gemm_mode<BM, BN, WM, WN, BK, 3>(ctx, g);
     }
 }
 
 // tile choice: 128x128 (8 waves) when that still gives >= 1 block per CU, else 64x64 (4 waves)
-static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g, int cls, int uniform_mode = 0) {
-    if (g.M % 64 || g.N % 64 || g.K % GEMM_BK)
+static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int uniform_mode = 0) {
+    const GemmArgs& g0 = g_in;
+    if (g0.M % 64 || g0.N % 64 || g0.K % GEMM_BK)
         return fail(ctx, "launch_gemm: dimensions must be padded to 64/64/16");
-    if (g.n_act > 64)
+    if (g0.n_act > 64)
         return fail(ctx, "more than 64 non-zero operator segments are not supported by the MFMA contraction yet");
+    GemmArgs g = g_in;
+    g.ablate = ctx->ablate;
+    g.splits = 1;
+    g.partial = nullptr;
     ProfScope ps(ctx, cls);
     bool big = (g.M % 128 == 0) && (g.N % 128 == 0) &&
                ((long long)(g.M / 128) * (g.N / 128) >= (long long)ctx->num_cu);
-    if (ctx->force_tile == 64) big = false;
-    if (ctx->force_tile == 128 && g.M % 128 == 0 && g.N % 128 == 0) big = true;
-    if (big) return launch_gemm_cfg<128, 128, 2, 4>(ctx, g, uniform_mode);
-    return launch_gemm_cfg<64, 64, 2, 2>(ctx, g, uniform_mode);
+    // 128x64x8, 4 waves, 48 KB LDS: TWO independent workgroups per CU (one wave of each per SIMD),
+    // so one group's barrier/LDS-latency bubble is covered by the other group's MFMAs.
+    bool duo = (g.M % 128 == 0) && ((long long)(g.M / 128) * (g.N / 64) >= 2LL * ctx->num_cu);
+    if (ctx->force_tile == 64) big = duo = false;
+    if (ctx->force_tile == 128) {
+        duo = false;
+        big = g.M % 128 == 0 && g.N % 128 == 0;
+    }
+    if (ctx->force_tile == 12864) {
+        big = false;
+        duo = g.M % 128 == 0;
+    }
+    if (duo && ctx->prefer_duo) return launch_gemm_cfg<128, 64, 2, 2, 8>(ctx, g, uniform_mode);
+    if (big) return launch_gemm_cfg<128, 128, 2, 4, 16>(ctx, g, uniform_mode);
+    if (duo && ctx->force_tile == 12864) return launch_gemm_cfg<128, 64, 2, 2, 8>(ctx, g, uniform_mode);
+    // Fewer tiles than CUs: split the K loop over `splits` workgroups per tile (partials in a
+    // workspace, summed + epilogue in splitk_reduce_kernel) so that the whole chip contracts.
+    const bool t128 = (g.M % 128 == 0) && (g.N % 128 == 0) && ctx->force_tile != 64;
+    const int bmn = t128 ? 128 : 64;
+    const long long tiles = (long long)(g.M / bmn) * (g.N / bmn);
+    const int KT = g.K / GEMM_BK;
+    int splits = 1;
+    if (ctx->split_k && tiles < ctx->num_cu) {
+        while (splits * 2 * tiles <= ctx->num_cu && KT % (splits * 2) == 0 && KT / (splits * 2) >= 2) splits *= 2;
+    }
+    if (ctx->force_splits > 0 && KT % ctx->force_splits == 0) splits = ctx->force_splits;
+    if (splits > 1) {
+        const size_t need = (size_t)splits * g.M * g.N * sizeof(double2);
+        if (ctx->splitk_bytes < need) {
+            if (ctx->splitk_ws) hipFree(ctx->splitk_ws);
+            ctx->splitk_ws = nullptr;
+            ctx->splitk_bytes = 0;
+            HIPCHK(ctx, hipMalloc(&ctx->splitk_ws, need));
+            ctx->splitk_bytes = need;
+        }
+        g.splits = splits;
+        g.partial = static_cast<double2*>(ctx->splitk_ws);
+    }
+    int st = t128 ? launch_gemm_cfg<128, 128, 2, 4, 16>(ctx, g, uniform_mode)
+                  : launch_gemm_cfg<64, 64, 2, 2, 16>(ctx, g, uniform_mode);
+    if (st) return st;
+    if (splits > 1) {
+        if (getenv("MIDYN_DEBUG"))
+            fprintf(stderr, "[midyn] reduce: splits=%d M=%d N=%d mode=%d ld=%d y=%p acc=%p yin_next=%p out=%p ecur=%p enext=%p partial=%p\n",
+                    splits, g.M, g.N, g.epi.mode, g.epi.ld, (void*)g.epi.y, (void*)g.epi.acc, (void*)g.epi.yin_next,
+                    (void*)g.epi.out, (void*)g.epi.e_cur, (void*)g.epi.e_next, (void*)g.partial);
+        const dim3 rgrid(grid_for((size_t)g.M * g.N, 2048)), rblock(256);
+#define MIDYN_REDUCE(MODE_) \
+    hipLaunchKernelGGL(splitk_reduce_kernel<MODE_>, rgrid, rblock, 0, ctx->stream, g.partial, splits, g.M, g.N, g.epi)
+        switch (g.epi.mode) {
+            case EPI_RHS: MIDYN_REDUCE(EPI_RHS); break;
+            case EPI_RK1: MIDYN_REDUCE(EPI_RK1); break;
+            case EPI_RK2: MIDYN_REDUCE(EPI_RK2); break;
+            case EPI_RK3: MIDYN_REDUCE(EPI_RK3); break;
+            case EPI_RK4: MIDYN_REDUCE(EPI_RK4); break;
+            default: MIDYN_REDUCE(EPI_PLAIN); break;
+        }
+#undef MIDYN_REDUCE
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return 0;
 }
 
 static int launch_stream(midyn_ctx* ctx, const StreamArgs& a) {
     ProfScope ps(ctx, KC_STREAM);
-    if (a.n_pad >= 1024)
-        hipLaunchKernelGGL(rhs_stream_kernel<4>, dim3(a.n_pad), dim3(256), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(rhs_stream_kernel<1>, dim3(a.n_pad), dim3(256), 0, ctx->stream, a);
+    if (a.n_pad >= 1024) {
+        switch (ctx->stream_variant) {
+            case 1: hipLaunchKernelGGL((rhs_stream_kernel<4, 1>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a); break;
+            case 2: hipLaunchKernelGGL((rhs_stream_kernel<2, 3>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a); break;
+            case 3: hipLaunchKernelGGL((rhs_stream_kernel<4, 9>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a); break;
+            case 4: hipLaunchKernelGGL((rhs_stream_kernel<2, 9>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a); break;
+            default: hipLaunchKernelGGL((rhs_stream_kernel<4, 3>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a); break;
+        }
+    } else {
+        hipLaunchKernelGGL((rhs_stream_kernel<1, 1>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a);
+    }
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
