@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the cfg-2 single-trajectory leg")
     ap.add_argument("--dense", action="store_true",
                     help="disable exact-zero plane skipping (time the general dense-complex path)")
+    ap.add_argument("--full-solve", action="store_true",
+                    help="additionally run the complete 1000-step sweep through the Solver API (end-to-end wall clock)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: kernel ablation bits (results wrong)")
     ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 | 12864 (kernel A/B testing)")
     args = ap.parse_args()
@@ -299,6 +301,24 @@ def main():
             "sample": f"{n_inst} instances x {n_steps} RK4 steps ({n_inst * n_steps * 4} RHS evals) of the same "
                       f"model with the NumPy oracle (tensordot + matvec); best of BLAS thread counts 8/32/all on a "
                       f"{os.cpu_count()}-CPU host: {best[1]} threads, {best[2]:.1f} s"}
+    # ---- optional: the complete cfg-3 solve through the public Solver API (host work included) ----
+    if args.full_solve and rank == 0:
+        t0f = time.perf_counter()
+        solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+        t_model = time.perf_counter() - t0f
+        sig_lists = []
+        for b in range(b_loc):
+            sig_lists.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - T_FINAL / 2) ** 2) / (2 * 1.0**2)), nu, ph)
+                              for a, nu, ph in zip(amps[b], cfg["carrier"], phs[b])])
+        t1f = time.perf_counter()
+        res = solver.solve(t_span=cfg["t_span"], y0=cfg["y0"], signals=sig_lists, method="RK4", max_dt=MAX_DT)
+        t_solve = time.perf_counter() - t1f
+        yf = np.array([r.y[-1] for r in res])
+        out["full_solve"] = {
+            "what": f"Solver.solve of {b_loc} instances x 1000 RK4 steps, list mode -> one batched device solve",
+            "model_build_s": round(t_model, 2), "solve_s": round(t_solve, 2),
+            "rhs_evals_per_s_end_to_end": round(b_loc * 4000 / t_solve, 1),
+            "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(yf, axis=1) - 1.0)))}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

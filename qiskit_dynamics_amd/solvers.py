@@ -170,16 +170,14 @@ def _signal_table(model, signals, times) -> np.ndarray:
     return sl.table(times)
 
 
-def _prepare_y0(model, kind, y0):
-    """y0 -> frame basis, as a (rows, m) matrix for the device; returns (matrix, restore)."""
+def _shape_y0(model, kind, y0):
+    """Validate one initial state and return it as the (rows, m) matrix the device works on
+    (still in the user's basis) plus the tag needed to undo the reshaping."""
     y0 = np.asarray(y0, dtype=complex)
-    frame = model.rotating_frame
     n = model.dim
     if kind == "lindblad":
-        if y0.shape[-2:] != (n, n) or y0.ndim != 2:
+        if y0.ndim != 2 or y0.shape != (n, n):
             raise DynamicsError("Shape mismatch for initial state y0 and LindbladModel.")
-        if not model.in_frame_basis:
-            y0 = frame.operator_into_frame_basis(y0)
         return y0.flatten(order="F").reshape(-1, 1), "lindblad"
     rows = n * n if kind == "lindblad_vec" else n
     if y0.ndim not in (1, 2) or y0.shape[0] != rows:
@@ -187,35 +185,71 @@ def _prepare_y0(model, kind, y0):
             raise DynamicsError("Shape mismatch for initial state y0 and LindbladModel in vectorized "
                                 "evaluation mode.")
         raise DynamicsError("Shape mismatch for initial state y0 and HamiltonianModel.")
-    if not model.in_frame_basis:
-        if kind == "lindblad_vec":
-            if frame.frame_basis is not None:
-                y0 = frame.vectorized_frame_basis_adjoint @ y0
-        else:
-            y0 = frame.state_into_frame_basis(y0)
     if y0.ndim == 1:
         return y0.reshape(-1, 1), "vector"
     return y0, "matrix"
 
 
-def _restore_y(model, kind, shape_tag, ys):
-    """(P, rows, m) device result -> user layout, out of the frame basis when required."""
+def _basis_matrix(model, kind):
+    """Matrix V with (state in user basis) = V @ (state in frame basis), or None."""
     frame = model.rotating_frame
+    if model.in_frame_basis or frame.frame_basis is None:
+        return None
+    if kind in ("lindblad", "lindblad_vec"):
+        return frame.vectorized_frame_basis  # kron(conj(U), U): vec(U rho U^dagger) = V vec(rho)
+    return frame.frame_basis
+
+
+def _apply_basis(ctx, mat, cols):
+    """mat @ cols for a (rows, ncols) block: one device zgemm for wide blocks (a sweep's states),
+    a host matvec for a handful of columns."""
+    if cols.shape[1] >= 16:
+        return ctx.zgemm(mat, cols)
+    return mat @ cols
+
+
+def _prepare_y0_batch(model, kind, y0_list, shared):
+    """y0 (shared) or list of y0 -> frame basis, device layout (rows, m) / (B, rows, m)."""
+    shaped = [_shape_y0(model, kind, y0_list[0])] if shared else [_shape_y0(model, kind, y) for y in y0_list]
+    tags = {t for _, t in shaped}
+    shapes = {y.shape for y, _ in shaped}
+    if len(tags) != 1 or len(shapes) != 1:
+        raise DynamicsError("internal: batched instances must share the y0 shape")
+    tag = shaped[0][1]
+    v = _basis_matrix(model, kind)
+    if shared:
+        y = shaped[0][0]
+        if v is not None:
+            y = _apply_basis(model._ctx, v.conj().T, y)
+        return np.ascontiguousarray(y), tag
+    ys = np.stack([y for y, _ in shaped])  # (B, rows, m)
+    if v is not None:
+        b, rows, m = ys.shape
+        cols = np.ascontiguousarray(ys.transpose(1, 0, 2).reshape(rows, b * m))
+        cols = _apply_basis(model._ctx, v.conj().T, cols)
+        ys = cols.reshape(rows, b, m).transpose(1, 0, 2)
+    return np.ascontiguousarray(ys), tag
+
+
+def _restore_batch(model, kind, tag, ys):
+    """(B, P, rows, m) device result -> list of per-instance arrays in the user's layout, out of the
+    frame basis when required (ONE basis-change product for the whole sweep)."""
+    b, p, rows, m = ys.shape
+    v = _basis_matrix(model, kind)
+    if v is not None:
+        cols = np.ascontiguousarray(ys.transpose(2, 0, 1, 3).reshape(rows, b * p * m))
+        cols = _apply_basis(model._ctx, v, cols)
+        ys = cols.reshape(rows, b, p, m).transpose(1, 2, 0, 3)
     n = model.dim
-    if shape_tag == "lindblad":
-        out = np.stack([y[:, 0].reshape(n, n, order="F") for y in ys])
-        if not model.in_frame_basis:
-            out = frame.operator_out_of_frame_basis(out)
-        return out
-    if not model.in_frame_basis:
-        if kind == "lindblad_vec":
-            if frame.frame_basis is not None:
-                ys = frame.vectorized_frame_basis @ ys
-        elif frame.frame_basis is not None:
-            ys = frame.frame_basis @ ys
-    if shape_tag == "vector":
-        return ys[:, :, 0]
-    return ys
+    out = []
+    for i in range(b):
+        yi = ys[i]
+        if tag == "lindblad":
+            yi = np.stack([y[:, 0].reshape(n, n, order="F") for y in yi])
+        elif tag == "vector":
+            yi = yi[:, :, 0]
+        out.append(np.ascontiguousarray(yi))
+    return out
 
 
 def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_dt=None,
@@ -236,14 +270,8 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     else:
         raise DynamicsError(f"Method {method} not supported by solve_lmde.")
     batch = len(y0_list)
-    prepared = [_prepare_y0(model, kind, y0) for y0 in y0_list]
-    tags = {p[1] for p in prepared}
-    shapes = {p[0].shape for p in prepared}
-    if len(tags) != 1 or len(shapes) != 1:
-        raise DynamicsError("internal: batched instances must share the y0 shape")
-    tag = prepared[0][1]
     shared_y0 = all(y is y0_list[0] for y in y0_list)
-    y0_dev = prepared[0][0] if shared_y0 else np.stack([p[0] for p in prepared])
+    y0_dev, tag = _prepare_y0_batch(model, kind, y0_list, shared_y0)
     shared_sig = all(s is signals_list[0] for s in signals_list)
     if shared_sig:
         one = _signal_table(model, signals_list[0], sched.times)
@@ -258,8 +286,8 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
         ys = stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                               sched.n_save, magnus_order, y0_dev, batch, shared_y0)
     results = []
-    for b in range(batch):
-        t_out, y_out = sched.trim(_restore_y(model, kind, tag, ys[b]))
+    for y_b in _restore_batch(model, kind, tag, ys):
+        t_out, y_out = sched.trim(y_b)
         results.append(OdeResult(t=t_out, y=y_out))
     return results
 
