@@ -108,6 +108,27 @@ int midyn_expm_solve(midyn_stack* stack, int B, int m, int R, const double* time
                      int P, int magnus_order, const midyn_complex* y0, int y0_shared,
                      midyn_complex* Y_out);
 
+/* ---- non-vectorised Lindblad RHS -------------------------------------
+ * LindbladCollection.evaluate_rhs (models/operator_collections.py:451-567) with n x n zgemms:
+ *   rhs = (A+B) rho + rho (A-B) + sum_j N_j rho N_j^+ + sum_j gamma_j L_j rho L_j^+,
+ *   B = -iH(t), A = -1/2 sum N^+N - 1/2 sum gamma_j L_j^+L_j,
+ * evaluated in the rotating frame / frame basis as LindbladModel.evaluate_rhs does
+ * (models/lindblad_model.py:477-538).  `left` / `right` are operator stacks for A+B and A-B that
+ * share the coefficient vector c = (s_0..s_{k_h-1}, gamma_0..gamma_{n_dyn-1}) (the frame diagonal
+ * is taken from `left`); `dissipators` = [n_static + n_dyn][n][n], static ones first.
+ * rho is [batch][n][n]; the RK4 solve mirrors midyn_rk4_solve with rho0 [B or 1][n][n] and
+ * out [B][P][n][n]. */
+typedef struct midyn_lindblad midyn_lindblad;
+int midyn_lindblad_create(midyn_stack* left, midyn_stack* right, int k_h, int n_static, int n_dyn,
+                          const midyn_complex* dissipators, midyn_lindblad** out);
+int midyn_lindblad_destroy(midyn_lindblad* lind);
+int midyn_lindblad_rhs(midyn_lindblad* lind, const double* coeffs, double t, const midyn_complex* rho,
+                       int batch, midyn_complex* out);
+int midyn_lindblad_rk4_solve(midyn_lindblad* lind, int B, int R, const double* times, const double* S,
+                             int nsteps, const int* step_rows, const double* step_h,
+                             const int* step_save, int P, const midyn_complex* rho0, int rho0_shared,
+                             midyn_complex* out);
+
 /* ---- plain complex GEMM on the same MFMA kernel (yardstick + tests) --------------------------- */
 int midyn_zgemm(midyn_ctx* ctx, int M, int N, int K, const midyn_complex* A, const midyn_complex* B,
                 midyn_complex* C);

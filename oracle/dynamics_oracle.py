@@ -273,6 +273,35 @@ def vectorized_lindblad_stack(h_d, h_ops, n_static, l_ops):
     return s_d, s
 
 
+def lindblad_rhs(h_d, h_ops, n_static, l_ops, ham_coeffs, dis_coeffs, d, t, rho):
+    """Non-vectorised Lindblad RHS in the frame basis: LindbladCollection.evaluate_rhs
+    (models/operator_collections.py:451-567)  (A+B) rho + rho (A-B) + sum N rho N^+ + sum g L rho L^+
+    with B = -iH, A = -1/2 sum N^+N - 1/2 sum g_j L_j^+L_j, wrapped by the frame maps of
+    LindbladModel.evaluate_rhs (models/lindblad_model.py:510-531)."""
+    rho = np.asarray(rho, dtype=complex)
+    n = rho.shape[-1]
+    if d is not None:
+        e = np.exp(d * t)
+        rho = rho * (e.reshape(n, 1) * e.conj())          # operator_out_of_frame = into_frame(-t)
+    ham = None
+    if h_d is not None or h_ops is not None:
+        ham = -1j * collection_evaluate(h_d, h_ops, ham_coeffs)
+    amat = np.zeros((n, n), dtype=complex)
+    both = np.zeros_like(rho)
+    if n_static is not None:
+        amat = amat - 0.5 * np.sum(np.swapaxes(n_static.conj(), -1, -2) @ n_static, axis=0)
+        both = both + np.sum(n_static @ (rho[..., None, :, :] @ np.swapaxes(n_static.conj(), -1, -2)), axis=-3)
+    if l_ops is not None:
+        amat = amat - 0.5 * np.tensordot(dis_coeffs, np.swapaxes(l_ops.conj(), -1, -2) @ l_ops, axes=1)
+        mats = l_ops @ (rho[..., None, :, :] @ np.swapaxes(l_ops.conj(), -1, -2))
+        both = both + np.tensordot(dis_coeffs, mats, axes=(-1, -3))
+    hm = np.zeros((n, n), dtype=complex) if ham is None else ham
+    out = (hm + amat) @ rho + rho @ (amat - hm) + both
+    if d is not None:
+        out = out * (e.conj().reshape(n, 1) * e)           # operator_into_frame
+    return out
+
+
 def vectorized_frame_diag(d):
     """Diagonal D with  vec(exp(-tF) X exp(tF)) = exp(-D t) o vec(X)  in column stacking:
     D[r + n c] = d_r - d_c.  Equivalent to the N x N Hadamard mask built at

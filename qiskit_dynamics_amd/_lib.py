@@ -22,7 +22,8 @@ ABI_SYMBOLS = [
     "midyn_stack_destroy", "midyn_stack_info", "midyn_stack_segment_modes", "midyn_eval_generator", "midyn_eval_rhs",
     "midyn_rk4_solve", "midyn_expm", "midyn_expm_solve", "midyn_zgemm", "midyn_rk4_plan_create",
     "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_get_counters",
-    "midyn_reset_counters", "midyn_microbench",
+    "midyn_reset_counters", "midyn_microbench", "midyn_lindblad_create", "midyn_lindblad_destroy",
+    "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve",
 ]
 
 
@@ -116,6 +117,10 @@ def load():
         lib.midyn_get_counters.argtypes = [_vp, ctypes.c_char_p, P(_cd)]
         lib.midyn_reset_counters.argtypes = [_vp]
         lib.midyn_microbench.argtypes = [_vp, ctypes.c_char_p, P(_cd)]
+        lib.midyn_lindblad_create.argtypes = [_vp, _vp, _ci, _ci, _ci, _vp, P(_vp)]
+        lib.midyn_lindblad_destroy.argtypes = [_vp]
+        lib.midyn_lindblad_rhs.argtypes = [_vp, _vp, _cd, _vp, _ci, _vp]
+        lib.midyn_lindblad_rk4_solve.argtypes = [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp]
         for name in ABI_SYMBOLS:
             if name != "midyn_last_error":
                 getattr(lib, name).restype = _ci
@@ -364,6 +369,58 @@ class Rk4Plan:
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle:
             self.stack.ctx.lib.midyn_rk4_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+class LindbladDevice:
+    """Non-vectorised Lindblad RHS on the device (``midyn_lindblad``): two operator stacks (A+B, A-B)
+    sharing one coefficient vector, plus the dissipators [static..., dynamic...], all in the frame basis."""
+
+    def __init__(self, left: Stack, right: Stack, k_h: int, n_static: int, n_dyn: int, dissipators):
+        self.left, self.right, self.ctx = left, right, left.ctx
+        self.n = left.n
+        self.k = left.k
+        d = None if dissipators is None else c128(dissipators)
+        h = _vp()
+        self.ctx.check(self.ctx.lib.midyn_lindblad_create(left.handle, right.handle, int(k_h), int(n_static),
+                                                         int(n_dyn), _ptr(d), ctypes.byref(h)))
+        self.handle = h
+
+    def rhs(self, coeffs, t, rho):
+        rho = c128(rho)
+        single = rho.ndim == 2
+        r = rho[None] if single else rho
+        if r.shape[1:] != (self.n, self.n):
+            raise DynamicsError("Shape mismatch for initial state y0 and LindbladModel.")
+        c = None if self.k == 0 else f64(coeffs)
+        out = np.empty_like(r)
+        self.ctx.check(self.ctx.lib.midyn_lindblad_rhs(self.handle, _ptr(c), float(t), _ptr(r), r.shape[0], _ptr(out)))
+        return out[0] if single else out
+
+    def rk4_solve(self, times, table, step_rows, step_h, step_save, n_save, rho0, batch, shared):
+        times = f64(times)
+        r = times.shape[0]
+        table = f64(table) if self.k > 0 else None
+        if table is not None and table.shape != (batch, r, self.k):
+            raise DynamicsError(f"coefficient table must be (B,R,k)={(batch, r, self.k)}, got {table.shape}")
+        step_rows = i32(step_rows).reshape(-1, 3)
+        step_h, step_save = f64(step_h), i32(step_save)
+        rho0 = c128(rho0)
+        out = np.empty((batch, n_save, self.n, self.n), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.midyn_lindblad_rk4_solve(
+            self.handle, batch, r, _ptr(times), _ptr(table), step_rows.shape[0], _ptr(step_rows), _ptr(step_h),
+            _ptr(step_save), n_save, _ptr(rho0), int(bool(shared)), _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:
+            self.ctx.lib.midyn_lindblad_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

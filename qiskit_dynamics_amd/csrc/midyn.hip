@@ -43,6 +43,7 @@ struct midyn_ctx {
     int ablate = 0;
     int stream_variant = 0;
     bool split_k = true;
+    bool combine_first = true;
     int force_splits = 0;
     void* splitk_ws = nullptr;
     size_t splitk_bytes = 0;
@@ -174,6 +175,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     else if (n == "ablate") ctx->ablate = (int)value;
     else if (n == "stream_variant") ctx->stream_variant = (int)value;
     else if (n == "split_k") ctx->split_k = value != 0;
+    else if (n == "combine_first") ctx->combine_first = value != 0;
     else if (n == "force_splits") ctx->force_splits = (int)value;
     else return fail(ctx, "midyn_ctx_set_option: unknown option " + n);
     return 0;
@@ -655,7 +657,8 @@ struct midyn_rk4_plan {
     midyn_stack* stack = nullptr;
     int B = 0, m = 0, ncol = 0, ld = 0, R = 0, nsteps = 0, P = 0;
     bool stream_path = false;
-    DevBuf d_S, d_times, d_E, d_y, d_acc, d_yin[2], d_out, d_tmp;
+    DevBuf d_S, d_times, d_E, d_y, d_acc, d_yin[2], d_out, d_tmp, d_G;
+    bool combine_first = false;  // one instance, many columns: form C(t) once, then ONE n^3 zgemm
     std::vector<int> rows;     // [nsteps][3]
     std::vector<double> hs;    // [nsteps]
     std::vector<int> save;     // [nsteps] or empty
@@ -681,6 +684,32 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
         a.yin = yin;
         a.epi = epi;
         return launch_stream(ctx, a);
+    }
+    if (p->combine_first) {
+        // All columns share the coefficients (B == 1): C(t) = sum_seg c_seg A_seg costs nseg*n^2
+        // element operations, after which the contraction is a single n x n x (m) zgemm instead of
+        // nseg of them (unitary / propagator simulations with m ~ n: nseg-fold fewer flops).
+        const double* cf = s->k > 0 ? p->d_S.as<double>() + (size_t)row * s->k : nullptr;
+        CHK(launch_gen_eval(s, cf, nullptr, 1.0, p->d_G.as<double2>()));
+        GemmArgs g{};
+        g.A = p->d_G.as<double2>();
+        g.a_seg_stride = 0;
+        g.lda = s->n_pad;
+        g.B = yin;
+        g.ldb = p->ld;
+        g.M = s->n_pad;
+        g.N = p->ld;
+        g.K = s->n_pad;
+        g.seg_list = ctx->d_one_seg;
+        g.n_act = 1;
+        g.has_static = 0;
+        g.coeff = nullptr;
+        g.inst_stride = 0;
+        g.m_cols = p->m;
+        g.n_inst = 1;
+        g.epi = epi;
+        const int um = (ctx->skip_zero_planes && (s->uniform_mode == 1 || s->uniform_mode == 2)) ? s->uniform_mode : 0;
+        return launch_gemm(ctx, g, KC_RHS_GEMM, um);
     }
     GemmArgs g{};
     g.A = s->ops;
@@ -742,6 +771,8 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
     const size_t y0_elems = (size_t)(y0_shared ? 1 : B) * s->n * m;
     guard(p->d_tmp.alloc(ctx, y0_elems * sizeof(double2)));
     if (P > 0) guard(p->d_out.alloc(ctx, (size_t)B * P * s->n * m * sizeof(double2)));
+    p->combine_first = (B == 1 && m >= 8 && s->nseg > 1 && ctx->combine_first);
+    if (p->combine_first) guard(p->d_G.alloc(ctx, (size_t)s->n_pad * s->n_pad * sizeof(double2)));
     if (st) {
         delete p;
         return st;
@@ -1195,6 +1226,226 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
         HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b * P * inst_elems, d_out.p, (size_t)P * inst_elems * sizeof(double2),
                               hipMemcpyDeviceToHost));
     }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Non-vectorised Lindblad RHS with n x n zgemms (SURVEY section 8 row f2;
+// LindbladCollection.evaluate_rhs, models/operator_collections.py:451-567):
+//     rhs = (A + B) rho + rho (A - B) + sum_j N_j rho N_j^+ + sum_j gamma_j(t) L_j rho L_j^+
+//     B = -i H(t),  A = -1/2 sum N^+N - 1/2 sum gamma_j L_j^+ L_j
+// The caller passes two ordinary operator stacks that share one coefficient vector c = (s, gamma):
+//     left  = A + B = [ -iH_d - 1/2 sum N^+N ;  -iH_j ;  -1/2 L_j^+L_j ]
+//     right = A - B = [ +iH_d - 1/2 sum N^+N ;  +iH_j ;  -1/2 L_j^+L_j ]
+// and the dissipators N_j (coefficient 1) followed by L_j.  In a rotating frame (frame basis)
+//     rhs = conj(e_a) e_b o R( e_a conj(e_b) o rho ),  e = exp(d t)   (lindblad_model.py:477-538).
+// Per evaluation: 2 gen_eval passes (HBM bound) + (2 + 2 n_diss) zgemm of n^3 (MFMA bound).
+// -------------------------------------------------------------------------------------------------
+struct midyn_lindblad {
+    midyn_ctx* ctx = nullptr;
+    midyn_stack* left = nullptr;
+    midyn_stack* right = nullptr;
+    int n = 0, np = 0, k = 0, k_h = 0, n_static = 0, n_dyn = 0;
+    DevBuf diss, diss_adj;           // [n_static + n_dyn][np][np]
+    DevBuf ML, MR, Xp, T, R, Y, Yt, K[4], coeff, E;
+};
+
+extern "C" int midyn_lindblad_create(midyn_stack* left, midyn_stack* right, int k_h, int n_static, int n_dyn,
+                                     const midyn_complex* dissipators, midyn_lindblad** out) {
+    if (!left || !right || !out) return fail(nullptr, "midyn_lindblad_create: NULL argument");
+    midyn_ctx* ctx = left->ctx;
+    if (right->ctx != ctx || right->n != left->n || right->k != left->k)
+        return fail(ctx, "midyn_lindblad_create: left/right stacks do not match");
+    if (k_h < 0 || n_static < 0 || n_dyn < 0 || k_h + n_dyn != left->k)
+        return fail(ctx, "midyn_lindblad_create: k_h + n_dyn must equal the number of stack operators");
+    if (n_static + n_dyn > 0 && !dissipators) return fail(ctx, "midyn_lindblad_create: dissipators is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    midyn_lindblad* L = new midyn_lindblad();
+    L->ctx = ctx;
+    L->left = left;
+    L->right = right;
+    L->n = left->n;
+    L->np = left->n_pad;
+    L->k = left->k;
+    L->k_h = k_h;
+    L->n_static = n_static;
+    L->n_dyn = n_dyn;
+    const int nd = n_static + n_dyn;
+    const size_t mat = (size_t)L->np * L->np * sizeof(double2);
+    int st = 0;
+    auto guard = [&](int r) { if (r && !st) st = r; };
+    if (nd > 0) {
+        guard(L->diss.alloc(ctx, mat * nd));
+        guard(L->diss_adj.alloc(ctx, mat * nd));
+    }
+    for (DevBuf* b : {&L->ML, &L->MR, &L->Xp, &L->T, &L->R, &L->Y, &L->Yt, &L->K[0], &L->K[1], &L->K[2], &L->K[3]})
+        guard(b->alloc(ctx, mat));
+    guard(L->coeff.alloc(ctx, std::max(1, L->k) * sizeof(double)));
+    guard(L->E.alloc(ctx, (size_t)L->np * sizeof(double2)));
+    if (st) {
+        delete L;
+        return st;
+    }
+    if (nd > 0) {
+        hipMemset(L->diss.p, 0, mat * nd);
+        hipMemset(L->diss_adj.p, 0, mat * nd);
+        std::vector<midyn_complex> adj((size_t)L->n * L->n);
+        for (int j = 0; j < nd; ++j) {
+            const midyn_complex* src = dissipators + (size_t)j * L->n * L->n;
+            for (int a = 0; a < L->n; ++a)
+                for (int b = 0; b < L->n; ++b) {
+                    adj[(size_t)b * L->n + a].re = src[(size_t)a * L->n + b].re;
+                    adj[(size_t)b * L->n + a].im = -src[(size_t)a * L->n + b].im;
+                }
+            if (upload_padded(ctx, src, L->n, L->n, L->diss.as<double2>() + (size_t)j * L->np * L->np, L->np) ||
+                upload_padded(ctx, adj.data(), L->n, L->n, L->diss_adj.as<double2>() + (size_t)j * L->np * L->np, L->np)) {
+                delete L;
+                return 1;
+            }
+        }
+    }
+    *out = L;
+    return 0;
+}
+
+extern "C" int midyn_lindblad_destroy(midyn_lindblad* L) {
+    if (!L) return 0;
+    hipSetDevice(L->ctx->device);
+    hipStreamSynchronize(L->ctx->stream);
+    delete L;
+    return 0;
+}
+
+// out = rhs(t, X) on device buffers (np x np, ld np); coefficients c_host (k) are also copied to the device
+static int lindblad_rhs_dev(midyn_lindblad* L, const double* c_host, double t, const double2* X, double2* out) {
+    midyn_ctx* ctx = L->ctx;
+    const int np = L->np;
+    const bool framed = L->left->has_frame;
+    if (L->k > 0)
+        HIPCHK(ctx, hipMemcpyAsync(L->coeff.p, c_host, L->k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const double2* Xin = X;
+    if (framed) {
+        // phases for this time: a one-row phase table written by phase_table_kernel
+        double* d_t = reinterpret_cast<double*>(L->T.p);  // scratch: T is free here
+        HIPCHK(ctx, hipMemcpyAsync(d_t, &t, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(phase_table_kernel, dim3(grid_for(np)), dim3(256), 0, ctx->stream, L->left->frame_im, d_t, np,
+                           1, L->E.as<double2>());
+        hipLaunchKernelGGL(frame_mask_kernel, dim3(grid_for((size_t)np * np)), dim3(256), 0, ctx->stream, X,
+                           L->E.as<double2>(), np, +1, L->Xp.as<double2>());
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // &t / c_host are caller stack memory
+        Xin = L->Xp.as<double2>();
+    } else if (L->k > 0) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const double* dc = L->k > 0 ? L->coeff.as<double>() : nullptr;
+    CHK(launch_gen_eval(L->left, dc, nullptr, 1.0, L->ML.as<double2>()));
+    CHK(launch_gen_eval(L->right, dc, nullptr, 1.0, L->MR.as<double2>()));
+    double2* R = L->R.as<double2>();
+    CHK(dev_zgemm(ctx, np, np, np, L->ML.as<double2>(), np, Xin, np, R, np, 1.0, 0.0, nullptr));
+    CHK(dev_zgemm(ctx, np, np, np, Xin, np, L->MR.as<double2>(), np, R, np, 1.0, 1.0, R));
+    const size_t mat = (size_t)np * np;
+    for (int j = 0; j < L->n_static + L->n_dyn; ++j) {
+        const double gam = j < L->n_static ? 1.0 : c_host[L->k_h + (j - L->n_static)];
+        if (gam == 0.0) continue;
+        CHK(dev_zgemm(ctx, np, np, np, L->diss.as<double2>() + j * mat, np, Xin, np, L->T.as<double2>(), np, 1.0, 0.0,
+                      nullptr));
+        CHK(dev_zgemm(ctx, np, np, np, L->T.as<double2>(), np, L->diss_adj.as<double2>() + j * mat, np, R, np, gam, 1.0, R));
+    }
+    if (framed) {
+        hipLaunchKernelGGL(frame_mask_kernel, dim3(grid_for((size_t)np * np)), dim3(256), 0, ctx->stream, R,
+                           L->E.as<double2>(), np, -1, out);
+        HIPCHK(ctx, hipGetLastError());
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(out, R, mat * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return 0;
+}
+
+extern "C" int midyn_lindblad_rhs(midyn_lindblad* L, const double* coeffs, double t, const midyn_complex* rho, int batch,
+                                  midyn_complex* out) {
+    if (!L || !rho || !out || batch <= 0) return fail(L ? L->ctx : nullptr, "midyn_lindblad_rhs: bad argument");
+    midyn_ctx* ctx = L->ctx;
+    if (L->k > 0 && !coeffs) return fail(ctx, "midyn_lindblad_rhs: coeffs is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nn = (size_t)L->n * L->n;
+    for (int b = 0; b < batch; ++b) {
+        HIPCHK(ctx, hipMemsetAsync(L->Y.p, 0, L->Y.bytes, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        CHK(upload_padded(ctx, rho + b * nn, L->n, L->n, L->Y.as<double2>(), L->np));
+        CHK(lindblad_rhs_dev(L, coeffs, t, L->Y.as<double2>(), L->K[0].as<double2>()));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy2D(out + b * nn, (size_t)L->n * sizeof(double2), L->K[0].p, (size_t)L->np * sizeof(double2),
+                                (size_t)L->n * sizeof(double2), L->n, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+extern "C" int midyn_lindblad_rk4_solve(midyn_lindblad* L, int B, int R, const double* times, const double* S,
+                                        int nsteps, const int* step_rows, const double* step_h, const int* step_save,
+                                        int P, const midyn_complex* rho0, int rho0_shared, midyn_complex* out) {
+    if (!L || !times || !step_rows || !step_h || !rho0 || !out)
+        return fail(L ? L->ctx : nullptr, "midyn_lindblad_rk4_solve: NULL argument");
+    midyn_ctx* ctx = L->ctx;
+    if (B <= 0 || R <= 0 || P < 1) return fail(ctx, "midyn_lindblad_rk4_solve: bad sizes");
+    if (L->k > 0 && !S) return fail(ctx, "midyn_lindblad_rk4_solve: S is NULL");
+    for (int i = 0; i < 3 * nsteps; ++i)
+        if (step_rows[i] < 0 || step_rows[i] >= R) return fail(ctx, "midyn_lindblad_rk4_solve: step_rows out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int np = L->np;
+    const size_t nn = (size_t)L->n * L->n;
+    double2 *Y = L->Y.as<double2>(), *Yt = L->Yt.as<double2>();
+    double2* K[4] = {L->K[0].as<double2>(), L->K[1].as<double2>(), L->K[2].as<double2>(), L->K[3].as<double2>()};
+    std::vector<double> zero(std::max(1, L->k), 0.0);
+    for (int b = 0; b < B; ++b) {
+        const midyn_complex* r0 = rho0 + (rho0_shared ? 0 : (size_t)b * nn);
+        midyn_complex* ob = out + (size_t)b * P * nn;
+        HIPCHK(ctx, hipMemsetAsync(L->Y.p, 0, L->Y.bytes, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        CHK(upload_padded(ctx, r0, L->n, L->n, Y, np));
+        memcpy(ob, r0, nn * sizeof(midyn_complex));
+        auto cf = [&](int row) { return L->k > 0 ? S + ((size_t)b * R + row) * L->k : zero.data(); };
+        for (int st = 0; st < nsteps; ++st) {
+            const double h = step_h[st];
+            const int* rr = step_rows + 3 * st;
+            // fixed_step_solvers.py:62-73
+            CHK(lindblad_rhs_dev(L, cf(rr[0]), times[rr[0]], Y, K[0]));
+            {
+                const double2* xs[2] = {Y, K[0]};
+                double al[2] = {1.0, 0.5 * h};
+                CHK(dev_lincomb(ctx, np, Yt, 2, xs, al, 0.0));
+            }
+            CHK(lindblad_rhs_dev(L, cf(rr[1]), times[rr[1]], Yt, K[1]));
+            {
+                const double2* xs[2] = {Y, K[1]};
+                double al[2] = {1.0, 0.5 * h};
+                CHK(dev_lincomb(ctx, np, Yt, 2, xs, al, 0.0));
+            }
+            CHK(lindblad_rhs_dev(L, cf(rr[1]), times[rr[1]], Yt, K[2]));
+            {
+                const double2* xs[2] = {Y, K[2]};
+                double al[2] = {1.0, h};
+                CHK(dev_lincomb(ctx, np, Yt, 2, xs, al, 0.0));
+            }
+            CHK(lindblad_rhs_dev(L, cf(rr[2]), times[rr[2]], Yt, K[3]));
+            {
+                const double2* xs[4] = {K[0], K[1], K[2], K[3]};
+                double al[4] = {1.0, 2.0, 2.0, 1.0};
+                CHK(dev_lincomb(ctx, np, Yt, 4, xs, al, 0.0));
+                const double2* ys[2] = {Y, Yt};
+                double bl[2] = {1.0, (1.0 / 6) * h};
+                CHK(dev_lincomb(ctx, np, Y, 2, ys, bl, 0.0));
+            }
+            if (step_save && step_save[st] >= 0) {
+                if (step_save[st] >= P) return fail(ctx, "midyn_lindblad_rk4_solve: save slot out of range");
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                HIPCHK(ctx, hipMemcpy2D(ob + (size_t)step_save[st] * nn, (size_t)L->n * sizeof(double2), Y,
+                                        (size_t)np * sizeof(double2), (size_t)L->n * sizeof(double2), L->n,
+                                        hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -763,6 +763,21 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const double2* src, int src
     }
 }
 
+// X[a][b] *= e_a * conj(e_b)  (dir = +1: operator OUT of the frame, rotating_frame.py:397-436 with -t)
+//           or conj(e_a) * e_b (dir = -1: operator INTO the frame, :372-395), e = exp(d t); in place or to dst
+__global__ __launch_bounds__(256) void frame_mask_kernel(const double2* src, const double2* e, int n_pad, int dir,
+                                                         double2* dst) {
+    const size_t total = (size_t)n_pad * n_pad;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int a = (int)(idx / n_pad);
+        const int b = (int)(idx - (size_t)a * n_pad);
+        const double2 ea = e[a], eb = e[b];
+        const double2 ph = dir > 0 ? cmul_conj_a(eb, ea) : cmul_conj_a(ea, eb);
+        dst[idx] = cmul(ph, src[idx]);
+    }
+}
+
 // ---- micro-benchmarks: the ceilings the roofline fractions are quoted against -------------------
 // 8 independent fp64 MFMA accumulators per wave (all in VGPRs), `iters` rounds, 4 waves per SIMD:
 // pure matrix-pipe throughput.

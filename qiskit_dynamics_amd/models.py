@@ -238,11 +238,9 @@ class HamiltonianModel(GeneratorModel):
 
 class LindbladModel(BaseGeneratorModel):
     """Lindblad master equation.  ``vectorized=True`` (needed by the LMDE/expm methods, as in the
-    reference) turns it into a dim^2 generator model handled by the same device kernels; the
-    non-vectorised ``evaluate_rhs`` is served through the same superoperator (small systems only --
-    the dedicated n x n kernel is the 'next' row f2 of SURVEY.md section 8)."""
-
-    _MAX_UNVECTORIZED_DIM = 64
+    reference) turns it into a dim^2 generator model handled by the same device kernels;
+    ``vectorized=False`` evaluates ``(A+B) rho + rho (A-B) + sum gamma L rho L^+`` with n x n MFMA
+    zgemms on the device (``_lib.LindbladDevice``; no dim^2 x dim^2 superoperator is ever built)."""
 
     def __init__(self, static_hamiltonian=None, hamiltonian_operators=None, hamiltonian_signals=None,
                  static_dissipators=None, dissipator_operators=None, dissipator_signals=None,
@@ -292,10 +290,14 @@ class LindbladModel(BaseGeneratorModel):
             if x is not None:
                 self._dim = x.shape[-1]
                 break
-        if not vectorized and self._dim > self._MAX_UNVECTORIZED_DIM:
-            raise DynamicsError(
-                "non-vectorised LindbladModel beyond dim "
-                f"{self._MAX_UNVECTORIZED_DIM} is not on the HIP path yet; use vectorized=True.")
+        self._ctx = context or _lib.default_context()
+        self._hamiltonian_signals = None
+        self._dissipator_signals = None
+        self._lind = None
+        if not vectorized:
+            self._build_unvectorized()
+            self.signals = (hamiltonian_signals, dissipator_signals)
+            return
         # superoperator stack (column stacking): static = vec_comm(H_d) + sum vec_diss(N_j),
         # operators = [vec_comm(H_j) ; vec_diss(L_j)]
         s_d = None
@@ -312,11 +314,43 @@ class LindbladModel(BaseGeneratorModel):
         s_ops = None
         if parts:
             s_ops = parts[0] if len(parts) == 1 else np.append(parts[0], parts[1], axis=0)
-        self._ctx = context or _lib.default_context()
         self._stack = _lib.Stack(self._ctx, s_ops, s_d, frame.vectorized_frame_diag_imag())
-        self._hamiltonian_signals = None
-        self._dissipator_signals = None
         self.signals = (hamiltonian_signals, dissipator_signals)
+
+    def _build_unvectorized(self):
+        """Operator stacks of the non-vectorised RHS (operator_collections.py:451-567):
+        left = A + B, right = A - B with B = -iH, A = -1/2 sum N^+N - 1/2 sum gamma_j L_j^+L_j; both
+        share the coefficient vector (ham signals, dissipator signals)."""
+        n = self._dim
+
+        def ldl(x):
+            return np.swapaxes(x.conj(), -1, -2) @ x
+
+        a_static = None if self._n_static is None else -0.5 * np.sum(ldl(self._n_static), axis=0)
+        left_static = right_static = None
+        if self._h_d is not None or a_static is not None:
+            hd = np.zeros((n, n), dtype=complex) if self._h_d is None else self._h_d
+            az = np.zeros((n, n), dtype=complex) if a_static is None else a_static
+            left_static, right_static = -1j * hd + az, 1j * hd + az
+        lops, rops = [], []
+        if self._h_ops is not None:
+            lops.append(-1j * self._h_ops)
+            rops.append(1j * self._h_ops)
+        if self._l_ops is not None:
+            half = -0.5 * ldl(self._l_ops)
+            lops.append(half)
+            rops.append(half)
+        left_ops = np.concatenate(lops, axis=0) if lops else None
+        right_ops = np.concatenate(rops, axis=0) if rops else None
+        fim = self._rotating_frame.frame_diag_imag
+        self._stack = _lib.Stack(self._ctx, left_ops, left_static, fim)
+        self._stack_right = _lib.Stack(self._ctx, right_ops, right_static, fim)
+        diss = [x for x in (self._n_static, self._l_ops) if x is not None]
+        n_static = 0 if self._n_static is None else self._n_static.shape[0]
+        n_dyn = 0 if self._l_ops is None else self._l_ops.shape[0]
+        k_h = 0 if self._h_ops is None else self._h_ops.shape[0]
+        self._lind = _lib.LindbladDevice(self._stack, self._stack_right, k_h, n_static, n_dyn,
+                                         np.concatenate(diss, axis=0) if diss else None)
 
     # -- properties -----------------------------------------------------------------------------
     @property
@@ -470,14 +504,14 @@ class LindbladModel(BaseGeneratorModel):
             if rotate:
                 out = self._rotating_frame.vectorized_frame_basis @ out
             return out
-        # non-vectorised: (n,n) or (l,n,n) density matrices through the superoperator
+        # non-vectorised: (n,n) or (l,n,n) density matrices, n x n zgemms on the device
         single = y.ndim == 2
         rho = y[None] if single else y
+        if rho.ndim != 3 or rho.shape[1:] != (n, n):
+            raise DynamicsError("Shape mismatch for initial state y0 and LindbladModel.")
         if rotate:
             rho = basis.conj().T @ rho @ basis
-        cols = np.stack([r.flatten(order="F") for r in rho], axis=1)  # (n^2, l)
-        out = self._stack.eval_rhs(coeffs, time, cols)
-        res = np.stack([out[:, i].reshape(n, n, order="F") for i in range(out.shape[1])])
+        res = self._lind.rhs(coeffs, time, rho)
         if rotate:
             res = basis @ res @ basis.conj().T
         return res[0] if single else res

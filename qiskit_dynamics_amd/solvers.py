@@ -271,6 +271,8 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
         raise DynamicsError(f"Method {method} not supported by solve_lmde.")
     batch = len(y0_list)
     shared_y0 = all(y is y0_list[0] for y in y0_list)
+    if kind == "lindblad":
+        return _solve_batch_lindblad(model, sched, y0_list, signals_list, shared_y0)
     y0_dev, tag = _prepare_y0_batch(model, kind, y0_list, shared_y0)
     shared_sig = all(s is signals_list[0] for s in signals_list)
     if shared_sig:
@@ -288,6 +290,45 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     results = []
     for y_b in _restore_batch(model, kind, tag, ys):
         t_out, y_out = sched.trim(y_b)
+        results.append(OdeResult(t=t_out, y=y_out))
+    return results
+
+
+def _rotate_density(model, mats, into_frame_basis):
+    """U^+ rho U (into) or U rho U^+ (out of the frame basis) for a stack of matrices."""
+    basis = model.rotating_frame.frame_basis
+    if model.in_frame_basis or basis is None:
+        return mats
+    ctx = model._ctx
+    a, b = (basis.conj().T, basis) if into_frame_basis else (basis, basis.conj().T)
+    n = basis.shape[0]
+    if n < 128:
+        return a @ mats @ b
+    return np.stack([ctx.zgemm(ctx.zgemm(a, m), b) for m in mats.reshape(-1, n, n)]).reshape(mats.shape)
+
+
+def _solve_batch_lindblad(model, sched, y0_list, signals_list, shared_y0):
+    """Non-vectorised Lindblad RK4: states are (n, n) density matrices, RHS by n x n zgemms."""
+    n = model.dim
+    batch = len(y0_list)
+    mats = [np.asarray(y0_list[0], dtype=complex)] if shared_y0 else [np.asarray(y, dtype=complex) for y in y0_list]
+    for m_ in mats:
+        if m_.shape != (n, n):
+            raise DynamicsError("Shape mismatch for initial state y0 and LindbladModel.")
+    rho0 = _rotate_density(model, np.stack(mats), True)
+    rho0 = rho0[0] if shared_y0 else rho0
+    shared_sig = all(s is signals_list[0] for s in signals_list)
+    if shared_sig:
+        one = _signal_table(model, signals_list[0], sched.times)
+        table = np.broadcast_to(one, (batch,) + one.shape)
+    else:
+        table = np.stack([_signal_table(model, s, sched.times) for s in signals_list])
+    ys = model._lind.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save,
+                               rho0, batch, shared_y0)
+    ys = _rotate_density(model, ys, False)
+    results = []
+    for b in range(batch):
+        t_out, y_out = sched.trim(ys[b])
         results.append(OdeResult(t=t_out, y=y_out))
     return results
 

@@ -606,3 +606,71 @@ def test_stack_adopt_roundtrip(tmp_path):
     script.write_text(ADOPT_SCRIPT)
     p = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "ADOPT_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def test_lindblad_unvectorized_large(qd):
+    """Row f2 at a size where the superoperator cannot exist (n=256 -> N=65536): device n x n zgemm
+    RHS against the oracle formula, batched rho input, and RK4 invariants (trace, Hermiticity)."""
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(256)
+    n = 256
+
+    def herm(k=1.0):
+        a = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+        return k * (a + a.conj().T) / np.sqrt(n)
+
+    h_static, h_ops = herm(), np.array([herm(0.5), herm(0.3)])
+    n_stat = (rng.normal(size=(2, n, n)) + 1j * rng.normal(size=(2, n, n))) * 0.05 / np.sqrt(n)
+    l_ops = (rng.normal(size=(1, n, n)) + 1j * rng.normal(size=(1, n, n))) * 0.05 / np.sqrt(n)
+    frame = np.diag(h_static).real.copy()
+    hsig = [qd.Signal(0.7, 0.3, 0.2), qd.Signal(lambda t: 0.4 * np.sin(2 * t) + 0j, 0.1)]
+    dsig = [qd.Signal(lambda t: 0.5 + 0.1 * np.cos(t) + 0j, 0.0)]
+    m = qd.LindbladModel(static_hamiltonian=h_static, hamiltonian_operators=h_ops, hamiltonian_signals=hsig,
+                         static_dissipators=n_stat, dissipator_operators=l_ops, dissipator_signals=dsig,
+                         rotating_frame=frame, vectorized=False)
+    a = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    rho = a @ a.conj().T
+    rho /= np.trace(rho)
+    h_d, ho, ns, lo, d, basis = orc.lindblad_model_build(h_static, h_ops, n_stat, l_ops, frame)
+    t = 0.37
+    hc = np.array([s(t) for s in hsig])
+    dc = np.array([s(t) for s in dsig])
+    ref = orc.lindblad_rhs(h_d, ho, ns, lo, hc, dc, d, t, rho)
+    assert_close(m.evaluate_rhs(t, rho), ref, EVAL_TOL)
+    both = m.evaluate_rhs(t, np.stack([rho, 2 * rho]))
+    assert_close(both[1], 2 * ref, EVAL_TOL)
+    r = qd.solve_lmde(m, [0.0, 0.05], rho, method="RK4", max_dt=0.01)
+    rf = r.y[-1]
+    assert abs(np.trace(rf) - 1.0) < 1e-10
+    assert np.linalg.norm(rf - rf.conj().T) < 1e-10
+
+    def rhs(tt, y):
+        return orc.lindblad_rhs(h_d, ho, ns, lo, np.array([s(tt) for s in hsig]),
+                                np.array([s(tt) for s in dsig]), d, tt, y)
+
+    _, yref = orc.rk4_solve(rhs, [0.0, 0.05], rho, 0.01)
+    assert_close(rf, yref[-1], SOLVE_TOL)
+
+
+def test_single_instance_many_columns_fast_path(qd, cfg2):
+    """B = 1 with m >= 8 columns forms C(t) once and runs ONE zgemm per stage; it must agree with the
+    per-segment contraction."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+    from qiskit_dynamics_amd import workloads
+
+    cfg, _, stack = cfg2
+    sched = FixedStepSchedule([1.0, 1.02], None, cfg["max_dt"], _rk4_points)
+    amps, phs = workloads.sweep_parameters(3, 8)
+    table = workloads.gaussian_coefficient_table(sched.times, amps[None], phs[None], cfg["carrier"], 5.0)
+    rng = np.random.default_rng(1)
+    y0 = crand(rng, 1024, 40)
+    outs = []
+    for flag in (1, 0):
+        stack.ctx.set_option("combine_first", flag)
+        try:
+            outs.append(stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                                        sched.n_save, y0, 1, True)[0, -1])
+        finally:
+            stack.ctx.set_option("combine_first", 1)
+    assert_close(outs[0], outs[1], 1e-12)

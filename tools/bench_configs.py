@@ -94,3 +94,50 @@ if "cfg5" in which:
                       "zgemm_launches_per_step": cz["launches"] / nsteps,
                       "tflops_8n3_per_zgemm": round(8 * 4096.0**3 * cz["launches"] / (cz["ms"] * 1e-3) / 1e12, 2),
                       "norm": float(np.linalg.norm(r.y[-1])), "segment_modes": hm.stack.segment_modes}), flush=True)
+
+if "lind1024" in which:
+    # 10-qubit open system, non-vectorised: n = 1024, 8 drives, 4 static sigma^- dissipators, RK4
+    t0 = time.time()
+    cfg = workloads.lindblad_config(n_qubits=10, n_drives=8, n_diss=4, gamma=1e-3, t_final=5.0, max_dt=0.005)
+    amps, phases = workloads.sweep_parameters(0, 8)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    m = qd.LindbladModel(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], hamiltonian_signals=sigs,
+                         static_dissipators=cfg["static_dissipators"], rotating_frame=np.diag(cfg["h_d"]).real.copy(),
+                         vectorized=False)
+    build_s = time.time() - t0
+    nsteps = 5
+    ctx.reset_counters(); ctx.set_option("profile", 1)
+    r, dt = timed(lambda: qd.solve_lmde(m, [0.0, nsteps * 0.005], cfg["rho0"], method="RK4", max_dt=0.005))
+    cz, cg = ctx.counters("zgemm"), ctx.counters("gen_eval")
+    ctx.set_option("profile", 0)
+    rho = r.y[-1]
+    print(json.dumps({"what": "10-qubit non-vectorised Lindblad (n=1024, 4 dissipators), RK4", "steps": nsteps,
+                      "model_build_s": round(build_s, 1), "wall_s": round(dt, 3),
+                      "ms_per_rhs_eval_device": round((cz["ms"] + cg["ms"]) / (4 * nsteps), 3),
+                      "zgemm_per_eval": cz["launches"] / (4 * nsteps),
+                      "zgemm_tflops": round(8 * 1024.0**3 * cz["launches"] / (cz["ms"] * 1e-3) / 1e12, 2),
+                      "trace": float(abs(np.trace(rho))), "hermiticity": float(np.linalg.norm(rho - rho.conj().T))}),
+          flush=True)
+
+if "unitary1024" in which:
+    from bench import build_frame_basis_stack
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+    cfg = workloads.schrodinger_config()
+    ops, static, frame_im = build_frame_basis_stack(cfg)
+    stack = qd.Stack(ctx, ops, static, frame_im)
+    sched = FixedStepSchedule([0.0, 0.1], None, 0.005, _rk4_points)
+    amps, phs = workloads.sweep_parameters(0, 8)
+    table = workloads.gaussian_coefficient_table(sched.times, amps[None], phs[None], cfg["carrier"], 5.0)
+    y0 = np.eye(1024, dtype=complex)
+    for flag in (1, 0):
+        ctx.set_option("combine_first", flag)
+        stack.rk4_solve(sched.times, table, sched.step_rows[:2], sched.step_h[:2], sched.step_save[:2], 2, y0, 1, True)
+        u, dt = timed(lambda: stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                                              sched.n_save, y0, 1, True))
+        uu = u[0, -1]
+        print(json.dumps({"what": "cfg2 model, unitary propagator (y0 = I, m = 1024), 20 RK4 steps",
+                          "combine_first": flag, "wall_s_incl_pcie": round(dt, 4),
+                          "ms_per_rhs_eval": round(dt / 80 * 1e3, 3),
+                          "unitarity": float(np.linalg.norm(uu.conj().T @ uu - np.eye(1024)))}), flush=True)
+    ctx.set_option("combine_first", 1)
