@@ -440,34 +440,28 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     g.splits = 1;
     g.partial = nullptr;
     ProfScope ps(ctx, cls);
-    bool big = (g.M % 128 == 0) && (g.N % 128 == 0) &&
-               ((long long)(g.M / 128) * (g.N / 128) >= (long long)ctx->num_cu);
-    // 128x64x8, 4 waves, 48 KB LDS: TWO independent workgroups per CU (one wave of each per SIMD),
-    // so one group's barrier/LDS-latency bubble is covered by the other group's MFMAs.
-    bool duo = (g.M % 128 == 0) && ((long long)(g.M / 128) * (g.N / 64) >= 2LL * ctx->num_cu);
-    if (ctx->force_tile == 64) big = duo = false;
-    if (ctx->force_tile == 128) {
-        duo = false;
-        big = g.M % 128 == 0 && g.N % 128 == 0;
-    }
-    if (ctx->force_tile == 12864) {
-        big = false;
-        duo = g.M % 128 == 0;
-    }
-    if (duo && ctx->prefer_duo) return launch_gemm_cfg<128, 64, 2, 2, 8>(ctx, g, uniform_mode);
-    if (big) return launch_gemm_cfg<128, 128, 2, 4, 16>(ctx, g, uniform_mode);
-    if (duo && ctx->force_tile == 12864) return launch_gemm_cfg<128, 64, 2, 2, 8>(ctx, g, uniform_mode);
-    // Fewer tiles than CUs: split the K loop over `splits` workgroups per tile (partials in a
-    // workspace, summed + epilogue in splitk_reduce_kernel) so that the whole chip contracts.
-    const bool t128 = (g.M % 128 == 0) && (g.N % 128 == 0) && ctx->force_tile != 64;
-    const int bmn = t128 ? 128 : 64;
-    const long long tiles = (long long)(g.M / bmn) * (g.N / bmn);
+    // ---- tile / split choice -----------------------------------------------------------------
+    //  * 128x128x16 (8 waves, 1 workgroup per CU) whenever M and N are multiples of 128, else 64x64x16;
+    //  * fewer tiles than CUs: split the K loop over `splits` workgroups per tile (partials in a
+    //    workspace, summed + epilogue in splitk_reduce_kernel) so that the whole chip contracts.
+    //  force_tile (64 | 128 | 12864) pins the tile for A/B runs; 12864 = 128x64x8 two-per-CU variant.
     const int KT = g.K / GEMM_BK;
-    int splits = 1;
-    if (ctx->split_k && tiles < ctx->num_cu) {
-        while (splits * 2 * tiles <= ctx->num_cu && KT % (splits * 2) == 0 && KT / (splits * 2) >= 2) splits *= 2;
-    }
-    if (ctx->force_splits > 0 && KT % ctx->force_splits == 0) splits = ctx->force_splits;
+    auto best_splits = [&](long long tiles) {
+        int sp = 1;
+        if (ctx->split_k && tiles < ctx->num_cu)
+            while ((long long)sp * 2 * tiles <= ctx->num_cu && KT % (sp * 2) == 0 && KT / (sp * 2) >= 2) sp *= 2;
+        if (ctx->force_splits > 0 && KT % ctx->force_splits == 0) sp = ctx->force_splits;
+        return sp;
+    };
+    const bool can128 = (g.M % 128 == 0) && (g.N % 128 == 0) && ctx->force_tile != 64;
+    const long long tiles128 = can128 ? (long long)(g.M / 128) * (g.N / 128) : 0;
+    const long long tiles64 = (long long)(g.M / 64) * (g.N / 64);
+    if (ctx->force_tile == 12864 && g.M % 128 == 0) return launch_gemm_cfg<128, 64, 2, 2, 8>(ctx, g, uniform_mode);
+    bool t128;
+    if (ctx->force_tile == 128 && can128) t128 = true;
+    else if (ctx->force_tile == 64) t128 = false;
+    else t128 = can128;  // measured: 128-tile + split-K beats 64-tile without split (n=1024: 49.9 vs 46.4 TF)
+    const int splits = best_splits(t128 ? tiles128 : tiles64);
     if (splits > 1) {
         const size_t need = (size_t)splits * g.M * g.N * sizeof(double2);
         if (ctx->splitk_bytes < need) {

@@ -26,6 +26,22 @@ def timed(fn):
     return out, time.perf_counter() - t0
 
 
+if "expm_ab" in which:
+    for n in (1024, 2048):
+        rng = np.random.default_rng(n)
+        a = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+        a = a - a.conj().T
+        a *= 2.0 / np.linalg.norm(a, 1)
+        for ft in (0, 64, 128):
+            ctx.set_option("force_tile", ft)
+            ctx.expm(a)
+            ctx.reset_counters(); ctx.set_option("profile", 1)
+            ctx.expm(a)
+            c = ctx.counters("zgemm"); ctx.set_option("profile", 0)
+            print(json.dumps({"what": "expm A/B", "n": n, "force_tile": ft, "zgemm_ms": round(c["ms"], 3),
+                              "tflops": round(8.0 * n**3 * c["launches"] / (c["ms"] * 1e-3) / 1e12, 2)}), flush=True)
+        ctx.set_option("force_tile", 0)
+
 if "expm" in which:
     for n in (1024, 2048, 4096):
         rng = np.random.default_rng(n)
