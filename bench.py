@@ -37,6 +37,24 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor FP64 matrix peak (SURVEY.md 8(d) 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
+def measured_traffic(kernel_prefix):
+    """HBM bytes per dispatch of the newest committed rocprofv3 PMC summary (profiles/*.traffic.json),
+    or None.  bench.py cannot collect PMC counters itself; the profile run is tools/profile_round.sh."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*.traffic.json"))):
+        try:
+            data = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for name, t in data.get("kernels", {}).items():
+            if name.startswith(kernel_prefix) and "fetch_bytes" in t:
+                best = {"bytes": round(t["fetch_bytes"] + t.get("write_bytes", 0.0)), "kernel": name,
+                        "source": os.path.basename(path)}
+    return best
+
+
 def build_frame_basis_stack(cfg):
     """Host model build (a3/a4): -iH, eigh of the frame, U^dagger . U.  Uses the product classes'
     own code path (RotatingFrame) so the stack is exactly what HamiltonianModel uploads."""
@@ -60,6 +78,7 @@ def main():
                     help="disable exact-zero plane skipping (time the general dense-complex path)")
     ap.add_argument("--full-solve", action="store_true",
                     help="additionally run the complete 1000-step sweep through the Solver API (end-to-end wall clock)")
+    ap.add_argument("--complex-3m", action="store_true", help="dense complex products with 3 real MFMAs (A/B testing)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: kernel ablation bits (results wrong)")
     ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 | 12864 (kernel A/B testing)")
     args = ap.parse_args()
@@ -89,6 +108,8 @@ def main():
         ctx.set_option("force_tile", args.force_tile)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
+    if args.complex_3m:
+        ctx.set_option("complex_3m", 1)
 
     cfg = workloads.schrodinger_config(N_QUBITS, N_DRIVES, T_FINAL, MAX_DT)
     n = 2**N_QUBITS
@@ -166,12 +187,15 @@ def main():
         flops_per_launch = (4 * k + 10) * n * n * b_loc          # useful flops, SURVEY 8(d) cfg 3
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         n_act = stack.n_active_segments
+        act_modes = [m for m in stack.segment_modes if m != 3]
+        stack_um = act_modes[0] if act_modes and all(m == act_modes[0] for m in act_modes) else 3
         modes = stack.segment_modes if not args.dense else [0] * stack.n_segments
-        executed = sum((8 if m == 0 else 4) for m in modes if m != 3) * n * n * b_loc
+        executed = sum((6 if m == 0 else 4) for m in modes if m != 3) * n * n * b_loc
         roofline = {
             "kernel": "zgemm_seg_kernel (batched RHS, fp64 MFMA 16x16x4)", "bound": "mfma",
             "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+            "traffic": measured_traffic("zgemm_seg_kernel<128, 128, 2, 4, 16, %d>" % (0 if args.dense else stack_um)),
             "avg_launch_ms": round(avg_ms, 4), "launches_timed": int(cnt["launches"]),
             "algorithmic_flops_per_launch": flops_per_launch,
             "executed_mfma_flops_per_launch": executed,
@@ -194,11 +218,12 @@ def main():
         ctx.set_option("profile", 0)
         ctx.set_option("skip_zero_planes", 1)
         avg_d = cd["ms"] / max(cd["launches"], 1)
-        ex_d = 8 * stack.n_segments * n * n * b_loc
+        ex_d = 6 * stack.n_segments * n * n * b_loc   # 3M: 3 real MFMA products per complex product
         dense = {"avg_launch_ms": round(avg_d, 4), "rhs_evals_per_s": round(b_loc / (avg_d * 1e-3), 1),
                  "useful_tflops": round(flops_per_launch / (avg_d * 1e-3) / 1e12, 3),
                  "executed_tflops": round(ex_d / (avg_d * 1e-3) / 1e12, 3),
-                 "frac_of_peak_executed": round(ex_d / (avg_d * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
+                 "frac_of_peak_executed": round(ex_d / (avg_d * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                 "scheme": "3M complex multiplication (3 real fp64 MFMAs per complex product), 64x64 tiles"}
     plan.close()
     measured_peaks = None
     if rank == 0:
@@ -255,7 +280,7 @@ def main():
             "ms_per_step": round(el1 / (s_total - 8) * 1e3, 4)}
         out["roofline_single_trajectory"] = {
             "kernel": "rhs_stream_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic("rhs_stream_kernel<4, 3>"),
             "avg_launch_ms": round(avg_ms1, 5), "launches_timed": int(c1["launches"]),
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "note": "stack (151 MB) fits the 256 MB Infinity Cache: effective rate may exceed HBM"}

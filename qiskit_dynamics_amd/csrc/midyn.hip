@@ -44,6 +44,7 @@ struct midyn_ctx {
     int stream_variant = 0;
     bool split_k = true;
     bool combine_first = true;
+    bool complex_3m = true;   // dense complex products by the 3M scheme (3 real MFMAs instead of 4)
     int force_splits = 0;
     void* splitk_ws = nullptr;
     size_t splitk_bytes = 0;
@@ -137,6 +138,7 @@ extern "C" int midyn_ctx_create(int device, midyn_ctx** out) {
     hipDeviceProp_t prop;
     HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
     ctx->num_cu = prop.multiProcessorCount;
+    if (const char* e = getenv("MIDYN_COMPLEX_3M")) ctx->complex_3m = atoi(e) != 0;
     HIPCHK(ctx, hipMalloc(&ctx->d_one_seg, sizeof(int)));
     int zero = 0;
     HIPCHK(ctx, hipMemcpy(ctx->d_one_seg, &zero, sizeof(int), hipMemcpyHostToDevice));
@@ -176,6 +178,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     else if (n == "stream_variant") ctx->stream_variant = (int)value;
     else if (n == "split_k") ctx->split_k = value != 0;
     else if (n == "combine_first") ctx->combine_first = value != 0;
+    else if (n == "complex_3m") ctx->complex_3m = value != 0;
     else if (n == "force_splits") ctx->force_splits = (int)value;
     else return fail(ctx, "midyn_ctx_set_option: unknown option " + n);
     return 0;
@@ -399,12 +402,12 @@ extern "C" int midyn_stack_segment_modes(midyn_stack* s, int* modes) {
 // -------------------------------------------------------------------------------------------------
 // kernel launch helpers
 // -------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BK, int MODE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2>
 static int launch_gemm_mode(midyn_ctx* ctx, const GemmArgs& g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr size_t SMEM = (size_t)2 * BK * (BM + BN) * sizeof(double2);
     static bool attr_set[16] = {false};
-    auto kern = zgemm_seg_kernel<BM, BN, WM, WN, BK, MODE>;
+    auto kern = zgemm_seg_kernel<BM, BN, WM, WN, BK, MODE, MINW>;
     if (!attr_set[ctx->device & 15]) {
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
@@ -424,6 +427,7 @@ static int launch_gemm_cfg(midyn_ctx* ctx, const GemmArgs& g, int uniform_mode) 
         case 0: return launch_gemm_mode<BM, BN, WM, WN, BK, 0>(ctx, g);
         case 1: return launch_gemm_mode<BM, BN, WM, WN, BK, 1>(ctx, g);
         case 2: return launch_gemm_mode<BM, BN, WM, WN, BK, 2>(ctx, g);
+        case 4: return launch_gemm_mode<BM, BN, WM, WN, BK, 4>(ctx, g);
         default: return launch_gemm_mode<BM, BN, WM, WN, BK, 3>(ctx, g);
     }
 }
@@ -436,6 +440,7 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     if (g0.n_act > 64)
         return fail(ctx, "more than 64 non-zero operator segments are not supported by the MFMA contraction yet");
     GemmArgs g = g_in;
+    if (uniform_mode == 0 && ctx->complex_3m) uniform_mode = 4;  // dense complex: 3 real MFMAs per product
     g.ablate = ctx->ablate;
     g.splits = 1;
     g.partial = nullptr;
@@ -460,6 +465,7 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     bool t128;
     if (ctx->force_tile == 128 && can128) t128 = true;
     else if (ctx->force_tile == 64) t128 = false;
+    else if (uniform_mode == 4) t128 = false;  // 3M: three accumulator sets only fit the 32x32 wave tile
     else t128 = can128;  // measured: 128-tile + split-K beats 64-tile without split (n=1024: 49.9 vs 46.4 TF)
     const int splits = best_splits(t128 ? tiles128 : tiles64);
     if (splits > 1) {

@@ -255,9 +255,40 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // MFMAs of one k-step (4 k) of the wave's TM x TN complex tile.  MODE: 0 = A complex, 1 = A real
 // only, 2 = A imaginary only (the other plane of the operator is exactly zero, so the two MFMAs that
 // would multiply it are skipped), 3 = decided at run time per segment (mixed stacks).
+//   4 = dense complex by the 3M (Karatsuba) scheme: T1 += Ar.Br, T2 += Ai.Bi, T3 += (Ar+Ai).(Br+Bi)
+//       with C_re = T1 - T2, C_im = T3 - T1 - T2 formed in the epilogue: 3 real MFMAs per complex
+//       product instead of 4 (cre = T1, cim = T3, c2 = T2).
 template <int MODE, int MT, int NT>
 __device__ __forceinline__ void mfma_kstep(const double2 (&a)[MT], const double2 (&b)[NT], int rt_mode,
-                                           const double (&sc)[NT], d4 (&cre)[MT][NT], d4 (&cim)[MT][NT]) {
+                                           const double (&sc)[NT], d4 (&cre)[MT][NT], d4 (&cim)[MT][NT],
+                                           d4 (&c2)[MT][NT]) {
+    if (MODE == 4) {
+        double br[NT], bi[NT], bs[NT], as[MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            br[nt] = b[nt].x * sc[nt];
+            bi[nt] = b[nt].y * sc[nt];
+            bs[nt] = br[nt] + bi[nt];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) as[mt] = a[mt].x + a[mt].y;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].x, br[nt], cre[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                c2[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt].y, bi[nt], c2[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[mt], bs[nt], cim[mt][nt], 0, 0, 0);
+        return;
+    }
     const bool do_re = MODE == 3 ? (rt_mode != 2) : (MODE != 2);
     const bool do_im = MODE == 3 ? (rt_mode != 1) : (MODE != 1);
     double br[NT], bi[NT], bin[NT];
@@ -311,8 +342,8 @@ __device__ __forceinline__ void read_frags(const double2* __restrict__ Ab, const
 
 // second launch-bound argument = waves per SIMD the register allocation must allow: the 4-wave
 // configurations are meant to run two workgroups per CU (2 waves per SIMD -> <= 256 registers).
-template <int BM, int BN, int WM, int WN, int BK, int MODE>
-__global__ __launch_bounds__(64 * WM * WN, 2) void zgemm_seg_kernel(GemmArgs g) {
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int NWAVE = WM * WN;
     constexpr int TM = BM / WM;  // wave tile
@@ -365,13 +396,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void zgemm_seg_kernel(GemmArgs g) 
         inst[nt] = in < g.n_inst ? in : g.n_inst - 1;
     }
 
-    d4 cre[MT][NT], cim[MT][NT];
+    d4 cre[MT][NT], cim[MT][NT], c2[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             cre[i][j] = d4{0.0, 0.0, 0.0, 0.0};
             cim[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+            c2[i][j] = d4{0.0, 0.0, 0.0, 0.0};
         }
 
     // LDS-DMA source offsets (per lane, fixed): lane l of chunk c fetches A row m = 4c + l/16,
@@ -441,7 +473,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void zgemm_seg_kernel(GemmArgs g) 
     //   MFMAs instead of idling the matrix pipe.
     constexpr int KS = BK / 4;
     static_assert(KS % 2 == 0, "fragment ping-pong assumes an even number of k-steps");
-    double2 fa[2][MT], fb[2][NT];
+    double2 fa[MODE == 4 ? 1 : 2][MT], fb[MODE == 4 ? 1 : 2][NT];
     const int a_lane_off = (wm * TM + lcol) * BK;
     const int b_lane_off = wn * TN + lcol;
     if (total > 0) read_frags<BK, BN, MT, NT>(As + a_lane_off, Bs + b_lane_off, 0, lk, lcol, fa[0], fb[0]);
@@ -459,30 +491,49 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void zgemm_seg_kernel(GemmArgs g) 
         const double2* Ab_n = As + ((it + 1) & 1) * BK * BM + a_lane_off;
         const double2* Bb_n = Bs + (kt_n & 1) * BK * BN + b_lane_off;
         const int mode = packed & 3;
+        auto issue_next_tile = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            packed_n = __builtin_amdgcn_readlane(seg_vec, s_n);
+            if (it + 1 < total && !MIDYN_ABL(g, 2)) {
+                dma_a(kt_n, packed_n >> 2, (it + 1) & 1);
+                if (s_n == 0) dma_b(kt_n, kt_n & 1);
+            }
+            load_sc(packed_n >> 2, sc_next);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (MODE == 4) {
+            // 3M keeps three accumulator sets (192 VGPRs): fragments are single-buffered here, the
+            // other wave of the SIMD covers the LDS latency between k-steps.
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < KS) {
-                if (!MIDYN_ABL(g, 8)) read_frags<BK, BN, MT, NT>(Ab, Bb, ks + 1, lk, lcol, fa[nxt], fb[nxt]);
-            } else {
-                __builtin_amdgcn_sched_barrier(0);
-                if (!MIDYN_ABL(g, 1)) {
+            for (int ks = 0; ks < KS; ++ks) {
+                mfma_kstep<MODE, MT, NT>(fa[0], fb[0], mode, sc, cre, cim, c2);
+                if (ks == 0) issue_next_tile();
+                if (ks + 1 < KS) {
+                    read_frags<BK, BN, MT, NT>(Ab, Bb, ks + 1, lk, lcol, fa[0], fb[0]);
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
+                    if (it + 1 < total) read_frags<BK, BN, MT, NT>(Ab_n, Bb_n, 0, lk, lcol, fa[0], fb[0]);
                 }
-                if (it + 1 < total && !MIDYN_ABL(g, 8))
-                    read_frags<BK, BN, MT, NT>(Ab_n, Bb_n, 0, lk, lcol, fa[nxt], fb[nxt]);
             }
-            mfma_kstep<MODE, MT, NT>(fa[cur], fb[cur], mode, sc, cre, cim);
-            if (ks == 0) {
-                __builtin_amdgcn_sched_barrier(0);
-                packed_n = __builtin_amdgcn_readlane(seg_vec, s_n);
-                if (it + 1 < total && !MIDYN_ABL(g, 2)) {
-                    dma_a(kt_n, packed_n >> 2, (it + 1) & 1);
-                    if (s_n == 0) dma_b(kt_n, kt_n & 1);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < KS) {
+                    if (!MIDYN_ABL(g, 8)) read_frags<BK, BN, MT, NT>(Ab, Bb, ks + 1, lk, lcol, fa[nxt], fb[nxt]);
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!MIDYN_ABL(g, 1)) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                    }
+                    if (it + 1 < total && !MIDYN_ABL(g, 8))
+                        read_frags<BK, BN, MT, NT>(Ab_n, Bb_n, 0, lk, lcol, fa[nxt], fb[nxt]);
                 }
-                load_sc(packed_n >> 2, sc_next);
-                __builtin_amdgcn_sched_barrier(0);
+                mfma_kstep<MODE, MT, NT>(fa[cur], fb[cur], mode, sc, cre, cim, c2);
+                if (ks == 0) issue_next_tile();
             }
         }
 #pragma unroll
@@ -492,6 +543,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void zgemm_seg_kernel(GemmArgs g) 
         packed = packed_n;
     }
 
+    if (MODE == 4) {  // 3M recombination: C_re = T1 - T2, C_im = T3 - T1 - T2
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double t1 = cre[mt][nt][r], t2 = c2[mt][nt][r], t3 = cim[mt][nt][r];
+                    cre[mt][nt][r] = t1 - t2;
+                    cim[mt][nt][r] = (t3 - t1) - t2;
+                }
+    }
     // epilogue: D[row = (lane>>4) + 4*reg][col = lane & 15]
     if (g.splits > 1) {
         double2* P = g.partial + (size_t)split * g.M * g.N;

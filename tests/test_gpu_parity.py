@@ -674,3 +674,22 @@ def test_single_instance_many_columns_fast_path(qd, cfg2):
         finally:
             stack.ctx.set_option("combine_first", 1)
     assert_close(outs[0], outs[1], 1e-12)
+
+
+def test_expm_lindbladian_vs_scipy(qd):
+    """Non-normal generator with a large norm (4-qubit vectorised Lindbladian, no frame, h = 0.05):
+    the Taylor/squaring device expm against scipy's Pade, plus trace preservation of the map."""
+    from qiskit_dynamics_amd import workloads
+    from qiskit_dynamics_amd.models import vec_commutator, vec_dissipator
+
+    cfg = workloads.lindblad_config(n_qubits=4, n_drives=4, n_diss=3, gamma=5e-2)
+    n = 16
+    lind = vec_commutator(cfg["h_d"] + 0.7 * cfg["ops"][0] - 0.4 * cfg["ops"][2]) \
+        + np.sum(vec_dissipator(cfg["static_dissipators"]), axis=0)
+    a = 0.05 * lind
+    e, info = qd.default_context().expm(a, return_info=True)
+    ref = scipy.linalg.expm(a)
+    assert info[0, 0] >= 3  # several squarings were needed
+    assert np.linalg.norm(e - ref, 1) / np.linalg.norm(ref, 1) < 1e-12
+    vec_id = np.eye(n).flatten(order="F")
+    assert np.max(np.abs(vec_id @ e - vec_id)) < 1e-12  # tr(rho) preserved: vec(I)^T E = vec(I)^T

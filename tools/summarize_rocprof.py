@@ -73,6 +73,24 @@ def main():
                     lines.append(f"| `{short(name)}` | MFMA busy / SQ busy | | "
                                  f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_BUSY_CYCLES']:.3f} | ratio of summed counters |")
             lines.append("")
+    # machine-readable HBM traffic per dispatch (read side x2 as the gfx950 note prescribes)
+    traffic = {}
+    for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+        for db in sorted(glob.glob(os.path.join(d, "*.db"))):
+            for name, cname, n, avg, tot in pmc_stats(db):
+                if cname in ("FETCH_SIZE", "WRITE_SIZE"):
+                    t = traffic.setdefault(short(name), {})
+                    if cname == "FETCH_SIZE":
+                        t["fetch_bytes"] = 2.0 * avg * 1024
+                    else:
+                        t["write_bytes"] = avg * 1024
+                    t["dispatches"] = n
+    if traffic:
+        import json
+
+        with open(os.path.splitext(out)[0] + ".traffic.json", "w") as f:
+            json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, {title}; FETCH_SIZE x2 (gfx950)",
+                       "kernels": traffic}, f, indent=1)
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     with open(out, "w") as f:
         f.write("\n".join(lines) + "\n")
