@@ -225,6 +225,8 @@ struct midyn_stack {
     int* flags = nullptr;       // [2*nseg] plane non-zero flags (device)
     int* seg_all = nullptr;     // [nseg] every segment, mode 0 (device)
     int* seg_act = nullptr;     // [nseg] active list with plane modes (device)
+    struct midyn_rk4_plan* eval_plan = nullptr;  // cached buffers of midyn_eval_rhs (keyed by m)
+    int eval_m = 0;
     int n_act = 0;
     int uniform_mode = 3;       // plane mode shared by all active segments, or 3 (mixed)
     std::vector<int> h_flags;
@@ -371,10 +373,14 @@ extern "C" int midyn_stack_adopt(midyn_ctx* ctx, int n, int k, int has_static, i
     return 0;
 }
 
+extern "C" int midyn_rk4_plan_destroy(struct midyn_rk4_plan* p);
+
 extern "C" int midyn_stack_destroy(midyn_stack* s) {
     if (!s) return 0;
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
+    if (s->eval_plan) midyn_rk4_plan_destroy(s->eval_plan);
+    s->eval_plan = nullptr;
     if (s->owns && s->buf) hipFree(s->buf);
     delete s;
     return 0;
@@ -657,7 +663,7 @@ struct midyn_rk4_plan {
     midyn_stack* stack = nullptr;
     int B = 0, m = 0, ncol = 0, ld = 0, R = 0, nsteps = 0, P = 0;
     bool stream_path = false;
-    DevBuf d_S, d_times, d_E, d_y, d_acc, d_yin[2], d_out, d_tmp, d_G;
+    DevBuf d_S, d_times, d_E, d_y, d_acc, d_yin[2], d_out, d_tmp, d_G, d_eval_out, d_eval_tmp;
     bool combine_first = false;  // one instance, many columns: form C(t) once, then ONE n^3 zgemm
     std::vector<int> rows;     // [nsteps][3]
     std::vector<double> hs;    // [nsteps]
@@ -905,35 +911,52 @@ extern "C" int midyn_eval_rhs(midyn_stack* s, const double* coeffs, double t, co
     midyn_ctx* ctx = s->ctx;
     if (m <= 0) return fail(ctx, "midyn_eval_rhs: m must be positive");
     if (s->k > 0 && !coeffs) return fail(ctx, "midyn_eval_rhs: coeffs is NULL but the stack has operators");
-    // one instance, m columns, one table row; reuse the plan machinery with a zero-step plan
-    midyn_rk4_plan* p = nullptr;
-    int rows3[3] = {0, 0, 0};
-    double h0 = 0.0;
-    // nsteps = 1 only so that rows[0] exists for the initial phasing; no step is run
-    CHK(plan_create_impl(s, 1, m, 1, &t, coeffs, 1, rows3, &h0, nullptr, 0, y, 1, &p));
-    DevBuf d_out;
-    int st = d_out.alloc(ctx, (size_t)s->n_pad * p->ld * sizeof(double2));
-    if (!st) {
-        Epilogue e{};
-        e.mode = EPI_RHS;
-        e.ld = p->ld;
-        e.e_cur = plan_E(p, 0);
-        e.out = d_out.as<double2>();
-        st = plan_rhs_launch(p, 0, e, p->d_yin[0].as<double2>());
-    }
-    DevBuf tmp;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // One instance, m columns, one table row.  The device buffers are cached in the stack (keyed by
+    // m) so that a caller evaluating the RHS in a loop (e.g. an adaptive host integrator using the
+    // model as a callback) pays kernel launches and two small copies per call, not allocations.
     const size_t elems = (size_t)s->n * m;
-    if (!st) st = tmp.alloc(ctx, elems * sizeof(double2));
-    if (!st) {
-        hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(elems)), dim3(256), 0, ctx->stream,
-                           d_out.as<double2>(), 1, s->n, m, p->ld, 1, 0, tmp.as<double2>());
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess) e = hipMemcpy(out, tmp.p, elems * sizeof(double2), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) st = fail(ctx, std::string("midyn_eval_rhs: ") + hipGetErrorString(e));
+    midyn_rk4_plan* p = s->eval_plan;
+    if (!p || s->eval_m != m) {
+        if (p) midyn_rk4_plan_destroy(p);
+        s->eval_plan = nullptr;
+        int rows3[3] = {0, 0, 0};
+        double h0 = 0.0;
+        CHK(plan_create_impl(s, 1, m, 1, &t, coeffs, 1, rows3, &h0, nullptr, 0, y, 1, &p));
+        int st = p->d_eval_out.alloc(ctx, (size_t)s->n_pad * p->ld * sizeof(double2));
+        if (!st) st = p->d_eval_tmp.alloc(ctx, elems * sizeof(double2));
+        if (st) {
+            midyn_rk4_plan_destroy(p);
+            return st;
+        }
+        s->eval_plan = p;
+        s->eval_m = m;
+    } else {
+        if (s->k > 0)
+            HIPCHK(ctx, hipMemcpyAsync(p->d_S.p, coeffs, s->k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if (s->has_frame) {
+            HIPCHK(ctx, hipMemcpyAsync(p->d_times.p, &t, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(phase_table_kernel, dim3(grid_for(s->n_pad)), dim3(256), 0, ctx->stream, s->frame_im,
+                               p->d_times.as<double>(), s->n_pad, 1, p->d_E.as<double2>());
+        }
+        HIPCHK(ctx, hipMemcpyAsync(p->d_tmp.p, y, elems * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(scatter_state_kernel, dim3(grid_for(elems)), dim3(256), 0, ctx->stream,
+                           p->d_tmp.as<double2>(), 1, 1, s->n, m, p->ld, plan_E(p, 0), (double2*)nullptr,
+                           p->d_yin[0].as<double2>());
+        HIPCHK(ctx, hipGetLastError());
     }
-    midyn_rk4_plan_destroy(p);
-    return st;
+    Epilogue e{};
+    e.mode = EPI_RHS;
+    e.ld = p->ld;
+    e.e_cur = plan_E(p, 0);
+    e.out = p->d_eval_out.as<double2>();
+    CHK(plan_rhs_launch(p, 0, e, p->d_yin[0].as<double2>()));
+    hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(elems)), dim3(256), 0, ctx->stream,
+                       p->d_eval_out.as<double2>(), 1, s->n, m, p->ld, 1, 0, p->d_eval_tmp.as<double2>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, p->d_eval_tmp.p, elems * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 // -------------------------------------------------------------------------------------------------
