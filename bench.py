@@ -195,7 +195,8 @@ def main():
             "kernel": "zgemm_seg_kernel (batched RHS, fp64 MFMA 16x16x4)", "bound": "mfma",
             "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-            "traffic": measured_traffic("zgemm_seg_kernel<128, 128, 2, 4, 16, %d>" % (0 if args.dense else stack_um)),
+            "traffic": measured_traffic("zgemm_seg_kernel<64, 64, 2, 2, 16, 4," if (args.dense or stack_um == 0)
+                                        else "zgemm_seg_kernel<128, 128, 2, 4, 16, %d," % stack_um),
             "avg_launch_ms": round(avg_ms, 4), "launches_timed": int(cnt["launches"]),
             "algorithmic_flops_per_launch": flops_per_launch,
             "executed_mfma_flops_per_launch": executed,
