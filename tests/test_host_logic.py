@@ -196,3 +196,20 @@ def test_no_cpu_fallback_without_gpu():
     x = np.array([[0, 1], [1, 0]], dtype=complex)
     with pytest.raises(qd.HipLibraryError):
         qd.HamiltonianModel(operators=[x], signals=[qd.Signal(1.0)])
+
+
+def test_header_is_plain_c_and_symbols_resolve(tmp_path):
+    """Compile a C99 consumer of include/midyn.h with gcc and resolve every entry point by dlsym."""
+    import subprocess
+
+    assert _lib.load() is not None
+    exe = tmp_path / "abi_probe"
+    src = os.path.join(ROOT, "tests", "abi_probe.c")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-o", str(exe), src, "-ldl"], check=True)
+    p = subprocess.run([str(exe), _lib.HIP_RUNTIME, _lib.LIB_PATH], capture_output=True, text=True)
+    assert p.returncode == 0 and "ABI_OK 28 symbols" in p.stdout, p.stdout + p.stderr
+    # and the same header as C++
+    cpp = tmp_path / "h.cpp"
+    cpp.write_text('#include "%s"\nint main() { midyn_complex z{1.0, 2.0}; return z.re > 0 ? 0 : 1; }\n'
+                   % os.path.join(ROOT, "include", "midyn.h"))
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-o", str(tmp_path / "h"), str(cpp)], check=True)
