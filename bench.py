@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--full-solve", action="store_true",
                     help="additionally run the complete 1000-step sweep through the Solver API (end-to-end wall clock)")
     ap.add_argument("--complex-3m", action="store_true", help="dense complex products with 3 real MFMAs (A/B testing)")
+    ap.add_argument("--plane-kernel", action="store_true", help="A/B: planar two-tiles-per-barrier kernel (opt-in)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: kernel ablation bits (results wrong)")
     ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 | 12864 (kernel A/B testing)")
     args = ap.parse_args()
@@ -110,6 +111,8 @@ def main():
         ctx.set_option("ablate", args.ablate)
     if args.complex_3m:
         ctx.set_option("complex_3m", 1)
+    if args.plane_kernel:
+        ctx.set_option("plane_kernel", 1)
 
     cfg = workloads.schrodinger_config(N_QUBITS, N_DRIVES, T_FINAL, MAX_DT)
     n = 2**N_QUBITS

@@ -44,6 +44,7 @@ struct midyn_ctx {
     int stream_variant = 0;
     bool split_k = true;
     bool combine_first = true;
+    bool plane_kernel = false;  // planar two-tiles-per-barrier variant: measured 4 % SLOWER (2.43 vs 2.33 ms), kept opt-in
     bool complex_3m = true;   // dense complex products by the 3M scheme (3 real MFMAs instead of 4)
     int force_splits = 0;
     void* splitk_ws = nullptr;
@@ -179,6 +180,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     else if (n == "split_k") ctx->split_k = value != 0;
     else if (n == "combine_first") ctx->combine_first = value != 0;
     else if (n == "complex_3m") ctx->complex_3m = value != 0;
+    else if (n == "plane_kernel") ctx->plane_kernel = value != 0;
     else if (n == "force_splits") ctx->force_splits = (int)value;
     else return fail(ctx, "midyn_ctx_set_option: unknown option " + n);
     return 0;
@@ -225,6 +227,8 @@ struct midyn_stack {
     int* flags = nullptr;       // [2*nseg] plane non-zero flags (device)
     int* seg_all = nullptr;     // [nseg] every segment, mode 0 (device)
     int* seg_act = nullptr;     // [nseg] active list with plane modes (device)
+    bool all_single_plane = false;  // every active segment is purely real or purely imaginary
+    double* planes = nullptr;       // [n_act][n_pad][n_pad] planar copy of the non-zero planes (lazy)
     struct midyn_rk4_plan* eval_plan = nullptr;  // cached buffers of midyn_eval_rhs (keyed by m)
     int eval_m = 0;
     int n_act = 0;
@@ -293,6 +297,9 @@ static int stack_finish_lists(midyn_stack* s) {
         act[s->n_act++] = (seg << 2) | mode;
     }
     s->uniform_mode = um < 0 ? 0 : um;
+    s->all_single_plane = s->n_act > 0;
+    for (int seg = 0; seg < s->nseg; ++seg)
+        if (s->h_modes[seg] == 0) s->all_single_plane = false;
     HIPCHK(ctx, hipMemcpy(s->seg_all, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(s->seg_act, act.data(), act.size() * sizeof(int), hipMemcpyHostToDevice));
     return 0;
@@ -381,6 +388,8 @@ extern "C" int midyn_stack_destroy(midyn_stack* s) {
     hipStreamSynchronize(s->ctx->stream);
     if (s->eval_plan) midyn_rk4_plan_destroy(s->eval_plan);
     s->eval_plan = nullptr;
+    if (s->planes) hipFree(s->planes);
+    s->planes = nullptr;
     if (s->owns && s->buf) hipFree(s->buf);
     delete s;
     return 0;
@@ -438,6 +447,44 @@ static int launch_gemm_cfg(midyn_ctx* ctx, const GemmArgs& g, int uniform_mode) 
     }
 }
 
+// split-K workspace + bookkeeping (g.splits / g.partial)
+static int setup_splits(midyn_ctx* ctx, GemmArgs& g, int splits) {
+    g.splits = 1;
+    g.partial = nullptr;
+    if (splits <= 1) return 0;
+    const size_t need = (size_t)splits * g.M * g.N * sizeof(double2);
+    if (ctx->splitk_bytes < need) {
+        if (ctx->splitk_ws) hipFree(ctx->splitk_ws);
+        ctx->splitk_ws = nullptr;
+        ctx->splitk_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->splitk_ws, need));
+        ctx->splitk_bytes = need;
+    }
+    g.splits = splits;
+    g.partial = static_cast<double2*>(ctx->splitk_ws);
+    return 0;
+}
+
+// sum the split-K partials and run the epilogue (no-op when the launch was not split)
+static int launch_reduce(midyn_ctx* ctx, const GemmArgs& g) {
+    if (g.splits <= 1) return 0;
+    const int splits = g.splits;
+    const dim3 rgrid(grid_for((size_t)g.M * g.N, 2048)), rblock(256);
+#define MIDYN_REDUCE(MODE_) \
+    hipLaunchKernelGGL(splitk_reduce_kernel<MODE_>, rgrid, rblock, 0, ctx->stream, g.partial, splits, g.M, g.N, g.epi)
+    switch (g.epi.mode) {
+        case EPI_RHS: MIDYN_REDUCE(EPI_RHS); break;
+        case EPI_RK1: MIDYN_REDUCE(EPI_RK1); break;
+        case EPI_RK2: MIDYN_REDUCE(EPI_RK2); break;
+        case EPI_RK3: MIDYN_REDUCE(EPI_RK3); break;
+        case EPI_RK4: MIDYN_REDUCE(EPI_RK4); break;
+        default: MIDYN_REDUCE(EPI_PLAIN); break;
+    }
+#undef MIDYN_REDUCE
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
 // tile choice: 128x128 (8 waves) when that still gives >= 1 block per CU, else 64x64 (4 waves)
 static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int uniform_mode = 0) {
     const GemmArgs& g0 = g_in;
@@ -474,41 +521,44 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     else if (uniform_mode == 4) t128 = false;  // 3M: three accumulator sets only fit the 32x32 wave tile
     else t128 = can128;  // measured: 128-tile + split-K beats 64-tile without split (n=1024: 49.9 vs 46.4 TF)
     const int splits = best_splits(t128 ? tiles128 : tiles64);
-    if (splits > 1) {
-        const size_t need = (size_t)splits * g.M * g.N * sizeof(double2);
-        if (ctx->splitk_bytes < need) {
-            if (ctx->splitk_ws) hipFree(ctx->splitk_ws);
-            ctx->splitk_ws = nullptr;
-            ctx->splitk_bytes = 0;
-            HIPCHK(ctx, hipMalloc(&ctx->splitk_ws, need));
-            ctx->splitk_bytes = need;
-        }
-        g.splits = splits;
-        g.partial = static_cast<double2*>(ctx->splitk_ws);
-    }
+    CHK(setup_splits(ctx, g, splits));
     int st = t128 ? launch_gemm_cfg<128, 128, 2, 4, 16>(ctx, g, uniform_mode)
                   : launch_gemm_cfg<64, 64, 2, 2, 16>(ctx, g, uniform_mode);
     if (st) return st;
-    if (splits > 1) {
-        if (getenv("MIDYN_DEBUG"))
-            fprintf(stderr, "[midyn] reduce: splits=%d M=%d N=%d mode=%d ld=%d y=%p acc=%p yin_next=%p out=%p ecur=%p enext=%p partial=%p\n",
-                    splits, g.M, g.N, g.epi.mode, g.epi.ld, (void*)g.epi.y, (void*)g.epi.acc, (void*)g.epi.yin_next,
-                    (void*)g.epi.out, (void*)g.epi.e_cur, (void*)g.epi.e_next, (void*)g.partial);
-        const dim3 rgrid(grid_for((size_t)g.M * g.N, 2048)), rblock(256);
-#define MIDYN_REDUCE(MODE_) \
-    hipLaunchKernelGGL(splitk_reduce_kernel<MODE_>, rgrid, rblock, 0, ctx->stream, g.partial, splits, g.M, g.N, g.epi)
-        switch (g.epi.mode) {
-            case EPI_RHS: MIDYN_REDUCE(EPI_RHS); break;
-            case EPI_RK1: MIDYN_REDUCE(EPI_RK1); break;
-            case EPI_RK2: MIDYN_REDUCE(EPI_RK2); break;
-            case EPI_RK3: MIDYN_REDUCE(EPI_RK3); break;
-            case EPI_RK4: MIDYN_REDUCE(EPI_RK4); break;
-            default: MIDYN_REDUCE(EPI_PLAIN); break;
-        }
-#undef MIDYN_REDUCE
-        HIPCHK(ctx, hipGetLastError());
+    return launch_reduce(ctx, g);
+}
+
+// The batched RHS contraction on the planar single-plane kernel (two operator tiles per barrier).
+static int launch_gemm_plane(midyn_ctx* ctx, const GemmArgs& g_in, const double* planes, long long seg_stride) {
+    GemmArgs g = g_in;
+    g.ablate = 0;
+    g.splits = 1;
+    g.partial = nullptr;
+    if (g.M % 128 || g.N % 128 || g.K % GEMM_BK || g.n_act > 64 || g.n_act < 1)
+        return fail(ctx, "launch_gemm_plane: unsupported shape");
+    ProfScope ps(ctx, KC_RHS_GEMM);
+    const long long tiles = (long long)(g.M / 128) * (g.N / 128);
+    const int KT = g.K / GEMM_BK;
+    int splits = 1;
+    if (ctx->split_k && tiles < ctx->num_cu)
+        while ((long long)splits * 2 * tiles <= ctx->num_cu && KT % (splits * 2) == 0 && KT / (splits * 2) >= 2) splits *= 2;
+    if (ctx->force_splits > 0 && KT % ctx->force_splits == 0) splits = ctx->force_splits;
+    CHK(setup_splits(ctx, g, splits));
+    constexpr size_t SMEM = (size_t)2 * 2 * 128 * 16 * sizeof(double) + (size_t)2 * 16 * 128 * sizeof(double2);
+    static bool attr_set[16] = {false};
+    auto kern = zgemm_plane_kernel<2, 4>;
+    if (!attr_set[ctx->device & 15]) {
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        attr_set[ctx->device & 15] = true;
     }
-    return 0;
+    PlaneArgs pa{};
+    pa.planes = planes;
+    pa.seg_stride = seg_stride;
+    pa.g = g;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * splits)), dim3(512), SMEM, ctx->stream, pa);
+    HIPCHK(ctx, hipGetLastError());
+    return launch_reduce(ctx, g);
 }
 
 static int launch_stream(midyn_ctx* ctx, const StreamArgs& a) {
@@ -733,6 +783,17 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
     g.m_cols = p->m;
     g.n_inst = p->B;
     g.epi = epi;
+    if (ctx->skip_zero_planes && ctx->plane_kernel && s->all_single_plane && g.M % 128 == 0 && g.N % 128 == 0 &&
+        ctx->force_tile == 0) {
+        const size_t plane = (size_t)s->n_pad * s->n_pad;
+        if (!s->planes) {
+            HIPCHK(ctx, hipMalloc(&s->planes, plane * s->n_act * sizeof(double)));
+            hipLaunchKernelGGL(extract_planes_kernel, dim3(grid_for(plane * s->n_act)), dim3(256), 0, ctx->stream,
+                               s->ops, s->seg_act, s->n_act, plane, s->planes);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        return launch_gemm_plane(ctx, g, s->planes, (long long)plane);
+    }
     return launch_gemm(ctx, g, KC_RHS_GEMM, ctx->skip_zero_planes ? s->uniform_mode : 0);
 }
 
@@ -1485,16 +1546,22 @@ extern "C" int midyn_microbench(midyn_ctx* ctx, const char* name, double* out) {
     DevBuf sink;
     CHK(sink.alloc(ctx, 64));
     float ms = 0.f;
-    if (n == "mfma_f64") {
-        // one 256-thread block per SIMD-pair: 8 blocks/CU worth of waves keeps every matrix pipe busy
-        const int blocks = ctx->num_cu * 4, iters = 4000;
-        hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink.as<double>(), 100);
+    if (n == "mfma_f64" || n == "mfma_f64_w1" || n == "mfma_f64_w2" || n == "mfma_f64_w2a16") {
+        // 256-thread blocks = one wave per SIMD each; `wps` of them per CU -> waves per SIMD
+        const int wps = n == "mfma_f64" ? 4 : (n == "mfma_f64_w1" ? 1 : 2);
+        const int blocks = ctx->num_cu * wps, iters = 4000;
+        const bool a16 = n == "mfma_f64_w2a16";
+        auto launch = [&](int it) {
+            if (a16) hipLaunchKernelGGL(mfma_peak_kernel<16>, dim3(blocks), dim3(256), 0, ctx->stream, sink.as<double>(), it);
+            else hipLaunchKernelGGL(mfma_peak_kernel<8>, dim3(blocks), dim3(256), 0, ctx->stream, sink.as<double>(), it);
+        };
+        launch(100);
         HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
-        hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, ctx->stream, sink.as<double>(), iters);
+        launch(iters);
         HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
         HIPCHK(ctx, hipEventSynchronize(e1));
         HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
-        const double flops = (double)blocks * 4 /*waves*/ * iters * 16 * 2048.0;
+        const double flops = (double)blocks * 4 /*waves*/ * iters * (a16 ? 32 : 16) * 2048.0;
         out[0] = flops / (ms * 1e-3) / 1e12;  // TFLOP/s
     } else if (n == "hbm_read" || n == "mall_read") {
         const size_t bytes = (n == "hbm_read") ? ((size_t)4 << 30) : ((size_t)144 << 20);

@@ -294,9 +294,15 @@ __device__ __forceinline__ void mfma_kstep(const double2 (&a)[MT], const double2
     double br[NT], bi[NT], bin[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+#ifdef MIDYN_NOSCALE  // profiling only: how much do the fp64 VALU scalings cost? (results wrong)
+        br[nt] = b[nt].x;
+        bi[nt] = b[nt].y;
+        bin[nt] = b[nt].y;
+#else
         br[nt] = b[nt].x * sc[nt];
         bi[nt] = b[nt].y * sc[nt];
         bin[nt] = -bi[nt];
+#endif
     }
     if (do_re) {
 #pragma unroll
@@ -473,6 +479,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
     //   MFMAs instead of idling the matrix pipe.
     constexpr int KS = BK / 4;
     static_assert(KS % 2 == 0, "fragment ping-pong assumes an even number of k-steps");
+    // single-plane tiles carry half the MFMAs per K tile: issue the next tile's LDS-DMA BEFORE the
+    // first k-step so that it has three k-steps (not two) to land ahead of the barrier
+    constexpr bool DMA_EARLY = false;  // measured: issuing before the first k-step is 1.5 % slower
     double2 fa[MODE == 4 ? 1 : 2][MT], fb[MODE == 4 ? 1 : 2][NT];
     const int a_lane_off = (wm * TM + lcol) * BK;
     const int b_lane_off = wn * TN + lcol;
@@ -532,8 +541,21 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
                     if (it + 1 < total && !MIDYN_ABL(g, 8))
                         read_frags<BK, BN, MT, NT>(Ab_n, Bb_n, 0, lk, lcol, fa[nxt], fb[nxt]);
                 }
+                if (ks == 0 && DMA_EARLY) issue_next_tile();
                 mfma_kstep<MODE, MT, NT>(fa[cur], fb[cur], mode, sc, cre, cim, c2);
-                if (ks == 0) issue_next_tile();
+                if (MODE != 3) {
+                    // Interleave the fragment reads of the NEXT k-step between the MFMAs of this one
+                    // (2 MFMAs : 1 ds_read) instead of issuing them as a block ahead of the MFMAs:
+                    // both waves of a SIMD run in lock-step behind the tile barrier, so a block of
+                    // non-MFMA instructions idles the matrix pipe in both at once.
+#pragma unroll
+                    for (int i = 0; i < MT + NT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+                }
+                if (ks == 0 && !DMA_EARLY) issue_next_tile();
             }
         }
 #pragma unroll
@@ -589,6 +611,265 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
                 const int col = n0 + wn * TN + nt * 16 + lcol;
                 apply_epilogue(g.epi, row, col, make_double2(cre[mt][nt][r], cim[mt][nt][r]));
             }
+}
+
+// ------------------------------------------------------------------------------------------------
+// zgemm_plane_kernel: the batched RHS contraction for stacks whose operators are ALL single-plane
+// (purely real or purely imaginary, e.g. -iH with real H in a real eigenbasis).  The non-zero plane of
+// every segment is kept as a planar fp64 copy, so an operator tile is half the bytes and TWO
+// operator tiles (segments s, s+1 of the same K tile) share one LDS stage and one barrier:
+//     per barrier 2 x (4 k-steps x 16 MFMAs) per wave instead of 1 x -- the fixed per-tile cost
+//     (barrier, DMA issue, LDS latency) is amortised over twice the matrix work.
+//   A stage in LDS: [2 seg][128 m][16 k] f64, element (m,k) at 8-B slot k ^ ((m>>1 & 7) << 1): every
+//     32-lane service group of ds_read_b64 (16 rows x 2 k) then touches 32 distinct 8-B bank pairs.
+//     The XOR is an even number, so 16-B DMA granules (slot pairs) stay intact; it is applied on the
+//     DMA source address.
+//   B stage: [16 k][128 n] complex as in zgemm_seg_kernel.
+//   real plane:  C_re += a * b_re, C_im += a * b_im;   imaginary plane: C_re += a * (-b_im), C_im += a * b_re.
+// ------------------------------------------------------------------------------------------------
+struct PlaneArgs {
+    const double* planes;     // [n_act][M][lda] non-zero plane of the active segments (active order)
+    long long seg_stride;     // elements between segments
+    GemmArgs g;               // everything else (A / a_seg_stride unused)
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void zgemm_plane_kernel(PlaneArgs pa) {
+    const GemmArgs& g = pa.g;
+    constexpr int BM = 128, BN = 128, BK = 16;
+    constexpr int NWAVE = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
+    constexpr int A_CHUNKS = BM / 8;             // 1-KiB DMA pieces per segment tile (8 rows x 128 B)
+    constexpr int A_PER_W = A_CHUNKS / NWAVE;    // per segment
+    constexpr int B_PER_ROW = BN / 64;
+    constexpr int B_PER_W = BK * B_PER_ROW / NWAVE;
+    static_assert(A_PER_W * NWAVE == A_CHUNKS, "DMA split");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* As = reinterpret_cast<double*>(smem_raw);                        // [2 stage][2 seg][BM][BK]
+    double2* Bs = reinterpret_cast<double2*>(As + 2 * 2 * BM * BK);          // [2][BK][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int grid_m = g.M / BM;
+    const int tiles = grid_m * (g.N / BN);
+    const int tile_id = blockIdx.x % tiles;
+    const int split = blockIdx.x / tiles;
+    const int m0 = (tile_id % grid_m) * BM;
+    const int n0 = (tile_id / grid_m) * BN;
+    const int KT = (g.K / BK) / g.splits;
+    const int kt0 = split * KT;
+    const int npair = (g.n_act + 1) >> 1;
+    const int total = npair * KT;
+
+    const int lcol = lane & 15, lk = lane >> 4;
+    int inst[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int in = (n0 + wn * TN + nt * 16 + lcol) / g.m_cols;
+        inst[nt] = in < g.n_inst ? in : g.n_inst - 1;
+    }
+    d4 cre[MT][NT], cim[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            cre[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+            cim[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+
+    // DMA source offsets: lane l of chunk c -> row m = 8c + l/8, 16-B granule p = l % 8 holding
+    // k = 2 (p ^ ((m >> 1) & 7)) and k + 1
+    int a_src[A_PER_W];
+#pragma unroll
+    for (int p = 0; p < A_PER_W; ++p) {
+        const int m = (wave + NWAVE * p) * 8 + (lane >> 3);
+        a_src[p] = m * g.lda + 2 * ((lane & 7) ^ ((m >> 1) & 7));
+    }
+    int b_src[B_PER_W];
+#pragma unroll
+    for (int p = 0; p < B_PER_W; ++p) {
+        const int c = wave + NWAVE * p;
+        b_src[p] = (c / B_PER_ROW) * g.ldb + (c % B_PER_ROW) * 64 + lane;
+    }
+    const double* Pbase = pa.planes + (size_t)m0 * g.lda + (size_t)kt0 * BK;
+    const double2* Bbase = g.B + n0 + (size_t)kt0 * BK * g.ldb;
+    const int seg_vec = lane < g.n_act ? g.seg_list[lane] : 0;   // (seg << 2) | mode, active order
+
+    auto dma_a = [&](int kt_, int pair, int stage) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int s_act = 2 * pair + q;
+            if (s_act < g.n_act) {
+                const double* Ab = Pbase + s_act * pa.seg_stride + kt_ * BK;
+                double* Ad = As + (stage * 2 + q) * BM * BK;
+#pragma unroll
+                for (int p = 0; p < A_PER_W; ++p)
+                    __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + a_src[p]),
+                                                     (lds_void_t*)(Ad + (wave + NWAVE * p) * 128), 16, 0, 0);
+            }
+        }
+    };
+    auto dma_b = [&](int kt_, int buf) {
+        const double2* Bb = Bbase + (size_t)(kt_ * BK) * g.ldb;
+        double2* Bd = Bs + buf * BK * BN;
+#pragma unroll
+        for (int p = 0; p < B_PER_W; ++p)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bb + b_src[p]),
+                                             (lds_void_t*)(Bd + (wave + NWAVE * p) * 64), 16, 0, 0);
+    };
+    // per pair: coefficients of both segments and their plane kinds (bit0: seg0 imaginary, bit1: seg1)
+    auto load_sc = [&](int pair, double (&scv)[2][NT], int& kinds) {
+        kinds = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int s_act = 2 * pair + q;
+            const int packed = __builtin_amdgcn_readlane(seg_vec, s_act < g.n_act ? s_act : 0);
+            const int seg = packed >> 2;
+            if ((packed & 3) == 2) kinds |= (1 << q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (s_act >= g.n_act) scv[q][nt] = 0.0;
+                else if (g.coeff == nullptr || (g.has_static && seg == 0)) scv[q][nt] = 1.0;
+                else scv[q][nt] = g.coeff[inst[nt] * g.inst_stride + (seg - g.has_static)];
+            }
+        }
+    };
+    // fragments of k-step ks of BOTH segment tiles + the shared B fragment
+    auto read_frags = [&](const double* Ab, const double2* Bb, int ks, double (&a)[2][MT], double2 (&b)[NT]) {
+        const int k = ks * 4 + lk;
+        const int slot = k ^ ((lcol >> 1) << 1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[q][mt] = Ab[q * BM * BK + mt * 16 * BK + slot];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = Bb[k * BN + nt * 16];
+    };
+    auto mfma_kstep2 = [&](const double (&a)[2][MT], const double2 (&b)[NT], const double (&scv)[2][NT], int kinds,
+                           bool second) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q == 1 && !second) break;
+            const bool imag = (kinds >> q) & 1;
+            double o_re[NT], o_im[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const double br = b[nt].x * scv[q][nt], bi = b[nt].y * scv[q][nt];
+                o_re[nt] = imag ? -bi : br;   // operand feeding C_re
+                o_im[nt] = imag ? br : bi;    // operand feeding C_im
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][mt], o_re[nt], cre[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][mt], o_im[nt], cim[mt][nt], 0, 0, 0);
+        }
+    };
+
+    double sc[2][NT], sc_next[2][NT];
+    int kinds = 0, kinds_next = 0;
+    if (total > 0) {
+        dma_a(0, 0, 0);
+        dma_b(0, 0);
+        load_sc(0, sc, kinds);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    constexpr int KS = BK / 4;
+    double fa[2][2][MT];
+    double2 fb[2][NT];
+    const int a_lane_off = (wm * TM + lcol) * BK;
+    const int b_lane_off = wn * TN + lcol;
+    if (total > 0) read_frags(As + a_lane_off, Bs + b_lane_off, 0, fa[0], fb[0]);
+
+    int kt = 0, pr = 0;
+    for (int it = 0; it < total; ++it) {
+        int pr_n = pr + 1, kt_n = kt;
+        if (pr_n == npair) {
+            pr_n = 0;
+            kt_n = kt + 1;
+        }
+        const bool second = 2 * pr + 1 < g.n_act;
+        const double* Ab = As + (it & 1) * 2 * BM * BK + a_lane_off;
+        const double2* Bb = Bs + (kt & 1) * BK * BN + b_lane_off;
+        const double* Ab_n = As + ((it + 1) & 1) * 2 * BM * BK + a_lane_off;
+        const double2* Bb_n = Bs + (kt_n & 1) * BK * BN + b_lane_off;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < KS) {
+                read_frags(Ab, Bb, ks + 1, fa[nxt], fb[nxt]);
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (it + 1 < total) read_frags(Ab_n, Bb_n, 0, fa[nxt], fb[nxt]);
+            }
+            mfma_kstep2(fa[cur], fb[cur], sc, kinds, second);
+            if (ks == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < total) {
+                    dma_a(kt_n, pr_n, (it + 1) & 1);
+                    if (pr_n == 0) dma_b(kt_n, kt_n & 1);
+                }
+                load_sc(it + 1 < total ? pr_n : pr, sc_next, kinds_next);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) sc[q][nt] = sc_next[q][nt];
+        kinds = kinds_next;
+        pr = pr_n;
+        kt = kt_n;
+    }
+
+    if (g.splits > 1) {
+        double2* P = g.partial + (size_t)split * g.M * g.N;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * TM + mt * 16 + lk + 4 * r;
+                    const int col = n0 + wn * TN + nt * 16 + lcol;
+                    P[(size_t)row * g.N + col] = make_double2(cre[mt][nt][r], cim[mt][nt][r]);
+                }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * TM + mt * 16 + lk + 4 * r;
+                const int col = n0 + wn * TN + nt * 16 + lcol;
+                apply_epilogue(g.epi, row, col, make_double2(cre[mt][nt][r], cim[mt][nt][r]));
+            }
+}
+
+// planes[act][i] = non-zero plane of active segment `act` (mode 1: real part, mode 2: imaginary part)
+__global__ __launch_bounds__(256) void extract_planes_kernel(const double2* ops, const int* seg_act, int n_act,
+                                                             size_t plane, double* planes) {
+    const size_t total = plane * n_act;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * 256) {
+        const int a = (int)(idx / plane);
+        const size_t e = idx - (size_t)a * plane;
+        const int packed = seg_act[a];
+        const double2 v = ops[(size_t)(packed >> 2) * plane + e];
+        planes[idx] = (packed & 3) == 2 ? v.y : v.x;
+    }
 }
 
 // Sum the split-K partials and run the fused epilogue (one thread per element).
@@ -844,24 +1125,25 @@ __global__ __launch_bounds__(256) void frame_mask_kernel(const double2* src, con
 // ---- micro-benchmarks: the ceilings the roofline fractions are quoted against -------------------
 // 8 independent fp64 MFMA accumulators per wave (all in VGPRs), `iters` rounds, 4 waves per SIMD:
 // pure matrix-pipe throughput.
+template <int NACC>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters) {
-    d4 acc[8];
+    d4 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
-    double a[8], b = 0.5 - threadIdx.x * 1e-9;
+    for (int i = 0; i < NACC; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double a[NACC], b = 0.5 - threadIdx.x * 1e-9;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = 1.0 + (threadIdx.x + 64 * i) * 1e-9;  // distinct: no CSE of chains
+    for (int i = 0; i < NACC; ++i) a[i] = 1.0 + (threadIdx.x + 64 * i) * 1e-9;  // distinct: no CSE of chains
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NACC; ++i)
             asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b));
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NACC; ++i)
             asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(b), "v"(a[i]));
     }
     double s = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 123.456) sink[0] = s;
 }
 

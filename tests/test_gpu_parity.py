@@ -693,3 +693,51 @@ def test_expm_lindbladian_vs_scipy(qd):
     assert np.linalg.norm(e - ref, 1) / np.linalg.norm(ref, 1) < 1e-12
     vec_id = np.eye(n).flatten(order="F")
     assert np.max(np.abs(vec_id @ e - vec_id)) < 1e-12  # tr(rho) preserved: vec(I)^T E = vec(I)^T
+
+
+def test_planar_single_plane_kernel(qd):
+    """Stacks whose operators are all purely real / purely imaginary run the planar two-tiles-per-
+    barrier kernel (M, N multiples of 128): mixed kinds, odd segment count, split-K and many
+    instances with different coefficients, against NumPy and against the generic kernel."""
+    rng = np.random.default_rng(128)
+    n, k = 128, 4
+    ops = np.zeros((k, n, n), dtype=complex)
+    ops[0] = rng.normal(size=(n, n))
+    ops[1] = 1j * rng.normal(size=(n, n))
+    ops[2] = 1j * rng.normal(size=(n, n))
+    ops[3] = rng.normal(size=(n, n))
+    static = 1j * rng.normal(size=(n, n))       # 5 active single-plane segments (odd)
+    frame_im = rng.normal(size=n)
+    ctx = qd.default_context()
+    stack = qd.Stack(ctx, ops, static, frame_im)
+    assert stack.segment_modes == [2, 1, 2, 2, 1]
+    c = rng.uniform(-1, 1, k)
+    y = crand(rng, n, 128)
+    e = np.exp(1j * frame_im * 0.7)
+    ref = np.conj(e)[:, None] * ((np.tensordot(c, ops, axes=1) + static) @ (e[:, None] * y))
+    ctx.set_option("plane_kernel", 1)          # opt-in variant (default off: measured slower)
+    try:
+        got = stack.eval_rhs(c, 0.7, y)
+    finally:
+        ctx.set_option("plane_kernel", 0)
+    assert_close(got, ref, EVAL_TOL)
+    assert_close(stack.eval_rhs(c, 0.7, y), got, 1e-13)
+    # sweep with per-instance coefficients: 256 instances, 3 RK4 steps, both kernels
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    sched = FixedStepSchedule([0.0, 0.03], None, 0.01, _rk4_points)
+    B = 256
+    table = rng.uniform(-1, 1, (B, len(sched.times), k))
+    y0 = crand(rng, n, 1)
+    outs = []
+    for flag in (1, 0):
+        ctx.set_option("plane_kernel", flag)
+        try:
+            outs.append(stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                                        sched.n_save, y0, B, True)[:, -1, :, 0])
+        finally:
+            ctx.set_option("plane_kernel", 0)
+    assert_close(outs[0], outs[1], 1e-12)
+    single = stack.rk4_solve(sched.times, table[5:6], sched.step_rows, sched.step_h, sched.step_save,
+                             sched.n_save, y0, 1, True)[0, -1, :, 0]
+    assert_close(outs[0][5], single, 1e-12)
