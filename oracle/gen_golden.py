@@ -102,6 +102,20 @@ def gen_signals():
     sl = SignalList([s_const, s_gauss, d, ssum, 1.5])
     out["list"] = sl(t)  # (T, 5)
     out["list_scalar_t"] = sl(0.613)
+    # signal algebra (signals/signals.py:838-1121): values only, the composite types are not pinned
+    out["prod_const_gauss"] = (s_const * s_gauss)(t)
+    out["prod_disc_gauss"] = (d * s_gauss)(t)
+    out["prod_gauss_gauss"] = (s_gauss * s_gauss)(t)
+    out["prod_scalar"] = (2.5 * s_gauss)(t)
+    out["neg_gauss"] = (-s_gauss)(t)
+    out["diff_gauss_disc"] = (s_gauss - d)(t)
+    out["conj_gauss_complex"] = s_gauss.conjugate().complex_value(t)
+    dsig = DiscreteSignal.from_Signal(s_gauss, dt=0.1, n_samples=20, start_time=0.0)
+    out["from_signal"] = dsig(t)
+    out["from_signal_samples"] = np.asarray(dsig.samples)
+    dsig2 = DiscreteSignal.from_Signal(s_gauss, dt=0.1, n_samples=20, start_time=0.0, sample_carrier=True)
+    out["from_signal_carrier"] = dsig2(t)
+    out["flatten_sum"] = ssum.flatten()(t)
     save("signals", **out)
 
 

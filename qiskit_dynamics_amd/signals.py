@@ -6,7 +6,11 @@ Mirrors the evaluation surface of the reference's ``signals/signals.py`` (``Sign
 ``Re[f(t) exp(i(2 pi nu t + phi))]`` with an array-vectorised complex envelope ``f``.  The
 arithmetic ORDER of the reference is kept (complex carrier argument, one ``exp``, sum over terms,
 real part) so that tables are bit-identical to ``SignalList(...)(t)`` of the reference.
-Signal algebra beyond ``+`` (products, RWA, transfer functions) is out of scope for this path.
+``+``, ``-``, unary ``-``, ``*`` (the two-term product rule of the reference, :838-1000),
+``conjugate``, ``DiscreteSignal.from_Signal`` and ``flatten`` are provided so that signals can be
+built the way the reference's users build them; the composite TYPE returned by a product may differ
+from the reference's (always a ``SignalSum`` of plain ``Signal``s here), its VALUES do not.
+RWA and transfer functions are out of scope for this path.
 """
 from __future__ import annotations
 
@@ -75,6 +79,25 @@ class Signal:
     def __radd__(self, other):
         return SignalSum(other, self)
 
+    def __neg__(self):
+        return signal_multiply(-1.0, self)
+
+    def __sub__(self, other):
+        return SignalSum(self, signal_multiply(-1.0, other))
+
+    def __rsub__(self, other):
+        return SignalSum(other, signal_multiply(-1.0, self))
+
+    def __mul__(self, other):
+        return signal_multiply(self, other)
+
+    def __rmul__(self, other):
+        return signal_multiply(other, self)
+
+    def conjugate(self):
+        """Signal whose complex value is the conjugate of this one's."""
+        return Signal(lambda t: np.conjugate(self.envelope(t)), -self.carrier_freq, -self.phase)
+
     def __str__(self):
         if self._name is not None:
             return str(self._name)
@@ -105,6 +128,22 @@ class DiscreteSignal(Signal):
             return self._padded_samples[idx]
 
         super().__init__(envelope=envelope, carrier_freq=carrier_freq, phase=phase, name=name)
+
+    @classmethod
+    def from_Signal(cls, signal: Signal, dt: float, n_samples: int, start_time: float = 0.0,
+                    sample_carrier: bool = False):
+        """Sample ``signal`` at the bin mid-points; with ``sample_carrier`` the carrier is folded
+        into the samples (carrier frequency 0, phase kept)."""
+        times = start_time + (np.arange(n_samples) + 0.5) * dt
+        if sample_carrier:
+            return cls(dt, signal(times), start_time=start_time, carrier_freq=0.0, phase=signal.phase,
+                       name=signal.name)
+        return cls(dt, signal.envelope(times), start_time=start_time, carrier_freq=signal.carrier_freq,
+                   phase=signal.phase, name=signal.name)
+
+    def conjugate(self):
+        return DiscreteSignal(self._dt, np.conjugate(self.samples), start_time=self._start_time,
+                              carrier_freq=-self.carrier_freq, phase=-self.phase)
 
     @property
     def dt(self):
@@ -165,6 +204,55 @@ class SignalSum(Signal):
     def complex_value(self, t):
         exp_phases = np.exp(np.expand_dims(t, -1) * self._carrier_arg + self._phase_arg)
         return np.sum(self.envelope(t) * exp_phases, axis=-1)
+
+    def conjugate(self):
+        return SignalSum(*[s.conjugate() for s in self._components])
+
+    def flatten(self) -> Signal:
+        """Merge into one ``Signal`` whose carrier is the average of the terms' carriers."""
+        if len(self) == 0:
+            return Signal(0.0)
+        if len(self) == 1:
+            return self._components[0]
+        ave = np.sum(self.carrier_freq) / len(self)
+        shifted = self._carrier_arg - (1j * 2 * np.pi * ave)
+
+        def merged(t):
+            return np.sum(self.envelope(t) * np.exp(np.expand_dims(t, -1) * shifted + self._phase_arg), axis=-1)
+
+        return Signal(envelope=merged, carrier_freq=ave, name=str(self))
+
+
+def _term_product(a: Signal, b: Signal) -> SignalSum:
+    """Product of two elementary signals as a sum of two signals:
+    Re[f e^{i x}] Re[g e^{i y}] = Re[(f g / 2) e^{i(x+y)}] + Re[(f conj(g) / 2) e^{i(x-y)}]."""
+    if a.is_constant and b.is_constant:
+        return SignalSum(Signal(a(0.0) * b(0.0)))
+    if a.is_constant or b.is_constant:
+        const, other = (a, b) if a.is_constant else (b, a)
+        c = const(0.0)
+        if type(other) is DiscreteSignal:
+            return SignalSum(DiscreteSignal(other.dt, c * other.samples, start_time=other.start_time,
+                                            carrier_freq=other.carrier_freq, phase=other.phase))
+        return SignalSum(Signal(lambda t: c * other.envelope(t), other.carrier_freq, other.phase))
+    plus = Signal(lambda t: 0.5 * a.envelope(t) * b.envelope(t), a.carrier_freq + b.carrier_freq,
+                  a.phase + b.phase)
+    minus = Signal(lambda t: 0.5 * a.envelope(t) * np.conjugate(b.envelope(t)),
+                   a.carrier_freq - b.carrier_freq, a.phase - b.phase)
+    return SignalSum(plus, minus)
+
+
+def signal_multiply(sig1, sig2) -> "SignalSum":
+    """Product of two signal-like objects (numbers count as constant signals)."""
+    try:
+        s1, s2 = to_SignalSum(sig1), to_SignalSum(sig2)
+    except DynamicsError as err:
+        raise DynamicsError("Only a number or a Signal instance can multiply a Signal.") from err
+    terms = []
+    for a in s1.components:
+        for b in s2.components:
+            terms += _term_product(a, b).components
+    return SignalSum(*terms)
 
 
 def to_SignalSum(sig) -> SignalSum:

@@ -213,3 +213,29 @@ def test_header_is_plain_c_and_symbols_resolve(tmp_path):
     cpp.write_text('#include "%s"\nint main() { midyn_complex z{1.0, 2.0}; return z.re > 0 ? 0 : 1; }\n'
                    % os.path.join(ROOT, "include", "midyn.h"))
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-o", str(tmp_path / "h"), str(cpp)], check=True)
+
+
+def test_signal_algebra_values_match_reference(golden):
+    g = golden("signals")
+    t = g["t"]
+    s_const = qd.Signal(0.37, carrier_freq=1.3, phase=0.4)
+    amp, t0, sig, nu, phi = g["gauss_params"]
+    s_gauss = qd.Signal(lambda tt: amp * np.exp(-((tt - t0) ** 2) / (2 * sig**2)), nu, phi)
+    dt, st, cf, ph = g["disc_params"]
+    d = qd.DiscreteSignal(dt=dt, samples=g["disc_samples"], start_time=st, carrier_freq=cf, phase=ph)
+    assert_close((s_const * s_gauss)(t), g["prod_const_gauss"], 1e-15)
+    assert_close((d * s_gauss)(t), g["prod_disc_gauss"], 1e-15)
+    assert_close((s_gauss * s_gauss)(t), g["prod_gauss_gauss"], 1e-15)
+    assert_close((2.5 * s_gauss)(t), g["prod_scalar"], 1e-15)
+    assert_close((-s_gauss)(t), g["neg_gauss"], 1e-15)
+    assert_close((s_gauss - d)(t), g["diff_gauss_disc"], 1e-15)
+    assert_close(s_gauss.conjugate().complex_value(t), g["conj_gauss_complex"], 1e-15)
+    ds = qd.DiscreteSignal.from_Signal(s_gauss, dt=0.1, n_samples=20, start_time=0.0)
+    assert_close(ds.samples, g["from_signal_samples"], 0)
+    assert_close(ds(t), g["from_signal"], 1e-15)
+    ds2 = qd.DiscreteSignal.from_Signal(s_gauss, dt=0.1, n_samples=20, start_time=0.0, sample_carrier=True)
+    assert_close(ds2(t), g["from_signal_carrier"], 1e-15)
+    assert_close((s_const + s_gauss).flatten()(t), g["flatten_sum"], 1e-15)
+    assert (qd.Signal(2.0) * qd.Signal(3.0)).components[0].is_constant
+    with pytest.raises(qd.DynamicsError):
+        s_gauss * "x"
