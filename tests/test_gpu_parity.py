@@ -741,3 +741,69 @@ def test_planar_single_plane_kernel(qd):
     single = stack.rk4_solve(sched.times, table[5:6], sched.step_rows, sched.step_h, sched.step_save,
                              sched.n_save, y0, 1, True)[0, -1, :, 0]
     assert_close(outs[0][5], single, 1e-12)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_models_vs_oracle(qd, seed):
+    """Random small models (ragged sizes, with/without static operator, frames of all kinds, vector and
+    matrix states, sweeps with per-instance signals and initial states, forwards/backwards, t_eval)
+    through the public Solver / solve_lmde API against the oracle."""
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(2, 40))
+    k = int(rng.integers(0, 5))
+    has_static = bool(rng.integers(0, 2)) or k == 0
+    frame_kind = ["none", "diag", "full"][int(rng.integers(0, 3))]
+    m = [None, 1, 3][int(rng.integers(0, 3))]          # None: vector state
+    batch = [1, 2, 5][int(rng.integers(0, 3))]
+    method = ["RK4", "scipy_expm"][int(rng.integers(0, 2))]
+    backwards = bool(rng.integers(0, 2))
+
+    def herm():
+        a = crand(rng, n, n)
+        return (a + a.conj().T) / 2
+
+    h_static = herm() if has_static else None
+    h_ops = np.array([herm() for _ in range(k)]) if k else None
+    frame = {"none": None, "diag": rng.normal(size=n), "full": herm()}[frame_kind]
+    t_span = [0.4, 0.0] if backwards else [0.0, 0.4]
+    t_eval = None if rng.integers(0, 2) else (sorted(rng.uniform(0, 0.4, 3), reverse=backwards))
+    max_dt = 0.01 if method == "RK4" else 0.05
+    mo = int(rng.integers(1, 4))
+
+    def make_sigs():
+        amps, nus, phs = rng.uniform(-1, 1, k), rng.uniform(0, 2, k), rng.uniform(-3, 3, k)
+        return ([qd.Signal(lambda t, a=a: a * np.cos(0.7 * t) + 0j, nu, ph) for a, nu, ph in zip(amps, nus, phs)],
+                (amps, nus, phs))
+
+    def make_y0():
+        y = crand(rng, n) if m is None else crand(rng, n, m)
+        return y / np.linalg.norm(y)
+
+    sig_sets = [make_sigs() for _ in range(batch)]
+    y0s = [make_y0() for _ in range(batch)]
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=frame)
+    kwargs = dict(method=method, max_dt=max_dt, t_eval=t_eval)
+    if method == "scipy_expm":
+        kwargs["magnus_order"] = mo
+    if k == 0:
+        res = solver.solve(t_span=t_span, y0=y0s if batch > 1 else y0s[0], **kwargs)
+    else:
+        res = solver.solve(t_span=t_span, y0=y0s if batch > 1 else y0s[0],
+                           signals=[s for s, _ in sig_sets] if batch > 1 else sig_sets[0][0], **kwargs)
+    res = res if isinstance(res, list) else [res]
+    assert len(res) == batch
+    a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
+    for b in range(batch):
+        amps, nus, phs = sig_sets[b][1]
+
+        def coeff(t, amps=amps, nus=nus, phs=phs):
+            return np.array([orc.signal_sum_value(np.array([a_ * np.cos(0.7 * t) + 0j]), [nu], [ph], t)
+                             for a_, nu, ph in zip(amps, nus, phs)])
+
+        t_ref, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff, t_span, y0s[b],
+                                                 "RK4" if method == "RK4" else "scipy_expm", max_dt,
+                                                 t_eval=t_eval, magnus_order=mo)
+        assert_close(res[b].t, t_ref, 0)
+        assert_close(res[b].y, y_ref, SOLVE_TOL)
