@@ -429,7 +429,7 @@ static int launch_gemm_mode(midyn_ctx* ctx, const GemmArgs& g) {
         attr_set[ctx->device & 15] = true;
     }
     const int blocks = (g.M / BM) * (g.N / BN) * g.splits;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(THREADS), SMEM, ctx->stream, g);
+    hipLaunchKernelGGL(kern, dim3(blocks, g.batch > 1 ? g.batch : 1), dim3(THREADS), SMEM, ctx->stream, g);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -506,6 +506,8 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     const int KT = g.K / GEMM_BK;
     auto best_splits = [&](long long tiles) {
         int sp = 1;
+        if (g.batch > 1) return 1;  // the batch dimension already fills the chip
+        tiles *= 1;
         if (ctx->split_k && tiles < ctx->num_cu)
             while ((long long)sp * 2 * tiles <= ctx->num_cu && KT % (sp * 2) == 0 && KT / (sp * 2) >= 2) sp *= 2;
         if (ctx->force_splits > 0 && KT % ctx->force_splits == 0) sp = ctx->force_splits;
@@ -578,9 +580,11 @@ static int launch_stream(midyn_ctx* ctx, const StreamArgs& a) {
     return 0;
 }
 
-// plain zgemm on device buffers: C = alpha * A.B + beta * Z   (all [n][n], ld n, n % 64 == 0)
-static int dev_zgemm(midyn_ctx* ctx, int M, int N, int K, const double2* A, int lda, const double2* B,
-                     int ldb, double2* C, int ldc, double alpha, double beta, const double2* Z) {
+// plain zgemm on device buffers: C = alpha * A.B + beta * Z; `batch` independent problems whose
+// operands are `sa`, `sb`, `sc` elements apart (C and Z share the stride)
+static int dev_zgemm_batched(midyn_ctx* ctx, int batch, int M, int N, int K, const double2* A, int lda, long long sa,
+                             const double2* B, int ldb, long long sb, double2* C, int ldc, long long sc, double alpha,
+                             double beta, const double2* Z) {
     GemmArgs g{};
     g.A = A;
     g.a_seg_stride = 0;
@@ -597,6 +601,10 @@ static int dev_zgemm(midyn_ctx* ctx, int M, int N, int K, const double2* A, int 
     g.inst_stride = 0;
     g.m_cols = 1;
     g.n_inst = N;
+    g.batch = batch;
+    g.batch_a = sa;
+    g.batch_b = sb;
+    g.batch_c = sc;
     g.epi.mode = EPI_PLAIN;
     g.epi.ld = ldc;
     g.epi.alpha = alpha;
@@ -606,8 +614,20 @@ static int dev_zgemm(midyn_ctx* ctx, int M, int N, int K, const double2* A, int 
     return launch_gemm(ctx, g, KC_ZGEMM);
 }
 
+static int dev_zgemm(midyn_ctx* ctx, int M, int N, int K, const double2* A, int lda, const double2* B,
+                     int ldb, double2* C, int ldc, double alpha, double beta, const double2* Z) {
+    return dev_zgemm_batched(ctx, 1, M, N, K, A, lda, 0, B, ldb, 0, C, ldc, 0, alpha, beta, Z);
+}
+
+// square [np][np] matrices laid out back to back
+static int dev_sqgemm(midyn_ctx* ctx, int batch, int np, const double2* A, const double2* B, double2* C, double alpha,
+                      double beta, const double2* Z) {
+    const long long st = (long long)np * np;
+    return dev_zgemm_batched(ctx, batch, np, np, np, A, np, st, B, np, st, C, np, st, alpha, beta, Z);
+}
+
 static int dev_lincomb(midyn_ctx* ctx, int n, double2* out, int nterms, const double2* const* xs,
-                       const double* alphas, double gamma) {
+                       const double* alphas, double gamma, int batch = 1) {
     LinArgs a{};
     a.nterms = nterms;
     for (int i = 0; i < nterms; ++i) {
@@ -616,9 +636,10 @@ static int dev_lincomb(midyn_ctx* ctx, int n, double2* out, int nterms, const do
     }
     a.gamma = gamma;
     a.n = n;
+    a.batch = batch;
     a.out = out;
     ProfScope ps(ctx, KC_ELEM);
-    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for((size_t)n * n)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for((size_t)n * n * batch)), dim3(256), 0, ctx->stream, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -655,9 +676,11 @@ static const int* stack_seg_list(midyn_stack* s, int* n_act) {
 }
 
 static int launch_gen_eval(midyn_stack* s, const double* d_coeff, const double2* d_e, double scale,
-                           double2* d_out) {
+                           double2* d_out, int batch = 1, long long coeff_stride = 0) {
     midyn_ctx* ctx = s->ctx;
     GenArgs a{};
+    a.batch = batch;
+    a.coeff_stride = coeff_stride;
     a.ops = s->ops;
     a.seg_list = stack_seg_list(s, &a.n_act);
     a.n_pad = s->n_pad;
@@ -667,7 +690,7 @@ static int launch_gen_eval(midyn_stack* s, const double* d_coeff, const double2*
     a.scale = scale;
     a.out = d_out;
     ProfScope ps(ctx, KC_GEN);
-    hipLaunchKernelGGL(gen_eval_kernel, dim3(grid_for((size_t)s->n_pad * s->n_pad, 8192)), dim3(256), 0,
+    hipLaunchKernelGGL(gen_eval_kernel, dim3(grid_for((size_t)s->n_pad * s->n_pad * batch, 8192)), dim3(256), 0,
                        ctx->stream, a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
@@ -1049,36 +1072,40 @@ extern "C" int midyn_zgemm(midyn_ctx* ctx, int M, int N, int K, const midyn_comp
     return 0;
 }
 
-// expm workspace: X (input/output), powers, temporaries; all [np][np]
+// expm workspace: powers and temporaries for `batch` matrices of [np][np]
 struct ExpmWork {
-    int np = 0;
+    int np = 0, batch = 0;
     DevBuf A2, A3, A4, T0, T1, colsum;
-    int ensure(midyn_ctx* ctx, int n_pad) {
-        if (np == n_pad) return 0;
-        const size_t b = (size_t)n_pad * n_pad * sizeof(double2);
+    int ensure(midyn_ctx* ctx, int n_pad, int nb) {
+        if (np == n_pad && batch >= nb) return 0;
+        const size_t b = (size_t)nb * n_pad * n_pad * sizeof(double2);
         CHK(A2.alloc(ctx, b));
         CHK(A3.alloc(ctx, b));
         CHK(A4.alloc(ctx, b));
         CHK(T0.alloc(ctx, b));
         CHK(T1.alloc(ctx, b));
-        CHK(colsum.alloc(ctx, (size_t)n_pad * sizeof(double)));
+        CHK(colsum.alloc(ctx, (size_t)nb * n_pad * sizeof(double)));
         np = n_pad;
+        batch = nb;
         return 0;
     }
 };
 
 static const double EXPM_THETA16 = 0.5;  // conservative: ||A/2^s||_1 <= 0.5 for the degree-16 Taylor
 
-// In place: X <- expm(X).  X is [np][np] on the device (padding rows/cols zero; the padded block of
-// the result becomes the identity, which is harmless).  Degree-16 Taylor polynomial evaluated with
-// Paterson-Stockmeyer (powers A^2,A^3,A^4 + Horner in A^4: 6 zgemm) and s squarings.
-static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int* s_out, double* norm_out) {
-    CHK(w.ensure(ctx, np));
-    hipLaunchKernelGGL(colsum_kernel, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, X, np,
+// In place: X[b] <- expm(X[b]) for `batch` matrices [np][np] stored back to back on the device
+// (padding rows/cols zero; the padded block of the result becomes the identity, which is harmless).
+// Degree-16 Taylor polynomial evaluated with Paterson-Stockmeyer (powers A^2,A^3,A^4 + Horner in
+// A^4: 6 zgemm) and s squarings; a batch shares s = max over its matrices (over-scaling a matrix is
+// harmless) so that every step is ONE batched launch.
+static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int* s_out, double* norm_out,
+                            int batch = 1) {
+    CHK(w.ensure(ctx, np, batch));
+    hipLaunchKernelGGL(colsum_kernel, dim3((np + 255) / 256, batch), dim3(256), 0, ctx->stream, X, np,
                        w.colsum.as<double>());
     HIPCHK(ctx, hipGetLastError());
-    std::vector<double> cs(np);
-    HIPCHK(ctx, hipMemcpyAsync(cs.data(), w.colsum.p, (size_t)np * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> cs((size_t)np * batch);
+    HIPCHK(ctx, hipMemcpyAsync(cs.data(), w.colsum.p, cs.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     double norm1 = 0.0;
     for (double v : cs) norm1 = std::max(norm1, v);
@@ -1100,16 +1127,16 @@ static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int
     if (s > 0) {
         const double2* xs[1] = {A};
         double al[1] = {scale};
-        CHK(dev_lincomb(ctx, np, A, 1, xs, al, 0.0));
+        CHK(dev_lincomb(ctx, np, A, 1, xs, al, 0.0, batch));
     }
-    CHK(dev_zgemm(ctx, np, np, np, A, np, A, np, A2, np, 1.0, 0.0, nullptr));
-    CHK(dev_zgemm(ctx, np, np, np, A2, np, A, np, A3, np, 1.0, 0.0, nullptr));
-    CHK(dev_zgemm(ctx, np, np, np, A2, np, A2, np, A4, np, 1.0, 0.0, nullptr));
+    CHK(dev_sqgemm(ctx, batch, np, A, A, A2, 1.0, 0.0, nullptr));
+    CHK(dev_sqgemm(ctx, batch, np, A2, A, A3, 1.0, 0.0, nullptr));
+    CHK(dev_sqgemm(ctx, batch, np, A2, A2, A4, 1.0, 0.0, nullptr));
     // B_j = c[4j] I + c[4j+1] A + c[4j+2] A2 + c[4j+3] A3 ;  P3 = B3 + c16 A4
     {
         const double2* xs[4] = {A, A2, A3, A4};
         double al[4] = {c[13], c[14], c[15], c[16]};
-        CHK(dev_lincomb(ctx, np, T0, 4, xs, al, c[12]));  // T0 = P3
+        CHK(dev_lincomb(ctx, np, T0, 4, xs, al, c[12], batch));  // T0 = P3
     }
     double2* P = T0;
     double2* Q = T1;
@@ -1118,25 +1145,36 @@ static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int
         const double2* xs[3] = {A, A2, A3};
         double al[3] = {c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]};
         if (j > 0) {
-            CHK(dev_lincomb(ctx, np, Q, 3, xs, al, c[4 * j]));
-            CHK(dev_zgemm(ctx, np, np, np, A4, np, P, np, Q, np, 1.0, 1.0, Q));
+            CHK(dev_lincomb(ctx, np, Q, 3, xs, al, c[4 * j], batch));
+            CHK(dev_sqgemm(ctx, batch, np, A4, P, Q, 1.0, 1.0, Q));
             std::swap(P, Q);
         } else {
             // final result goes back into X (= A); build B_0 in Q first because A is an input of B_0
-            CHK(dev_lincomb(ctx, np, Q, 3, xs, al, c[0]));
-            CHK(dev_zgemm(ctx, np, np, np, A4, np, P, np, X, np, 1.0, 1.0, Q));
+            CHK(dev_lincomb(ctx, np, Q, 3, xs, al, c[0], batch));
+            CHK(dev_sqgemm(ctx, batch, np, A4, P, X, 1.0, 1.0, Q));
         }
     }
     // squarings: X <- X.X, ping-pong through T0
     double2* cur = X;
     double2* oth = T0;
     for (int i = 0; i < s; ++i) {
-        CHK(dev_zgemm(ctx, np, np, np, cur, np, cur, np, oth, np, 1.0, 0.0, nullptr));
+        CHK(dev_sqgemm(ctx, batch, np, cur, cur, oth, 1.0, 0.0, nullptr));
         std::swap(cur, oth);
     }
     if (cur != X)
-        HIPCHK(ctx, hipMemcpyAsync(X, cur, (size_t)np * np * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(X, cur, (size_t)batch * np * np * sizeof(double2), hipMemcpyDeviceToDevice,
+                                   ctx->stream));
     return 0;
+}
+
+// how many [np][np] problems are advanced together: enough to fill the chip, bounded by ~3 GB of
+// workspace (12 matrices per problem)
+static int expm_chunk(midyn_ctx* ctx, int np, int total) {
+    const size_t per = (size_t)np * np * sizeof(double2) * 12;
+    long long cap = (long long)(((size_t)3 << 30) / per);
+    if (np >= 1024) cap = 1;          // one such expm already fills the device
+    cap = std::max(1LL, std::min<long long>(cap, 4096));
+    return (int)std::min<long long>(cap, total);
 }
 
 extern "C" int midyn_expm(midyn_ctx* ctx, int n, int batch, const midyn_complex* A, midyn_complex* E_out,
@@ -1144,21 +1182,28 @@ extern "C" int midyn_expm(midyn_ctx* ctx, int n, int batch, const midyn_complex*
     if (!ctx || !A || !E_out || n <= 0 || batch <= 0) return fail(ctx, "midyn_expm: bad argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int np = round_up(n, 64);
+    const int chunk = expm_chunk(ctx, np, batch);
+    const size_t mat = (size_t)np * np;
     ExpmWork w;
     DevBuf X;
-    CHK(X.alloc(ctx, (size_t)np * np * sizeof(double2)));
-    for (int b = 0; b < batch; ++b) {
-        HIPCHK(ctx, hipMemset(X.p, 0, X.bytes));
-        CHK(upload_padded(ctx, A + (size_t)b * n * n, n, n, X.as<double2>(), np));
+    CHK(X.alloc(ctx, (size_t)chunk * mat * sizeof(double2)));
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        const int nb = std::min(chunk, batch - b0);
+        HIPCHK(ctx, hipMemset(X.p, 0, (size_t)nb * mat * sizeof(double2)));
+        for (int b = 0; b < nb; ++b)
+            CHK(upload_padded(ctx, A + (size_t)(b0 + b) * n * n, n, n, X.as<double2>() + b * mat, np));
         int s = 0;
         double nrm = 0;
-        CHK(dev_expm_inplace(ctx, w, X.as<double2>(), np, &s, &nrm));
+        CHK(dev_expm_inplace(ctx, w, X.as<double2>(), np, &s, &nrm, nb));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        HIPCHK(ctx, hipMemcpy2D(E_out + (size_t)b * n * n, (size_t)n * sizeof(double2), X.p,
-                                (size_t)np * sizeof(double2), (size_t)n * sizeof(double2), n, hipMemcpyDeviceToHost));
-        if (info) {
-            info[2 * b] = s;
-            info[2 * b + 1] = (long long)(nrm * 1e6);
+        for (int b = 0; b < nb; ++b) {
+            HIPCHK(ctx, hipMemcpy2D(E_out + (size_t)(b0 + b) * n * n, (size_t)n * sizeof(double2),
+                                    X.as<double2>() + b * mat, (size_t)np * sizeof(double2), (size_t)n * sizeof(double2),
+                                    n, hipMemcpyDeviceToHost));
+            if (info) {
+                info[2 * (b0 + b)] = s;
+                info[2 * (b0 + b) + 1] = (long long)(nrm * 1e6);
+            }
         }
     }
     return 0;
@@ -1167,10 +1212,11 @@ extern "C" int midyn_expm(midyn_ctx* ctx, int n, int batch, const midyn_complex*
 // -------------------------------------------------------------------------------------------------
 // Magnus / expm fixed-step solver
 // -------------------------------------------------------------------------------------------------
-static int commutator(midyn_ctx* ctx, int np, const double2* a, const double2* b, double2* out, double2* tmp) {
+static int commutator(midyn_ctx* ctx, int np, const double2* a, const double2* b, double2* out, double2* tmp,
+                      int batch = 1) {
     // out = a.b - b.a
-    CHK(dev_zgemm(ctx, np, np, np, b, np, a, np, tmp, np, 1.0, 0.0, nullptr));
-    CHK(dev_zgemm(ctx, np, np, np, a, np, b, np, out, np, 1.0, -1.0, tmp));
+    CHK(dev_sqgemm(ctx, batch, np, b, a, tmp, 1.0, 0.0, nullptr));
+    CHK(dev_sqgemm(ctx, batch, np, a, b, out, 1.0, -1.0, tmp));
     return 0;
 }
 
@@ -1189,8 +1235,12 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int np = s->n_pad;
     const int ld = round_up(m, 64);
-    const size_t mat = (size_t)np * np * sizeof(double2);
-    const size_t stb = (size_t)np * ld * sizeof(double2);
+    // Instances advance together in chunks: every generator evaluation, Magnus combination, expm
+    // product and propagation is ONE batched launch over the chunk (a single instance per chunk
+    // when one n x n expm already fills the device).
+    const int chunk = expm_chunk(ctx, np, B);
+    const size_t mat = (size_t)np * np;          // elements per matrix
+    const size_t stv = (size_t)np * ld;          // elements per state block
     DevBuf d_S, d_times, d_E, d_y[2], d_tmp, d_out, G[3], W[4], Om;
     ExpmWork w;
     if (s->k > 0) {
@@ -1198,53 +1248,65 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
         HIPCHK(ctx, hipMemcpy(d_S.p, S, d_S.bytes, hipMemcpyHostToDevice));
     }
     CHK(make_phase_rows(s, times, R, d_times, d_E));
-    CHK(d_y[0].alloc(ctx, stb));
-    CHK(d_y[1].alloc(ctx, stb));
-    CHK(d_tmp.alloc(ctx, (size_t)s->n * m * sizeof(double2)));
-    CHK(d_out.alloc(ctx, (size_t)P * s->n * m * sizeof(double2)));
-    CHK(Om.alloc(ctx, mat));
-    for (int i = 0; i < magnus_order; ++i) CHK(G[i].alloc(ctx, mat));
+    CHK(d_y[0].alloc(ctx, chunk * stv * sizeof(double2)));
+    CHK(d_y[1].alloc(ctx, chunk * stv * sizeof(double2)));
+    const size_t inst_elems = (size_t)s->n * m;
+    CHK(d_tmp.alloc(ctx, inst_elems * sizeof(double2)));
+    CHK(d_out.alloc(ctx, (size_t)chunk * P * inst_elems * sizeof(double2)));
+    CHK(Om.alloc(ctx, chunk * mat * sizeof(double2)));
+    for (int i = 0; i < magnus_order; ++i) CHK(G[i].alloc(ctx, chunk * mat * sizeof(double2)));
     if (magnus_order >= 2)
-        for (int i = 0; i < (magnus_order == 2 ? 2 : 4); ++i) CHK(W[i].alloc(ctx, mat));
+        for (int i = 0; i < (magnus_order == 2 ? 2 : 4); ++i) CHK(W[i].alloc(ctx, chunk * mat * sizeof(double2)));
     auto Erow = [&](int row) -> const double2* {
         return s->has_frame ? d_E.as<double2>() + (size_t)row * np : nullptr;
     };
-    const size_t inst_elems = (size_t)s->n * m;
-    for (int b = 0; b < B; ++b) {
-        const midyn_complex* y0b = y0 + (y0_shared ? 0 : (size_t)b * inst_elems);
-        HIPCHK(ctx, hipMemsetAsync(d_y[0].p, 0, stb, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(d_y[1].p, 0, stb, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(d_tmp.p, y0b, inst_elems * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(scatter_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
-                           d_tmp.as<double2>(), 1, 1, s->n, m, ld, (const double2*)nullptr, d_y[0].as<double2>(),
-                           (double2*)nullptr);
-        hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
-                           d_y[0].as<double2>(), 1, s->n, m, ld, P, 0, d_out.as<double2>());
+    const long long cstride = (long long)R * s->k;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        HIPCHK(ctx, hipMemsetAsync(d_y[0].p, 0, nb * stv * sizeof(double2), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_y[1].p, 0, nb * stv * sizeof(double2), ctx->stream));
+        for (int b = 0; b < nb; ++b) {
+            const midyn_complex* y0b = y0 + (y0_shared ? 0 : (size_t)(b0 + b) * inst_elems);
+            if (b == 0 || !y0_shared) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // d_tmp is reused
+                HIPCHK(ctx, hipMemcpyAsync(d_tmp.p, y0b, inst_elems * sizeof(double2), hipMemcpyHostToDevice,
+                                           ctx->stream));
+            }
+            hipLaunchKernelGGL(scatter_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                               d_tmp.as<double2>(), 1, 1, s->n, m, ld, (const double2*)nullptr,
+                               d_y[0].as<double2>() + b * stv, (double2*)nullptr);
+            hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                               d_y[0].as<double2>() + b * stv, 1, s->n, m, ld, P, 0,
+                               d_out.as<double2>() + (size_t)b * P * inst_elems);
+        }
         HIPCHK(ctx, hipGetLastError());
         int cur = 0;
-        const double* coeff_b = s->k > 0 ? d_S.as<double>() + (size_t)b * R * s->k : nullptr;
+        const double* coeff_b = s->k > 0 ? d_S.as<double>() + (size_t)b0 * R * s->k : nullptr;
         for (int st = 0; st < nsteps; ++st) {
             const double h = step_h[st];
             const int* rr = step_rows + 3 * st;
             auto cf = [&](int row) { return coeff_b ? coeff_b + (size_t)row * s->k : nullptr; };
+            auto gen = [&](int row, double scale, double2* out) {
+                return launch_gen_eval(s, cf(row), Erow(row), scale, out, nb, cstride);
+            };
             double2* Omega = Om.as<double2>();
             if (magnus_order == 1) {
-                CHK(launch_gen_eval(s, cf(rr[0]), Erow(rr[0]), h, Omega));
+                CHK(gen(rr[0], h, Omega));
             } else if (magnus_order == 2) {
                 // fixed_step_solvers.py:348-363
-                CHK(launch_gen_eval(s, cf(rr[0]), Erow(rr[0]), 1.0, G[0].as<double2>()));
-                CHK(launch_gen_eval(s, cf(rr[1]), Erow(rr[1]), 1.0, G[1].as<double2>()));
-                CHK(commutator(ctx, np, G[1].as<double2>(), G[0].as<double2>(), W[0].as<double2>(), W[1].as<double2>()));
+                CHK(gen(rr[0], 1.0, G[0].as<double2>()));
+                CHK(gen(rr[1], 1.0, G[1].as<double2>()));
+                CHK(commutator(ctx, np, G[1].as<double2>(), G[0].as<double2>(), W[0].as<double2>(), W[1].as<double2>(), nb));
                 const double p2 = std::sqrt(3.0) / 12;
                 const double2* xs[3] = {G[0].as<double2>(), G[1].as<double2>(), W[0].as<double2>()};
                 double al[3] = {h / 2, h / 2, p2 * (h * h)};
-                CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0));
+                CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0, nb));
             } else {
                 // fixed_step_solvers.py:365-392
                 const double c0 = std::sqrt(15.0) / 3, c1 = 10.0 / 3;
-                CHK(launch_gen_eval(s, cf(rr[0]), Erow(rr[0]), 1.0, G[0].as<double2>()));
-                CHK(launch_gen_eval(s, cf(rr[1]), Erow(rr[1]), 1.0, G[1].as<double2>()));
-                CHK(launch_gen_eval(s, cf(rr[2]), Erow(rr[2]), 1.0, G[2].as<double2>()));
+                CHK(gen(rr[0], 1.0, G[0].as<double2>()));
+                CHK(gen(rr[1], 1.0, G[1].as<double2>()));
+                CHK(gen(rr[2], 1.0, G[2].as<double2>()));
                 double2 *g1 = G[0].as<double2>(), *g2 = G[1].as<double2>(), *g3 = G[2].as<double2>();
                 double2 *w0 = W[0].as<double2>(), *w1 = W[1].as<double2>(), *w2 = W[2].as<double2>(),
                         *w3 = W[3].as<double2>();
@@ -1252,62 +1314,64 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
                 {
                     const double2* xs[2] = {g3, g1};
                     double al[2] = {c0 * h, -c0 * h};
-                    CHK(dev_lincomb(ctx, np, w0, 2, xs, al, 0.0));
+                    CHK(dev_lincomb(ctx, np, w0, 2, xs, al, 0.0, nb));
                 }
                 {
                     const double2* xs[3] = {g3, g2, g1};
                     double al[3] = {c1 * h, -2 * c1 * h, c1 * h};
-                    CHK(dev_lincomb(ctx, np, w1, 3, xs, al, 0.0));
+                    CHK(dev_lincomb(ctx, np, w1, 3, xs, al, 0.0, nb));
                 }
                 {
                     const double2* xs[1] = {g2};
                     double al[1] = {h};
-                    CHK(dev_lincomb(ctx, np, g2, 1, xs, al, 0.0));
+                    CHK(dev_lincomb(ctx, np, g2, 1, xs, al, 0.0, nb));
                 }
                 double2 *a1 = g2, *a2 = w0, *a3 = w1;
                 // comm1 = [a1, a2] -> w2 (tmp g1)
-                CHK(commutator(ctx, np, a1, a2, w2, g1));
+                CHK(commutator(ctx, np, a1, a2, w2, g1, nb));
                 double2* comm1 = w2;
                 // X = 2 a3 + comm1 -> g3 ; comm2 = [X, a1]/60 -> w3 (tmp g1)
                 {
                     const double2* xs[2] = {a3, comm1};
                     double al[2] = {2.0, 1.0};
-                    CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0));
+                    CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0, nb));
                 }
-                CHK(commutator(ctx, np, g3, a1, w3, g1));
+                CHK(commutator(ctx, np, g3, a1, w3, g1, nb));
                 // Y2 = a2 + comm2/60 -> g3 ; Y1 = -20 a1 - a3 + comm1 -> g1
                 {
                     const double2* xs[2] = {a2, w3};
                     double al[2] = {1.0, 1.0 / 60};
-                    CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0));
+                    CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0, nb));
                 }
                 {
                     const double2* xs[3] = {a1, a3, comm1};
                     double al[3] = {-20.0, -1.0, 1.0};
-                    CHK(dev_lincomb(ctx, np, g1, 3, xs, al, 0.0));
+                    CHK(dev_lincomb(ctx, np, g1, 3, xs, al, 0.0, nb));
                 }
                 // comm3 = [Y1, Y2] -> w3 (tmp w2: comm1 no longer needed)
-                CHK(commutator(ctx, np, g1, g3, w3, w2));
+                CHK(commutator(ctx, np, g1, g3, w3, w2, nb));
                 {
                     const double2* xs[3] = {a1, a3, w3};
                     double al[3] = {1.0, 1.0 / 12, 1.0 / 240};
-                    CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0));
+                    CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0, nb));
                 }
             }
-            CHK(dev_expm_inplace(ctx, w, Omega, np, nullptr, nullptr));
-            // y <- expm(Omega) y
-            CHK(dev_zgemm(ctx, np, ld, np, Omega, np, d_y[cur].as<double2>(), ld, d_y[cur ^ 1].as<double2>(), ld,
-                          1.0, 0.0, nullptr));
+            CHK(dev_expm_inplace(ctx, w, Omega, np, nullptr, nullptr, nb));
+            // y <- expm(Omega) y  for every instance of the chunk
+            CHK(dev_zgemm_batched(ctx, nb, np, ld, np, Omega, np, (long long)mat, d_y[cur].as<double2>(), ld,
+                                  (long long)stv, d_y[cur ^ 1].as<double2>(), ld, (long long)stv, 1.0, 0.0, nullptr));
             cur ^= 1;
             if (step_save && step_save[st] >= 0) {
                 if (step_save[st] >= P) return fail(ctx, "midyn_expm_solve: save slot out of range");
-                hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
-                                   d_y[cur].as<double2>(), 1, s->n, m, ld, P, step_save[st], d_out.as<double2>());
+                for (int b = 0; b < nb; ++b)
+                    hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                                       d_y[cur].as<double2>() + b * stv, 1, s->n, m, ld, P, step_save[st],
+                                       d_out.as<double2>() + (size_t)b * P * inst_elems);
                 HIPCHK(ctx, hipGetLastError());
             }
         }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b * P * inst_elems, d_out.p, (size_t)P * inst_elems * sizeof(double2),
+        HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b0 * P * inst_elems, d_out.p, (size_t)nb * P * inst_elems * sizeof(double2),
                               hipMemcpyDeviceToHost));
     }
     return 0;

@@ -71,9 +71,14 @@ struct Epilogue {
     const double2* z;        // EPI_PLAIN addend or nullptr
 };
 
-__device__ __forceinline__ void apply_epilogue(const Epilogue& e, int row, int col, double2 c) {
+// Compile-time mode: every instantiation is straight-line code.  (With a run-time mode chain
+// inlined into a store loop, hipcc 7.2 was seen to merge the branches' final stores through one
+// pointer register and leave it unset on one path -- see splitk_reduce_kernel -- so all kernels
+// dispatch on the mode ONCE, outside their store loops.)
+template <int EMODE>
+__device__ __forceinline__ void apply_epilogue_t(const Epilogue& e, int row, int col, double2 c) {
     const size_t idx = (size_t)row * e.ld + col;
-    if (e.mode == EPI_PLAIN) {
+    if (EMODE == EPI_PLAIN) {
         double2 r = make_double2(e.alpha * c.x, e.alpha * c.y);
         if (e.z) {
             const double2 z = e.z[idx];
@@ -85,21 +90,21 @@ __device__ __forceinline__ void apply_epilogue(const Epilogue& e, int row, int c
     }
     double2 k = c;
     if (e.e_cur) k = cmul_conj_a(e.e_cur[row], c);
-    if (e.mode == EPI_RHS) {
+    if (EMODE == EPI_RHS) {
         e.out[idx] = k;
         return;
     }
     const double2 en = e.e_next ? e.e_next[row] : make_double2(1.0, 0.0);
     const double h = e.h;
-    if (e.mode == EPI_RK1) {
+    if (EMODE == EPI_RK1) {
         const double2 y = e.y[idx];
         e.acc[idx] = cfma_r(h * (1.0 / 6), k, y);
         e.yin_next[idx] = cmul(en, cfma_r(0.5 * h, k, y));
-    } else if (e.mode == EPI_RK2) {
+    } else if (EMODE == EPI_RK2) {
         const double2 y = e.y[idx];
         e.acc[idx] = cfma_r(h * (1.0 / 3), k, e.acc[idx]);
         e.yin_next[idx] = cmul(en, cfma_r(0.5 * h, k, y));
-    } else if (e.mode == EPI_RK3) {
+    } else if (EMODE == EPI_RK3) {
         const double2 y = e.y[idx];
         e.acc[idx] = cfma_r(h * (1.0 / 3), k, e.acc[idx]);
         e.yin_next[idx] = cmul(en, cfma_r(h, k, y));
@@ -107,6 +112,45 @@ __device__ __forceinline__ void apply_epilogue(const Epilogue& e, int row, int c
         const double2 yn = cfma_r(h * (1.0 / 6), k, e.acc[idx]);
         e.y[idx] = yn;
         e.yin_next[idx] = cmul(en, yn);
+    }
+}
+
+// run-time dispatch for a single element (stream kernel: one output per workgroup)
+__device__ __forceinline__ void apply_epilogue(const Epilogue& e, int row, int col, double2 c) {
+    switch (e.mode) {
+        case EPI_RHS: apply_epilogue_t<EPI_RHS>(e, row, col, c); break;
+        case EPI_RK1: apply_epilogue_t<EPI_RK1>(e, row, col, c); break;
+        case EPI_RK2: apply_epilogue_t<EPI_RK2>(e, row, col, c); break;
+        case EPI_RK3: apply_epilogue_t<EPI_RK3>(e, row, col, c); break;
+        case EPI_RK4: apply_epilogue_t<EPI_RK4>(e, row, col, c); break;
+        default: apply_epilogue_t<EPI_PLAIN>(e, row, col, c); break;
+    }
+}
+
+// store a wave's accumulator tile through the epilogue: D[row = (lane>>4) + 4*reg][col = lane & 15]
+template <int EMODE, int MT, int NT>
+__device__ __forceinline__ void store_tile_t(const Epilogue& e, int row0, int col0, const d4 (&cre)[MT][NT],
+                                             const d4 (&cim)[MT][NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                apply_epilogue_t<EMODE>(e, row0 + mt * 16 + 4 * r, col0 + nt * 16,
+                                        make_double2(cre[mt][nt][r], cim[mt][nt][r]));
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void store_tile(const Epilogue& e, int row0, int col0, const d4 (&cre)[MT][NT],
+                                           const d4 (&cim)[MT][NT]) {
+    switch (e.mode) {  // wave-uniform
+        case EPI_RHS: store_tile_t<EPI_RHS, MT, NT>(e, row0, col0, cre, cim); break;
+        case EPI_RK1: store_tile_t<EPI_RK1, MT, NT>(e, row0, col0, cre, cim); break;
+        case EPI_RK2: store_tile_t<EPI_RK2, MT, NT>(e, row0, col0, cre, cim); break;
+        case EPI_RK3: store_tile_t<EPI_RK3, MT, NT>(e, row0, col0, cre, cim); break;
+        case EPI_RK4: store_tile_t<EPI_RK4, MT, NT>(e, row0, col0, cre, cim); break;
+        default: store_tile_t<EPI_PLAIN, MT, NT>(e, row0, col0, cre, cim); break;
     }
 }
 
@@ -239,6 +283,8 @@ struct GemmArgs {
     long long inst_stride;
     int m_cols;              // columns per instance
     int n_inst;              // number of instances (columns beyond are padding)
+    int batch;               // > 1: blockIdx.y indexes independent problems (EPI_PLAIN only)
+    long long batch_a, batch_b, batch_c;  // element strides of A, B and C/Z between problems
     int splits;              // split-K: gridDim = tiles * splits; split z handles K tiles [z*KT/splits, ...)
     double2* partial;        // [splits][M][N] raw partial sums when splits > 1 (epilogue runs in
                              // splitk_reduce_kernel), nullptr otherwise
@@ -427,8 +473,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
         const int c = wave + NWAVE * p;
         b_src[p] = (c / B_PER_ROW) * g.ldb + (c % B_PER_ROW) * 64 + lane;
     }
-    const double2* Abase = g.A + (size_t)m0 * g.lda + (size_t)kt0 * BK;
-    const double2* Bbase = g.B + n0 + (size_t)kt0 * BK * g.ldb;
+    const double2* Abase = g.A + (size_t)blockIdx.y * g.batch_a + (size_t)m0 * g.lda + (size_t)kt0 * BK;
+    const double2* Bbase = g.B + (size_t)blockIdx.y * g.batch_b + n0 + (size_t)kt0 * BK * g.ldb;
 
     // Loop order: K tile outer, operator segment inner -- the B (state) tile is staged ONCE per K
     // tile and reused by all n_act operator tiles, so per launch the state block is read once per
@@ -592,6 +638,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
                 }
         return;
     }
+    Epilogue epi = g.epi;
+    if (g.batch > 1) {  // batched plain zgemm: every problem has its own output / addend block
+        epi.out += (size_t)blockIdx.y * g.batch_c;
+        if (epi.z) epi.z += (size_t)blockIdx.y * g.batch_c;
+    }
     if (MIDYN_ABL(g, 4)) {
         double sdump = 0.0;
 #pragma unroll
@@ -601,16 +652,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
         if (sdump == 1.2345e300) g.epi.out[0] = make_double2(sdump, 0.0);
         return;
     }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * TM + mt * 16 + lk + 4 * r;
-                const int col = n0 + wn * TN + nt * 16 + lcol;
-                apply_epilogue(g.epi, row, col, make_double2(cre[mt][nt][r], cim[mt][nt][r]));
-            }
+    store_tile<MT, NT>(epi, m0 + wm * TM + lk, n0 + wn * TN + lcol, cre, cim);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -846,16 +888,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void zgemm_plane_kernel(PlaneArgs 
                 }
         return;
     }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * TM + mt * 16 + lk + 4 * r;
-                const int col = n0 + wn * TN + nt * 16 + lcol;
-                apply_epilogue(g.epi, row, col, make_double2(cre[mt][nt][r], cim[mt][nt][r]));
-            }
+    store_tile<MT, NT>(g.epi, m0 + wm * TM + lk, n0 + wn * TN + lcol, cre, cim);
 }
 
 // planes[act][i] = non-zero plane of active segment `act` (mode 1: real part, mode 2: imaginary part)
@@ -890,42 +923,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const double2* parti
             c.y += v.y;
         }
         const int row = (int)(idx / N);
-        const size_t o = (size_t)row * epi.ld + (idx - (size_t)row * N);
-        if (EMODE == EPI_PLAIN) {
-            double2 r = make_double2(epi.alpha * c.x, epi.alpha * c.y);
-            if (epi.z) {
-                const double2 z = epi.z[o];
-                r.x = fma(epi.beta, z.x, r.x);
-                r.y = fma(epi.beta, z.y, r.y);
-            }
-            epi.out[o] = r;
-            continue;
-        }
-        double2 k = c;
-        if (epi.e_cur) k = cmul_conj_a(epi.e_cur[row], c);
-        if (EMODE == EPI_RHS) {
-            epi.out[o] = k;
-            continue;
-        }
-        const double2 en = epi.e_next ? epi.e_next[row] : make_double2(1.0, 0.0);
-        const double h = epi.h;
-        if (EMODE == EPI_RK1) {
-            const double2 y = epi.y[o];
-            epi.acc[o] = cfma_r(h * (1.0 / 6), k, y);
-            epi.yin_next[o] = cmul(en, cfma_r(0.5 * h, k, y));
-        } else if (EMODE == EPI_RK2) {
-            const double2 y = epi.y[o];
-            epi.acc[o] = cfma_r(h * (1.0 / 3), k, epi.acc[o]);
-            epi.yin_next[o] = cmul(en, cfma_r(0.5 * h, k, y));
-        } else if (EMODE == EPI_RK3) {
-            const double2 y = epi.y[o];
-            epi.acc[o] = cfma_r(h * (1.0 / 3), k, epi.acc[o]);
-            epi.yin_next[o] = cmul(en, cfma_r(h, k, y));
-        } else {
-            const double2 yn = cfma_r(h * (1.0 / 6), k, epi.acc[o]);
-            epi.y[o] = yn;
-            epi.yin_next[o] = cmul(en, yn);
-        }
+        apply_epilogue_t<EMODE>(epi, row, (int)(idx - (size_t)row * N), c);
     }
 }
 
@@ -943,19 +941,24 @@ struct GenArgs {
     const double* coeff;
     const double2* e;  // [n_pad] phases or nullptr
     double scale;
-    double2* out;      // [n_pad][n_pad]
+    double2* out;      // [batch][n_pad][n_pad]
+    int batch;         // instances evaluated at once (same time, own coefficient row)
+    long long coeff_stride;  // doubles between the coefficient rows of consecutive instances
 };
 
 __global__ __launch_bounds__(256) void gen_eval_kernel(GenArgs a) {
     const int n = a.n_pad;
     const size_t plane = (size_t)n * n;
-    const size_t total = plane;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * 256) {
+    const size_t total = plane * (a.batch > 0 ? a.batch : 1);
+    for (size_t gidx = (size_t)blockIdx.x * 256 + threadIdx.x; gidx < total;
+         gidx += (size_t)gridDim.x * 256) {
+        const size_t inst = gidx / plane;
+        const size_t idx = gidx - inst * plane;
+        const double* coeff = a.coeff ? a.coeff + inst * a.coeff_stride : nullptr;
         double2 gsum = make_double2(0.0, 0.0);
         for (int s = 0; s < a.n_act; ++s) {
             const int seg = a.seg_list[s] >> 2;
-            const double cf = (a.has_static && seg == 0) ? 1.0 : a.coeff[seg - a.has_static];
+            const double cf = (a.has_static && seg == 0) ? 1.0 : coeff[seg - a.has_static];
             const double2 v = a.ops[seg * plane + idx];
             gsum.x = fma(cf, v.x, gsum.x);
             gsum.y = fma(cf, v.y, gsum.y);
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(256) void gen_eval_kernel(GenArgs a) {
             const double2 ph = cmul_conj_a(a.e[r], a.e[c]);
             gsum = cmul(ph, gsum);
         }
-        a.out[idx] = make_double2(a.scale * gsum.x, a.scale * gsum.y);
+        a.out[gidx] = make_double2(a.scale * gsum.x, a.scale * gsum.y);
     }
 }
 
@@ -977,11 +980,13 @@ struct LinArgs {
     int nterms;
     double gamma;
     int n;
+    int batch;   // matrices laid out back to back; gamma * I is added to each
     double2* out;
 };
 
 __global__ __launch_bounds__(256) void lincomb_kernel(LinArgs a) {
-    const size_t total = (size_t)a.n * a.n;
+    const size_t plane = (size_t)a.n * a.n;
+    const size_t total = plane * (a.batch > 0 ? a.batch : 1);
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * 256) {
         double2 r = make_double2(0.0, 0.0);
@@ -991,8 +996,9 @@ __global__ __launch_bounds__(256) void lincomb_kernel(LinArgs a) {
             r.y = fma(a.alpha[i], v.y, r.y);
         }
         if (a.gamma != 0.0) {
-            const size_t rr = idx / a.n;
-            if (idx - rr * a.n == rr) r.x += a.gamma;
+            const size_t e = idx % plane;
+            const size_t rr = e / a.n;
+            if (e - rr * a.n == rr) r.x += a.gamma;
         }
         a.out[idx] = r;
     }
@@ -1087,12 +1093,13 @@ __global__ __launch_bounds__(256) void plane_flags_kernel(const double2* ops, si
 __global__ __launch_bounds__(256) void colsum_kernel(const double2* A, int n, double* sums) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
+    const double2* Ab = A + (size_t)blockIdx.y * n * n;   // blockIdx.y: matrix of a batch
     double s = 0.0;
     for (int r = 0; r < n; ++r) {
-        const double2 v = A[(size_t)r * n + c];
+        const double2 v = Ab[(size_t)r * n + c];
         s += hypot(v.x, v.y);
     }
-    sums[c] = s;
+    sums[(size_t)blockIdx.y * n + c] = s;
 }
 
 // pad copy: src [rows][cols] (ld src_ld) -> dst (ld dst_ld), both complex
