@@ -343,6 +343,18 @@ def main():
         res = solver.solve(t_span=cfg["t_span"], y0=cfg["y0"], signals=sig_lists, method="RK4", max_dt=MAX_DT)
         t_solve = time.perf_counter() - t1f
         yf = np.array([r.y[-1] for r in res])
+        # the same sweep with the pulses given as DiscreteSignals (samples + carrier): the coefficient
+        # table is then evaluated on the device instead of on the host
+        disc_lists = [[qd.DiscreteSignal.from_Signal(sg, dt=0.05, n_samples=int(round(T_FINAL / 0.05))) for sg in sl]
+                      for sl in sig_lists]
+        t2f = time.perf_counter()
+        res_d = solver.solve(t_span=cfg["t_span"], y0=cfg["y0"], signals=disc_lists, method="RK4", max_dt=MAX_DT)
+        t_solve_d = time.perf_counter() - t2f
+        yd = np.array([r.y[-1] for r in res_d])
+        out["full_solve_discrete_signals"] = {
+            "what": "same sweep, pulses as DiscreteSignal(dt=0.05) + carrier: coefficient table evaluated on the device",
+            "solve_s": round(t_solve_d, 2), "rhs_evals_per_s_end_to_end": round(b_loc * 4000 / t_solve_d, 1),
+            "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(yd, axis=1) - 1.0)))}
         out["full_solve"] = {
             "what": f"Solver.solve of {b_loc} instances x 1000 RK4 steps, list mode -> one batched device solve",
             "model_build_s": round(t_model, 2), "solve_s": round(t_solve, 2),

@@ -80,6 +80,28 @@ int midyn_eval_generator(midyn_stack* stack, const double* coeffs, double t, mid
 int midyn_eval_rhs(midyn_stack* stack, const double* coeffs, double t, const midyn_complex* y,
                    int m, midyn_complex* out);
 
+/* ---- coefficient table evaluated on the device ------------------------
+ * SignalList.__call__ over SignalSums of DiscreteSignals / constants (signals/signals.py:148-155,
+ * 302-311,574-577,801-803; the sweep precedent is _solve_schedule_list_jax, solvers/solver_classes.py:
+ * 592-676, whose signals are all DiscreteSignals):
+ *   S[b][r][j] = sum over the terms q of signal j of instance b of
+ *                Re[ f_q(t_r) exp(i (2 pi nu_q t_r + phi_q)) ],
+ *   f_q(t) = samples_q[ clip(floor_divide(t - t0_q, dt_q), -1, len_q) ]  (0 outside the window).
+ * term_ptr[B*k+1] is a CSR index (terms of signal j of instance b are term_ptr[b*k+j] ..
+ * term_ptr[b*k+j+1]-1); term_params[q] = (dt, start_time, carrier_freq, phase), dt == 0 marking a
+ * constant envelope (= its one sample); sample_ptr[q] = (offset, length) into `samples`, so terms may
+ * share sample arrays.  The table stays in HBM: pass the pointer from midyn_sigtable_data as `S`
+ * to any solve entry point below (every `S` parameter accepts a host OR a device pointer). */
+typedef struct midyn_sigtable midyn_sigtable;
+int midyn_sigtable_create(midyn_ctx* ctx, int B, int k, int R, const double* times,
+                          const long long* term_ptr, const double* term_params,
+                          const long long* sample_ptr, const midyn_complex* samples,
+                          midyn_sigtable** out);
+/* dims (optional) = B, R, k */
+int midyn_sigtable_data(midyn_sigtable* tab, const double** dev_S, long long* dims);
+int midyn_sigtable_fetch(midyn_sigtable* tab, double* S_out);
+int midyn_sigtable_destroy(midyn_sigtable* tab);
+
 /* ---- fixed-step RK4 (solvers/fixed_step_solvers.py:43-77 inside the template :406-459) --------
  * B independent instances advance together (the loop of solvers/solver_classes.py:556-590 turned
  * into one batched contraction).  The caller evaluates the signals on the host into the table
@@ -102,7 +124,8 @@ int midyn_expm(midyn_ctx* ctx, int n, int batch, const midyn_complex* A, midyn_c
 /* ---- fixed-step Magnus/expm solver (solvers/fixed_step_solvers.py:80-108,321-403) ----------------
  * y <- expm(Omega_m) y per step; the generator evaluations use table rows step_rows[s][0..m-1]
  * (m = magnus_order Gauss points, in the order of fixed_step_solvers.py:345-377).
- * Instances are processed one after the other (each expm fills the device). */
+ * Instances advance together in chunks sized so that one batched launch fills the device (a
+ * chunk is a single instance once one n x n product does; hundreds of instances for small n). */
 int midyn_expm_solve(midyn_stack* stack, int B, int m, int R, const double* times, const double* S,
                      int nsteps, const int* step_rows, const double* step_h, const int* step_save,
                      int P, int magnus_order, const midyn_complex* y0, int y0_shared,

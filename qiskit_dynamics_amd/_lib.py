@@ -23,7 +23,8 @@ ABI_SYMBOLS = [
     "midyn_rk4_solve", "midyn_expm", "midyn_expm_solve", "midyn_zgemm", "midyn_rk4_plan_create",
     "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_get_counters",
     "midyn_reset_counters", "midyn_microbench", "midyn_lindblad_create", "midyn_lindblad_destroy",
-    "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve",
+    "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve", "midyn_sigtable_create", "midyn_sigtable_data",
+    "midyn_sigtable_fetch", "midyn_sigtable_destroy",
 ]
 
 
@@ -121,6 +122,10 @@ def load():
         lib.midyn_lindblad_destroy.argtypes = [_vp]
         lib.midyn_lindblad_rhs.argtypes = [_vp, _vp, _cd, _vp, _ci, _vp]
         lib.midyn_lindblad_rk4_solve.argtypes = [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp]
+        lib.midyn_sigtable_create.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, P(_vp)]
+        lib.midyn_sigtable_data.argtypes = [_vp, P(_vp), _vp]
+        lib.midyn_sigtable_fetch.argtypes = [_vp, _vp]
+        lib.midyn_sigtable_destroy.argtypes = [_vp]
         for name in ABI_SYMBOLS:
             if name != "midyn_last_error":
                 getattr(lib, name).restype = _ci
@@ -129,7 +134,11 @@ def load():
 
 
 def _ptr(a):
-    return None if a is None else a.ctypes.data_as(_vp)
+    if a is None:
+        return None
+    if isinstance(a, SignalTable):
+        return _vp(a.dev_ptr)
+    return a.ctypes.data_as(_vp)
 
 
 def c128(a):
@@ -295,7 +304,8 @@ class Stack:
         times = f64(times)
         r = times.shape[0]
         if self.k > 0:
-            table = f64(table)
+            if not isinstance(table, SignalTable):
+                table = f64(table)
             if table.shape != (batch, r, self.k):
                 raise DynamicsError(f"coefficient table must be (B,R,k)={(batch, r, self.k)}, got {table.shape}")
         else:
@@ -332,6 +342,52 @@ class Stack:
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:
             self.ctx.lib.midyn_stack_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+class SignalTable:
+    """Coefficient table S[B][R][k] evaluated ON THE DEVICE from piecewise-constant samples and
+    carriers (``midyn_sigtable_create``).  Accepted wherever the solve
+    methods take a ``table``; ``fetch()`` copies it to the host."""
+
+    def __init__(self, ctx: "Context", batch, k, times, term_ptr, term_params, sample_ptr, samples):
+        self.ctx = ctx
+        times = f64(times)
+        term_ptr = np.ascontiguousarray(term_ptr, dtype=np.int64)
+        term_params = f64(term_params).reshape(-1, 4)
+        sample_ptr = np.ascontiguousarray(sample_ptr, dtype=np.int64).reshape(-1, 2)
+        samples = c128(samples)
+        if term_ptr.shape != (batch * k + 1,):
+            raise DynamicsError("term_ptr must have B*k+1 entries")
+        n_terms = int(term_ptr[-1])
+        if term_params.shape[0] != n_terms or sample_ptr.shape[0] != n_terms:
+            raise DynamicsError("term_params / sample_ptr must have one row per term")
+        if n_terms and int((sample_ptr[:, 0] + sample_ptr[:, 1]).max()) > samples.shape[0]:
+            raise DynamicsError("sample_ptr points past the end of samples")
+        self.shape = (int(batch), int(times.shape[0]), int(k))
+        h = _vp()
+        ctx.check(ctx.lib.midyn_sigtable_create(
+            ctx.handle, int(batch), int(k), self.shape[1], _ptr(times), _ptr(term_ptr), _ptr(term_params),
+            _ptr(sample_ptr), _ptr(samples), ctypes.byref(h)))
+        self.handle = h
+        dev = ctypes.c_void_p()
+        ctx.check(ctx.lib.midyn_sigtable_data(self.handle, ctypes.byref(dev), None))
+        self.dev_ptr = dev.value
+
+    def fetch(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float64)
+        self.ctx.check(self.ctx.lib.midyn_sigtable_fetch(self.handle, _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:
+            self.ctx.lib.midyn_sigtable_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -406,7 +462,10 @@ class LindbladDevice:
     def rk4_solve(self, times, table, step_rows, step_h, step_save, n_save, rho0, batch, shared):
         times = f64(times)
         r = times.shape[0]
-        table = f64(table) if self.k > 0 else None
+        if self.k == 0:
+            table = None
+        elif not isinstance(table, SignalTable):
+            table = f64(table)
         if table is not None and table.shape != (batch, r, self.k):
             raise DynamicsError(f"coefficient table must be (B,R,k)={(batch, r, self.k)}, got {table.shape}")
         step_rows = i32(step_rows).reshape(-1, 3)

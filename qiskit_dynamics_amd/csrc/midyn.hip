@@ -710,6 +710,116 @@ static int make_phase_rows(midyn_stack* s, const double* h_times, int rows, DevB
     return 0;
 }
 
+// -------------------------------------------------------------------------------------------------
+// row f1: coefficient table evaluated on the device
+// -------------------------------------------------------------------------------------------------
+struct midyn_sigtable {
+    midyn_ctx* ctx = nullptr;
+    int B = 0, R = 0, k = 0;
+    DevBuf d_S;
+};
+
+extern "C" int midyn_sigtable_create(midyn_ctx* ctx, int B, int k, int R, const double* times,
+                                     const long long* term_ptr, const double* term_params,
+                                     const long long* sample_ptr, const midyn_complex* samples,
+                                     midyn_sigtable** out) {
+    if (!ctx || !out) return fail(ctx, "midyn_sigtable_create: NULL argument");
+    if (B <= 0 || k <= 0 || R <= 0) return fail(ctx, "midyn_sigtable_create: bad sizes");
+    if (!times || !term_ptr || !term_params || !sample_ptr || !samples)
+        return fail(ctx, "midyn_sigtable_create: NULL argument");
+    const size_t nsig = (size_t)B * k;
+    const long long n_terms = term_ptr[nsig];
+    if (term_ptr[0] != 0 || n_terms < 0) return fail(ctx, "midyn_sigtable_create: term_ptr must start at 0");
+    for (size_t i = 0; i < nsig; ++i)
+        if (term_ptr[i + 1] < term_ptr[i]) return fail(ctx, "midyn_sigtable_create: term_ptr must be non-decreasing");
+    long long n_samples = 0;
+    for (long long q = 0; q < n_terms; ++q) {
+        // terms may SHARE sample ranges: sample_ptr is [n_terms][2] = (offset, length)
+        const long long off = sample_ptr[2 * q], len = sample_ptr[2 * q + 1];
+        if (off < 0 || len < 0) return fail(ctx, "midyn_sigtable_create: negative sample range");
+        if (term_params[4 * q] == 0.0 && len < 1)
+            return fail(ctx, "midyn_sigtable_create: a constant term needs one sample");
+        n_samples = std::max(n_samples, off + len);
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    midyn_sigtable* tab = new midyn_sigtable();
+    tab->ctx = ctx;
+    tab->B = B;
+    tab->R = R;
+    tab->k = k;
+    DevBuf d_times, d_ptr, d_par, d_sp, d_smp;
+    std::vector<long long> sp((size_t)n_terms + 1, 0);
+    int st = 0;
+    auto guard = [&](int r) { if (r && !st) st = r; };
+    guard(tab->d_S.alloc(ctx, (size_t)B * R * k * sizeof(double)));
+    guard(d_times.alloc(ctx, (size_t)R * sizeof(double)));
+    guard(d_ptr.alloc(ctx, (nsig + 1) * sizeof(long long)));
+    guard(d_par.alloc(ctx, std::max<size_t>(1, (size_t)n_terms) * 4 * sizeof(double)));
+    guard(d_sp.alloc(ctx, std::max<size_t>(1, (size_t)n_terms) * 2 * sizeof(long long)));
+    guard(d_smp.alloc(ctx, std::max<size_t>(1, (size_t)n_samples) * sizeof(double2)));
+    auto cp = [&](void* d, const void* h, size_t bytes) {
+        if (st || bytes == 0) return;
+        hipError_t e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) st = fail(ctx, std::string("midyn_sigtable_create upload: ") + hipGetErrorString(e));
+    };
+    cp(d_times.p, times, (size_t)R * sizeof(double));
+    cp(d_ptr.p, term_ptr, (nsig + 1) * sizeof(long long));
+    cp(d_par.p, term_params, (size_t)n_terms * 4 * sizeof(double));
+    cp(d_sp.p, sample_ptr, (size_t)n_terms * 2 * sizeof(long long));
+    cp(d_smp.p, samples, (size_t)n_samples * sizeof(double2));
+    if (!st) {
+        SigTableArgs a{};
+        a.B = B;
+        a.R = R;
+        a.k = k;
+        a.times = d_times.as<double>();
+        a.term_ptr = d_ptr.as<long long>();
+        a.params = d_par.as<double>();
+        a.sample_ptr = d_sp.as<long long>();
+        a.samples = d_smp.as<double2>();
+        a.S = tab->d_S.as<double>();
+        {
+            ProfScope ps(ctx, KC_ELEM);
+            hipLaunchKernelGGL(signal_table_kernel, dim3(grid_for((size_t)B * R * k, 16384)), dim3(256), 0, ctx->stream,
+                               a);
+        }
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = fail(ctx, std::string("midyn_sigtable_create: ") + hipGetErrorString(e));
+    }
+    if (st) {
+        delete tab;
+        return st;
+    }
+    *out = tab;
+    return 0;
+}
+
+extern "C" int midyn_sigtable_data(midyn_sigtable* tab, const double** dev_S, long long* dims) {
+    if (!tab || !dev_S) return fail(tab ? tab->ctx : nullptr, "midyn_sigtable_data: NULL argument");
+    *dev_S = tab->d_S.as<double>();
+    if (dims) {
+        dims[0] = tab->B;
+        dims[1] = tab->R;
+        dims[2] = tab->k;
+    }
+    return 0;
+}
+
+extern "C" int midyn_sigtable_fetch(midyn_sigtable* tab, double* S_out) {
+    if (!tab || !S_out) return fail(tab ? tab->ctx : nullptr, "midyn_sigtable_fetch: NULL argument");
+    HIPCHK(tab->ctx, hipSetDevice(tab->ctx->device));
+    HIPCHK(tab->ctx, hipMemcpy(S_out, tab->d_S.p, tab->d_S.bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int midyn_sigtable_destroy(midyn_sigtable* tab) {
+    if (!tab) return 0;
+    hipSetDevice(tab->ctx->device);
+    delete tab;
+    return 0;
+}
+
 extern "C" int midyn_eval_generator(midyn_stack* s, const double* coeffs, double t, midyn_complex* G_out) {
     if (!s || !G_out) return fail(s ? s->ctx : nullptr, "midyn_eval_generator: NULL argument");
     midyn_ctx* ctx = s->ctx;
@@ -872,7 +982,8 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
         return r;
     };
     if (s->k > 0) {
-        hipError_t e = hipMemcpy(p->d_S.p, S, (size_t)B * R * s->k * sizeof(double), hipMemcpyHostToDevice);
+        // S may live on the host or on the device (midyn_sigtable_data): hipMemcpyDefault resolves it
+        hipError_t e = hipMemcpy(p->d_S.p, S, (size_t)B * R * s->k * sizeof(double), hipMemcpyDefault);
         if (e != hipSuccess) return bail(fail(ctx, std::string("upload S: ") + hipGetErrorString(e)));
     }
     if (int r = make_phase_rows(s, times, R, p->d_times, p->d_E)) return bail(r);
@@ -1245,7 +1356,7 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
     ExpmWork w;
     if (s->k > 0) {
         CHK(d_S.alloc(ctx, (size_t)B * R * s->k * sizeof(double)));
-        HIPCHK(ctx, hipMemcpy(d_S.p, S, d_S.bytes, hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(d_S.p, S, d_S.bytes, hipMemcpyDefault));  // host or device table
     }
     CHK(make_phase_rows(s, times, R, d_times, d_E));
     CHK(d_y[0].alloc(ctx, chunk * stv * sizeof(double2)));
@@ -1545,6 +1656,18 @@ extern "C" int midyn_lindblad_rk4_solve(midyn_lindblad* L, int B, int R, const d
     double2 *Y = L->Y.as<double2>(), *Yt = L->Yt.as<double2>();
     double2* K[4] = {L->K[0].as<double2>(), L->K[1].as<double2>(), L->K[2].as<double2>(), L->K[3].as<double2>()};
     std::vector<double> zero(std::max(1, L->k), 0.0);
+    std::vector<double> s_host;
+    if (L->k > 0) {
+        // the per-evaluation coefficient vectors are read on the host: bring a device table over
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, S) == hipSuccess && at.type == hipMemoryTypeDevice) {
+            s_host.resize((size_t)B * R * L->k);
+            HIPCHK(ctx, hipMemcpy(s_host.data(), S, s_host.size() * sizeof(double), hipMemcpyDeviceToHost));
+            S = s_host.data();
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     for (int b = 0; b < B; ++b) {
         const midyn_complex* r0 = rho0 + (rho0_shared ? 0 : (size_t)b * nn);
         midyn_complex* ob = out + (size_t)b * P * nn;

@@ -1018,6 +1018,80 @@ __global__ __launch_bounds__(256) void phase_table_kernel(const double* frame_im
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// signal_table_kernel: the coefficient table S[B][R][k] evaluated on the
+// device from piecewise-constant samples + carriers,
+//     S[b][r][j] = sum_{terms q of signal j of instance b} Re[ f_q(t_r) exp(i(2 pi nu_q t_r + phi_q)) ],
+//     f_q(t) = samples_q[ clip( floor_divide(t - t0_q, dt_q), -1, len_q ) ]   (zero outside the window),
+// i.e. SignalList.__call__ over SignalSums of DiscreteSignals (signals/signals.py:148-155,302-311,
+// 574-577,801-803).  The arithmetic ORDER of the reference is kept: carrier argument (2 pi nu) * t + phi
+// with separately rounded products, real part f.x cos - f.y sin, terms summed left to right; the
+// sample index uses NumPy's floor_divide algorithm (fmod based) so that times that sit exactly on
+// a sample edge pick the same sample as the reference.  dt_q == 0 marks a constant envelope.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double np_floor_divide(double a, double b) {
+// plain operators under contract(off): hipcc's default -ffp-contract=fast would fuse a*b+c (and the
+// __dmul_rn/__dadd_rn helpers are ordinary inline functions that carry the contract flag with them)
+#pragma clang fp contract(off)
+    // numpy/core/src/npymath: npy_divmod -> floor_divide for doubles
+    double mod = fmod(a, b);
+    double div = (a - mod) / b;
+    if (mod != 0.0) {
+        if ((b < 0) != (mod < 0)) div = div - 1.0;
+    }
+    if (div != 0.0) {
+        double fl = floor(div);
+        if (div - fl > 0.5) fl = fl + 1.0;
+        return fl;
+    }
+    return copysign(0.0, a / b);
+}
+
+struct SigTableArgs {
+    int B, R, k;
+    const double* times;          // [R]
+    const long long* term_ptr;    // [B*k + 1]
+    const double* params;         // [n_terms][4] = dt, start_time, carrier_freq, phase
+    const long long* sample_ptr;  // [n_terms][2] = offset, length (terms may share samples)
+    const double2* samples;
+    double* S;                    // [B][R][k]
+};
+
+__global__ __launch_bounds__(256) void signal_table_kernel(SigTableArgs a) {
+// the reference rounds the carrier product, the phase addition and the two products of the real part
+// separately: no FMA contraction in this kernel
+#pragma clang fp contract(off)
+    const size_t total = (size_t)a.B * a.R * a.k;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int j = (int)(idx % a.k);
+        const size_t br = idx / a.k;
+        const int r = (int)(br % a.R);
+        const size_t b = br / a.R;
+        const double t = a.times[r];
+        const long long lo = a.term_ptr[b * a.k + j], hi = a.term_ptr[b * a.k + j + 1];
+        double acc = 0.0;
+        for (long long q = lo; q < hi; ++q) {
+            const double dt = a.params[4 * q], t0 = a.params[4 * q + 1];
+            const double freq = a.params[4 * q + 2], ph = a.params[4 * q + 3];
+            const long long s0 = a.sample_ptr[2 * q], ns = a.sample_ptr[2 * q + 1];
+            double2 f = make_double2(0.0, 0.0);
+            if (dt == 0.0) {
+                f = a.samples[s0];
+            } else {
+                const double fd = np_floor_divide(t - t0, dt);
+                if (fd >= 0.0 && fd < (double)ns) f = a.samples[s0 + (long long)fd];
+            }
+            const double two_pi_nu = 6.283185307179586 * freq;
+            const double arg = t * two_pi_nu + ph;
+            double sn, cs;
+            sincos(arg, &sn, &cs);
+            const double re = f.x * cs - f.y * sn;
+            acc = (q == lo) ? re : acc + re;
+        }
+        a.S[idx] = acc;
+    }
+}
+
 // Host batch layout [B][n][m] (or shared [n][m]) -> device column block [n_pad][ld]; also writes the
 // pre-phased copy yin = E o y.  Padding rows/cols are zeroed by the caller (memset).
 __global__ __launch_bounds__(256) void scatter_state_kernel(const double2* src, int shared, int B, int n,

@@ -310,3 +310,50 @@ class SignalList:
         if len(self._components) == 0:
             return np.zeros((times.size, 0))
         return np.ascontiguousarray(self(times), dtype=np.float64)
+
+
+def discrete_term_arrays(instances):
+    """Flatten ``instances`` (B lists of k signal-likes) into the CSR arrays ``midyn_sigtable_create``
+    takes: ``(term_ptr[B*k+1], term_params[T][4], sample_ptr[T][2],
+    samples)``.  Returns ``None`` when any term cannot be evaluated on the device, i.e. is not a
+    plain ``DiscreteSignal`` with 1-D samples or a constant ``Signal`` with scalar carrier/phase (a
+    Python-callable envelope stays on the host, row a8)."""
+    term_ptr = [0]
+    params: List[tuple] = []
+    ranges: List[tuple] = []
+    pool: List[np.ndarray] = []
+    seen = {}
+    n_pool = 0
+    for sigs in instances:
+        for sig in sigs:
+            for term in to_SignalSum(sig).components:
+                if np.ndim(term.carrier_freq) != 0 or np.ndim(term.phase) != 0:
+                    return None
+                if type(term) is DiscreteSignal:
+                    smp = term._padded_samples
+                    if smp.ndim != 1 or term.dt == 0:
+                        return None
+                    key = id(smp)
+                    if key not in seen:
+                        seen[key] = (n_pool, smp.shape[0] - 1, smp)  # keep smp alive: ids stay unique
+                        pool.append(smp[:-1])
+                        n_pool += smp.shape[0] - 1
+                    ranges.append(seen[key][:2])
+                    params.append((float(term.dt), float(term.start_time), float(term.carrier_freq),
+                                   float(term.phase)))
+                elif type(term) is Signal and term.is_constant:
+                    val = np.asarray(term.envelope(0.0))
+                    if val.ndim != 0:
+                        return None
+                    ranges.append((n_pool, 1))
+                    pool.append(np.asarray([val]))
+                    n_pool += 1
+                    params.append((0.0, 0.0, float(term.carrier_freq), float(term.phase)))
+                else:
+                    return None
+            term_ptr.append(len(params))
+    samples = np.concatenate(pool).astype(np.complex128) if pool else np.zeros(1, dtype=np.complex128)
+    if samples.shape[0] == 0:
+        samples = np.zeros(1, dtype=np.complex128)
+    return (np.asarray(term_ptr, dtype=np.int64), np.asarray(params, dtype=np.float64).reshape(-1, 4),
+            np.asarray(ranges, dtype=np.int64).reshape(-1, 2), samples)

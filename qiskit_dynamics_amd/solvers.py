@@ -26,9 +26,9 @@ from typing import List, Optional, Tuple, Union
 import numpy as np
 from scipy.integrate._ivp.ivp import OdeResult
 
-from ._lib import DynamicsError
+from ._lib import DynamicsError, SignalTable
 from .models import BaseGeneratorModel, GeneratorModel, HamiltonianModel, LindbladModel
-from .signals import Signal, SignalList
+from .signals import Signal, SignalList, discrete_term_arrays
 
 RK4_METHODS = ("RK4", "hip_RK4")
 EXPM_METHODS = ("scipy_expm", "hip_expm")
@@ -252,6 +252,44 @@ def _restore_batch(model, kind, tag, ys):
     return out
 
 
+# Sweeps whose signals are all DiscreteSignals / constants get their coefficient table evaluated on
+# the device once it has at least this many entries; smaller tables and
+# Python-callable envelopes are evaluated on the host (row a8), bit-identically to the reference.
+DEVICE_SIGNAL_TABLE_MIN = 1 << 16
+
+
+def _signal_components(model, signals):
+    """The k signal-likes behind one instance's coefficient vector, or None if there are none."""
+    if isinstance(model, LindbladModel):
+        if signals is None:
+            ham, dis = model.signals
+        else:
+            ham, dis = signals if isinstance(signals, tuple) else (signals, None)
+        out = []
+        for part in (ham, dis):
+            if part is not None:
+                out += list(part)
+        return out
+    sl = model.signals if signals is None else signals
+    return None if sl is None else list(sl)
+
+
+def _batch_table(model, signals_list, times, batch, n_coeff):
+    """Coefficient table of a batch: (B,R,k) ndarray (host evaluation, row a8) or a device
+    ``SignalTable`` (row f1) when every signal is piecewise constant and the table is large."""
+    shared_sig = all(s is signals_list[0] for s in signals_list)
+    if n_coeff > 0 and not shared_sig and batch * len(times) * n_coeff >= DEVICE_SIGNAL_TABLE_MIN:
+        comps = [_signal_components(model, s) for s in signals_list]
+        if all(c is not None and len(c) == n_coeff for c in comps):
+            arrays = discrete_term_arrays(comps)
+            if arrays is not None:
+                return SignalTable(model._ctx, batch, n_coeff, times, *arrays)
+    if shared_sig:
+        one = _signal_table(model, signals_list[0], times)
+        return np.broadcast_to(one, (batch,) + one.shape)
+    return np.stack([_signal_table(model, s, times) for s in signals_list])
+
+
 def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_dt=None,
                  magnus_order=1, **unknown):
     """Solve ``len(y0_list)`` instances that share t_span/t_eval in one device call."""
@@ -274,13 +312,8 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     if kind == "lindblad":
         return _solve_batch_lindblad(model, sched, y0_list, signals_list, shared_y0)
     y0_dev, tag = _prepare_y0_batch(model, kind, y0_list, shared_y0)
-    shared_sig = all(s is signals_list[0] for s in signals_list)
-    if shared_sig:
-        one = _signal_table(model, signals_list[0], sched.times)
-        table = np.broadcast_to(one, (batch,) + one.shape)
-    else:
-        table = np.stack([_signal_table(model, s, sched.times) for s in signals_list])
     stack = model.stack
+    table = _batch_table(model, signals_list, sched.times, batch, stack.k)
     if method in RK4_METHODS:
         ys = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                              sched.n_save, y0_dev, batch, shared_y0)
@@ -317,12 +350,7 @@ def _solve_batch_lindblad(model, sched, y0_list, signals_list, shared_y0):
             raise DynamicsError("Shape mismatch for initial state y0 and LindbladModel.")
     rho0 = _rotate_density(model, np.stack(mats), True)
     rho0 = rho0[0] if shared_y0 else rho0
-    shared_sig = all(s is signals_list[0] for s in signals_list)
-    if shared_sig:
-        one = _signal_table(model, signals_list[0], sched.times)
-        table = np.broadcast_to(one, (batch,) + one.shape)
-    else:
-        table = np.stack([_signal_table(model, s, sched.times) for s in signals_list])
+    table = _batch_table(model, signals_list, sched.times, batch, model._lind.k)
     ys = model._lind.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save,
                                rho0, batch, shared_y0)
     ys = _rotate_density(model, ys, False)

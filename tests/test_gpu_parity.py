@@ -877,3 +877,127 @@ def test_in_kernel_rk_epilogue_without_split(qd, cfg2):
                 stack.ctx.set_option(k_, v_)
     for name in outs:
         assert_close(outs[name], outs["split"], 1e-12)
+
+
+# ---- row f1: coefficient table evaluated on the device --------------------------------------------
+def _device_table(qd, instances, times):
+    from qiskit_dynamics_amd import _lib
+    from qiskit_dynamics_amd.signals import discrete_term_arrays
+
+    arrays = discrete_term_arrays(instances)
+    assert arrays is not None
+    tab = _lib.SignalTable(_lib.default_context(), len(instances), len(instances[0]), times, *arrays)
+    return tab
+
+
+def test_device_signal_table_matches_reference_values(qd, golden):
+    """DiscreteSignal values captured from the reference (incl. times exactly on sample edges)."""
+    g = golden("signals")
+    dt, t0, nu, phi = g["disc_params"]
+    d = qd.DiscreteSignal(dt=dt, samples=g["disc_samples"], start_time=t0, carrier_freq=nu, phase=phi)
+    for times, want in ((g["t"], g["disc"]), (g["disc_edges_t"], g["disc_edges"])):
+        got = _device_table(qd, [[d]], times).fetch()[0, :, 0]
+        assert_close(got, want, 1e-15 * 8)
+        # the piecewise-constant sample picked must be the same one: zero exactly where the reference is
+        np.testing.assert_array_equal(got == 0.0, want == 0.0)
+    ds = qd.DiscreteSignal(dt=0.1, samples=g["from_signal_samples"], start_time=0.0,
+                           carrier_freq=g["gauss_params"][3], phase=g["gauss_params"][4])
+    got = _device_table(qd, [[ds]], g["t"]).fetch()[0, :, 0]
+    assert_close(got, g["from_signal"], 1e-15 * 8)
+
+
+def test_device_signal_table_sample_index_is_exact(qd):
+    """carrier 0, integer samples: the table must equal the host table BIT FOR BIT, in particular at
+    times that are float multiples of dt (NumPy's fmod-based floor_divide decides the bin)."""
+    rng = np.random.default_rng(5)
+    for dt, t0 in ((0.1, 0.0), (0.1, -0.3), (1.0 / 3, 0.7), (0.222, 1e-3), (2.0**-4, -1.0)):
+        ns = 57
+        smp = np.arange(1, ns + 1) + 1j * np.arange(ns, 0, -1)
+        d = qd.DiscreteSignal(dt=dt, samples=smp, start_time=t0)
+        k_ = np.arange(-5, ns + 6)
+        times = np.concatenate([t0 + k_ * dt, t0 + dt * k_.astype(float) * (1 + 2.0**-52), (t0 + k_ * dt) - 1e-17,
+                                np.nextafter(t0 + k_ * dt, -np.inf), np.nextafter(t0 + k_ * dt, np.inf),
+                                rng.uniform(t0 - 1, t0 + ns * dt + 1, 300)])
+        got = _device_table(qd, [[d]], times).fetch()[0, :, 0]
+        want = qd.SignalList([d]).table(times)[:, 0]
+        np.testing.assert_array_equal(got, want)
+
+
+def test_device_signal_table_random_sums(qd):
+    """Random SignalSums of DiscreteSignals + constants, many instances: device vs host table."""
+    rng = np.random.default_rng(11)
+    B, k = 37, 5
+    times = np.sort(rng.uniform(-1.0, 12.0, 211))
+    inst = []
+    for _ in range(B):
+        sigs = []
+        for j in range(k):
+            terms = []
+            for _t in range(rng.integers(1, 4)):
+                ns = int(rng.integers(1, 40))
+                terms.append(qd.DiscreteSignal(dt=rng.uniform(0.05, 0.7), samples=rng.normal(size=ns) + 1j * rng.normal(size=ns),
+                                               start_time=rng.uniform(-0.5, 2.0), carrier_freq=rng.uniform(-6, 6),
+                                               phase=rng.uniform(-3, 3)))
+            if j == 1:
+                terms.append(qd.Signal(rng.normal(), 0.0, rng.uniform(-1, 1)))
+            sig = terms[0]
+            for t_ in terms[1:]:
+                sig = sig + t_
+            sigs.append(sig if j != 3 else 0.75)
+        inst.append(sigs)
+    got = _device_table(qd, inst, times).fetch()
+    want = np.stack([qd.SignalList(s).table(times) for s in inst])
+    assert got.shape == want.shape == (B, len(times), k)
+    assert np.max(np.abs(got - want)) <= 2e-14, np.max(np.abs(got - want))
+
+
+def test_solver_sweep_with_device_table(qd, monkeypatch):
+    """Solver.solve list mode over DiscreteSignal sweeps: device-evaluated table vs host table, for the
+    RK4, expm and non-vectorised Lindblad routes."""
+    from qiskit_dynamics_amd import solvers as S
+    from qiskit_dynamics_amd import workloads as W
+
+    rng = np.random.default_rng(3)
+    c1 = W.config1()
+    B = 6
+    sig_lists = []
+    for _ in range(B):
+        sig_lists.append([qd.DiscreteSignal(dt=0.05, samples=rng.uniform(0.2, 1.0, 24) * np.exp(1j * rng.uniform(0, 1, 24)),
+                                            carrier_freq=c1["carrier"][j] if "carrier" in c1 else 5.0, phase=rng.uniform(0, 3))
+                          for j in range(len(c1["ops"]))])
+    created = []
+    orig = S.SignalTable
+
+    def spy(*a, **kw):
+        tab = orig(*a, **kw)
+        created.append(tab)
+        return tab
+
+    solver = qd.Solver(static_hamiltonian=c1["h_d"], hamiltonian_operators=c1["ops"], rotating_frame=c1["h_d"])
+    y0 = np.eye(c1["h_d"].shape[0], dtype=complex)[:, 0]
+    for method, kw in (("RK4", {}), ("scipy_expm", {"magnus_order": 2})):
+        monkeypatch.setattr(S, "DEVICE_SIGNAL_TABLE_MIN", 1 << 62)
+        host = solver.solve(t_span=[0.0, 1.0], y0=y0, signals=sig_lists, method=method, max_dt=0.01, **kw)
+        monkeypatch.setattr(S, "DEVICE_SIGNAL_TABLE_MIN", 0)
+        monkeypatch.setattr(S, "SignalTable", spy)
+        n0 = len(created)
+        dev = solver.solve(t_span=[0.0, 1.0], y0=y0, signals=sig_lists, method=method, max_dt=0.01, **kw)
+        monkeypatch.setattr(S, "SignalTable", orig)
+        assert len(created) == n0 + 1, "the device table route was not taken"
+        for a, b in zip(host, dev):
+            assert_close(b.y, a.y, 1e-12)
+    # non-vectorised Lindblad (host-side coefficient reads from a device table)
+    lops = [np.array([[0, 1], [0, 0]], dtype=complex)]
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    ls = qd.Solver(static_hamiltonian=2 * np.pi * 2.5 * z, hamiltonian_operators=[2 * np.pi * 0.1 * x],
+                   static_dissipators=[0.1 * lops[0]], rotating_frame=2 * np.pi * 2.5 * z, vectorized=False)
+    sigs = [[qd.DiscreteSignal(dt=0.1, samples=rng.uniform(0.2, 1, 10), carrier_freq=5.0, phase=rng.uniform(0, 1))]
+            for _ in range(4)]
+    rho0 = np.diag([1.0, 0.0]).astype(complex)
+    monkeypatch.setattr(S, "DEVICE_SIGNAL_TABLE_MIN", 1 << 62)
+    host = ls.solve(t_span=[0.0, 1.0], y0=rho0, signals=sigs, method="RK4", max_dt=0.01)
+    monkeypatch.setattr(S, "DEVICE_SIGNAL_TABLE_MIN", 0)
+    dev = ls.solve(t_span=[0.0, 1.0], y0=rho0, signals=sigs, method="RK4", max_dt=0.01)
+    for a, b in zip(host, dev):
+        assert_close(b.y, a.y, 1e-12)

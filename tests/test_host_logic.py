@@ -239,3 +239,28 @@ def test_signal_algebra_values_match_reference(golden):
     assert (qd.Signal(2.0) * qd.Signal(3.0)).components[0].is_constant
     with pytest.raises(qd.DynamicsError):
         s_gauss * "x"
+
+
+def test_discrete_term_arrays_layout():
+    """Row f1 host side: CSR flattening of DiscreteSignal / constant terms; callable envelopes are
+    not representable on the device."""
+    from qiskit_dynamics_amd.signals import DiscreteSignal, Signal, discrete_term_arrays
+
+    smp = np.array([1.0 + 2.0j, 2.0, -0.5j])
+    d1 = DiscreteSignal(0.5, smp, start_time=0.25, carrier_freq=0.9, phase=0.2)
+    d2 = DiscreteSignal(0.25, np.array([3.0, 4.0]), carrier_freq=1.5)
+    inst = [[d1, d1 + d2, 1.5], [d2, Signal(0.3, 0.0, 0.7), d1]]
+    term_ptr, params, ranges, samples = discrete_term_arrays(inst)
+    assert term_ptr.tolist() == [0, 1, 3, 4, 5, 6, 7]
+    assert params.shape == (7, 4) and ranges.shape == (7, 2)
+    np.testing.assert_array_equal(params[0], [0.5, 0.25, 0.9, 0.2])
+    np.testing.assert_array_equal(params[3], [0.0, 0.0, 0.0, 0.0])           # the constant 1.5
+    np.testing.assert_array_equal(params[5], [0.0, 0.0, 0.0, 0.7])           # constant with a phase
+    # d1 appears three times and shares ONE sample range
+    assert ranges[0].tolist() == ranges[1].tolist() == ranges[6].tolist() == [0, 3]
+    np.testing.assert_array_equal(samples[:3], smp)
+    assert samples[ranges[3, 0]] == 1.5 and samples[ranges[5, 0]] == 0.3
+    # a Python-callable envelope cannot go to the device
+    assert discrete_term_arrays([[Signal(lambda t: t, 1.0)]]) is None
+    # array-valued carrier (a SignalSum passed as one term is flattened first, so this is fine)
+    assert discrete_term_arrays([[d1 + d2]]) is not None
