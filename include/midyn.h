@@ -131,6 +131,18 @@ int midyn_expm_solve(midyn_stack* stack, int B, int m, int R, const double* time
                      int P, int magnus_order, const midyn_complex* y0, int y0_shared,
                      midyn_complex* Y_out);
 
+/* ---- parallel-in-time propagation --------------------------------------
+ * fixed_step_lmde_solver_parallel_template_jax (solvers/fixed_step_solvers.py:524-613) with the step
+ * rule of jax_RK4_parallel_solver (:222-258; method 0) or jax_expm_parallel_solver (:289-316; method =
+ * Magnus order 1..3): the propagators of all steps are formed by batched launches, the ones between
+ * consecutive output times are multiplied by a binary tree (one batched zgemm per level), and the
+ * interval propagators are applied to y0 in time order.  Arguments as midyn_rk4_solve /
+ * midyn_expm_solve (step_rows[s] = the table rows of step s: (t, t+h/2, t+h) for method 0, the
+ * Gauss points for Magnus).  Instances (B) are processed one after the other. */
+int midyn_parallel_solve(midyn_stack* stack, int B, int m, int R, const double* times, const double* S,
+                         int nsteps, const int* step_rows, const double* step_h, const int* step_save,
+                         int P, int method, const midyn_complex* y0, int y0_shared, midyn_complex* Y_out);
+
 /* ---- non-vectorised Lindblad RHS -------------------------------------
  * LindbladCollection.evaluate_rhs (models/operator_collections.py:451-567) with n x n zgemms:
  *   rhs = (A+B) rho + rho (A-B) + sum_j N_j rho N_j^+ + sum_j gamma_j L_j rho L_j^+,

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_get_counters",
     "midyn_reset_counters", "midyn_microbench", "midyn_lindblad_create", "midyn_lindblad_destroy",
     "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve", "midyn_sigtable_create", "midyn_sigtable_data",
-    "midyn_sigtable_fetch", "midyn_sigtable_destroy",
+    "midyn_sigtable_fetch", "midyn_sigtable_destroy", "midyn_parallel_solve",
 ]
 
 
@@ -122,6 +122,8 @@ def load():
         lib.midyn_lindblad_destroy.argtypes = [_vp]
         lib.midyn_lindblad_rhs.argtypes = [_vp, _vp, _cd, _vp, _ci, _vp]
         lib.midyn_lindblad_rk4_solve.argtypes = [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp]
+        lib.midyn_parallel_solve.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _ci,
+                                             _vp, _ci, _vp]
         lib.midyn_sigtable_create.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, P(_vp)]
         lib.midyn_sigtable_data.argtypes = [_vp, P(_vp), _vp]
         lib.midyn_sigtable_fetch.argtypes = [_vp, _vp]
@@ -337,6 +339,19 @@ class Stack:
         self.ctx.check(self.ctx.lib.midyn_expm_solve(
             self.handle, batch, m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows), _ptr(step_h),
             _ptr(step_save), n_save, int(magnus_order), _ptr(y0), int(bool(y0_shared)), _ptr(out)))
+        return out
+
+    def parallel_solve(self, times, table, step_rows, step_h, step_save, n_save, method, y0, batch,
+                       y0_shared):
+        """Parallel-in-time propagation (row f3): ``method`` 0 = RK4 step propagators, 1..3 = expm of
+        the Magnus expansion of that order."""
+        times, r, table, step_rows, step_h, step_save, nsteps, y0 = self._solve_args(
+            times, table, step_rows, step_h, step_save, y0, batch)
+        m = y0.shape[-1]
+        out = np.empty((batch, n_save, self.n, m), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.midyn_parallel_solve(
+            self.handle, batch, m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows), _ptr(step_h),
+            _ptr(step_save), n_save, int(method), _ptr(y0), int(bool(y0_shared)), _ptr(out)))
         return out
 
     def close(self):

@@ -506,7 +506,7 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     const int KT = g.K / GEMM_BK;
     auto best_splits = [&](long long tiles) {
         int sp = 1;
-        if (g.batch > 1) return 1;  // the batch dimension already fills the chip
+        if (g.batch > 1 || g.batch_offs) return 1;  // the batch dimension already fills the chip
         tiles *= 1;
         if (ctx->split_k && tiles < ctx->num_cu)
             while ((long long)sp * 2 * tiles <= ctx->num_cu && KT % (sp * 2) == 0 && KT / (sp * 2) >= 2) sp *= 2;
@@ -584,8 +584,9 @@ static int launch_stream(midyn_ctx* ctx, const StreamArgs& a) {
 // operands are `sa`, `sb`, `sc` elements apart (C and Z share the stride)
 static int dev_zgemm_batched(midyn_ctx* ctx, int batch, int M, int N, int K, const double2* A, int lda, long long sa,
                              const double2* B, int ldb, long long sb, double2* C, int ldc, long long sc, double alpha,
-                             double beta, const double2* Z) {
+                             double beta, const double2* Z, const long long* d_offs = nullptr) {
     GemmArgs g{};
+    g.batch_offs = d_offs;
     g.A = A;
     g.a_seg_stride = 0;
     g.lda = lda;
@@ -676,11 +677,14 @@ static const int* stack_seg_list(midyn_stack* s, int* n_act) {
 }
 
 static int launch_gen_eval(midyn_stack* s, const double* d_coeff, const double2* d_e, double scale,
-                           double2* d_out, int batch = 1, long long coeff_stride = 0) {
+                           double2* d_out, int batch = 1, long long coeff_stride = 0, long long e_stride = 0,
+                           const double* scale_vec = nullptr) {
     midyn_ctx* ctx = s->ctx;
     GenArgs a{};
     a.batch = batch;
     a.coeff_stride = coeff_stride;
+    a.e_stride = e_stride;
+    a.scale_vec = scale_vec;
     a.ops = s->ops;
     a.seg_list = stack_seg_list(s, &a.n_act);
     a.n_pad = s->n_pad;
@@ -1331,6 +1335,82 @@ static int commutator(midyn_ctx* ctx, int np, const double2* a, const double2* b
     return 0;
 }
 
+// Omega_m of the Magnus step (solvers/fixed_step_solvers.py:345-392) for `nb` problems at once.
+// gen(i, scale, out) must write scale * G(t_i) for the i-th Gauss point of every problem; with
+// generators that already carry their step size (gen ignores nothing, h == 1) the same code serves the
+// parallel-in-time solver, because Omega_m is homogeneous in h G.
+template <class Gen>
+static int magnus_omega(midyn_ctx* ctx, int np, int nb, int magnus_order, double h, Gen&& gen, DevBuf* G, DevBuf* W,
+                        double2* Omega) {
+    if (magnus_order == 1) {
+        CHK(gen(0, h, Omega));
+    } else if (magnus_order == 2) {
+        // fixed_step_solvers.py:348-363
+        CHK(gen(0, 1.0, G[0].as<double2>()));
+        CHK(gen(1, 1.0, G[1].as<double2>()));
+        CHK(commutator(ctx, np, G[1].as<double2>(), G[0].as<double2>(), W[0].as<double2>(), W[1].as<double2>(), nb));
+        const double p2 = std::sqrt(3.0) / 12;
+        const double2* xs[3] = {G[0].as<double2>(), G[1].as<double2>(), W[0].as<double2>()};
+        double al[3] = {h / 2, h / 2, p2 * (h * h)};
+        CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0, nb));
+    } else {
+        // fixed_step_solvers.py:365-392
+        const double c0 = std::sqrt(15.0) / 3, c1 = 10.0 / 3;
+        CHK(gen(0, 1.0, G[0].as<double2>()));
+        CHK(gen(1, 1.0, G[1].as<double2>()));
+        CHK(gen(2, 1.0, G[2].as<double2>()));
+        double2 *g1 = G[0].as<double2>(), *g2 = G[1].as<double2>(), *g3 = G[2].as<double2>();
+        double2 *w0 = W[0].as<double2>(), *w1 = W[1].as<double2>(), *w2 = W[2].as<double2>(),
+                *w3 = W[3].as<double2>();
+        // a1 -> g2 (in place), a2 -> w0, a3 -> w1
+        {
+            const double2* xs[2] = {g3, g1};
+            double al[2] = {c0 * h, -c0 * h};
+            CHK(dev_lincomb(ctx, np, w0, 2, xs, al, 0.0, nb));
+        }
+        {
+            const double2* xs[3] = {g3, g2, g1};
+            double al[3] = {c1 * h, -2 * c1 * h, c1 * h};
+            CHK(dev_lincomb(ctx, np, w1, 3, xs, al, 0.0, nb));
+        }
+        {
+            const double2* xs[1] = {g2};
+            double al[1] = {h};
+            CHK(dev_lincomb(ctx, np, g2, 1, xs, al, 0.0, nb));
+        }
+        double2 *a1 = g2, *a2 = w0, *a3 = w1;
+        // comm1 = [a1, a2] -> w2 (tmp g1)
+        CHK(commutator(ctx, np, a1, a2, w2, g1, nb));
+        double2* comm1 = w2;
+        // X = 2 a3 + comm1 -> g3 ; comm2 = [X, a1]/60 -> w3 (tmp g1)
+        {
+            const double2* xs[2] = {a3, comm1};
+            double al[2] = {2.0, 1.0};
+            CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0, nb));
+        }
+        CHK(commutator(ctx, np, g3, a1, w3, g1, nb));
+        // Y2 = a2 + comm2/60 -> g3 ; Y1 = -20 a1 - a3 + comm1 -> g1
+        {
+            const double2* xs[2] = {a2, w3};
+            double al[2] = {1.0, 1.0 / 60};
+            CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0, nb));
+        }
+        {
+            const double2* xs[3] = {a1, a3, comm1};
+            double al[3] = {-20.0, -1.0, 1.0};
+            CHK(dev_lincomb(ctx, np, g1, 3, xs, al, 0.0, nb));
+        }
+        // comm3 = [Y1, Y2] -> w3 (tmp w2: comm1 no longer needed)
+        CHK(commutator(ctx, np, g1, g3, w3, w2, nb));
+        {
+            const double2* xs[3] = {a1, a3, w3};
+            double al[3] = {1.0, 1.0 / 12, 1.0 / 240};
+            CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0, nb));
+        }
+    }
+    return 0;
+}
+
 extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const double* times, const double* S,
                                 int nsteps, const int* step_rows, const double* step_h, const int* step_save,
                                 int P, int magnus_order, const midyn_complex* y0, int y0_shared,
@@ -1397,76 +1477,11 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
             const double h = step_h[st];
             const int* rr = step_rows + 3 * st;
             auto cf = [&](int row) { return coeff_b ? coeff_b + (size_t)row * s->k : nullptr; };
-            auto gen = [&](int row, double scale, double2* out) {
-                return launch_gen_eval(s, cf(row), Erow(row), scale, out, nb, cstride);
+            auto gen = [&](int gi, double scale, double2* out) {
+                return launch_gen_eval(s, cf(rr[gi]), Erow(rr[gi]), scale, out, nb, cstride);
             };
             double2* Omega = Om.as<double2>();
-            if (magnus_order == 1) {
-                CHK(gen(rr[0], h, Omega));
-            } else if (magnus_order == 2) {
-                // fixed_step_solvers.py:348-363
-                CHK(gen(rr[0], 1.0, G[0].as<double2>()));
-                CHK(gen(rr[1], 1.0, G[1].as<double2>()));
-                CHK(commutator(ctx, np, G[1].as<double2>(), G[0].as<double2>(), W[0].as<double2>(), W[1].as<double2>(), nb));
-                const double p2 = std::sqrt(3.0) / 12;
-                const double2* xs[3] = {G[0].as<double2>(), G[1].as<double2>(), W[0].as<double2>()};
-                double al[3] = {h / 2, h / 2, p2 * (h * h)};
-                CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0, nb));
-            } else {
-                // fixed_step_solvers.py:365-392
-                const double c0 = std::sqrt(15.0) / 3, c1 = 10.0 / 3;
-                CHK(gen(rr[0], 1.0, G[0].as<double2>()));
-                CHK(gen(rr[1], 1.0, G[1].as<double2>()));
-                CHK(gen(rr[2], 1.0, G[2].as<double2>()));
-                double2 *g1 = G[0].as<double2>(), *g2 = G[1].as<double2>(), *g3 = G[2].as<double2>();
-                double2 *w0 = W[0].as<double2>(), *w1 = W[1].as<double2>(), *w2 = W[2].as<double2>(),
-                        *w3 = W[3].as<double2>();
-                // a1 -> g2 (in place), a2 -> w0, a3 -> w1
-                {
-                    const double2* xs[2] = {g3, g1};
-                    double al[2] = {c0 * h, -c0 * h};
-                    CHK(dev_lincomb(ctx, np, w0, 2, xs, al, 0.0, nb));
-                }
-                {
-                    const double2* xs[3] = {g3, g2, g1};
-                    double al[3] = {c1 * h, -2 * c1 * h, c1 * h};
-                    CHK(dev_lincomb(ctx, np, w1, 3, xs, al, 0.0, nb));
-                }
-                {
-                    const double2* xs[1] = {g2};
-                    double al[1] = {h};
-                    CHK(dev_lincomb(ctx, np, g2, 1, xs, al, 0.0, nb));
-                }
-                double2 *a1 = g2, *a2 = w0, *a3 = w1;
-                // comm1 = [a1, a2] -> w2 (tmp g1)
-                CHK(commutator(ctx, np, a1, a2, w2, g1, nb));
-                double2* comm1 = w2;
-                // X = 2 a3 + comm1 -> g3 ; comm2 = [X, a1]/60 -> w3 (tmp g1)
-                {
-                    const double2* xs[2] = {a3, comm1};
-                    double al[2] = {2.0, 1.0};
-                    CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0, nb));
-                }
-                CHK(commutator(ctx, np, g3, a1, w3, g1, nb));
-                // Y2 = a2 + comm2/60 -> g3 ; Y1 = -20 a1 - a3 + comm1 -> g1
-                {
-                    const double2* xs[2] = {a2, w3};
-                    double al[2] = {1.0, 1.0 / 60};
-                    CHK(dev_lincomb(ctx, np, g3, 2, xs, al, 0.0, nb));
-                }
-                {
-                    const double2* xs[3] = {a1, a3, comm1};
-                    double al[3] = {-20.0, -1.0, 1.0};
-                    CHK(dev_lincomb(ctx, np, g1, 3, xs, al, 0.0, nb));
-                }
-                // comm3 = [Y1, Y2] -> w3 (tmp w2: comm1 no longer needed)
-                CHK(commutator(ctx, np, g1, g3, w3, w2, nb));
-                {
-                    const double2* xs[3] = {a1, a3, w3};
-                    double al[3] = {1.0, 1.0 / 12, 1.0 / 240};
-                    CHK(dev_lincomb(ctx, np, Omega, 3, xs, al, 0.0, nb));
-                }
-            }
+            CHK(magnus_omega(ctx, np, nb, magnus_order, h, gen, G, W, Omega));
             CHK(dev_expm_inplace(ctx, w, Omega, np, nullptr, nullptr, nb));
             // y <- expm(Omega) y  for every instance of the chunk
             CHK(dev_zgemm_batched(ctx, nb, np, ld, np, Omega, np, (long long)mat, d_y[cur].as<double2>(), ld,
@@ -1483,6 +1498,172 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
         }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b0 * P * inst_elems, d_out.p, (size_t)nb * P * inst_elems * sizeof(double2),
+                              hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Parallel-in-time propagation (fixed_step_lmde_solver_parallel_template_jax,
+// solvers/fixed_step_solvers.py:524-613, with the step rules of jax_RK4_parallel_solver :222-258 and
+// jax_expm_parallel_solver :289-316):
+//   1. the propagators of ALL time steps of a chunk are formed by batched launches
+//        RK4:   P_i = I + (k1 + 2 k2 + 2 k3 + k4)/6,  k1 = hG(t), k2 = hG(t+h/2)(I + k1/2), ...
+//        expm:  P_i = expm(Omega_m(t_i, h_i))
+//   2. the propagators between consecutive output times are multiplied by a binary tree, every tree
+//      level being ONE batched zgemm over all pairs of all intervals (work T-1 products, depth log2),
+//   3. the (few) interval propagators are applied to the state in time order.
+// The reference scans all prefix products (associative_scan) and keeps the ones at t_list; only those
+// are formed here.  Products are re-associated, so results agree with the sequential methods to
+// rounding, not bit for bit (as in the reference, whose tests compare the two the same way).
+// -------------------------------------------------------------------------------------------------
+extern "C" int midyn_parallel_solve(midyn_stack* s, int B, int m, int R, const double* times, const double* S,
+                                    int nsteps, const int* step_rows, const double* step_h, const int* step_save,
+                                    int P, int method, const midyn_complex* y0, int y0_shared,
+                                    midyn_complex* Y_out) {
+    if (!s || !Y_out || !y0 || !times || !step_rows || !step_h || !step_save)
+        return fail(s ? s->ctx : nullptr, "midyn_parallel_solve: NULL argument");
+    midyn_ctx* ctx = s->ctx;
+    if (method < 0 || method > 3) return fail(ctx, "midyn_parallel_solve: method must be 0 (RK4) or a Magnus order 1..3");
+    if (B <= 0 || m <= 0 || R <= 0 || P < 1 || nsteps < 0) return fail(ctx, "midyn_parallel_solve: bad sizes");
+    if (s->k > 0 && !S) return fail(ctx, "midyn_parallel_solve: S is NULL but the stack has operators");
+    for (int i = 0; i < 3 * nsteps; ++i)
+        if (step_rows[i] < 0 || step_rows[i] >= R) return fail(ctx, "midyn_parallel_solve: step_rows out of range");
+    for (int i = 0; i < nsteps; ++i)
+        if (step_save[i] >= P) return fail(ctx, "midyn_parallel_solve: save slot out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int np = s->n_pad;
+    const int ld = round_up(m, 64);
+    const size_t mat = (size_t)np * np, stv = (size_t)np * ld;
+    const int npts = method == 0 ? 3 : method;  // generator evaluations per step
+    const int cap = std::max(1, expm_chunk(ctx, np, std::max(1, nsteps)));
+    const int k = s->k;
+    DevBuf d_S, d_times, d_E, d_rows, d_h, d_C[3], d_Eg[3], X, G[3], W[4], d_offs, d_y[2], d_tmp, d_out;
+    ExpmWork w;
+    if (k > 0) CHK(d_S.alloc(ctx, (size_t)R * k * sizeof(double)));
+    CHK(make_phase_rows(s, times, R, d_times, d_E));
+    // step tables, transposed to [point][step] so that a chunk of steps is contiguous
+    std::vector<int> rows_t((size_t)3 * std::max(1, nsteps));
+    for (int i = 0; i < nsteps; ++i)
+        for (int gi = 0; gi < 3; ++gi) rows_t[(size_t)gi * nsteps + i] = step_rows[3 * i + gi];
+    CHK(d_rows.alloc(ctx, rows_t.size() * sizeof(int)));
+    CHK(d_h.alloc(ctx, (size_t)std::max(1, nsteps) * sizeof(double)));
+    if (nsteps > 0) {
+        HIPCHK(ctx, hipMemcpy(d_rows.p, rows_t.data(), rows_t.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(d_h.p, step_h, (size_t)nsteps * sizeof(double), hipMemcpyHostToDevice));
+    }
+    for (int gi = 0; gi < npts; ++gi) {
+        if (k > 0) CHK(d_C[gi].alloc(ctx, (size_t)cap * k * sizeof(double)));
+        if (s->has_frame) CHK(d_Eg[gi].alloc(ctx, (size_t)cap * np * sizeof(double2)));
+    }
+    CHK(X.alloc(ctx, 2 * (size_t)cap * mat * sizeof(double2)));
+    const int n_g = method == 0 ? 3 : (method == 1 ? 0 : method);
+    const int n_w = method == 0 ? 3 : (method == 2 ? 2 : (method == 3 ? 4 : 0));
+    for (int i = 0; i < n_g; ++i) CHK(G[i].alloc(ctx, (size_t)cap * mat * sizeof(double2)));
+    for (int i = 0; i < n_w; ++i) CHK(W[i].alloc(ctx, (size_t)cap * mat * sizeof(double2)));
+    CHK(d_offs.alloc(ctx, (size_t)3 * cap * sizeof(long long)));
+    CHK(d_y[0].alloc(ctx, stv * sizeof(double2)));
+    CHK(d_y[1].alloc(ctx, stv * sizeof(double2)));
+    const size_t inst_elems = (size_t)s->n * m;
+    CHK(d_tmp.alloc(ctx, inst_elems * sizeof(double2)));
+    CHK(d_out.alloc(ctx, (size_t)P * inst_elems * sizeof(double2)));
+    double2* Xb = X.as<double2>();
+    std::vector<long long> offs;
+    std::vector<int> loc(cap), round_start;
+    for (int b = 0; b < B; ++b) {
+        if (k > 0)  // host or device table (midyn_sigtable_data)
+            HIPCHK(ctx, hipMemcpy(d_S.p, S + (size_t)b * R * k, (size_t)R * k * sizeof(double), hipMemcpyDefault));
+        HIPCHK(ctx, hipMemsetAsync(d_y[0].p, 0, stv * sizeof(double2), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_y[1].p, 0, stv * sizeof(double2), ctx->stream));
+        if (b == 0 || !y0_shared)
+            HIPCHK(ctx, hipMemcpy(d_tmp.p, y0 + (y0_shared ? 0 : (size_t)b * inst_elems), inst_elems * sizeof(double2),
+                                  hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(scatter_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                           d_tmp.as<double2>(), 1, 1, s->n, m, ld, (const double2*)nullptr, d_y[0].as<double2>(),
+                           (double2*)nullptr);
+        hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                           d_y[0].as<double2>(), 1, s->n, m, ld, P, 0, d_out.as<double2>());
+        HIPCHK(ctx, hipGetLastError());
+        int cur = 0;
+        for (int c0 = 0; c0 < nsteps; c0 += cap) {
+            const int nb = std::min(cap, nsteps - c0);
+            // -- 1. coefficient / phase rows of the chunk's steps, then all step propagators -> X[0..nb)
+            for (int gi = 0; gi < npts; ++gi) {
+                const int* rows_g = d_rows.as<int>() + (size_t)gi * nsteps + c0;
+                if (k > 0)
+                    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)nb * k)), dim3(256), 0, ctx->stream,
+                                       d_S.as<double>(), rows_g, nb, k, d_C[gi].as<double>());
+                if (s->has_frame)
+                    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)nb * np * 2)), dim3(256), 0,
+                                       ctx->stream, d_E.as<double>(), rows_g, nb, 2 * np, d_Eg[gi].as<double>());
+            }
+            HIPCHK(ctx, hipGetLastError());
+            const double* hvec = d_h.as<double>() + c0;
+            auto gen = [&](int gi, double scale, double2* out) {
+                return launch_gen_eval(s, k > 0 ? d_C[gi].as<double>() : nullptr,
+                                       s->has_frame ? d_Eg[gi].as<double2>() : nullptr, scale, out, nb, k, np, hvec);
+            };
+            if (method == 0) {
+                double2 *k1 = G[0].as<double2>(), *gh = G[1].as<double2>(), *g1 = G[2].as<double2>();
+                double2 *k2 = W[0].as<double2>(), *k3 = W[1].as<double2>(), *k4 = W[2].as<double2>();
+                CHK(gen(0, 1.0, k1));
+                CHK(gen(1, 1.0, gh));
+                CHK(gen(2, 1.0, g1));
+                CHK(dev_sqgemm(ctx, nb, np, gh, k1, k2, 0.5, 1.0, gh));  // k2 = hG(t+h/2) (I + k1/2)
+                CHK(dev_sqgemm(ctx, nb, np, gh, k2, k3, 0.5, 1.0, gh));  // k3 = hG(t+h/2) (I + k2/2)
+                CHK(dev_sqgemm(ctx, nb, np, g1, k3, k4, 1.0, 1.0, g1));  // k4 = hG(t+h)   (I + k3)
+                const double2* xs[4] = {k1, k2, k3, k4};
+                double al[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
+                CHK(dev_lincomb(ctx, np, Xb, 4, xs, al, 1.0, nb));
+            } else {
+                CHK(magnus_omega(ctx, np, nb, method, 1.0, gen, G, W, Xb));  // generators carry h already
+                CHK(dev_expm_inplace(ctx, w, Xb, np, nullptr, nullptr, nb));
+            }
+            // -- 2. binary-tree products inside every interval [a, e) between output times
+            std::vector<std::pair<int, int>> segs;
+            for (int a = 0; a < nb;) {
+                int e = a;
+                while (e < nb && step_save[c0 + e] < 0) ++e;
+                e = std::min(nb, e + 1);
+                segs.emplace_back(a, e);
+                a = e;
+            }
+            std::fill(loc.begin(), loc.begin() + nb, 0);
+            auto slot = [&](int which, int i) { return (long long)((size_t)which * cap + i) * (long long)mat; };
+            int longest = 0;
+            for (auto& sg : segs) longest = std::max(longest, sg.second - sg.first);
+            for (int st = 1; st < longest; st *= 2) {
+                offs.clear();
+                for (auto& sg : segs)
+                    for (int i = sg.first; i + st < sg.second; i += 2 * st) {
+                        offs.push_back(slot(loc[i + st], i + st));  // later steps multiply from the left
+                        offs.push_back(slot(loc[i], i));
+                        offs.push_back(slot(loc[i] ^ 1, i));
+                        loc[i] ^= 1;
+                    }
+                const int cnt = (int)(offs.size() / 3);
+                if (cnt == 0) continue;
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the previous level may still read d_offs
+                HIPCHK(ctx, hipMemcpy(d_offs.p, offs.data(), offs.size() * sizeof(long long), hipMemcpyHostToDevice));
+                CHK(dev_zgemm_batched(ctx, cnt, np, np, np, Xb, np, 0, Xb, np, 0, Xb, np, 0, 1.0, 0.0, nullptr,
+                                      d_offs.as<long long>()));
+            }
+            // -- 3. apply the interval propagators in time order, store the states at the output times
+            for (auto& sg : segs) {
+                const double2* Q = Xb + slot(loc[sg.first], sg.first);
+                CHK(dev_zgemm(ctx, np, ld, np, Q, np, d_y[cur].as<double2>(), ld, d_y[cur ^ 1].as<double2>(), ld, 1.0,
+                              0.0, nullptr));
+                cur ^= 1;
+                const int sv = step_save[c0 + sg.second - 1];
+                if (sv >= 0) {
+                    hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                                       d_y[cur].as<double2>(), 1, s->n, m, ld, P, sv, d_out.as<double2>());
+                    HIPCHK(ctx, hipGetLastError());
+                }
+            }
+        }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b * P * inst_elems, d_out.p, (size_t)P * inst_elems * sizeof(double2),
                               hipMemcpyDeviceToHost));
     }
     return 0;

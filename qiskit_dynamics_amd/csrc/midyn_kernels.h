@@ -285,6 +285,8 @@ struct GemmArgs {
     int n_inst;              // number of instances (columns beyond are padding)
     int batch;               // > 1: blockIdx.y indexes independent problems (EPI_PLAIN only)
     long long batch_a, batch_b, batch_c;  // element strides of A, B and C/Z between problems
+    const long long* batch_offs;          // optional [batch][3] element offsets of A, B, C/Z per problem
+                                          // (replaces the strides: products of scattered matrices)
     int splits;              // split-K: gridDim = tiles * splits; split z handles K tiles [z*KT/splits, ...)
     double2* partial;        // [splits][M][N] raw partial sums when splits > 1 (epilogue runs in
                              // splitk_reduce_kernel), nullptr otherwise
@@ -473,8 +475,15 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
         const int c = wave + NWAVE * p;
         b_src[p] = (c / B_PER_ROW) * g.ldb + (c % B_PER_ROW) * 64 + lane;
     }
-    const double2* Abase = g.A + (size_t)blockIdx.y * g.batch_a + (size_t)m0 * g.lda + (size_t)kt0 * BK;
-    const double2* Bbase = g.B + (size_t)blockIdx.y * g.batch_b + n0 + (size_t)kt0 * BK * g.ldb;
+    long long off_a = (long long)blockIdx.y * g.batch_a, off_b = (long long)blockIdx.y * g.batch_b;
+    long long off_c = (long long)blockIdx.y * g.batch_c;
+    if (g.batch_offs) {
+        off_a = g.batch_offs[3 * blockIdx.y];
+        off_b = g.batch_offs[3 * blockIdx.y + 1];
+        off_c = g.batch_offs[3 * blockIdx.y + 2];
+    }
+    const double2* Abase = g.A + off_a + (size_t)m0 * g.lda + (size_t)kt0 * BK;
+    const double2* Bbase = g.B + off_b + n0 + (size_t)kt0 * BK * g.ldb;
 
     // Loop order: K tile outer, operator segment inner -- the B (state) tile is staged ONCE per K
     // tile and reused by all n_act operator tiles, so per launch the state block is read once per
@@ -639,9 +648,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
         return;
     }
     Epilogue epi = g.epi;
-    if (g.batch > 1) {  // batched plain zgemm: every problem has its own output / addend block
-        epi.out += (size_t)blockIdx.y * g.batch_c;
-        if (epi.z) epi.z += (size_t)blockIdx.y * g.batch_c;
+    if (g.batch > 1 || g.batch_offs) {  // batched plain zgemm: every problem has its own output / addend block
+        epi.out += off_c;
+        if (epi.z) epi.z += off_c;
     }
     if (MIDYN_ABL(g, 4)) {
         double sdump = 0.0;
@@ -942,8 +951,10 @@ struct GenArgs {
     const double2* e;  // [n_pad] phases or nullptr
     double scale;
     double2* out;      // [batch][n_pad][n_pad]
-    int batch;         // instances evaluated at once (same time, own coefficient row)
+    int batch;         // instances evaluated at once (own coefficient row)
     long long coeff_stride;  // doubles between the coefficient rows of consecutive instances
+    long long e_stride;      // 0: all instances share the phases e (same time); else elements between rows
+    const double* scale_vec; // optional per-instance factor on top of `scale` (step sizes)
 };
 
 __global__ __launch_bounds__(256) void gen_eval_kernel(GenArgs a) {
@@ -966,10 +977,12 @@ __global__ __launch_bounds__(256) void gen_eval_kernel(GenArgs a) {
         if (a.e) {
             const int r = (int)(idx / n);
             const int c = (int)(idx - (size_t)r * n);
-            const double2 ph = cmul_conj_a(a.e[r], a.e[c]);
+            const double2* e = a.e + inst * a.e_stride;
+            const double2 ph = cmul_conj_a(e[r], e[c]);
             gsum = cmul(ph, gsum);
         }
-        a.out[gidx] = make_double2(a.scale * gsum.x, a.scale * gsum.y);
+        const double sc = a.scale_vec ? a.scale * a.scale_vec[inst] : a.scale;
+        a.out[gidx] = make_double2(sc * gsum.x, sc * gsum.y);
     }
 }
 
@@ -1089,6 +1102,17 @@ __global__ __launch_bounds__(256) void signal_table_kernel(SigTableArgs a) {
             acc = (q == lo) ? re : acc + re;
         }
         a.S[idx] = acc;
+    }
+}
+
+// out[i][0..w) = src[rows[i]][0..w)  (rows of the coefficient table / of the phase table gathered
+// into the order of a batch of time steps)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double* src, const int* rows, int count,
+                                                          int w, double* out) {
+    const size_t total = (size_t)count * w;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t i = idx / w;
+        out[idx] = src[(size_t)rows[i] * w + (idx - i * w)];
     }
 }
 

@@ -32,8 +32,11 @@ from .signals import Signal, SignalList, discrete_term_arrays
 
 RK4_METHODS = ("RK4", "hip_RK4")
 EXPM_METHODS = ("scipy_expm", "hip_expm")
+# parallel-in-time LMDE methods; the reference names are accepted as aliases
+RK4_PARALLEL_METHODS = ("hip_RK4_parallel", "jax_RK4_parallel")
+EXPM_PARALLEL_METHODS = ("hip_expm_parallel", "jax_expm_parallel")
 ODE_METHODS = list(RK4_METHODS)
-LMDE_METHODS = list(EXPM_METHODS)
+LMDE_METHODS = list(EXPM_METHODS + RK4_PARALLEL_METHODS + EXPM_PARALLEL_METHODS)
 
 
 # -------------------------------------------------------------------------------------------------
@@ -298,11 +301,12 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     if max_dt is None:
         raise DynamicsError("max_dt must be specified for fixed-step methods.")
     kind = _model_kind(model)
-    if method in EXPM_METHODS:
+    if method in EXPM_METHODS + EXPM_PARALLEL_METHODS + RK4_PARALLEL_METHODS:
         if kind == "lindblad":
             raise DynamicsError(
                 "LMDE-specific methods with LindbladModel requires setting a vectorized=True.")
-        sched = FixedStepSchedule(t_span, t_eval, max_dt, _magnus_points(magnus_order))
+        points = _rk4_points if method in RK4_PARALLEL_METHODS else _magnus_points(magnus_order)
+        sched = FixedStepSchedule(t_span, t_eval, max_dt, points)
     elif method in RK4_METHODS:
         sched = FixedStepSchedule(t_span, t_eval, max_dt, _rk4_points)
     else:
@@ -317,6 +321,10 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     if method in RK4_METHODS:
         ys = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                              sched.n_save, y0_dev, batch, shared_y0)
+    elif method in RK4_PARALLEL_METHODS + EXPM_PARALLEL_METHODS:
+        ys = stack.parallel_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                                  sched.n_save, 0 if method in RK4_PARALLEL_METHODS else magnus_order,
+                                  y0_dev, batch, shared_y0)
     else:
         ys = stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                               sched.n_save, magnus_order, y0_dev, batch, shared_y0)
@@ -367,7 +375,7 @@ def solve_lmde(generator, t_span, y0, method: str = "RK4", t_eval=None, **kwargs
         raise DynamicsError(
             "solve_lmde on the HIP path requires a model instance (GeneratorModel, HamiltonianModel "
             "or LindbladModel); Python callables cannot be evaluated on the device.")
-    if method not in RK4_METHODS + EXPM_METHODS:
+    if method not in RK4_METHODS + EXPM_METHODS + RK4_PARALLEL_METHODS + EXPM_PARALLEL_METHODS:
         raise DynamicsError(f"Method {method} not supported by solve_lmde.")
     return _solve_batch(generator, t_span, [y0], [None], method, t_eval=t_eval, **kwargs)[0]
 

@@ -1001,3 +1001,118 @@ def test_solver_sweep_with_device_table(qd, monkeypatch):
     dev = ls.solve(t_span=[0.0, 1.0], y0=rho0, signals=sigs, method="RK4", max_dt=0.01)
     for a, b in zip(host, dev):
         assert_close(b.y, a.y, 1e-12)
+
+
+# ---- row f3: parallel-in-time propagation ---------------------------------------------------------
+@pytest.mark.parametrize("seed", range(8))
+def test_parallel_in_time_vs_sequential_and_oracle(qd, seed):
+    """``hip_RK4_parallel`` / ``hip_expm_parallel`` (step propagators formed together, tree products,
+    fixed_step_solvers.py:524-613) against the sequential device methods and the oracle: vector, matrix
+    and square (propagator) states, frames, t_eval (several intervals), backwards, sweeps."""
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(2, 70))
+    k = int(rng.integers(1, 4))
+    frame_kind = ["none", "diag", "full"][seed % 3]
+    m = [None, 2, "square"][int(rng.integers(0, 3))]
+    batch = [1, 3][int(rng.integers(0, 2))]
+    backwards = bool(rng.integers(0, 2))
+    mo = 1 + seed % 3
+    par_method, seq_method = (("hip_RK4_parallel", "RK4") if seed % 2 == 0 else ("hip_expm_parallel", "scipy_expm"))
+
+    def herm():
+        a = crand(rng, n, n)
+        return (a + a.conj().T) / 2
+
+    h_static = herm()
+    h_ops = np.array([herm() for _ in range(k)])
+    frame = {"none": None, "diag": rng.normal(size=n), "full": herm()}[frame_kind]
+    t_span = [0.3, 0.0] if backwards else [0.0, 0.3]
+    t_eval = [None, sorted(rng.uniform(0, 0.3, 4), reverse=backwards),
+              np.linspace(t_span[0], t_span[1], 31)][int(rng.integers(0, 3))]
+    max_dt = 0.004 if seq_method == "RK4" else 0.02
+
+    def make_sigs():
+        amps, nus, phs = rng.uniform(-1, 1, k), rng.uniform(0, 2, k), rng.uniform(-3, 3, k)
+        return ([qd.Signal(lambda t, a=a: a * np.cos(0.7 * t) + 0j, nu, ph) for a, nu, ph in zip(amps, nus, phs)],
+                (amps, nus, phs))
+
+    def make_y0():
+        if m == "square":
+            return np.linalg.qr(crand(rng, n, n))[0]
+        y = crand(rng, n) if m is None else crand(rng, n, m)
+        return y / np.linalg.norm(y)
+
+    sig_sets = [make_sigs() for _ in range(batch)]
+    y0s = [make_y0() for _ in range(batch)]
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=frame)
+    kw = dict(max_dt=max_dt, t_eval=t_eval)
+    if seq_method == "scipy_expm":
+        kw["magnus_order"] = mo
+    args = dict(t_span=t_span, y0=y0s if batch > 1 else y0s[0],
+                signals=[s for s, _ in sig_sets] if batch > 1 else sig_sets[0][0])
+    par = solver.solve(method=par_method, **args, **kw)
+    seq = solver.solve(method=seq_method, **args, **kw)
+    par = par if isinstance(par, list) else [par]
+    seq = seq if isinstance(seq, list) else [seq]
+    a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
+    for b in range(batch):
+        assert_close(par[b].t, seq[b].t, 0)
+        assert_close(par[b].y, seq[b].y, SOLVE_TOL)
+        amps, nus, phs = sig_sets[b][1]
+
+        def coeff(t, amps=amps, nus=nus, phs=phs):
+            return np.array([orc.signal_sum_value(np.array([a_ * np.cos(0.7 * t) + 0j]), [nu], [ph], t)
+                             for a_, nu, ph in zip(amps, nus, phs)])
+
+        t_ref, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff, t_span, y0s[b], seq_method, max_dt,
+                                                 t_eval=t_eval, magnus_order=mo)
+        assert_close(par[b].t, t_ref, 0)
+        assert_close(par[b].y, y_ref, SOLVE_TOL)
+
+
+def test_parallel_in_time_many_steps_and_lindblad(qd):
+    """More steps than one chunk holds (intervals split across chunks), the jax_* aliases of the
+    reference, the 128-tile product path, and a vectorised Lindblad model."""
+    from qiskit_dynamics_amd import workloads as W
+
+    c1 = W.config1()
+    solver = qd.Solver(static_hamiltonian=c1["h_d"], hamiltonian_operators=c1["ops"], rotating_frame=c1["h_d"])
+    sigs = [qd.Signal(lambda t: 0.3 * np.exp(-((t - 2.0) ** 2)) + 0j, 5.0, 0.1 * j) for j in range(len(c1["ops"]))]
+    n = c1["h_d"].shape[0]
+    y0 = np.eye(n, dtype=complex)
+    t_eval = [0.0, 1.3, 2.0, 4.0]
+    # 4 / 0.0008 = 5000 steps > 4096 per chunk at this size
+    par = solver.solve(t_span=[0.0, 4.0], y0=y0, signals=sigs, method="jax_RK4_parallel", max_dt=0.0008, t_eval=t_eval)
+    seq = solver.solve(t_span=[0.0, 4.0], y0=y0, signals=sigs, method="RK4", max_dt=0.0008, t_eval=t_eval)
+    assert_close(par.y, seq.y, SOLVE_TOL)
+    par = solver.solve(t_span=[0.0, 4.0], y0=y0[:, 0], signals=sigs, method="jax_expm_parallel", max_dt=0.0009,
+                       magnus_order=2, t_eval=t_eval)
+    seq = solver.solve(t_span=[0.0, 4.0], y0=y0[:, 0], signals=sigs, method="scipy_expm", max_dt=0.0009,
+                       magnus_order=2, t_eval=t_eval)
+    assert_close(par.y, seq.y, SOLVE_TOL)
+    # n = 128: products on the 128x128 tile with per-problem offsets
+    cfg = W.schrodinger_config(7)
+    s7 = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+    sig7 = [qd.Signal(lambda t, j=j: 0.2 * np.cos(0.3 * t + j) + 0j, 4.0 + 0.1 * j, 0.0) for j in range(len(cfg["ops"]))]
+    y7 = np.zeros(128, dtype=complex)
+    y7[3] = 1.0
+    for pm, sm, kw in (("hip_RK4_parallel", "RK4", {}), ("hip_expm_parallel", "scipy_expm", {"magnus_order": 3})):
+        par = s7.solve(t_span=[0.0, 0.5], y0=y7, signals=sig7, method=pm, max_dt=0.01, t_eval=[0.0, 0.2, 0.5], **kw)
+        seq = s7.solve(t_span=[0.0, 0.5], y0=y7, signals=sig7, method=sm, max_dt=0.01, t_eval=[0.0, 0.2, 0.5], **kw)
+        assert_close(par.y, seq.y, SOLVE_TOL)
+        assert abs(np.linalg.norm(par.y[-1]) - 1.0) < 1e-8
+    # vectorised Lindblad (N = 16)
+    lc = W.lindblad_config(2, n_drives=2, n_diss=2, gamma=0.05)
+    ls = qd.Solver(static_hamiltonian=lc["h_d"], hamiltonian_operators=lc["ops"], static_dissipators=lc["static_dissipators"],
+                   rotating_frame=lc["h_d"], vectorized=True)
+    lsig = [qd.Signal(lambda t: 0.5 * np.sin(t) ** 2 + 0j, nu, 0.0) for nu in lc["carrier"]]
+    rho0 = lc["rho0"].flatten(order="F")  # plain arrays are not reshaped (solver_classes.py:781-790)
+    par = ls.solve(t_span=[0.0, 1.0], y0=rho0, signals=lsig, method="hip_expm_parallel", max_dt=0.01, magnus_order=1)
+    seq = ls.solve(t_span=[0.0, 1.0], y0=rho0, signals=lsig, method="scipy_expm", max_dt=0.01, magnus_order=1)
+    assert_close(par.y, seq.y, SOLVE_TOL)
+    with pytest.raises(qd.DynamicsError):
+        qd.Solver(static_hamiltonian=lc["h_d"], hamiltonian_operators=lc["ops"], static_dissipators=lc["static_dissipators"],
+                  vectorized=False).solve(t_span=[0.0, 1.0], y0=lc["rho0"], signals=lsig, method="hip_expm_parallel",
+                                          max_dt=0.01)
