@@ -42,6 +42,7 @@ struct midyn_ctx {
     bool prefer_duo = false;
     int ablate = 0;
     int stream_variant = 0;
+    bool stream_planes = true;   // single-plane stacks: the one-column kernel streams only non-zero planes
     bool split_k = true;
     bool combine_first = true;
     bool plane_kernel = false;  // planar two-tiles-per-barrier variant: measured 4 % SLOWER (2.43 vs 2.33 ms), kept opt-in
@@ -177,6 +178,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     else if (n == "prefer_duo") ctx->prefer_duo = value != 0;
     else if (n == "ablate") ctx->ablate = (int)value;
     else if (n == "stream_variant") ctx->stream_variant = (int)value;
+    else if (n == "stream_planes") ctx->stream_planes = value != 0;
     else if (n == "split_k") ctx->split_k = value != 0;
     else if (n == "combine_first") ctx->combine_first = value != 0;
     else if (n == "complex_3m") ctx->complex_3m = value != 0;
@@ -563,8 +565,23 @@ static int launch_gemm_plane(midyn_ctx* ctx, const GemmArgs& g_in, const double*
     return launch_reduce(ctx, g);
 }
 
-static int launch_stream(midyn_ctx* ctx, const StreamArgs& a) {
+static int launch_stream(midyn_ctx* ctx, const StreamArgs& a, const double* planes = nullptr) {
     ProfScope ps(ctx, KC_STREAM);
+    if (planes) {  // single-plane stack: stream only the non-zero planes (half the bytes)
+        if (a.n_pad >= 1024) {
+            switch (ctx->stream_variant) {
+                case 1: hipLaunchKernelGGL((rhs_stream_plane_kernel<2, 1>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a, planes); break;
+                case 2: hipLaunchKernelGGL((rhs_stream_plane_kernel<1, 3>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a, planes); break;
+                case 3: hipLaunchKernelGGL((rhs_stream_plane_kernel<2, 9>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a, planes); break;
+                case 4: hipLaunchKernelGGL((rhs_stream_plane_kernel<1, 9>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a, planes); break;
+                default: hipLaunchKernelGGL((rhs_stream_plane_kernel<2, 3>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a, planes); break;
+            }
+        } else {
+            hipLaunchKernelGGL((rhs_stream_plane_kernel<1, 1>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a, planes);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        return 0;
+    }
     if (a.n_pad >= 1024) {
         switch (ctx->stream_variant) {
             case 1: hipLaunchKernelGGL((rhs_stream_kernel<4, 1>), dim3(a.n_pad), dim3(256), 0, ctx->stream, a); break;
@@ -859,6 +876,18 @@ struct midyn_rk4_plan {
     int next_step = 0;         // next step expected (state continuity)
 };
 
+// planar copy of a single-plane stack: planes[act] = the non-zero plane of active segment `act`
+static int stack_planes(midyn_stack* s) {
+    if (s->planes) return 0;
+    midyn_ctx* ctx = s->ctx;
+    const size_t plane = (size_t)s->n_pad * s->n_pad;
+    HIPCHK(ctx, hipMalloc(&s->planes, plane * s->n_act * sizeof(double)));
+    hipLaunchKernelGGL(extract_planes_kernel, dim3(grid_for(plane * s->n_act)), dim3(256), 0, ctx->stream, s->ops,
+                       s->seg_act, s->n_act, plane, s->planes);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
 static const double2* plan_E(midyn_rk4_plan* p, int row) {
     if (!p->stack->has_frame) return nullptr;
     return p->d_E.as<double2>() + (size_t)row * p->stack->n_pad;
@@ -876,7 +905,12 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
         a.coeff = s->k > 0 ? p->d_S.as<double>() + (size_t)row * s->k : nullptr;
         a.yin = yin;
         a.epi = epi;
-        return launch_stream(ctx, a);
+        const double* planes = nullptr;
+        if (ctx->skip_zero_planes && ctx->stream_planes && s->all_single_plane) {
+            CHK(stack_planes(s));
+            planes = s->planes;
+        }
+        return launch_stream(ctx, a, planes);
     }
     if (p->combine_first) {
         // All columns share the coefficients (B == 1): C(t) = sum_seg c_seg A_seg costs nseg*n^2
@@ -922,14 +956,8 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
     g.epi = epi;
     if (ctx->skip_zero_planes && ctx->plane_kernel && s->all_single_plane && g.M % 128 == 0 && g.N % 128 == 0 &&
         ctx->force_tile == 0) {
-        const size_t plane = (size_t)s->n_pad * s->n_pad;
-        if (!s->planes) {
-            HIPCHK(ctx, hipMalloc(&s->planes, plane * s->n_act * sizeof(double)));
-            hipLaunchKernelGGL(extract_planes_kernel, dim3(grid_for(plane * s->n_act)), dim3(256), 0, ctx->stream,
-                               s->ops, s->seg_act, s->n_act, plane, s->planes);
-            HIPCHK(ctx, hipGetLastError());
-        }
-        return launch_gemm_plane(ctx, g, s->planes, (long long)plane);
+        CHK(stack_planes(s));
+        return launch_gemm_plane(ctx, g, s->planes, (long long)s->n_pad * s->n_pad);
     }
     return launch_gemm(ctx, g, KC_RHS_GEMM, ctx->skip_zero_planes ? s->uniform_mode : 0);
 }

@@ -257,6 +257,107 @@ __global__ __launch_bounds__(256) void rhs_stream_kernel(StreamArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// rhs_stream_plane_kernel: the same contraction for stacks whose active operators are ALL purely real
+// or purely imaginary (-iH of a real-symmetric H is purely imaginary: cfg 2/3).  The exactly-zero
+// plane of every operator is not stored at all (`planes[act][n][n]` doubles, built once by
+// extract_planes_kernel), so an evaluation streams 8*n_act*n^2 bytes instead of 16*nseg*n^2: half
+// the HBM traffic for bit-identical results (the skipped products are exact zeros).  Every lane
+// loads 16 B = the entries of two neighbouring columns.
+// ------------------------------------------------------------------------------------------------
+template <int UNROLL, int SEGU>
+__global__ __launch_bounds__(256) void rhs_stream_plane_kernel(StreamArgs a, const double* planes) {
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = a.n_pad;  // multiple of 64
+    const size_t plane = (size_t)n * n;
+    const int ld = a.epi.ld;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int c0 = 2 * tid; c0 < n; c0 += 512 * UNROLL) {
+        double2 gre[UNROLL], gim[UNROLL];  // (column c, column c+1) of Re g and Im g
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) gre[u] = gim[u] = make_double2(0.0, 0.0);
+        int s = 0;
+        for (; s + SEGU <= a.n_act; s += SEGU) {
+            double cr[SEGU], ci[SEGU];
+            const double* p[SEGU];
+            double2 v[SEGU][UNROLL];
+#pragma unroll
+            for (int q = 0; q < SEGU; ++q) {
+                const int packed = a.seg_list[s + q];
+                const int seg = packed >> 2;
+                const double cf = (a.has_static && seg == 0) ? 1.0 : a.coeff[seg - a.has_static];
+                cr[q] = (packed & 3) == 2 ? 0.0 : cf;
+                ci[q] = (packed & 3) == 2 ? cf : 0.0;
+                p[q] = planes + (size_t)(s + q) * plane + (size_t)row * n;
+            }
+#pragma unroll
+            for (int q = 0; q < SEGU; ++q)
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int c = c0 + u * 512;
+                    v[q][u] = c < n ? *reinterpret_cast<const double2*>(p[q] + c) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+            for (int q = 0; q < SEGU; ++q)
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    gre[u].x = fma(cr[q], v[q][u].x, gre[u].x);
+                    gre[u].y = fma(cr[q], v[q][u].y, gre[u].y);
+                    gim[u].x = fma(ci[q], v[q][u].x, gim[u].x);
+                    gim[u].y = fma(ci[q], v[q][u].y, gim[u].y);
+                }
+        }
+        for (; s < a.n_act; ++s) {
+            const int packed = a.seg_list[s];
+            const int seg = packed >> 2;
+            const double cf = (a.has_static && seg == 0) ? 1.0 : a.coeff[seg - a.has_static];
+            const double cr = (packed & 3) == 2 ? 0.0 : cf, ci = (packed & 3) == 2 ? cf : 0.0;
+            const double* p = planes + (size_t)s * plane + (size_t)row * n;
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int c = c0 + u * 512;
+                if (c < n) {
+                    const double2 v = *reinterpret_cast<const double2*>(p + c);
+                    gre[u].x = fma(cr, v.x, gre[u].x);
+                    gre[u].y = fma(cr, v.y, gre[u].y);
+                    gim[u].x = fma(ci, v.x, gim[u].x);
+                    gim[u].y = fma(ci, v.y, gim[u].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int c = c0 + u * 512;
+            if (c < n) {
+                const double2 y0 = a.yin[(size_t)c * ld], y1 = a.yin[(size_t)(c + 1) * ld];
+                acc.x = fma(gre[u].x, y0.x, acc.x);
+                acc.x = fma(-gim[u].x, y0.y, acc.x);
+                acc.y = fma(gre[u].x, y0.y, acc.y);
+                acc.y = fma(gim[u].x, y0.x, acc.y);
+                acc.x = fma(gre[u].y, y1.x, acc.x);
+                acc.x = fma(-gim[u].y, y1.y, acc.x);
+                acc.y = fma(gre[u].y, y1.y, acc.y);
+                acc.y = fma(gim[u].y, y1.x, acc.y);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        acc.x += __shfl_down(acc.x, off, 64);
+        acc.y += __shfl_down(acc.y, off, 64);
+    }
+    __shared__ double2 part[4];
+    if ((tid & 63) == 0) part[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double2 c = part[0];
+        c.x += part[1].x + part[2].x + part[3].x;
+        c.y += part[1].y + part[2].y + part[3].y;
+        apply_epilogue(a.epi, row, 0, c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // zgemm_seg_kernel:  C[M][N] = sum_{seg in active} A_seg[M][K] . ( B[K][N] o s_seg[col] )
 // fp64 MFMA v_mfma_f64_16x16x4_f64; complex product = 4 real MFMAs on (re,im) of the fragments
 // (2 when a plane of A_seg is exactly zero).  Fragment maps (one f64 per lane):

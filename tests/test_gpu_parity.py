@@ -1116,3 +1116,37 @@ def test_parallel_in_time_many_steps_and_lindblad(qd):
         qd.Solver(static_hamiltonian=lc["h_d"], hamiltonian_operators=lc["ops"], static_dissipators=lc["static_dissipators"],
                   vectorized=False).solve(t_span=[0.0, 1.0], y0=lc["rho0"], signals=lsig, method="hip_expm_parallel",
                                           max_dt=0.01)
+
+
+def test_planar_stream_kernel_matches_interleaved(qd, cfg2):
+    """Single-plane stacks: the one-column kernel streams only the non-zero planes (half the bytes);
+    the skipped products are exact zeros, so it must agree with the interleaved kernel to rounding
+    (different summation order across lanes) and with the oracle."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    cfg, ref, stack = cfg2
+    assert all(m in (1, 2, 3) for m in stack.segment_modes)
+    rng = np.random.default_rng(2)
+    y = crand(rng, 1024)
+    c = rng.normal(size=8)
+    outs = {}
+    for planes in (1, 0):
+        stack.ctx.set_option("stream_planes", planes)
+        for variant in (0, 1, 2, 3, 4):
+            stack.ctx.set_option("stream_variant", variant)
+            outs[(planes, variant)] = stack.eval_rhs(c, 0.37, y)
+    stack.ctx.set_option("stream_planes", 1)
+    stack.ctx.set_option("stream_variant", 0)
+    for key, val in outs.items():
+        assert_close(val, outs[(0, 0)], 1e-13)
+    sched = FixedStepSchedule([0.0, 0.1], None, cfg["max_dt"], _rk4_points)
+    table, _, _ = _table_for(cfg, range(1), sched.times)
+    y0 = np.zeros((1024, 1), dtype=complex)
+    y0[7, 0] = 1.0
+    res = {}
+    for planes in (1, 0):
+        stack.ctx.set_option("stream_planes", planes)
+        res[planes] = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                                      sched.n_save, y0, 1, True)
+    stack.ctx.set_option("stream_planes", 1)
+    assert_close(res[1], res[0], 1e-13)

@@ -19,6 +19,8 @@ table = workloads.gaussian_coefficient_table(sched.times[:nr], amps[None], phs[N
 y0 = cfg["y0"].reshape(-1, 1)
 nbytes = 16 * stack.n_segments * 1024 * 1024 + 32 * 1024
 for rnd in range(2):
+  for planes in (0, 1):
+    ctx.set_option("stream_planes", planes)
     for v in (0, 1, 2, 3, 4):
         ctx.set_option("stream_variant", v)
         p = qd.Rk4Plan(stack, sched.times[:nr], table, rows, sched.step_h[:S], y0, 1, True)
@@ -27,5 +29,5 @@ for rnd in range(2):
         p.run(10, S); ctx.synchronize()
         c = ctx.counters("rhs_stream"); ctx.set_option("profile", 0)
         ms = c["ms"] / c["launches"]
-        print(f"variant {v}: {ms*1e3:.2f} us  {nbytes/ms/1e6:.0f} GB/s", flush=True)
+        print(f"planes {planes} variant {v}: {ms*1e3:.2f} us  algorithmic {nbytes/ms/1e6:.0f} GB/s", flush=True)
         p.close()
