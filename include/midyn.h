@@ -143,6 +143,24 @@ int midyn_parallel_solve(midyn_stack* stack, int B, int m, int R, const double* 
                          int nsteps, const int* step_rows, const double* step_h, const int* step_save,
                          int P, int method, const midyn_complex* y0, int y0_shared, midyn_complex* Y_out);
 
+/* ---- perturbative Dyson / Magnus expansion step -------------------------
+ * Run-time part of DysonSolver / MagnusSolver (solvers/perturbative_solvers/dyson_solver.py:187-207,
+ * magnus_solver.py:107-129, perturbative_solver.py:172-219): per time step k the array polynomial
+ * (perturbation/array_polynomial.py:524-544)   X_k = [constant_term +] sum_I mono[k][I] terms[I]
+ * gives the step propagator P_k = X_k (use_expm == 0, Dyson; constant_term = Udt and the terms
+ * already carry Udt) or P_k = post . expm(X_k) (use_expm != 0, Magnus; post = Udt), and
+ * y <- P_{T-1} ... P_0 y.  terms is [M][n][n]; mono[B][nsteps][M] holds the monomials c^I of the
+ * Chebyshev coefficients of every step (host or device pointer); y0 is [B or 1][n][m];
+ * Y_out [B][n][m] receives the final states.  All steps of a chunk are evaluated by ONE GEMM and
+ * multiplied by a binary tree (cf. midyn_parallel_solve). */
+typedef struct midyn_expansion midyn_expansion;
+int midyn_expansion_create(midyn_ctx* ctx, int n, int M, const midyn_complex* terms,
+                           const midyn_complex* constant_term, const midyn_complex* post, int use_expm,
+                           midyn_expansion** out);
+int midyn_expansion_destroy(midyn_expansion* exp);
+int midyn_expansion_solve(midyn_expansion* exp, int B, int nsteps, const double* mono, int m,
+                          const midyn_complex* y0, int y0_shared, midyn_complex* Y_out);
+
 /* ---- non-vectorised Lindblad RHS -------------------------------------
  * LindbladCollection.evaluate_rhs (models/operator_collections.py:451-567) with n x n zgemms:
  *   rhs = (A+B) rho + rho (A-B) + sum_j N_j rho N_j^+ + sum_j gamma_j L_j rho L_j^+,

@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE.  Only `tests/`, `__graft_entry__.smoke()` and the `cpu_base
 `bench.py` may import this module; the product package `qiskit_dynamics_amd` never does (its
 compute path is the HIP library and it fails loudly when that library is missing).
 
-Parity status: PINNED.  Every function below is checked in `tests/test_oracle_golden.py` against
+Parity status: PINNED.  Every function below (incl. the row-f4 perturbative step at the end) is checked in `tests/test_oracle_golden.py` against
 `tests/golden/*.npz`, which hold (inputs, outputs) captured from the real reference
 (`/root/reference/qiskit_dynamics`, v0.6.0) executed in the build container through
 `oracle/ref_shim.py` by `oracle/gen_golden.py`.  Exception: `expm_pade` (own restatement of the
@@ -556,3 +556,97 @@ def solve_generator_model(a_d, a, d, basis, coeff_fn, t_span, y0, method="RK4", 
     if not in_frame_basis:
         y = results_out_of_frame_basis(y, basis, kind, y0.ndim)
     return t, y
+
+
+# --------------------------------------------------------------------------------------------
+# f4  perturbative (Dyson / Magnus expansion) solvers -- the RUN-TIME step; the expansion terms
+#     themselves are inputs here (the product computes them in qiskit_dynamics_amd/perturbative.py
+#     and is checked against the reference's terms directly, tests/golden/perturbative.npz)
+# --------------------------------------------------------------------------------------------
+
+
+def frame_state_map(d, basis, t, y, into=True):
+    """`RotatingFrame.state_into_frame` (into) / `state_out_of_frame` for a state in the LAB basis
+    (models/rotating_frame.py:225-284): U (exp(-/+ d t) o (U^+ y))."""
+    y = np.asarray(y, dtype=complex)
+    if d is None:
+        return y
+    yb = y if basis is None else basis.conj().T @ y
+    yb = (np.exp(d * (-t if into else t)) * yb.T).T
+    return yb if basis is None else basis @ yb
+
+
+def chebyshev_dct(degree, dt):
+    """DCT matrix and shifted Chebyshev points on [0, dt]
+    (solvers/perturbative_solvers/expansion_model.py:518-551)."""
+    from numpy.polynomial.chebyshev import chebpts1, chebvander
+
+    order = degree + 1
+    xcheb = chebpts1(order)
+    shifted = 0.5 * (dt * xcheb + dt)
+    mat = chebvander(xcheb, degree).T
+    mat[0] /= order
+    mat[1:] /= 0.5 * order
+    return mat, shifted
+
+
+def signal_envelope_dct(complex_value, reference_freq, degree, t0, dt, n_intervals):
+    """Chebyshev coefficients of the envelope of one signal relative to `reference_freq` on each of
+    `n_intervals` intervals (expansion_model.py:457-515): (degree+1, n_intervals) complex."""
+    t_vals = t0 + np.arange(n_intervals) * dt
+    phase_arg = -1j * 2 * np.pi * reference_freq
+    final_shift = np.exp(-phase_arg * t_vals)
+    mat, xcheb = chebyshev_dct(degree, dt)
+    x_vals = np.add.outer(xcheb, t_vals)
+    return (mat @ (complex_value(x_vals) * np.exp(phase_arg * x_vals))) * np.expand_dims(final_shift, 0)
+
+
+def signal_list_envelope_dct(complex_values, reference_freqs, degrees, t0, dt, n_intervals, include_imag=None):
+    """Real coefficient rows of all signals: Re rows, then Im rows when included
+    (expansion_model.py:410-454)."""
+    if include_imag is None:
+        include_imag = [True] * len(complex_values)
+    rows = []
+    for cv, fr, dg, inc in zip(complex_values, reference_freqs, degrees, include_imag):
+        c = signal_envelope_dct(cv, fr, dg, t0, dt, n_intervals)
+        rows.append(c.real)
+        if inc:
+            rows.append(c.imag)
+    return np.concatenate(rows, axis=0)
+
+
+def monomials(labels, c):
+    """c^I = prod_{i in I} c_i for each label row (padded with -1)
+    (perturbation/array_polynomial.py:547-601); c is (n_vars,) or (n_vars, T)."""
+    c = np.asarray(c)
+    out = []
+    for lab in np.asarray(labels):
+        v = np.ones(c.shape[1:], dtype=c.dtype)
+        for i in lab:
+            if i >= 0:
+                v = v * c[i]
+        out.append(v)
+    return np.asarray(out)
+
+
+def array_polynomial_eval(terms, labels, c, constant_term=None):
+    """sum_I c^I A_I (+ constant) (perturbation/array_polynomial.py:524-544)."""
+    val = np.tensordot(np.asarray(terms), monomials(labels, c), axes=(0, 0))
+    return val if constant_term is None else constant_term + val
+
+
+def perturbative_solve(kind, terms, labels, udt, d, basis, cheb_coeffs, y0, t0, n_steps, dt):
+    """`_perturbative_solve` (solvers/perturbative_solvers/perturbative_solver.py:172-192) with the
+    Dyson step `(Udt + sum c^I Udt D_I) y` (dyson_solver.py:204-207; the terms already carry Udt,
+    expansion_model.py:149-158) or the Magnus step `Udt expm(sum c^I O_I) y` (magnus_solver.py:122-125)."""
+    n = np.asarray(udt).shape[0]
+    u0 = frame_state_map(d, basis, t0, np.eye(n, dtype=complex), into=False)
+    uf = frame_state_map(d, basis, t0 + n_steps * dt, np.eye(n, dtype=complex), into=True)
+    y = u0 @ np.asarray(y0, dtype=complex)
+    for k in range(n_steps):
+        c = cheb_coeffs[:, k]
+        if kind == "dyson":
+            y = array_polynomial_eval(terms, labels, c, constant_term=udt) @ y
+        else:
+            y = udt @ scipy.linalg.expm(array_polynomial_eval(terms, labels, c)) @ y
+    return uf @ y

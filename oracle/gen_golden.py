@@ -405,8 +405,94 @@ def gen_solver_list():
     save("solver_list", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+def _labels_array(labels):
+    """Multiset labels -> (M, max_order) int array of sorted indices, padded with -1."""
+    lists = [sorted(list(lab)) for lab in labels]
+    width = max(len(x) for x in lists)
+    return np.array([x + [-1] * (width - len(x)) for x in lists], dtype=np.int64)
+
+
+def gen_perturbative():
+    """f4: DysonSolver / MagnusSolver (test_dyson_magnus_solvers.py:75-330): Chebyshev coefficients
+    of the signals, the expansion terms, and the propagated states."""
+    from oracle.ref_shim import load_reference_perturbation
+
+    load_reference_perturbation()
+    from qiskit_dynamics.solvers.perturbative_solvers import DysonSolver, MagnusSolver
+
+    out = {}
+    # ---- the qubit of the reference test (:86-140), shorter horizon
+    r = 0.2
+    sig_w = 0.399128 / r
+    t_c = 3.5 * sig_w
+
+    def gauss(t):
+        return 1.0 * np.exp(-((t - t_c) ** 2) / (2 * sig_w**2))
+
+    gauss_signal = Signal(gauss, carrier_freq=5.0)
+    dt = 0.0125
+    h_ops = 2 * np.pi * r * np.array([[[0.0, 1.0], [1.0, 0.0]]]) / 2
+    h_static = 2 * np.pi * 5.0 * np.array([[1.0, 0.0], [0.0, -1.0]]) / 2
+    rng = np.random.default_rng(21342)
+    y_rand = crand(rng, 2, 2)
+    out["q1_params"] = np.array([r, sig_w, t_c, dt, 5.0])
+    out["q1_ops"] = -1j * h_ops
+    out["q1_frame"] = -1j * h_static
+    out["q1_y_rand"] = y_rand
+    for name, cls, order in (("dyson", DysonSolver, 6), ("magnus", MagnusSolver, 3)):
+        sol = cls(operators=-1j * h_ops, rotating_frame=-1j * h_static, dt=dt, carrier_freqs=[5.0],
+                  chebyshev_orders=[1], expansion_order=order, integration_method="DOP853", atol=1e-12,
+                  rtol=1e-12)
+        poly = sol.model.expansion_polynomial
+        out[f"q1_{name}_labels"] = _labels_array(poly.monomial_labels)
+        out[f"q1_{name}_terms"] = np.asarray(poly.array_coefficients)
+        out[f"q1_{name}_udt"] = np.asarray(sol.model.Udt)
+        out[f"q1_{name}_cheb_t0"] = np.asarray(sol.model.approximate_signals([gauss_signal], 0.0, 120))
+        out[f"q1_{name}_cheb_t1"] = np.asarray(sol.model.approximate_signals([gauss_signal], 3.1, 50))
+        out[f"q1_{name}_y_eye"] = sol.solve(t0=0.0, n_steps=120, y0=np.eye(2, dtype=complex),
+                                            signals=[gauss_signal]).y[-1]
+        out[f"q1_{name}_y_rand_t1"] = sol.solve(t0=3.1, n_steps=50, y0=y_rand, signals=[gauss_signal]).y[-1]
+        out[f"q1_{name}_y_vec"] = sol.solve(t0=0.0, n_steps=30, y0=y_rand[:, 0], signals=[gauss_signal]).y[-1]
+        c = np.asarray(sol.model.approximate_signals([gauss_signal], 3.1, 3))[:, 1]
+        out[f"q1_{name}_eval_c"] = c
+        out[f"q1_{name}_eval"] = np.asarray(sol.model.evaluate(c))
+    # ---- a 3-level transmon with two drives: mixed Chebyshev orders, one real-only envelope, extra labels
+    dim = 3
+    a = np.diag(np.sqrt(np.arange(1, dim)), 1)
+    num = np.diag(np.arange(dim)).astype(float)
+    h0 = 2 * np.pi * 4.9 * num + np.pi * (-0.33) * num @ (num - np.eye(dim))
+    hd1 = 2 * np.pi * 0.05 * (a + a.T)
+    hd2 = 2 * np.pi * 0.02 * num
+    sig_a = Signal(lambda t: 0.8 * np.exp(-((t - 1.0) ** 2) / 0.5) * np.exp(0.3j * t), carrier_freq=4.9, phase=0.2)
+    sig_b = Signal(lambda t: 0.4 * np.cos(0.7 * t) + 0j, carrier_freq=0.0)
+    sig_c = Signal(lambda t: 0.5 * np.exp(-((t - 0.7) ** 2) / 0.3) + 0j, carrier_freq=4.95, phase=-0.4)
+    out["t3_ops"] = np.array([-1j * hd1, -1j * hd2])
+    out["t3_frame"] = -1j * h0
+    y3 = crand(rng, 3, 2)
+    out["t3_y0"] = y3
+    for name, cls in (("dyson", DysonSolver), ("magnus", MagnusSolver)):
+        sol = cls(operators=[-1j * hd1, -1j * hd2], rotating_frame=-1j * h0, dt=0.02, carrier_freqs=[4.9, 0.0],
+                  chebyshev_orders=[1, 0], expansion_order=2, expansion_labels=[[0, 0, 1], [0, 1, 4]],
+                  include_imag=[True, False], integration_method="DOP853", atol=1e-12, rtol=1e-12)
+        poly = sol.model.expansion_polynomial
+        out[f"t3_{name}_labels"] = _labels_array(poly.monomial_labels)
+        out[f"t3_{name}_terms"] = np.asarray(poly.array_coefficients)
+        out[f"t3_{name}_udt"] = np.asarray(sol.model.Udt)
+        out[f"t3_{name}_cheb"] = np.asarray(sol.model.approximate_signals([sig_a, sig_b], 0.1, 60))
+        res = sol.solve(t0=0.1, n_steps=60, y0=[np.eye(3, dtype=complex), y3],
+                        signals=[[sig_a, sig_b], [sig_c, sig_b]])
+        out[f"t3_{name}_y_list0"] = res[0].y[-1]
+        out[f"t3_{name}_y_list1"] = res[1].y[-1]
+        out[f"t3_{name}_t"] = np.asarray(res[0].t)
+    save("perturbative", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "perturbative":
+        gen_perturbative()
+        sys.exit(0)
     gen_collection()
     gen_signals()
     gen_generator_model()
@@ -414,3 +500,4 @@ if __name__ == "__main__":
     gen_solve_lmde()
     gen_lindblad()
     gen_solver_list()
+    gen_perturbative()

@@ -228,3 +228,176 @@ def load_reference():
     importlib.import_module("qiskit_dynamics.solvers.solver_classes")
     _LOADED = True
     return qd
+
+
+# ---------------------------------------------------------------------------------------------
+# Row f4 (perturbative Dyson / Magnus solvers): the reference additionally imports the third-party
+# `multiset` package (setup.py: multiset>=3.0.1), which is not installed here.  `Multiset` is only
+# used as a LABEL type (which perturbation indices a term belongs to): a counter with multiset
+# algebra.  The stand-in below implements the published semantics of multiset.Multiset that the
+# reference uses; every number is computed by the reference's own NumPy/SciPy code.
+# ---------------------------------------------------------------------------------------------
+class Multiset:
+    """Minimal stand-in for multiset.Multiset (mutable multiset: element -> multiplicity)."""
+
+    def __init__(self, iterable=None):
+        self._c = {}
+        if iterable is None:
+            return
+        if isinstance(iterable, Multiset):
+            self._c = dict(iterable._c)
+        elif isinstance(iterable, dict):
+            for k_, v_ in iterable.items():
+                if v_ > 0:
+                    self._c[k_] = int(v_)
+        else:
+            for e in iterable:
+                self._c[e] = self._c.get(e, 0) + 1
+
+    # -- container protocol
+    def __len__(self):
+        return sum(self._c.values())
+
+    def __iter__(self):
+        for e, m in self._c.items():
+            for _ in range(m):
+                yield e
+
+    def __contains__(self, e):
+        return e in self._c
+
+    def __getitem__(self, e):
+        return self._c.get(e, 0)
+
+    def __bool__(self):
+        return bool(self._c)
+
+    def __eq__(self, other):
+        if isinstance(other, Multiset):
+            return self._c == other._c
+        return NotImplemented
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else not r
+
+    __hash__ = None
+
+    def __repr__(self):
+        return "Multiset(%r)" % (self._c,)
+
+    def __str__(self):
+        return "{%s}" % ", ".join(str(e) for e in self)
+
+    # -- queries
+    def distinct_elements(self):
+        return self._c.keys()
+
+    def items(self):
+        return self._c.items()
+
+    def multiplicities(self):
+        return self._c.values()
+
+    def get(self, e, default=0):
+        return self._c.get(e, default)
+
+    def copy(self):
+        return Multiset(self)
+
+    def issubset(self, other):
+        other = other if isinstance(other, Multiset) else Multiset(other)
+        return all(other[e] >= m for e, m in self._c.items())
+
+    def issuperset(self, other):
+        other = other if isinstance(other, Multiset) else Multiset(other)
+        return other.issubset(self)
+
+    def __le__(self, other):
+        return self.issubset(other)
+
+    def __lt__(self, other):
+        return self.issubset(other) and len(self) < len(other)
+
+    def __ge__(self, other):
+        return self.issuperset(other)
+
+    def __gt__(self, other):
+        return self.issuperset(other) and len(self) > len(other)
+
+    # -- algebra
+    def combine(self, *others):
+        out = Multiset(self)
+        for o in others:
+            for e, m in Multiset(o)._c.items():
+                out._c[e] = out._c.get(e, 0) + m
+        return out
+
+    __add__ = combine
+
+    def difference(self, *others):
+        out = Multiset(self)
+        for o in others:
+            for e, m in Multiset(o)._c.items():
+                if e in out._c:
+                    left = out._c[e] - m
+                    if left > 0:
+                        out._c[e] = left
+                    else:
+                        del out._c[e]
+        return out
+
+    __sub__ = difference
+
+    def union(self, *others):
+        out = Multiset(self)
+        for o in others:
+            for e, m in Multiset(o)._c.items():
+                out._c[e] = max(out._c.get(e, 0), m)
+        return out
+
+    __or__ = union
+
+    def intersection(self, *others):
+        out = Multiset(self)
+        for o in others:
+            o = Multiset(o)
+            out._c = {e: min(m, o[e]) for e, m in out._c.items() if o[e] > 0}
+        return out
+
+    __and__ = intersection
+
+    # -- mutation
+    def add(self, e, multiplicity=1):
+        self._c[e] = self._c.get(e, 0) + multiplicity
+
+    def remove(self, e, multiplicity=None):
+        if e not in self._c:
+            raise KeyError(e)
+        old = self._c[e]
+        if multiplicity is None or multiplicity >= old:
+            del self._c[e]
+        else:
+            self._c[e] = old - multiplicity
+        return old
+
+    def discard(self, e, multiplicity=None):
+        if e in self._c:
+            return self.remove(e, multiplicity)
+        return 0
+
+    def update(self, *others):
+        for o in others:
+            for e, m in Multiset(o)._c.items():
+                self._c[e] = self._c.get(e, 0) + m
+
+
+def load_reference_perturbation():
+    """`load_reference()` + the perturbation package and the Dyson / Magnus solvers (row f4)."""
+    qd = load_reference()
+    if "qiskit_dynamics.solvers.perturbative_solvers" in sys.modules:
+        return qd
+    _mod("multiset", Multiset=Multiset, FrozenMultiset=Multiset)
+    importlib.import_module("qiskit_dynamics.perturbation")
+    importlib.import_module("qiskit_dynamics.solvers.perturbative_solvers")
+    return qd

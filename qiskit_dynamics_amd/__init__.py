@@ -10,10 +10,12 @@ from .signals import Signal, DiscreteSignal, SignalSum, SignalList
 from .rotating_frame import RotatingFrame
 from .models import GeneratorModel, HamiltonianModel, LindbladModel
 from .solvers import Solver, solve_lmde, solve_ode
+from .perturbative import DysonSolver, MagnusSolver, ExpansionModel
 
 __all__ = [
     "DynamicsError", "HipLibraryError", "Context", "Stack", "Rk4Plan", "default_context",
     "Signal", "DiscreteSignal", "SignalSum", "SignalList", "RotatingFrame",
     "GeneratorModel", "HamiltonianModel", "LindbladModel", "Solver", "solve_lmde", "solve_ode",
+    "DysonSolver", "MagnusSolver", "ExpansionModel",
 ]
 __version__ = "0.1.0"

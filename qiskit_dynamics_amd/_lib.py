@@ -24,7 +24,8 @@ ABI_SYMBOLS = [
     "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_get_counters",
     "midyn_reset_counters", "midyn_microbench", "midyn_lindblad_create", "midyn_lindblad_destroy",
     "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve", "midyn_sigtable_create", "midyn_sigtable_data",
-    "midyn_sigtable_fetch", "midyn_sigtable_destroy", "midyn_parallel_solve",
+    "midyn_sigtable_fetch", "midyn_sigtable_destroy", "midyn_parallel_solve", "midyn_expansion_create",
+    "midyn_expansion_destroy", "midyn_expansion_solve",
 ]
 
 
@@ -124,6 +125,9 @@ def load():
         lib.midyn_lindblad_rk4_solve.argtypes = [_vp, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp]
         lib.midyn_parallel_solve.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _ci,
                                              _vp, _ci, _vp]
+        lib.midyn_expansion_create.argtypes = [_vp, _ci, _ci, _vp, _vp, _vp, _ci, P(_vp)]
+        lib.midyn_expansion_destroy.argtypes = [_vp]
+        lib.midyn_expansion_solve.argtypes = [_vp, _ci, _ci, _vp, _ci, _vp, _ci, _vp]
         lib.midyn_sigtable_create.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, P(_vp)]
         lib.midyn_sigtable_data.argtypes = [_vp, P(_vp), _vp]
         lib.midyn_sigtable_fetch.argtypes = [_vp, _vp]
@@ -403,6 +407,49 @@ class SignalTable:
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:
             self.ctx.lib.midyn_sigtable_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+class Expansion:
+    """Device-resident terms of a Dyson / Magnus expansion (row f4, ``midyn_expansion_*``)."""
+
+    def __init__(self, ctx: "Context", terms, constant_term=None, post=None, use_expm=False):
+        self.ctx = ctx
+        terms = c128(terms)
+        if terms.ndim != 3 or terms.shape[1] != terms.shape[2]:
+            raise DynamicsError("expansion terms must be (M, n, n)")
+        self.n_terms, self.n = int(terms.shape[0]), int(terms.shape[1])
+        const = None if constant_term is None else c128(constant_term)
+        post = None if post is None else c128(post)
+        for arr in (const, post):
+            if arr is not None and arr.shape != (self.n, self.n):
+                raise DynamicsError("constant_term / post must be (n, n)")
+        h = _vp()
+        ctx.check(ctx.lib.midyn_expansion_create(ctx.handle, self.n, self.n_terms, _ptr(terms), _ptr(const),
+                                                 _ptr(post), int(bool(use_expm)), ctypes.byref(h)))
+        self.handle = h
+
+    def solve(self, mono, y0, batch, y0_shared):
+        """mono (B, nsteps, M) real; y0 (n, m) if shared else (B, n, m) -> final states (B, n, m)."""
+        mono = f64(mono)
+        if mono.ndim != 3 or mono.shape[0] != batch or mono.shape[2] != self.n_terms:
+            raise DynamicsError(f"monomial table must be (B, nsteps, M) = ({batch}, *, {self.n_terms})")
+        y0 = c128(y0)
+        m = y0.shape[-1]
+        out = np.empty((batch, self.n, m), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.midyn_expansion_solve(self.handle, int(batch), int(mono.shape[1]), _ptr(mono),
+                                                          int(m), _ptr(y0), int(bool(y0_shared)), _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:
+            self.ctx.lib.midyn_expansion_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

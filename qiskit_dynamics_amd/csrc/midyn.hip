@@ -54,7 +54,7 @@ struct midyn_ctx {
     std::vector<hipEvent_t> pool;
     double cls_ms[KC_COUNT] = {0};
     double cls_n[KC_COUNT] = {0};
-    int* d_one_seg = nullptr;  // device int {0}: single full segment list for plain zgemm
+    int* d_one_seg = nullptr;  // device int {0, 1}: single-segment lists for plain zgemm (dense A / real-only A)
     int num_cu = 256;
 };
 
@@ -141,9 +141,9 @@ extern "C" int midyn_ctx_create(int device, midyn_ctx** out) {
     HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
     ctx->num_cu = prop.multiProcessorCount;
     if (const char* e = getenv("MIDYN_COMPLEX_3M")) ctx->complex_3m = atoi(e) != 0;
-    HIPCHK(ctx, hipMalloc(&ctx->d_one_seg, sizeof(int)));
-    int zero = 0;
-    HIPCHK(ctx, hipMemcpy(ctx->d_one_seg, &zero, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc(&ctx->d_one_seg, 2 * sizeof(int)));
+    int one_seg[2] = {0, 1};  // [0]: segment 0, dense complex A;  [1]: segment 0, A real-only (mode 1)
+    HIPCHK(ctx, hipMemcpy(ctx->d_one_seg, one_seg, sizeof(one_seg), hipMemcpyHostToDevice));
     *out = ctx;
     return 0;
 }
@@ -601,7 +601,8 @@ static int launch_stream(midyn_ctx* ctx, const StreamArgs& a, const double* plan
 // operands are `sa`, `sb`, `sc` elements apart (C and Z share the stride)
 static int dev_zgemm_batched(midyn_ctx* ctx, int batch, int M, int N, int K, const double2* A, int lda, long long sa,
                              const double2* B, int ldb, long long sb, double2* C, int ldc, long long sc, double alpha,
-                             double beta, const double2* Z, const long long* d_offs = nullptr) {
+                             double beta, const double2* Z, const long long* d_offs = nullptr,
+                             bool a_real_only = false) {
     GemmArgs g{};
     g.batch_offs = d_offs;
     g.A = A;
@@ -629,6 +630,10 @@ static int dev_zgemm_batched(midyn_ctx* ctx, int batch, int M, int N, int K, con
     g.epi.beta = beta;
     g.epi.out = C;
     g.epi.z = Z;
+    if (a_real_only) {  // Im A == 0 exactly: the two real MFMAs that would multiply it are skipped
+        g.seg_list = ctx->d_one_seg + 1;
+        return launch_gemm(ctx, g, KC_ZGEMM, 1);
+    }
     return launch_gemm(ctx, g, KC_ZGEMM);
 }
 
@@ -1692,6 +1697,160 @@ extern "C" int midyn_parallel_solve(midyn_stack* s, int B, int m, int R, const d
         }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b * P * inst_elems, d_out.p, (size_t)P * inst_elems * sizeof(double2),
+                              hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Perturbative (Dyson / Magnus expansion) step, parallel in time:
+//   per step k:  X_k = [constant +] sum_I mono[k][I] A_I      (ArrayPolynomial.__call__,
+//                                                              perturbation/array_polynomial.py:524-544)
+//   Dyson:       P_k = X_k                                      (dyson_solver.py:204-207)
+//   Magnus:      P_k = post . expm(X_k)                         (magnus_solver.py:122-125)
+//   y <- P_{T-1} ... P_1 P_0 y                                  (perturbative_solver.py:172-192, and
+//                                                              the associative scan of :195-219)
+// The polynomial of ALL steps of a chunk is ONE real-by-complex GEMM  X[T][n_pad^2] = mono[T][M] .
+// terms[M][n_pad^2] on the MFMA kernel (the row of step k IS its padded n_pad x n_pad matrix), then
+// batched expm / post-multiplication, then the tree product of midyn_parallel_solve.
+// -------------------------------------------------------------------------------------------------
+struct midyn_expansion {
+    midyn_ctx* ctx = nullptr;
+    int n = 0, np = 0, M = 0, K = 0;   // K = padded number of GEMM rows of `terms` (M + constant)
+    bool has_const = false, has_post = false, use_expm = false;
+    DevBuf d_terms, d_post;
+};
+
+extern "C" int midyn_expansion_create(midyn_ctx* ctx, int n, int M, const midyn_complex* terms,
+                                      const midyn_complex* constant_term, const midyn_complex* post, int use_expm,
+                                      midyn_expansion** out) {
+    if (!ctx || !out || !terms || n <= 0 || M <= 0) return fail(ctx, "midyn_expansion_create: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    midyn_expansion* e = new midyn_expansion();
+    e->ctx = ctx;
+    e->n = n;
+    e->np = round_up(n, 64);
+    e->M = M;
+    e->has_const = constant_term != nullptr;
+    e->has_post = post != nullptr;
+    e->use_expm = use_expm != 0;
+    e->K = round_up(M + (e->has_const ? 1 : 0), GEMM_BK);
+    const size_t mat = (size_t)e->np * e->np;
+    std::vector<double2> host((size_t)e->K * mat, make_double2(0.0, 0.0));
+    auto put = [&](size_t slot, const midyn_complex* src) {
+        for (int r = 0; r < n; ++r)
+            memcpy(&host[slot * mat + (size_t)r * e->np], src + (size_t)r * n, (size_t)n * sizeof(double2));
+    };
+    for (int i = 0; i < M; ++i) put(i, terms + (size_t)i * n * n);
+    if (e->has_const) put(M, constant_term);
+    int st = e->d_terms.alloc(ctx, host.size() * sizeof(double2));
+    if (!st && hipMemcpy(e->d_terms.p, host.data(), host.size() * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess)
+        st = fail(ctx, "midyn_expansion_create: upload failed");
+    if (!st && e->has_post) {
+        st = e->d_post.alloc(ctx, mat * sizeof(double2));
+        if (!st) st = hipMemset(e->d_post.p, 0, mat * sizeof(double2)) == hipSuccess ? 0 : fail(ctx, "memset");
+        if (!st) st = upload_padded(ctx, post, n, n, e->d_post.as<double2>(), e->np);
+    }
+    if (st) {
+        delete e;
+        return st;
+    }
+    *out = e;
+    return 0;
+}
+
+extern "C" int midyn_expansion_destroy(midyn_expansion* e) {
+    if (!e) return 0;
+    hipSetDevice(e->ctx->device);
+    hipStreamSynchronize(e->ctx->stream);
+    delete e;
+    return 0;
+}
+
+extern "C" int midyn_expansion_solve(midyn_expansion* e, int B, int nsteps, const double* mono, int m,
+                                     const midyn_complex* y0, int y0_shared, midyn_complex* Y_out) {
+    if (!e || !mono || !y0 || !Y_out) return fail(e ? e->ctx : nullptr, "midyn_expansion_solve: NULL argument");
+    midyn_ctx* ctx = e->ctx;
+    if (B <= 0 || nsteps < 0 || m <= 0) return fail(ctx, "midyn_expansion_solve: bad sizes");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int np = e->np, n = e->n, M = e->M, K = e->K;
+    const int ld = round_up(m, 64);
+    const size_t mat = (size_t)np * np, stv = (size_t)np * ld;
+    // steps per chunk: a multiple of 64 (GEMM rows), bounded like the batched expm
+    int cap = expm_chunk(ctx, np, std::max(1, nsteps));
+    cap = round_up(cap, 64);
+    DevBuf X, d_mono, d_A, d_offs, d_y[2], d_tmp, d_res;
+    ExpmWork w;
+    CHK(X.alloc(ctx, 2 * (size_t)cap * mat * sizeof(double2)));
+    CHK(d_mono.alloc(ctx, (size_t)cap * M * sizeof(double)));
+    CHK(d_A.alloc(ctx, (size_t)cap * K * sizeof(double2)));
+    CHK(d_offs.alloc(ctx, (size_t)3 * cap * sizeof(long long)));
+    CHK(d_y[0].alloc(ctx, stv * sizeof(double2)));
+    CHK(d_y[1].alloc(ctx, stv * sizeof(double2)));
+    const size_t inst_elems = (size_t)n * m;
+    CHK(d_tmp.alloc(ctx, inst_elems * sizeof(double2)));
+    CHK(d_res.alloc(ctx, inst_elems * sizeof(double2)));
+    double2* Xb = X.as<double2>();
+    std::vector<long long> offs;
+    std::vector<int> loc(cap);
+    auto slot = [&](int which, int i) { return (long long)((size_t)which * cap + i) * (long long)mat; };
+    for (int b = 0; b < B; ++b) {
+        HIPCHK(ctx, hipMemsetAsync(d_y[0].p, 0, stv * sizeof(double2), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_y[1].p, 0, stv * sizeof(double2), ctx->stream));
+        if (b == 0 || !y0_shared)
+            HIPCHK(ctx, hipMemcpy(d_tmp.p, y0 + (y0_shared ? 0 : (size_t)b * inst_elems), inst_elems * sizeof(double2),
+                                  hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(scatter_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                           d_tmp.as<double2>(), 1, 1, n, m, ld, (const double2*)nullptr, d_y[0].as<double2>(),
+                           (double2*)nullptr);
+        HIPCHK(ctx, hipGetLastError());
+        int cur = 0;
+        for (int c0 = 0; c0 < nsteps; c0 += cap) {
+            const int nb = std::min(cap, nsteps - c0);
+            const int T = round_up(nb, 64);
+            // -- 1. monomial rows of the chunk -> complex GEMM operand (imaginary part exactly zero)
+            HIPCHK(ctx, hipMemcpy(d_mono.p, mono + ((size_t)b * nsteps + c0) * M, (size_t)nb * M * sizeof(double),
+                                  hipMemcpyDefault));
+            hipLaunchKernelGGL(mono_operand_kernel, dim3(grid_for((size_t)T * K)), dim3(256), 0, ctx->stream,
+                               d_mono.as<double>(), nb, M, e->has_const ? 1 : 0, T, K, d_A.as<double2>());
+            HIPCHK(ctx, hipGetLastError());
+            // -- 2. all step matrices in one GEMM: row k of the product is the padded matrix of step k
+            CHK(dev_zgemm_batched(ctx, 1, T, (int)mat, K, d_A.as<double2>(), K, 0, e->d_terms.as<double2>(), (int)mat, 0,
+                                  Xb, (int)mat, 0, 1.0, 0.0, nullptr, nullptr, true));
+            std::fill(loc.begin(), loc.begin() + nb, 0);
+            if (e->use_expm) {
+                CHK(dev_expm_inplace(ctx, w, Xb, np, nullptr, nullptr, nb));
+                if (e->has_post) {  // P_k = post . expm(X_k) -> second slot set
+                    CHK(dev_zgemm_batched(ctx, nb, np, np, np, e->d_post.as<double2>(), np, 0, Xb, np, (long long)mat,
+                                          Xb + slot(1, 0), np, (long long)mat, 1.0, 0.0, nullptr));
+                    std::fill(loc.begin(), loc.begin() + nb, 1);
+                }
+            }
+            // -- 3. tree product of the chunk's propagators, then one application to the state
+            for (int st = 1; st < nb; st *= 2) {
+                offs.clear();
+                for (int i = 0; i + st < nb; i += 2 * st) {
+                    offs.push_back(slot(loc[i + st], i + st));  // later steps multiply from the left
+                    offs.push_back(slot(loc[i], i));
+                    offs.push_back(slot(loc[i] ^ 1, i));
+                    loc[i] ^= 1;
+                }
+                const int cnt = (int)(offs.size() / 3);
+                if (cnt == 0) continue;
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                HIPCHK(ctx, hipMemcpy(d_offs.p, offs.data(), offs.size() * sizeof(long long), hipMemcpyHostToDevice));
+                CHK(dev_zgemm_batched(ctx, cnt, np, np, np, Xb, np, 0, Xb, np, 0, Xb, np, 0, 1.0, 0.0, nullptr,
+                                      d_offs.as<long long>()));
+            }
+            CHK(dev_zgemm(ctx, np, ld, np, Xb + slot(loc[0], 0), np, d_y[cur].as<double2>(), ld,
+                          d_y[cur ^ 1].as<double2>(), ld, 1.0, 0.0, nullptr));
+            cur ^= 1;
+        }
+        hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
+                           d_y[cur].as<double2>(), 1, n, m, ld, 1, 0, d_res.as<double2>());
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b * inst_elems, d_res.p, inst_elems * sizeof(double2),
                               hipMemcpyDeviceToHost));
     }
     return 0;

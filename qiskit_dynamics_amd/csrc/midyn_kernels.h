@@ -1217,6 +1217,23 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const double* src, con
     }
 }
 
+// A[t][j] = (mono[t][j], 0) for t < nb, j < M;  A[t][M] = (1, 0) when a constant term follows the
+// M expansion terms; zero padding elsewhere (row f4: GEMM operand of the polynomial evaluation)
+__global__ __launch_bounds__(256) void mono_operand_kernel(const double* mono, int nb, int M, int has_const,
+                                                           int T, int K, double2* A) {
+    const size_t total = (size_t)T * K;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int t = (int)(idx / K);
+        const int j = (int)(idx - (size_t)t * K);
+        double v = 0.0;
+        if (t < nb) {
+            if (j < M) v = mono[(size_t)t * M + j];
+            else if (j == M && has_const) v = 1.0;
+        }
+        A[idx] = make_double2(v, 0.0);
+    }
+}
+
 // Host batch layout [B][n][m] (or shared [n][m]) -> device column block [n_pad][ld]; also writes the
 // pre-phased copy yin = E o y.  Padding rows/cols are zeroed by the caller (memset).
 __global__ __launch_bounds__(256) void scatter_state_kernel(const double2* src, int shared, int B, int n,

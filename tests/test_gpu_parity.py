@@ -1150,3 +1150,65 @@ def test_planar_stream_kernel_matches_interleaved(qd, cfg2):
                                       sched.n_save, y0, 1, True)
     stack.ctx.set_option("stream_planes", 1)
     assert_close(res[1], res[0], 1e-13)
+
+
+# ---- row f4: perturbative Dyson / Magnus solvers ------------------------------------------------------
+@pytest.mark.parametrize("kind", ["dyson", "magnus"])
+def test_perturbative_solvers_golden(qd, golden, kind):
+    """DysonSolver / MagnusSolver through the device (one GEMM for the polynomial of all steps, batched
+    expm, tree product) against final states captured from the reference (its sequential host loop)."""
+    g = golden("perturbative")
+    r, sig_w, t_c, dt, nu = g["q1_params"]
+    cls = qd.DysonSolver if kind == "dyson" else qd.MagnusSolver
+    sol = cls(operators=g["q1_ops"], rotating_frame=g["q1_frame"], dt=dt, carrier_freqs=[nu], chebyshev_orders=[1],
+              expansion_order=6 if kind == "dyson" else 3, integration_method="DOP853", atol=1e-12, rtol=1e-12)
+    gauss = qd.Signal(lambda t: 1.0 * np.exp(-((t - t_c) ** 2) / (2 * sig_w**2)), carrier_freq=nu)
+    res = sol.solve(t0=0.0, n_steps=120, y0=np.eye(2, dtype=complex), signals=[gauss])
+    assert_close(res.t, np.array([0.0, 120 * dt]), 1e-15)
+    assert_close(res.y[0], np.eye(2), 0)
+    assert_close(res.y[-1], g[f"q1_{kind}_y_eye"], 1e-9)
+    res = sol.solve(t0=3.1, n_steps=50, y0=g["q1_y_rand"], signals=[gauss])
+    assert_close(res.y[-1], g[f"q1_{kind}_y_rand_t1"], 1e-9)
+    res = sol.solve(t0=0.0, n_steps=30, y0=g["q1_y_rand"][:, 0], signals=[gauss])
+    assert res.y[-1].shape == (2,)
+    assert_close(res.y[-1], g[f"q1_{kind}_y_vec"], 1e-9)
+    if kind == "dyson":
+        assert_close(sol.model.evaluate(g["q1_dyson_eval_c"]), g["q1_dyson_eval"], 1e-10)
+    # transmon, list mode (two signal sets, two initial states of different shapes)
+    sol = cls(operators=g["t3_ops"], rotating_frame=g["t3_frame"], dt=0.02, carrier_freqs=[4.9, 0.0],
+              chebyshev_orders=[1, 0], expansion_order=2, expansion_labels=[[0, 0, 1], [0, 1, 4]],
+              include_imag=[True, False], integration_method="DOP853", atol=1e-12, rtol=1e-12)
+    sig_a = qd.Signal(lambda t: 0.8 * np.exp(-((t - 1.0) ** 2) / 0.5) * np.exp(0.3j * t), carrier_freq=4.9, phase=0.2)
+    sig_b = qd.Signal(lambda t: 0.4 * np.cos(0.7 * t) + 0j, carrier_freq=0.0)
+    sig_c = qd.Signal(lambda t: 0.5 * np.exp(-((t - 0.7) ** 2) / 0.3) + 0j, carrier_freq=4.95, phase=-0.4)
+    res = sol.solve(t0=0.1, n_steps=60, y0=[np.eye(3, dtype=complex), g["t3_y0"]],
+                    signals=[[sig_a, sig_b], [sig_c, sig_b]])
+    assert isinstance(res, list) and len(res) == 2
+    assert_close(res[0].t, g[f"t3_{kind}_t"], 1e-15)
+    assert_close(res[0].y[-1], g[f"t3_{kind}_y_list0"], 1e-9)
+    assert_close(res[1].y[-1], g[f"t3_{kind}_y_list1"], 1e-9)
+    with pytest.raises(qd.DynamicsError, match="same length as the operators"):
+        sol.solve(t0=0.0, n_steps=5, y0=np.eye(3, dtype=complex), signals=[sig_a])
+
+
+def test_perturbative_solvers_vs_direct_solution(qd):
+    """As test_dyson_magnus_solvers.py:222-246: the perturbative solvers reproduce the direct solution
+    of the same model (here: the device RK4 with a small step), many steps (> one chunk of 64 rows)."""
+    r = 0.2
+    sig_w = 0.399128 / r
+    t_c = 3.5 * sig_w
+    gauss = qd.Signal(lambda t: np.exp(-((t - t_c) ** 2) / (2 * sig_w**2)), carrier_freq=5.0)
+    dt = 0.0125
+    n_steps = int((7 * sig_w) // dt) // 3
+    h_ops = 2 * np.pi * r * np.array([[[0.0, 1.0], [1.0, 0.0]]]) / 2
+    h_static = 2 * np.pi * 5.0 * np.array([[1.0, 0.0], [0.0, -1.0]]) / 2
+    direct = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=h_static).solve(
+        t_span=[0.0, dt * n_steps], y0=np.eye(2, dtype=complex), signals=[gauss], method="RK4", max_dt=dt / 8).y[-1]
+    dys = qd.DysonSolver(operators=-1j * h_ops, rotating_frame=-1j * h_static, dt=dt, carrier_freqs=[5.0],
+                         chebyshev_orders=[1], expansion_order=6, integration_method="DOP853", atol=1e-10, rtol=1e-10)
+    mag = qd.MagnusSolver(operators=-1j * h_ops, rotating_frame=-1j * h_static, dt=dt, carrier_freqs=[5.0],
+                          chebyshev_orders=[1], expansion_order=3, integration_method="DOP853", atol=1e-10,
+                          rtol=1e-10)
+    for sol in (dys, mag):
+        yf = sol.solve(t0=0.0, n_steps=n_steps, y0=np.eye(2, dtype=complex), signals=[gauss]).y[-1]
+        assert np.max(np.abs(yf - direct)) < 1e-6, np.max(np.abs(yf - direct))

@@ -264,3 +264,62 @@ def test_discrete_term_arrays_layout():
     assert discrete_term_arrays([[Signal(lambda t: t, 1.0)]]) is None
     # array-valued carrier (a SignalSum passed as one term is flattened first, so this is fine)
     assert discrete_term_arrays([[d1 + d2]]) is not None
+
+
+# ---- row f4: host side of the perturbative solvers ----------------------------------------------------
+def _load_golden(name):
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+
+
+@pytest.mark.parametrize("kind", ["dyson", "magnus"])
+def test_expansion_model_terms_match_reference(kind):
+    """The expansion terms (own ODE formulation + series logarithm), their labels, Udt and the Chebyshev
+    coefficients against arrays captured from the reference's DysonSolver / MagnusSolver."""
+    from qiskit_dynamics_amd import Signal
+    from qiskit_dynamics_amd.perturbative import ExpansionModel
+
+    g = _load_golden("perturbative")
+    r, sig_w, t_c, dt, nu = g["q1_params"]
+    model = ExpansionModel(operators=g["q1_ops"], rotating_frame=g["q1_frame"], dt=dt, carrier_freqs=[nu],
+                           chebyshev_orders=[1], expansion_method=kind, expansion_order=6 if kind == "dyson" else 3,
+                           integration_method="DOP853", atol=1e-12, rtol=1e-12)
+    want_labels = [tuple(int(i) for i in row if i >= 0) for row in g[f"q1_{kind}_labels"]]
+    assert model.monomial_labels == want_labels
+    np.testing.assert_allclose(model.Udt, g[f"q1_{kind}_udt"], atol=1e-14)
+    np.testing.assert_allclose(model.array_coefficients, g[f"q1_{kind}_terms"], atol=2e-11)
+    gauss = Signal(lambda t: 1.0 * np.exp(-((t - t_c) ** 2) / (2 * sig_w**2)), carrier_freq=nu)
+    np.testing.assert_allclose(model.approximate_signals([gauss], 0.0, 120), g[f"q1_{kind}_cheb_t0"], atol=1e-13)
+    np.testing.assert_allclose(model.approximate_signals([gauss], 3.1, 50), g[f"q1_{kind}_cheb_t1"], atol=1e-13)
+    # transmon: two operators, one real-only envelope, extra labels
+    model = ExpansionModel(operators=g["t3_ops"], rotating_frame=g["t3_frame"], dt=0.02, carrier_freqs=[4.9, 0.0],
+                           chebyshev_orders=[1, 0], expansion_method=kind, expansion_order=2,
+                           expansion_labels=[[0, 0, 1], [0, 1, 4]], include_imag=[True, False],
+                           integration_method="DOP853", atol=1e-12, rtol=1e-12)
+    want_labels = [tuple(int(i) for i in row if i >= 0) for row in g[f"t3_{kind}_labels"]]
+    assert model.monomial_labels == want_labels
+    np.testing.assert_allclose(model.Udt, g[f"t3_{kind}_udt"], atol=1e-13)
+    np.testing.assert_allclose(model.array_coefficients, g[f"t3_{kind}_terms"], atol=2e-11)
+    # monomials: products of the coefficient entries named by each label
+    c = np.arange(1.0, 6.0).reshape(5, 1) * np.array([[1.0, -0.5]])
+    mono = model.monomial_table(c)
+    assert mono.shape == (2, len(want_labels))
+    for j, lab in enumerate(want_labels):
+        np.testing.assert_allclose(mono[:, j], np.prod(c[list(lab)], axis=0), rtol=1e-15)
+
+
+def test_perturbative_solver_argument_errors():
+    from qiskit_dynamics_amd.perturbative import DysonSolver, MagnusSolver, complete_labels
+
+    for cls in (DysonSolver, MagnusSolver):
+        with pytest.raises(qd.DynamicsError, match="carrier_freqs must have the same length"):
+            cls(operators=np.array([[[1.0]], [[2.0]]]), rotating_frame=np.array([[1.0]]), dt=1.0,
+                carrier_freqs=np.array([1.0]), chebyshev_orders=np.array([1, 1]))
+        with pytest.raises(qd.DynamicsError, match="chebyshev_orders must have the same length"):
+            cls(operators=np.array([[[1.0]], [[2.0]]]), rotating_frame=np.array([[1.0]]), dt=1.0,
+                carrier_freqs=np.array([1.0, 1.0]), chebyshev_orders=np.array([1, 1, 1]))
+    with pytest.raises(qd.DynamicsError):
+        complete_labels(3, None, None)
+    # closure under sub-multisets + canonical order
+    assert complete_labels(3, 1, [[0, 0, 2]]) == [(0,), (1,), (2,), (0, 0), (0, 2), (0, 0, 2)]
