@@ -114,9 +114,9 @@ int midyn_rk4_solve(midyn_stack* stack, int B, int m, int R, const double* times
                     int P, const midyn_complex* y0, int y0_shared, midyn_complex* Y_out);
 
 /* ---- matrix exponential (scipy.linalg.expm as called at solvers/fixed_step_solvers.py:22,104) --
- * E_out[b] = expm(A[b]) for `batch` n x n matrices.  Algorithm: scaling and squaring of a
- * degree-16 Taylor polynomial evaluated with Paterson-Stockmeyer (matrix products only, all on
- * the fp64 MFMA zgemm); see DESIGN.md for the parity statement. info (optional, [batch][2]):
+ * E_out[b] = expm(A[b]) for `batch` n x n matrices.  Algorithm: scaling and squaring of a Taylor
+ * polynomial (degree 2..16 chosen from the 1-norm) evaluated with Paterson-Stockmeyer (matrix
+ * products only, all on the fp64 MFMA zgemm); see DESIGN.md for the parity statement. info (optional, [batch][2]):
  * squarings s and the 1-norm (as a truncated integer *1e6). */
 int midyn_expm(midyn_ctx* ctx, int n, int batch, const midyn_complex* A, midyn_complex* E_out,
                long long* info);

@@ -42,6 +42,7 @@ struct midyn_ctx {
     bool prefer_duo = false;
     int ablate = 0;
     int stream_variant = 0;
+    int expm_degree = 0;         // 0: Taylor degree chosen from the norm; else forced (2,4,6,9,12,16)
     bool stream_planes = true;   // single-plane stacks: the one-column kernel streams only non-zero planes
     bool split_k = true;
     bool combine_first = true;
@@ -179,6 +180,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     else if (n == "ablate") ctx->ablate = (int)value;
     else if (n == "stream_variant") ctx->stream_variant = (int)value;
     else if (n == "stream_planes") ctx->stream_planes = value != 0;
+    else if (n == "expm_degree") ctx->expm_degree = (int)value;
     else if (n == "split_k") ctx->split_k = value != 0;
     else if (n == "combine_first") ctx->combine_first = value != 0;
     else if (n == "complex_3m") ctx->complex_3m = value != 0;
@@ -1239,13 +1241,45 @@ struct ExpmWork {
     }
 };
 
-static const double EXPM_THETA16 = 0.5;  // conservative: ||A/2^s||_1 <= 0.5 for the degree-16 Taylor
+// Taylor polynomial of degree m evaluated with Paterson-Stockmeyer in blocks of A^q:
+//   T_m(A) = sum_{j=0}^{r} (A^q)^j B_j,  B_j = sum_{i<q} c[qj+i] A^i  (+ c[m] A^q in the top block),
+// m = q (r + 1): q - 1 products for the powers + r Horner products.  theta = largest ||A||_1 for which
+// the truncation error theta^(m+1)/(m+1)! stays below the fp64 unit round-off (with a safety margin);
+// larger norms are scaled by 2^-s and squared s times.  The (degree, s) pair of least cost is used,
+// so that the small generators of rotating-frame / Magnus steps do not pay for degree 16
+// (scipy's expm picks its Pade degree from the norm in the same spirit, a11).
+struct TaylorScheme {
+    int degree, q, r;
+    double theta;
+};
+static const TaylorScheme EXPM_SCHEMES[] = {
+    {2, 2, 0, 8.0e-6}, {4, 2, 1, 1.5e-3}, {6, 3, 1, 1.6e-2}, {9, 3, 2, 0.1}, {12, 4, 2, 0.3}, {16, 4, 3, 0.75},
+};
+static const int EXPM_N_SCHEMES = 6;
+
+static void expm_choose(double norm1, int force_degree, int* scheme_out, int* s_out) {
+    int best = EXPM_N_SCHEMES - 1, best_s = 0, best_cost = 1 << 30;
+    for (int i = 0; i < EXPM_N_SCHEMES; ++i) {
+        const TaylorScheme& sc = EXPM_SCHEMES[i];
+        if (force_degree > 0 && sc.degree != force_degree) continue;
+        int s = 0;
+        if (norm1 > sc.theta) s = std::max(0, (int)std::ceil(std::log2(norm1 / sc.theta)));
+        const int cost = (sc.q - 1) + sc.r + s;
+        if (cost <= best_cost) {  // ties: the higher degree (fewer squarings)
+            best_cost = cost;
+            best = i;
+            best_s = s;
+        }
+    }
+    *scheme_out = best;
+    *s_out = best_s;
+}
 
 // In place: X[b] <- expm(X[b]) for `batch` matrices [np][np] stored back to back on the device
 // (padding rows/cols zero; the padded block of the result becomes the identity, which is harmless).
-// Degree-16 Taylor polynomial evaluated with Paterson-Stockmeyer (powers A^2,A^3,A^4 + Horner in
-// A^4: 6 zgemm) and s squarings; a batch shares s = max over its matrices (over-scaling a matrix is
-// harmless) so that every step is ONE batched launch.
+// Scaling and squaring of a Taylor polynomial (matrix products only, all on the fp64 MFMA zgemm);
+// a batch shares the scheme and s of its largest matrix (over-scaling a matrix is harmless) so that
+// every step is ONE batched launch.
 static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int* s_out, double* norm_out,
                             int batch = 1) {
     CHK(w.ensure(ctx, np, batch));
@@ -1258,8 +1292,9 @@ static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int
     double norm1 = 0.0;
     for (double v : cs) norm1 = std::max(norm1, v);
     if (!std::isfinite(norm1)) return fail(ctx, "midyn_expm: matrix has non-finite entries");
-    int s = 0;
-    if (norm1 > EXPM_THETA16) s = std::max(0, (int)std::ceil(std::log2(norm1 / EXPM_THETA16)));
+    int scheme = 0, s = 0;
+    expm_choose(norm1, ctx->expm_degree, &scheme, &s);
+    const TaylorScheme& sc = EXPM_SCHEMES[scheme];
     if (s_out) *s_out = s;
     if (norm_out) *norm_out = norm1;
     const double scale = std::ldexp(1.0, -s);
@@ -1267,9 +1302,7 @@ static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int
     c[0] = 1.0;
     for (int i = 1; i <= 16; ++i) c[i] = c[i - 1] / i;
     double2* A = X;
-    double2* A2 = w.A2.as<double2>();
-    double2* A3 = w.A3.as<double2>();
-    double2* A4 = w.A4.as<double2>();
+    double2* pw[5] = {nullptr, A, w.A2.as<double2>(), w.A3.as<double2>(), w.A4.as<double2>()};
     double2* T0 = w.T0.as<double2>();
     double2* T1 = w.T1.as<double2>();
     if (s > 0) {
@@ -1277,29 +1310,36 @@ static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int
         double al[1] = {scale};
         CHK(dev_lincomb(ctx, np, A, 1, xs, al, 0.0, batch));
     }
-    CHK(dev_sqgemm(ctx, batch, np, A, A, A2, 1.0, 0.0, nullptr));
-    CHK(dev_sqgemm(ctx, batch, np, A2, A, A3, 1.0, 0.0, nullptr));
-    CHK(dev_sqgemm(ctx, batch, np, A2, A2, A4, 1.0, 0.0, nullptr));
-    // B_j = c[4j] I + c[4j+1] A + c[4j+2] A2 + c[4j+3] A3 ;  P3 = B3 + c16 A4
-    {
-        const double2* xs[4] = {A, A2, A3, A4};
-        double al[4] = {c[13], c[14], c[15], c[16]};
-        CHK(dev_lincomb(ctx, np, T0, 4, xs, al, c[12], batch));  // T0 = P3
-    }
-    double2* P = T0;
-    double2* Q = T1;
-    for (int j = 2; j >= 0; --j) {
-        // Q = B_j + A4 . P
-        const double2* xs[3] = {A, A2, A3};
-        double al[3] = {c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]};
-        if (j > 0) {
-            CHK(dev_lincomb(ctx, np, Q, 3, xs, al, c[4 * j], batch));
-            CHK(dev_sqgemm(ctx, batch, np, A4, P, Q, 1.0, 1.0, Q));
+    const int q = sc.q, r = sc.r;
+    CHK(dev_sqgemm(ctx, batch, np, A, A, pw[2], 1.0, 0.0, nullptr));
+    if (q >= 3) CHK(dev_sqgemm(ctx, batch, np, pw[2], A, pw[3], 1.0, 0.0, nullptr));
+    if (q >= 4) CHK(dev_sqgemm(ctx, batch, np, pw[2], pw[2], pw[4], 1.0, 0.0, nullptr));
+    // block j: c[qj] I + c[qj+1] A + ... + c[qj+q-1] A^(q-1)   (+ c[q(r+1)] A^q for the top block j = r)
+    auto block = [&](int j, bool top, double2* out) {
+        const double2* xs[4];
+        double al[4];
+        int nt = 0;
+        for (int i = 1; i < q; ++i) {
+            xs[nt] = pw[i];
+            al[nt++] = c[q * j + i];
+        }
+        if (top) {
+            xs[nt] = pw[q];
+            al[nt++] = c[q * (r + 1)];
+        }
+        return dev_lincomb(ctx, np, out, nt, xs, al, c[q * j], batch);
+    };
+    if (r == 0) {
+        CHK(block(0, true, X));  // elementwise, in place on A
+    } else {
+        CHK(block(r, true, T0));
+        double2* P = T0;
+        double2* Q = T1;
+        for (int j = r - 1; j >= 0; --j) {
+            // Q = B_j + A^q . P ; the last product goes back into X (= A), B_0 being built first
+            CHK(block(j, false, Q));
+            CHK(dev_sqgemm(ctx, batch, np, pw[q], P, j > 0 ? Q : X, 1.0, 1.0, Q));
             std::swap(P, Q);
-        } else {
-            // final result goes back into X (= A); build B_0 in Q first because A is an input of B_0
-            CHK(dev_lincomb(ctx, np, Q, 3, xs, al, c[0], batch));
-            CHK(dev_sqgemm(ctx, batch, np, A4, P, X, 1.0, 1.0, Q));
         }
     }
     // squarings: X <- X.X, ping-pong through T0

@@ -1212,3 +1212,34 @@ def test_perturbative_solvers_vs_direct_solution(qd):
     for sol in (dys, mag):
         yf = sol.solve(t0=0.0, n_steps=n_steps, y0=np.eye(2, dtype=complex), signals=[gauss]).y[-1]
         assert np.max(np.abs(yf - direct)) < 1e-6, np.max(np.abs(yf - direct))
+
+
+@pytest.mark.parametrize("kind", ["antiherm", "general"])
+def test_expm_adaptive_degree(qd, kind):
+    """The Taylor degree is chosen from the 1-norm (schemes 2,4,6,9,12,16 + squarings): every scheme at
+    the edge of its range, and the automatic choice across the thresholds, against scipy."""
+    ctx = qd.default_context()
+    rng = np.random.default_rng(77)
+    n = 24
+    a0 = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    if kind == "antiherm":
+        a0 = a0 - a0.conj().T
+    a0 /= np.linalg.norm(a0, 1)
+    thetas = {2: 8.0e-6, 4: 1.5e-3, 6: 1.6e-2, 9: 0.1, 12: 0.3, 16: 0.75}
+    try:
+        for deg, theta in thetas.items():
+            ctx.set_option("expm_degree", deg)
+            for scale in (theta, 3.7 * theta):           # at the edge, and with two squarings
+                a = a0 * scale
+                e, info = ctx.expm(a, return_info=True)
+                ref = scipy.linalg.expm(a)
+                err = np.linalg.norm(e - ref, 1) / np.linalg.norm(ref, 1)
+                assert err < 3e-15 * (1 + int(info[0, 0])) + 2e-16, (deg, scale, err, info)
+    finally:
+        ctx.set_option("expm_degree", 0)
+    for scale in (0.0, 1e-9, 7e-6, 9e-6, 1e-3, 2e-3, 0.015, 0.02, 0.09, 0.12, 0.29, 0.35, 0.7, 0.8, 1.4, 3.3, 11.0):
+        a = a0 * scale
+        e, info = ctx.expm(a, return_info=True)
+        ref = scipy.linalg.expm(a)
+        err = np.linalg.norm(e - ref, 1) / np.linalg.norm(ref, 1)
+        assert err < 3e-15 * (1 + int(info[0, 0])) + 2e-16, (scale, err, info)
