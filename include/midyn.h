@@ -125,7 +125,10 @@ int midyn_expm(midyn_ctx* ctx, int n, int batch, const midyn_complex* A, midyn_c
  * y <- expm(Omega_m) y per step; the generator evaluations use table rows step_rows[s][0..m-1]
  * (m = magnus_order Gauss points, in the order of fixed_step_solvers.py:345-377).
  * Instances advance together in chunks sized so that one batched launch fills the device (a
- * chunk is a single instance once one n x n product does; hundreds of instances for small n). */
+ * chunk is a single instance once one n x n product does; hundreds of instances for small n).
+ * For states with few columns (16 m <= n_pad) and magnus_order <= 2 the exponential is not formed:
+ * expm(Omega) y is evaluated as a scaled Taylor series of products Omega.v on the batched RHS
+ * contraction (all instances at once; option "expm_action" = 0 forces the dense route). */
 int midyn_expm_solve(midyn_stack* stack, int B, int m, int R, const double* times, const double* S,
                      int nsteps, const int* step_rows, const double* step_h, const int* step_save,
                      int P, int magnus_order, const midyn_complex* y0, int y0_shared,

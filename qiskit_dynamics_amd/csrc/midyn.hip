@@ -43,6 +43,8 @@ struct midyn_ctx {
     int ablate = 0;
     int stream_variant = 0;
     int expm_degree = 0;         // 0: Taylor degree chosen from the norm; else forced (2,4,6,9,12,16)
+    bool expm_action = true;     // few state columns: y <- expm(Omega) y as a Taylor series of matrix-vector
+                                 // products instead of forming expm(Omega) (Magnus orders 1 and 2)
     bool stream_planes = true;   // single-plane stacks: the one-column kernel streams only non-zero planes
     bool split_k = true;
     bool combine_first = true;
@@ -56,6 +58,8 @@ struct midyn_ctx {
     double cls_ms[KC_COUNT] = {0};
     double cls_n[KC_COUNT] = {0};
     int* d_one_seg = nullptr;  // device int {0, 1}: single-segment lists for plain zgemm (dense A / real-only A)
+    double* h_pinned = nullptr;                  // pinned host scratch for small device-to-host results (norms)
+    static constexpr size_t PINNED_DOUBLES = 1 << 17;
     int num_cu = 256;
 };
 
@@ -142,6 +146,7 @@ extern "C" int midyn_ctx_create(int device, midyn_ctx** out) {
     HIPCHK(ctx, hipGetDeviceProperties(&prop, device));
     ctx->num_cu = prop.multiProcessorCount;
     if (const char* e = getenv("MIDYN_COMPLEX_3M")) ctx->complex_3m = atoi(e) != 0;
+    HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_pinned, midyn_ctx::PINNED_DOUBLES * sizeof(double), hipHostMallocDefault));
     HIPCHK(ctx, hipMalloc(&ctx->d_one_seg, 2 * sizeof(int)));
     int one_seg[2] = {0, 1};  // [0]: segment 0, dense complex A;  [1]: segment 0, A real-only (mode 1)
     HIPCHK(ctx, hipMemcpy(ctx->d_one_seg, one_seg, sizeof(one_seg), hipMemcpyHostToDevice));
@@ -155,6 +160,7 @@ extern "C" int midyn_ctx_destroy(midyn_ctx* ctx) {
     drain_events(ctx);
     for (auto e : ctx->pool) hipEventDestroy(e);
     if (ctx->d_one_seg) hipFree(ctx->d_one_seg);
+    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->splitk_ws) hipFree(ctx->splitk_ws);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -181,6 +187,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     else if (n == "stream_variant") ctx->stream_variant = (int)value;
     else if (n == "stream_planes") ctx->stream_planes = value != 0;
     else if (n == "expm_degree") ctx->expm_degree = (int)value;
+    else if (n == "expm_action") ctx->expm_action = value != 0;
     else if (n == "split_k") ctx->split_k = value != 0;
     else if (n == "combine_first") ctx->combine_first = value != 0;
     else if (n == "complex_3m") ctx->complex_3m = value != 0;
@@ -239,6 +246,7 @@ struct midyn_stack {
     int uniform_mode = 3;       // plane mode shared by all active segments, or 3 (mixed)
     std::vector<int> h_flags;
     std::vector<int> h_modes;   // per segment: 0 full, 1 real only, 2 imaginary only, 3 zero
+    std::vector<double> seg_norm1;  // ||A_seg||_1 per segment (lazy; norm bounds of the expm action)
 };
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -482,6 +490,7 @@ static int launch_reduce(midyn_ctx* ctx, const GemmArgs& g) {
         case EPI_RK2: MIDYN_REDUCE(EPI_RK2); break;
         case EPI_RK3: MIDYN_REDUCE(EPI_RK3); break;
         case EPI_RK4: MIDYN_REDUCE(EPI_RK4); break;
+        case EPI_TAYLOR: MIDYN_REDUCE(EPI_TAYLOR); break;
         default: MIDYN_REDUCE(EPI_PLAIN); break;
     }
 #undef MIDYN_REDUCE
@@ -687,6 +696,32 @@ struct DevBuf {
     template <class T>
     T* as() { return static_cast<T*>(p); }
 };
+
+// 1-norms of `batch` [np][np] matrices stored back to back (one small D2H copy + stream sync)
+static int dev_norm1(midyn_ctx* ctx, const double2* A, int np, int batch, DevBuf& scratch, std::vector<double>& norms) {
+    const int nchunk = std::max(1, std::min(32, np / 128));
+    const size_t cnt = (size_t)batch * nchunk * np;
+    if (scratch.bytes < cnt * sizeof(double)) CHK(scratch.alloc(ctx, cnt * sizeof(double)));
+    hipLaunchKernelGGL(colsum_kernel, dim3((np + 255) / 256, batch, nchunk), dim3(256), 0, ctx->stream, A, np, nchunk,
+                       scratch.as<double>());
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<double> h_pageable;
+    double* h = ctx->h_pinned;
+    if (cnt > midyn_ctx::PINNED_DOUBLES) {
+        h_pageable.resize(cnt);
+        h = h_pageable.data();
+    }
+    HIPCHK(ctx, hipMemcpyAsync(h, scratch.p, cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    norms.assign(batch, 0.0);
+    for (int b = 0; b < batch; ++b)
+        for (int c = 0; c < np; ++c) {
+            double sum = 0.0;
+            for (int z = 0; z < nchunk; ++z) sum += h[((size_t)b * nchunk + z) * np + c];
+            norms[b] = std::max(norms[b], sum);
+        }
+    return 0;
+}
 
 // -------------------------------------------------------------------------------------------------
 // single evaluations
@@ -1283,14 +1318,10 @@ static void expm_choose(double norm1, int force_degree, int* scheme_out, int* s_
 static int dev_expm_inplace(midyn_ctx* ctx, ExpmWork& w, double2* X, int np, int* s_out, double* norm_out,
                             int batch = 1) {
     CHK(w.ensure(ctx, np, batch));
-    hipLaunchKernelGGL(colsum_kernel, dim3((np + 255) / 256, batch), dim3(256), 0, ctx->stream, X, np,
-                       w.colsum.as<double>());
-    HIPCHK(ctx, hipGetLastError());
-    std::vector<double> cs((size_t)np * batch);
-    HIPCHK(ctx, hipMemcpyAsync(cs.data(), w.colsum.p, cs.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<double> norms;
+    CHK(dev_norm1(ctx, X, np, batch, w.colsum, norms));
     double norm1 = 0.0;
-    for (double v : cs) norm1 = std::max(norm1, v);
+    for (double v : norms) norm1 = std::max(norm1, v);
     if (!std::isfinite(norm1)) return fail(ctx, "midyn_expm: matrix has non-finite entries");
     int scheme = 0, s = 0;
     expm_choose(norm1, ctx->expm_degree, &scheme, &s);
@@ -1484,6 +1515,227 @@ static int magnus_omega(midyn_ctx* ctx, int np, int nb, int magnus_order, double
     return 0;
 }
 
+// -------------------------------------------------------------------------------------------------
+// expm ACTION: y <- expm(Omega_m) y without forming the exponential (a10/a11 for states with few
+// columns).  The reference computes scipy.linalg.expm(Omega) (n^3 work, ~(7+s) zgemm) and multiplies
+// it into y even when y is a single vector; the result only needs  expm(Omega) y = sum_j Omega^j y / j!,
+// i.e. products Omega.v, which for
+//     order 1:  Omega v = h G(t1) v
+//     order 2:  Omega v = h/2 (g1 v + g2 v) + sqrt(3)/12 h^2 (g2 (g1 v) - g1 (g2 v))     (commutator free)
+// are exactly the batched RHS contraction of row a2/a7 (all instances of a sweep in ONE MFMA GEMM over
+// the operator stack, per-instance coefficients; the streaming kernel for one column).  Scaling:
+// y <- (T_p(Omega / s))^s y with (p, s) of least p*s such that bound/s <= theta_p, where
+// bound >= ||Omega||_1 follows from the per-segment norms: ||G(t)||_1 <= sum_seg |c_seg| ||A_seg||_1
+// (the frame phases have modulus 1).  One instance: G(t_i) is formed once per step (gen_eval) and the
+// products run on that single matrix.
+// -------------------------------------------------------------------------------------------------
+struct ActionScheme {
+    int p;
+    double theta;
+};
+static const ActionScheme ACTION_SCHEMES[] = {{2, 8.0e-6}, {3, 2.0e-4}, {4, 1.5e-3}, {5, 6.0e-3}, {6, 1.6e-2},
+                                              {8, 6.5e-2}, {10, 0.16}, {12, 0.3},   {15, 0.62},  {20, 1.35}};
+
+static void action_choose(double bound, int* p_out, int* s_out) {
+    long long best_cost = -1;
+    for (const ActionScheme& sc : ACTION_SCHEMES) {
+        const int s = bound > sc.theta ? (int)std::ceil(bound / sc.theta) : 1;
+        const long long cost = (long long)sc.p * s;
+        if (best_cost < 0 || cost <= best_cost) {
+            best_cost = cost;
+            *p_out = sc.p;
+            *s_out = s;
+        }
+    }
+}
+
+static int stack_seg_norms(midyn_stack* s) {
+    if (!s->seg_norm1.empty()) return 0;
+    midyn_ctx* ctx = s->ctx;
+    DevBuf cs;
+    CHK(dev_norm1(ctx, s->ops, s->n_pad, s->nseg, cs, s->seg_norm1));
+    return 0;
+}
+
+static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* times, const double* S_host,
+                             const double* S_any, int nsteps, const int* step_rows, const double* step_h,
+                             const int* step_save, int P, int magnus_order, const midyn_complex* y0, int y0_shared,
+                             midyn_complex* Y_out) {
+    midyn_ctx* ctx = s->ctx;
+    CHK(stack_seg_norms(s));
+    midyn_rk4_plan* p = nullptr;
+    CHK(plan_create_impl(s, B, m, R, times, S_any, nsteps, step_rows, step_h, step_save, P, y0, y0_shared, &p));
+    struct Guard {
+        midyn_rk4_plan* p;
+        ~Guard() { midyn_rk4_plan_destroy(p); }
+    } guard{p};
+    const int np = s->n_pad, ld = p->ld;
+    const size_t stv = (size_t)np * ld, state_bytes = stv * sizeof(double2);
+    const bool one = (B == 1);  // one instance: explicit G(t_i), products on a single matrix
+    const int npts = magnus_order;
+    DevBuf Gx[2], U[2], V[2], W, d_cs;
+    std::vector<double> h_cs;
+    if (one)
+        for (int i = 0; i < npts; ++i) CHK(Gx[i].alloc(ctx, (size_t)np * np * sizeof(double2)));
+    if (magnus_order == 2) {
+        for (int i = 0; i < 2; ++i) {
+            CHK(U[i].alloc(ctx, state_bytes));
+            CHK(V[i].alloc(ctx, state_bytes));
+        }
+        CHK(W.alloc(ctx, state_bytes));
+        HIPCHK(ctx, hipMemsetAsync(W.p, 0, state_bytes, ctx->stream));
+    }
+    double2* y = p->d_y.as<double2>();
+    double2* acc = p->d_acc.as<double2>();
+    double2* yin[2] = {p->d_yin[0].as<double2>(), p->d_yin[1].as<double2>()};
+    // out = G(point i) . w   (EPI_RHS)  or the fused Taylor update (EPI_TAYLOR) with the given epilogue
+    auto product = [&](int i, int row, const double2* w_plain, const double2* w_phased, Epilogue epi) -> int {
+        if (one) {
+            epi.e_cur = nullptr;   // gen_eval already applied the frame: G = Delta(t) o C(t)
+            epi.e_next = nullptr;
+            if (p->stream_path) {
+                StreamArgs a{};
+                a.ops = Gx[i].as<double2>();
+                a.seg_list = ctx->d_one_seg;
+                a.n_act = 1;
+                a.n_pad = np;
+                a.has_static = 1;
+                a.coeff = nullptr;
+                a.yin = w_plain;
+                a.epi = epi;
+                return launch_stream(ctx, a);
+            }
+            GemmArgs g{};
+            g.A = Gx[i].as<double2>();
+            g.lda = np;
+            g.B = w_plain;
+            g.ldb = ld;
+            g.M = np;
+            g.N = ld;
+            g.K = np;
+            g.seg_list = ctx->d_one_seg;
+            g.n_act = 1;
+            g.m_cols = m;
+            g.n_inst = 1;
+            g.epi = epi;
+            return launch_gemm(ctx, g, KC_RHS_GEMM);
+        }
+        (void)row;
+        return plan_rhs_launch(p, row, epi, w_phased);
+    };
+    auto rephase = [&](const double2* src, int row, double2* dst) -> int {
+        hipLaunchKernelGGL(rephase_kernel, dim3(grid_for(stv)), dim3(256), 0, ctx->stream, src, plan_E(p, row), np, ld,
+                           dst);
+        HIPCHK(ctx, hipGetLastError());
+        return 0;
+    };
+    const double p2 = std::sqrt(3.0) / 12;
+    for (int st = 0; st < nsteps; ++st) {
+        const double h = step_h[st];
+        const int* rr = step_rows + 3 * st;
+        // ---- norm bound over the instances -> (degree, scaling)
+        double bound = 0.0;
+        for (int b = 0; b < B; ++b) {
+            double gn[2] = {0.0, 0.0};
+            for (int i = 0; i < npts; ++i) {
+                const double* c = s->k > 0 ? S_host + ((size_t)b * R + rr[i]) * s->k : nullptr;
+                for (int seg = 0; seg < s->nseg; ++seg) {
+                    const double cf = (s->has_static && seg == 0) ? 1.0 : std::fabs(c[seg - s->has_static]);
+                    gn[i] += cf * s->seg_norm1[seg];
+                }
+            }
+            const double ah = std::fabs(h);
+            const double bb = magnus_order == 1 ? ah * gn[0] : 0.5 * ah * (gn[0] + gn[1]) + 2 * p2 * ah * ah * gn[0] * gn[1];
+            bound = std::max(bound, bb);
+        }
+        if (one) {
+            for (int i = 0; i < npts; ++i)
+                CHK(launch_gen_eval(s, s->k > 0 ? p->d_S.as<double>() + (size_t)rr[i] * s->k : nullptr, plan_E(p, rr[i]),
+                                    1.0, Gx[i].as<double2>()));
+            // The generators exist explicitly: their exact 1-norms can replace the triangle bound.  That
+            // costs a stream synchronisation, so only when the products it may save are worth > 1 ms.
+            int deg0 = 2, sc0 = 1;
+            action_choose(bound, &deg0, &sc0);
+            const double product_s = std::max(5e-6, (double)np * np * 16.0 / 5e12);
+            if ((double)deg0 * sc0 * (magnus_order == 1 ? 1 : 4) * product_s > 1e-3) {
+                double gn[2] = {0.0, 0.0};
+                for (int i = 0; i < npts; ++i) {
+                    CHK(dev_norm1(ctx, Gx[i].as<double2>(), np, 1, d_cs, h_cs));
+                    gn[i] = h_cs[0];
+                }
+                const double ah = std::fabs(h);
+                bound = std::min(bound, magnus_order == 1 ? ah * gn[0]
+                                                          : 0.5 * ah * (gn[0] + gn[1]) + 2 * p2 * ah * ah * gn[0] * gn[1]);
+            }
+        }
+        if (!std::isfinite(bound)) return fail(ctx, "midyn_expm_solve: non-finite generator norm");
+        int deg = 2, sc = 1;
+        action_choose(bound, &deg, &sc);
+        for (int rep = 0; rep < sc; ++rep) {
+            HIPCHK(ctx, hipMemcpyAsync(acc, y, state_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            if (magnus_order == 1) {
+                int cur = 0;
+                if (one) HIPCHK(ctx, hipMemcpyAsync(yin[0], y, state_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                else CHK(rephase(y, rr[0], yin[0]));
+                for (int j = 1; j <= deg; ++j) {
+                    Epilogue e{};
+                    e.mode = EPI_TAYLOR;
+                    e.ld = ld;
+                    e.h = h / ((double)sc * j);
+                    e.e_cur = plan_E(p, rr[0]);
+                    e.e_next = plan_E(p, rr[0]);
+                    e.acc = acc;
+                    e.yin_next = yin[cur ^ 1];
+                    CHK(product(0, rr[0], yin[cur], yin[cur], e));
+                    cur ^= 1;
+                }
+            } else {
+                const double2* term = y;
+                double2 *u1 = U[0].as<double2>(), *u2 = U[1].as<double2>(), *v1 = V[0].as<double2>(),
+                        *v2 = V[1].as<double2>(), *w = W.as<double2>();
+                for (int j = 1; j <= deg; ++j) {
+                    Epilogue e{};
+                    e.mode = EPI_RHS;
+                    e.ld = ld;
+                    // u1 = g1 term, u2 = g2 term
+                    if (!one) CHK(rephase(term, rr[0], yin[0]));
+                    e.e_cur = plan_E(p, rr[0]);
+                    e.out = u1;
+                    CHK(product(0, rr[0], term, yin[0], e));
+                    if (!one) CHK(rephase(term, rr[1], yin[1]));
+                    e.e_cur = plan_E(p, rr[1]);
+                    e.out = u2;
+                    CHK(product(1, rr[1], term, yin[1], e));
+                    // v1 = g2 u1, v2 = g1 u2
+                    if (!one) CHK(rephase(u1, rr[1], yin[0]));
+                    e.e_cur = plan_E(p, rr[1]);
+                    e.out = v1;
+                    CHK(product(1, rr[1], u1, yin[0], e));
+                    if (!one) CHK(rephase(u2, rr[0], yin[1]));
+                    e.e_cur = plan_E(p, rr[0]);
+                    e.out = v2;
+                    CHK(product(0, rr[0], u2, yin[1], e));
+                    const double f = 1.0 / ((double)sc * j);
+                    hipLaunchKernelGGL(magnus2_term_kernel, dim3(grid_for(stv)), dim3(256), 0, ctx->stream, u1, u2, v1, v2,
+                                       0.5 * h * f, p2 * h * h * f, stv, w, acc);
+                    HIPCHK(ctx, hipGetLastError());
+                    term = w;
+                }
+            }
+            std::swap(y, acc);
+        }
+        if (step_save && step_save[st] >= 0) {
+            if (step_save[st] >= P) return fail(ctx, "midyn_expm_solve: save slot out of range");
+            hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for((size_t)B * s->n * m)), dim3(256), 0, ctx->stream, y,
+                               B, s->n, m, ld, P, step_save[st], p->d_out.as<double2>());
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(Y_out, p->d_out.p, (size_t)B * P * s->n * m * sizeof(double2), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const double* times, const double* S,
                                 int nsteps, const int* step_rows, const double* step_h, const int* step_save,
                                 int P, int magnus_order, const midyn_complex* y0, int y0_shared,
@@ -1498,6 +1750,23 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
         if (step_rows[i] < 0 || step_rows[i] >= R) return fail(ctx, "midyn_expm_solve: step_rows out of range");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int np = s->n_pad;
+    if (ctx->expm_action && magnus_order <= 2 && (long long)m * 16 <= np) {
+        // few columns per instance: expm(Omega) y by matrix-vector products (see expm_action_solve)
+        std::vector<double> s_host;
+        const double* S_h = S;
+        if (s->k > 0) {
+            hipPointerAttribute_t at{};
+            if (hipPointerGetAttributes(&at, S) == hipSuccess && at.type == hipMemoryTypeDevice) {
+                s_host.resize((size_t)B * R * s->k);
+                HIPCHK(ctx, hipMemcpy(s_host.data(), S, s_host.size() * sizeof(double), hipMemcpyDeviceToHost));
+                S_h = s_host.data();
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        return expm_action_solve(s, B, m, R, times, S_h, S, nsteps, step_rows, step_h, step_save, P, magnus_order, y0,
+                                 y0_shared, Y_out);
+    }
     const int ld = round_up(m, 64);
     // Instances advance together in chunks: every generator evaluation, Magnus combination, expm
     // product and propagation is ONE batched launch over the chunk (a single instance per chunk

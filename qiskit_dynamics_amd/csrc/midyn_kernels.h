@@ -51,11 +51,13 @@ __device__ __forceinline__ double2 cfma_r(double s, double2 a, double2 c) {  // 
 //              3: acc += h/3 k            ; yin_next = Enext * (y + h k)
 //              4: y = acc + h/6 k         ; yin_next = Enext * y
 //   EPI_PLAIN  out = alpha * C + beta * Z                          (expm pipeline zgemm)
+//   EPI_TAYLOR one term of the Taylor series of the ACTION expm(Omega) y (Omega = h G(t)):
+//              k = conj(Ecur) * C ; term = h * k ; acc += term ; yin_next = Enext * term
 // The stage input is kept PRE-PHASED (yin = exp(d t_stage) o y_stage) so the contraction kernels
 // never touch the frame; yin ping-pongs between two buffers because other workgroups still read
 // the current one while this one already writes the next.
 // ------------------------------------------------------------------------------------------------
-enum { EPI_RHS = 0, EPI_RK1 = 1, EPI_RK2 = 2, EPI_RK3 = 3, EPI_RK4 = 4, EPI_PLAIN = 5 };
+enum { EPI_RHS = 0, EPI_RK1 = 1, EPI_RK2 = 2, EPI_RK3 = 3, EPI_RK4 = 4, EPI_PLAIN = 5, EPI_TAYLOR = 6 };
 
 struct Epilogue {
     int mode;
@@ -96,6 +98,13 @@ __device__ __forceinline__ void apply_epilogue_t(const Epilogue& e, int row, int
     }
     const double2 en = e.e_next ? e.e_next[row] : make_double2(1.0, 0.0);
     const double h = e.h;
+    if (EMODE == EPI_TAYLOR) {
+        const double2 term = make_double2(h * k.x, h * k.y);
+        const double2 a = e.acc[idx];
+        e.acc[idx] = make_double2(a.x + term.x, a.y + term.y);
+        e.yin_next[idx] = cmul(en, term);
+        return;
+    }
     if (EMODE == EPI_RK1) {
         const double2 y = e.y[idx];
         e.acc[idx] = cfma_r(h * (1.0 / 6), k, y);
@@ -123,6 +132,7 @@ __device__ __forceinline__ void apply_epilogue(const Epilogue& e, int row, int c
         case EPI_RK2: apply_epilogue_t<EPI_RK2>(e, row, col, c); break;
         case EPI_RK3: apply_epilogue_t<EPI_RK3>(e, row, col, c); break;
         case EPI_RK4: apply_epilogue_t<EPI_RK4>(e, row, col, c); break;
+        case EPI_TAYLOR: apply_epilogue_t<EPI_TAYLOR>(e, row, col, c); break;
         default: apply_epilogue_t<EPI_PLAIN>(e, row, col, c); break;
     }
 }
@@ -150,6 +160,7 @@ __device__ __forceinline__ void store_tile(const Epilogue& e, int row0, int col0
         case EPI_RK2: store_tile_t<EPI_RK2, MT, NT>(e, row0, col0, cre, cim); break;
         case EPI_RK3: store_tile_t<EPI_RK3, MT, NT>(e, row0, col0, cre, cim); break;
         case EPI_RK4: store_tile_t<EPI_RK4, MT, NT>(e, row0, col0, cre, cim); break;
+        case EPI_TAYLOR: store_tile_t<EPI_TAYLOR, MT, NT>(e, row0, col0, cre, cim); break;
         default: store_tile_t<EPI_PLAIN, MT, NT>(e, row0, col0, cre, cim); break;
     }
 }
@@ -1278,6 +1289,20 @@ __global__ __launch_bounds__(256) void rephase_kernel(const double2* y, const do
     }
 }
 
+// One Taylor term of the commutator-free Magnus-2 action (fixed_step_solvers.py:348-363 applied to a
+// vector):  w = a (u1 + u2) + b (v1 - v2),  u_i = g_i term, v1 = g2 u1, v2 = g1 u2;  acc += w.
+__global__ __launch_bounds__(256) void magnus2_term_kernel(const double2* u1, const double2* u2, const double2* v1,
+                                                           const double2* v2, double a, double b, size_t total,
+                                                           double2* w, double2* acc) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const double2 p = u1[idx], q = u2[idx], r = v1[idx], t = v2[idx];
+        const double2 o = make_double2(a * (p.x + q.x) + b * (r.x - t.x), a * (p.y + q.y) + b * (r.y - t.y));
+        w[idx] = o;
+        const double2 c = acc[idx];
+        acc[idx] = make_double2(c.x + o.x, c.y + o.y);
+    }
+}
+
 // flags[2*seg + 0/1] = 1 if any real / imaginary part of segment seg is non zero
 __global__ __launch_bounds__(256) void plane_flags_kernel(const double2* ops, size_t plane, int nseg,
                                                           int* flags) {
@@ -1305,17 +1330,21 @@ __global__ __launch_bounds__(256) void plane_flags_kernel(const double2* ops, si
     }
 }
 
-// column abs sums of an [n][n] matrix (ld n): sums[c] = sum_r |A[r][c]|   (1-norm = max_c)
-__global__ __launch_bounds__(256) void colsum_kernel(const double2* A, int n, double* sums) {
+// partial column abs sums of [n][n] matrices (ld n): sums[(mat * nchunk + z) * n + c] = sum over the
+// rows of chunk z of |A[r][c]|; the host adds the chunks (fixed order) and takes max_c = the 1-norm.
+// grid (ceil(n/256), batch, nchunk): enough workgroups to stream a large matrix at HBM rate.
+__global__ __launch_bounds__(256) void colsum_kernel(const double2* A, int n, int nchunk, double* sums) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
     const double2* Ab = A + (size_t)blockIdx.y * n * n;   // blockIdx.y: matrix of a batch
+    const int rows = (n + nchunk - 1) / nchunk;
+    const int r0 = blockIdx.z * rows, r1 = min(n, r0 + rows);
     double s = 0.0;
-    for (int r = 0; r < n; ++r) {
+    for (int r = r0; r < r1; ++r) {
         const double2 v = Ab[(size_t)r * n + c];
         s += hypot(v.x, v.y);
     }
-    sums[(size_t)blockIdx.y * n + c] = s;
+    sums[((size_t)blockIdx.y * nchunk + blockIdx.z) * n + c] = s;
 }
 
 // pad copy: src [rows][cols] (ld src_ld) -> dst (ld dst_ld), both complex

@@ -1243,3 +1243,66 @@ def test_expm_adaptive_degree(qd, kind):
         ref = scipy.linalg.expm(a)
         err = np.linalg.norm(e - ref, 1) / np.linalg.norm(ref, 1)
         assert err < 3e-15 * (1 + int(info[0, 0])) + 2e-16, (scale, err, info)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_expm_action_matches_dense_expm(qd, seed):
+    """States with few columns take the expm ACTION path (Taylor series of matrix-vector products on the
+    batched contraction kernel, commutator-free Magnus-2); it must agree with the dense expm path and
+    the oracle: frames / no frame (large norms -> scaling), sweeps and single instances, 1-2 columns."""
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(4200 + seed)
+    n = [6, 33, 70, 130][seed % 4]
+    k = int(rng.integers(1, 4))
+    frame_kind = ["none", "full", "diag"][seed % 3]
+    batch = [1, 4][seed % 2]
+    m = [None, 2][(seed // 2) % 2]
+    mo = 1 + seed % 2
+
+    def herm(scale=1.0):
+        a = crand(rng, n, n)
+        return scale * (a + a.conj().T) / 2
+
+    h_static = herm(6.0 if frame_kind == "none" else 2.0)   # no frame: ||h G|| of order 10 -> several scalings
+    h_ops = np.array([herm() for _ in range(k)])
+    frame = {"none": None, "diag": rng.normal(size=n), "full": h_static}[frame_kind]
+    t_span, t_eval, max_dt = [0.0, 0.5], [0.0, 0.2, 0.5], 0.05
+
+    def make_sigs():
+        amps, nus, phs = rng.uniform(-1, 1, k), rng.uniform(0, 2, k), rng.uniform(-3, 3, k)
+        return ([qd.Signal(lambda t, a=a: a * np.cos(0.7 * t) + 0j, nu, ph) for a, nu, ph in zip(amps, nus, phs)],
+                (amps, nus, phs))
+
+    def make_y0():
+        y = crand(rng, n) if m is None else crand(rng, n, m)
+        return y / np.linalg.norm(y)
+
+    sig_sets = [make_sigs() for _ in range(batch)]
+    y0s = [make_y0() for _ in range(batch)]
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=frame)
+    args = dict(t_span=t_span, y0=y0s if batch > 1 else y0s[0],
+                signals=[s for s, _ in sig_sets] if batch > 1 else sig_sets[0][0], method="scipy_expm",
+                max_dt=max_dt, t_eval=t_eval, magnus_order=mo)
+    ctx = qd.default_context()
+    act = solver.solve(**args)
+    ctx.set_option("expm_action", 0)
+    try:
+        dense = solver.solve(**args)
+    finally:
+        ctx.set_option("expm_action", 1)
+    act = act if isinstance(act, list) else [act]
+    dense = dense if isinstance(dense, list) else [dense]
+    a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
+    for b in range(batch):
+        assert_close(act[b].y, dense[b].y, 1e-11)
+        amps, nus, phs = sig_sets[b][1]
+
+        def coeff(t, amps=amps, nus=nus, phs=phs):
+            return np.array([orc.signal_sum_value(np.array([a_ * np.cos(0.7 * t) + 0j]), [nu], [ph], t)
+                             for a_, nu, ph in zip(amps, nus, phs)])
+
+        _, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff, t_span, y0s[b], "scipy_expm", max_dt,
+                                             t_eval=t_eval, magnus_order=mo)
+        assert_close(act[b].y, y_ref, SOLVE_TOL)
+        assert abs(np.linalg.norm(act[b].y[-1]) - 1.0) < 1e-10

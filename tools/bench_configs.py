@@ -62,6 +62,29 @@ if "expm" in which:
                           "tflops_in_zgemm": round(flops / (c["ms"] * 1e-3) / 1e12, 2),
                           "unitarity_per_n": unit}), flush=True)
 
+def all_counters():
+    return {k_: ctx.counters(k_) for k_ in ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise")}
+
+
+def run_modes(label, fn, nsteps, extra):
+    """Time `fn` with the expm-action path (default for few columns) and with the dense expm path."""
+    for mode, flag in (("action", 1), ("dense_expm", 0)):
+        ctx.set_option("expm_action", flag)
+        fn()  # warm (allocations, lazy norms)
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        r, dt = timed(fn)
+        cs = all_counters()
+        ctx.set_option("profile", 0)
+        dev_ms = sum(c["ms"] for c in cs.values())
+        out = {"what": label, "propagation": mode, "steps": nsteps, "wall_ms_per_step": round(dt * 1e3 / nsteps, 3),
+               "device_ms_per_step": round(dev_ms / nsteps, 3),
+               "launches_per_step": {k_: c["launches"] / nsteps for k_, c in cs.items() if c["launches"]}}
+        out.update(extra(r))
+        print(json.dumps(out), flush=True)
+    ctx.set_option("expm_action", 1)
+
+
 if "cfg4" in which:
     t0 = time.time()
     cfg = workloads.lindblad_config()  # 6 qubits, N = 4096
@@ -72,44 +95,56 @@ if "cfg4" in which:
                        static_dissipators=cfg["static_dissipators"], vectorized=True)
     build_s = time.time() - t0
     nsteps = 5
-    ctx.reset_counters()
-    ctx.set_option("profile", 1)
-    r, dt = timed(lambda: solver.solve(t_span=[0.0, nsteps * cfg["max_dt"]], y0=cfg["rho0"].flatten(order="F"),
-                                       signals=sigs, method="scipy_expm", max_dt=cfg["max_dt"]))
-    cz, cg = ctx.counters("zgemm"), ctx.counters("gen_eval")
-    ctx.set_option("profile", 0)
-    rho = r.y[-1].reshape(64, 64, order="F")
-    print(json.dumps({"what": "cfg4 (6-qubit vectorised Lindblad, N=4096, scipy_expm m=1, no frame)",
-                      "steps": nsteps, "model_build_s": round(build_s, 1), "wall_s": round(dt, 3),
-                      "ms_per_step_device": round((cz["ms"] + cg["ms"]) / nsteps, 2),
-                      "zgemm_launches_per_step": cz["launches"] / nsteps, "zgemm_ms_per_step": round(cz["ms"] / nsteps, 2),
-                      "gen_eval_ms_per_step": round(cg["ms"] / nsteps, 3),
-                      "trace": float(abs(np.trace(rho))), "hermiticity": float(np.linalg.norm(rho - rho.conj().T))}),
-          flush=True)
+
+    def extra4(r):
+        rho = r.y[-1].reshape(64, 64, order="F")
+        return {"model_build_s": round(build_s, 1), "trace": float(abs(np.trace(rho))),
+                "hermiticity": float(np.linalg.norm(rho - rho.conj().T))}
+
+    run_modes("cfg4 (6-qubit vectorised Lindblad, N=4096, scipy_expm m=1, no frame), 1 trajectory",
+              lambda: solver.solve(t_span=[0.0, nsteps * cfg["max_dt"]], y0=cfg["rho0"].flatten(order="F"),
+                                   signals=sigs, method="scipy_expm", max_dt=cfg["max_dt"]), nsteps, extra4)
     del solver
 
 if "cfg5" in which:
     t0 = time.time()
     cfg = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
     frame = np.diag(cfg["h_d"]).real.copy()
-    amps, phases = workloads.sweep_parameters(0, 8)
-    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
-            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
-    hm = qd.HamiltonianModel(static_operator=cfg["h_d"], operators=cfg["ops"], signals=sigs, rotating_frame=frame)
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
     build_s = time.time() - t0
     nsteps = 2
+
+    def sig_list(b):
+        amps, phases = workloads.sweep_parameters(b, 8)
+        return [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+                for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+
+    def extra5(r):
+        rr = r if isinstance(r, list) else [r]
+        return {"model_build_s": round(build_s, 1),
+                "max_norm_deviation": float(max(abs(np.linalg.norm(x.y[-1]) - 1.0) for x in rr))}
+
+    run_modes("cfg5 (12-qubit Schrodinger n=4096, diagonal frame, Magnus-2 expm), 1 instance",
+              lambda: solver.solve(t_span=[0.0, nsteps * 0.25], y0=cfg["y0"], signals=sig_list(0), method="scipy_expm",
+                                   max_dt=0.25, magnus_order=2), nsteps, extra5)
+    # the per-GPU shard of the 1024-instance sweep on 8 GPUs: 128 instances in one batched solve
+    shard = [sig_list(b) for b in range(128)]
+    ctx.set_option("expm_action", 1)
+    fn = lambda: solver.solve(t_span=[0.0, nsteps * 0.25], y0=cfg["y0"], signals=shard, method="scipy_expm",
+                              max_dt=0.25, magnus_order=2)
+    fn()
     ctx.reset_counters()
     ctx.set_option("profile", 1)
-    r, dt = timed(lambda: qd.solve_lmde(hm, [0.0, nsteps * 0.25], cfg["y0"], method="scipy_expm", max_dt=0.25,
-                                        magnus_order=2))
-    cz, cg = ctx.counters("zgemm"), ctx.counters("gen_eval")
+    r, dt = timed(fn)
+    cs = all_counters()
     ctx.set_option("profile", 0)
-    print(json.dumps({"what": "cfg5 (12-qubit Schrodinger n=4096, diagonal frame, Magnus-2 expm), 1 instance",
-                      "steps": nsteps, "model_build_s": round(build_s, 1), "wall_s": round(dt, 3),
-                      "ms_per_instance_step_device": round((cz["ms"] + cg["ms"]) / nsteps, 2),
-                      "zgemm_launches_per_step": cz["launches"] / nsteps,
-                      "tflops_8n3_per_zgemm": round(8 * 4096.0**3 * cz["launches"] / (cz["ms"] * 1e-3) / 1e12, 2),
-                      "norm": float(np.linalg.norm(r.y[-1])), "segment_modes": hm.stack.segment_modes}), flush=True)
+    print(json.dumps({"what": "cfg5 shard: 128 instances (1024-instance sweep / 8 GPUs), Magnus-2, expm action",
+                      "steps": nsteps, "wall_ms_per_step": round(dt * 1e3 / nsteps, 2),
+                      "wall_ms_per_instance_step": round(dt * 1e3 / nsteps / 128, 4),
+                      "device_ms_per_step": round(sum(c["ms"] for c in cs.values()) / nsteps, 2),
+                      "launches_per_step": {k_: c["launches"] / nsteps for k_, c in cs.items() if c["launches"]},
+                      **extra5(r)}), flush=True)
+    del solver
 
 if "lind1024" in which:
     # 10-qubit open system, non-vectorised: n = 1024, 8 drives, 4 static sigma^- dissipators, RK4
