@@ -1406,19 +1406,39 @@ extern "C" int midyn_expm(midyn_ctx* ctx, int n, int batch, const midyn_complex*
     ExpmWork w;
     DevBuf X;
     CHK(X.alloc(ctx, (size_t)chunk * mat * sizeof(double2)));
+    // many small matrices: pad / unpad on the host and move each chunk with ONE copy per direction
+    const bool pack = batch > 1 && np <= 512;
+    std::vector<double2> stage;
+    if (pack) stage.resize((size_t)chunk * mat);
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = std::min(chunk, batch - b0);
-        HIPCHK(ctx, hipMemset(X.p, 0, (size_t)nb * mat * sizeof(double2)));
-        for (int b = 0; b < nb; ++b)
-            CHK(upload_padded(ctx, A + (size_t)(b0 + b) * n * n, n, n, X.as<double2>() + b * mat, np));
+        if (pack) {
+            std::fill(stage.begin(), stage.begin() + (size_t)nb * mat, make_double2(0.0, 0.0));
+            for (int b = 0; b < nb; ++b)
+                for (int r = 0; r < n; ++r)
+                    memcpy(&stage[(size_t)b * mat + (size_t)r * np], A + ((size_t)(b0 + b) * n + r) * n,
+                           (size_t)n * sizeof(double2));
+            HIPCHK(ctx, hipMemcpy(X.p, stage.data(), (size_t)nb * mat * sizeof(double2), hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(ctx, hipMemset(X.p, 0, (size_t)nb * mat * sizeof(double2)));
+            for (int b = 0; b < nb; ++b)
+                CHK(upload_padded(ctx, A + (size_t)(b0 + b) * n * n, n, n, X.as<double2>() + b * mat, np));
+        }
         int s = 0;
         double nrm = 0;
         CHK(dev_expm_inplace(ctx, w, X.as<double2>(), np, &s, &nrm, nb));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (pack) HIPCHK(ctx, hipMemcpy(stage.data(), X.p, (size_t)nb * mat * sizeof(double2), hipMemcpyDeviceToHost));
         for (int b = 0; b < nb; ++b) {
-            HIPCHK(ctx, hipMemcpy2D(E_out + (size_t)(b0 + b) * n * n, (size_t)n * sizeof(double2),
-                                    X.as<double2>() + b * mat, (size_t)np * sizeof(double2), (size_t)n * sizeof(double2),
-                                    n, hipMemcpyDeviceToHost));
+            if (pack) {
+                for (int r = 0; r < n; ++r)
+                    memcpy(E_out + ((size_t)(b0 + b) * n + r) * n, &stage[(size_t)b * mat + (size_t)r * np],
+                           (size_t)n * sizeof(double2));
+            } else {
+                HIPCHK(ctx, hipMemcpy2D(E_out + (size_t)(b0 + b) * n * n, (size_t)n * sizeof(double2),
+                                        X.as<double2>() + b * mat, (size_t)np * sizeof(double2),
+                                        (size_t)n * sizeof(double2), n, hipMemcpyDeviceToHost));
+            }
             if (info) {
                 info[2 * (b0 + b)] = s;
                 info[2 * (b0 + b) + 1] = (long long)(nrm * 1e6);
@@ -2028,6 +2048,11 @@ struct midyn_expansion {
     int n = 0, np = 0, M = 0, K = 0;   // K = padded number of GEMM rows of `terms` (M + constant)
     bool has_const = false, has_post = false, use_expm = false;
     DevBuf d_terms, d_post;
+    // work buffers kept between solves (a solve of ~1000 small steps is a few hundred microseconds of
+    // kernels; allocating ~0.5 GB of scratch per call would dominate it)
+    int w_cap = 0, w_ld = 0;
+    DevBuf X, d_mono, d_A, d_offs, d_y[2], d_tmp, d_res;
+    ExpmWork work;
 };
 
 extern "C" int midyn_expansion_create(midyn_ctx* ctx, int n, int M, const midyn_complex* terms,
@@ -2088,17 +2113,26 @@ extern "C" int midyn_expansion_solve(midyn_expansion* e, int B, int nsteps, cons
     // steps per chunk: a multiple of 64 (GEMM rows), bounded like the batched expm
     int cap = expm_chunk(ctx, np, std::max(1, nsteps));
     cap = round_up(cap, 64);
-    DevBuf X, d_mono, d_A, d_offs, d_y[2], d_tmp, d_res;
-    ExpmWork w;
-    CHK(X.alloc(ctx, 2 * (size_t)cap * mat * sizeof(double2)));
-    CHK(d_mono.alloc(ctx, (size_t)cap * M * sizeof(double)));
-    CHK(d_A.alloc(ctx, (size_t)cap * K * sizeof(double2)));
-    CHK(d_offs.alloc(ctx, (size_t)3 * cap * sizeof(long long)));
-    CHK(d_y[0].alloc(ctx, stv * sizeof(double2)));
-    CHK(d_y[1].alloc(ctx, stv * sizeof(double2)));
+    DevBuf &X = e->X, &d_mono = e->d_mono, &d_A = e->d_A, &d_offs = e->d_offs, &d_tmp = e->d_tmp, &d_res = e->d_res;
+    DevBuf* d_y = e->d_y;
+    ExpmWork& w = e->work;
     const size_t inst_elems = (size_t)n * m;
-    CHK(d_tmp.alloc(ctx, inst_elems * sizeof(double2)));
-    CHK(d_res.alloc(ctx, inst_elems * sizeof(double2)));
+    if (cap > e->w_cap) {
+        CHK(X.alloc(ctx, 2 * (size_t)cap * mat * sizeof(double2)));
+        CHK(d_mono.alloc(ctx, (size_t)cap * M * sizeof(double)));
+        CHK(d_A.alloc(ctx, (size_t)cap * K * sizeof(double2)));
+        CHK(d_offs.alloc(ctx, (size_t)3 * cap * sizeof(long long)));
+        e->w_cap = cap;
+    } else {
+        cap = e->w_cap;  // slot layout of X follows the allocated capacity
+    }
+    if (ld > e->w_ld) {
+        CHK(d_y[0].alloc(ctx, stv * sizeof(double2)));
+        CHK(d_y[1].alloc(ctx, stv * sizeof(double2)));
+        CHK(d_tmp.alloc(ctx, (size_t)np * ld * sizeof(double2)));
+        CHK(d_res.alloc(ctx, (size_t)np * ld * sizeof(double2)));
+        e->w_ld = ld;
+    }
     double2* Xb = X.as<double2>();
     std::vector<long long> offs;
     std::vector<int> loc(cap);
