@@ -1306,3 +1306,47 @@ def test_expm_action_matches_dense_expm(qd, seed):
                                              t_eval=t_eval, magnus_order=mo)
         assert_close(act[b].y, y_ref, SOLVE_TOL)
         assert abs(np.linalg.norm(act[b].y[-1]) - 1.0) < 1e-10
+
+
+@pytest.mark.parametrize("n,batch,m", [(63, 1, None), (64, 3, None), (65, 64, None), (127, 65, None), (128, 130, None),
+                                       (129, 2, 2), (191, 33, 3), (200, 128, None), (256, 257, None), (70, 1, 64)])
+def test_tile_boundary_shapes_rk4_and_expm(qd, n, batch, m):
+    """Sizes that straddle the 64/128 tile and split-K boundaries (n, B*m on both sides of multiples of
+    64/128; 1, few, many instances): batched RK4 and expm solves through Solver.solve vs the oracle."""
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(n * 1000 + batch)
+    k = 3
+
+    def herm():
+        a = crand(rng, n, n)
+        return (a + a.conj().T) / 2
+
+    h_static = herm()
+    h_ops = np.array([herm() for _ in range(k)])
+    frame = h_static if n % 2 else rng.normal(size=n)
+    params = [(rng.uniform(-1, 1, k), rng.uniform(0, 2, k), rng.uniform(-3, 3, k)) for _ in range(batch)]
+    sigs = [[qd.Signal(lambda t, a=a: a * np.cos(0.7 * t) + 0j, nu, ph) for a, nu, ph in zip(*p)] for p in params]
+    y0s = []
+    for _ in range(batch):
+        y = crand(rng, n) if m is None else crand(rng, n, m)
+        y0s.append(y / np.linalg.norm(y))
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=frame)
+    a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
+    check = sorted(set([0, batch // 2, batch - 1]))
+    for method, kw, t_span in (("RK4", {"max_dt": 0.01}, [0.0, 0.05]),
+                               ("scipy_expm", {"max_dt": 0.02, "magnus_order": 2}, [0.0, 0.06])):
+        res = solver.solve(t_span=t_span, y0=y0s if batch > 1 else y0s[0], signals=sigs if batch > 1 else sigs[0],
+                           method=method, **kw)
+        res = res if isinstance(res, list) else [res]
+        assert len(res) == batch
+        for b in check:
+            amps, nus, phs = params[b]
+
+            def coeff(t, amps=amps, nus=nus, phs=phs):
+                return np.array([orc.signal_sum_value(np.array([a_ * np.cos(0.7 * t) + 0j]), [nu], [ph], t)
+                                 for a_, nu, ph in zip(amps, nus, phs)])
+
+            _, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff, t_span, y0s[b], method, kw["max_dt"],
+                                                 magnus_order=kw.get("magnus_order", 1))
+            assert_close(res[b].y, y_ref, SOLVE_TOL)
