@@ -476,7 +476,12 @@ class Solver:
             return (signals, None)
         return signals
 
-    def solve(self, t_span, y0, signals=None, **kwargs):
+    def solve(self, t_span, y0, signals=None, convert_results: bool = True, **kwargs):
+        """As ``Solver.solve`` of the reference (solver_classes.py:384-554).  ``convert_results`` is
+        accepted for signature compatibility: states are plain arrays here (the qiskit
+        ``QuantumState``/``Operator`` wrappers belong to the provider shell, out of scope), so there
+        is nothing to convert."""
+        del convert_results
         (t_spans, y0s, sigs), multiple = _setup_args_lists(t_span, y0, signals)
         method = kwargs.pop("method", "RK4")
         t_eval = kwargs.get("t_eval", None)
