@@ -94,3 +94,38 @@ def gather_sweep_results(local: np.ndarray, n_total: int):
         torch.view_as_complex(o.cpu().contiguous()).numpy()[: hi - lo] for o, (lo, hi) in zip(outs, sizes)
     ])
     return full
+
+
+def solve_sweep(solver, t_span, y0, signals, **kwargs):
+    """``solver.solve`` of a list-mode sweep, sharded over the ranks of the initialised process group
+    (one process per GPU): rank r solves the contiguous shard ``shard_bounds(B, r, world)`` of the
+    ``B = len(signals)`` instances with ONE batched device solve, then the states are all-gathered so
+    that every rank returns the full list of ``OdeResult``s in sweep order.  ``y0`` is one state
+    shared by all instances or a list of B states; ``t_span`` is shared.  No per-step communication.
+    """
+    import torch.distributed as dist
+    from scipy.integrate._ivp.ivp import OdeResult
+
+    if not isinstance(signals, list) or not signals or not isinstance(signals[0], (list, tuple)):
+        raise ValueError("solve_sweep needs a list of per-instance signal lists")
+    n_total = len(signals)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_bounds(n_total, rank, world)
+    y0_is_list = isinstance(y0, list)
+    if y0_is_list and len(y0) != n_total:
+        raise ValueError("y0 list and signals list must have the same length")
+    local_t, local_y = None, None
+    if hi > lo:
+        res = solver.solve(t_span=t_span, y0=y0[lo:hi] if y0_is_list else y0, signals=signals[lo:hi], **kwargs)
+        res = res if isinstance(res, list) else [res]
+        local_t = np.asarray(res[0].t, dtype=float)
+        local_y = np.stack([np.asarray(r.y, dtype=np.complex128) for r in res])
+    # ranks with an empty shard (B < world) learn the result shape from the others
+    shapes = [None] * world
+    dist.all_gather_object(shapes, None if local_y is None else (local_y.shape[1:], local_t.tolist()))
+    known = next(s_ for s_ in shapes if s_ is not None)
+    if local_y is None:
+        local_y = np.zeros((0,) + tuple(known[0]), dtype=np.complex128)
+    full = gather_sweep_results(local_y, n_total)
+    t_out = np.asarray(known[1], dtype=float)
+    return [OdeResult(t=t_out, y=full[b]) for b in range(n_total)]

@@ -25,6 +25,41 @@ WORKER = textwrap.dedent("""
     full = gather_sweep_results(local, B)
     expect = np.array([[b + 1j * (b * b), -b + 0.5j] for b in range(B)], dtype=np.complex128)
     assert full.shape == expect.shape and np.array_equal(full, expect), (rank, full)
+    # solve_sweep: shards of uneven size, shared and per-instance y0, fewer instances than ranks
+    from scipy.integrate._ivp.ivp import OdeResult
+    from qiskit_dynamics_amd.distributed import solve_sweep
+
+    class FakeSolver:
+        # Stands in for Solver.solve (which needs a GPU): the 'solution' encodes which signals and
+        # which y0 it was given, and counts the calls (one batched solve per rank).
+        calls = 0
+
+        def solve(self, t_span, y0, signals, **kw):
+            FakeSolver.calls += 1
+            assert kw == {"method": "RK4", "max_dt": 0.1}
+            out = []
+            for i, sig in enumerate(signals):
+                y = y0[i] if isinstance(y0, list) else y0
+                out.append(OdeResult(t=np.array(t_span, dtype=float),
+                                     y=np.array([y, y * sig[0] + 1j * sig[1]], dtype=complex)))
+            return out
+
+    for n_inst in (5, 2, 1):
+        sigs = [[float(b + 1), float(10 * b)] for b in range(n_inst)]
+        y_shared = np.array([1.0 + 0j, 2.0])
+        FakeSolver.calls = 0
+        res = solve_sweep(FakeSolver(), [0.0, 1.0], y_shared, sigs, method="RK4", max_dt=0.1)
+        lo_, hi_ = shard_bounds(n_inst, rank, world)
+        assert FakeSolver.calls == (1 if hi_ > lo_ else 0)
+        assert len(res) == n_inst
+        for b in range(n_inst):
+            assert np.array_equal(res[b].t, [0.0, 1.0])
+            assert np.array_equal(res[b].y[1], y_shared * (b + 1) + 10j * b), (rank, b, res[b].y)
+        y_list = [np.array([b + 0.5j, -b]) for b in range(n_inst)]
+        res = solve_sweep(FakeSolver(), [0.0, 1.0], y_list, sigs, method="RK4", max_dt=0.1)
+        for b in range(n_inst):
+            assert np.array_equal(res[b].y[0], y_list[b])
+            assert np.array_equal(res[b].y[1], y_list[b] * (b + 1) + 10j * b)
     # max-over-ranks timing reduction used by bench.py
     import torch
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
