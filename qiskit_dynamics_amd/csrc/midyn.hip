@@ -2050,8 +2050,8 @@ struct midyn_expansion {
     DevBuf d_terms, d_post;
     // work buffers kept between solves (a solve of ~1000 small steps is a few hundred microseconds of
     // kernels; allocating ~0.5 GB of scratch per call would dominate it)
-    int w_cap = 0, w_ld = 0;
-    DevBuf X, d_mono, d_A, d_offs, d_y[2], d_tmp, d_res;
+    int w_cap = 0;
+    DevBuf X, d_mono, d_A, d_offs, d_y[2], d_tmp, d_res;   // d_y[0]: state pool, d_y[1]: per-instance half flags
     ExpmWork work;
 };
 
@@ -2108,51 +2108,55 @@ extern "C" int midyn_expansion_solve(midyn_expansion* e, int B, int nsteps, cons
     if (B <= 0 || nsteps < 0 || m <= 0) return fail(ctx, "midyn_expansion_solve: bad sizes");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int np = e->np, n = e->n, M = e->M, K = e->K;
-    const int ld = round_up(m, 64);
-    const size_t mat = (size_t)np * np, stv = (size_t)np * ld;
-    // steps per chunk: a multiple of 64 (GEMM rows), bounded like the batched expm
-    int cap = expm_chunk(ctx, np, std::max(1, nsteps));
-    cap = round_up(cap, 64);
-    DevBuf &X = e->X, &d_mono = e->d_mono, &d_A = e->d_A, &d_offs = e->d_offs, &d_tmp = e->d_tmp, &d_res = e->d_res;
-    DevBuf* d_y = e->d_y;
-    ExpmWork& w = e->work;
+    const int ldm = round_up(m, 64);                 // columns per instance on the device
+    const size_t mat = (size_t)np * np;
     const size_t inst_elems = (size_t)n * m;
+    // Instances are processed in groups whose states fit ~2 GB; inside a group ALL (instance, step)
+    // pairs are rows of one long table that is cut into chunks of `cap` rows, whatever instance
+    // they belong to: a sweep of many short solves fills the device like one long solve does.
+    const int Bg = (int)std::max<long long>(1, std::min<long long>(B, ((long long)2 << 30) / (long long)(np * (size_t)ldm * 32)));
+    int cap = round_up(expm_chunk(ctx, np, std::max(1, std::min(B, Bg) * std::max(1, nsteps))), 64);
+    DevBuf &X = e->X, &d_mono = e->d_mono, &d_A = e->d_A, &d_offs = e->d_offs, &d_tmp = e->d_tmp, &d_res = e->d_res;
+    DevBuf& Ypool = e->d_y[0];
+    DevBuf& d_flags = e->d_y[1];
+    ExpmWork& w = e->work;
     if (cap > e->w_cap) {
         CHK(X.alloc(ctx, 2 * (size_t)cap * mat * sizeof(double2)));
         CHK(d_mono.alloc(ctx, (size_t)cap * M * sizeof(double)));
         CHK(d_A.alloc(ctx, (size_t)cap * K * sizeof(double2)));
-        CHK(d_offs.alloc(ctx, (size_t)3 * cap * sizeof(long long)));
+        CHK(d_offs.alloc(ctx, (size_t)3 * 3 * cap * sizeof(long long)));  // all tree levels (< 2 cap) + applications
         e->w_cap = cap;
     } else {
         cap = e->w_cap;  // slot layout of X follows the allocated capacity
     }
-    if (ld > e->w_ld) {
-        CHK(d_y[0].alloc(ctx, stv * sizeof(double2)));
-        CHK(d_y[1].alloc(ctx, stv * sizeof(double2)));
-        CHK(d_tmp.alloc(ctx, (size_t)np * ld * sizeof(double2)));
-        CHK(d_res.alloc(ctx, (size_t)np * ld * sizeof(double2)));
-        e->w_ld = ld;
-    }
+    const int ldy = Bg * ldm;                       // leading dimension of the state pool
+    const size_t half = (size_t)np * ldy;           // elements of one ping-pong half
+    if (Ypool.bytes < 2 * half * sizeof(double2)) CHK(Ypool.alloc(ctx, 2 * half * sizeof(double2)));
+    if (d_flags.bytes < (size_t)Bg * sizeof(int)) CHK(d_flags.alloc(ctx, (size_t)Bg * sizeof(int)));
+    if (d_tmp.bytes < (size_t)Bg * inst_elems * sizeof(double2)) CHK(d_tmp.alloc(ctx, (size_t)Bg * inst_elems * sizeof(double2)));
+    if (d_res.bytes < (size_t)Bg * inst_elems * sizeof(double2)) CHK(d_res.alloc(ctx, (size_t)Bg * inst_elems * sizeof(double2)));
     double2* Xb = X.as<double2>();
+    double2* Yb = Ypool.as<double2>();
     std::vector<long long> offs;
-    std::vector<int> loc(cap);
+    std::vector<int> loc(cap), ycur(Bg), level_start, level_cnt;
     auto slot = [&](int which, int i) { return (long long)((size_t)which * cap + i) * (long long)mat; };
-    for (int b = 0; b < B; ++b) {
-        HIPCHK(ctx, hipMemsetAsync(d_y[0].p, 0, stv * sizeof(double2), ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(d_y[1].p, 0, stv * sizeof(double2), ctx->stream));
-        if (b == 0 || !y0_shared)
-            HIPCHK(ctx, hipMemcpy(d_tmp.p, y0 + (y0_shared ? 0 : (size_t)b * inst_elems), inst_elems * sizeof(double2),
-                                  hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(scatter_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
-                           d_tmp.as<double2>(), 1, 1, n, m, ld, (const double2*)nullptr, d_y[0].as<double2>(),
-                           (double2*)nullptr);
+    auto ystate = [&](int which, int b) { return (long long)((size_t)which * half + (size_t)b * ldm); };
+    for (int g0 = 0; g0 < B; g0 += Bg) {
+        const int gb = std::min(Bg, B - g0);
+        HIPCHK(ctx, hipMemsetAsync(Ypool.p, 0, 2 * half * sizeof(double2), ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_tmp.p, y0 + (y0_shared ? 0 : (size_t)g0 * inst_elems),
+                                   (y0_shared ? 1 : gb) * inst_elems * sizeof(double2), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(scatter_padded_kernel, dim3(grid_for((size_t)gb * inst_elems)), dim3(256), 0, ctx->stream,
+                           d_tmp.as<double2>(), y0_shared ? 1 : 0, gb, n, m, ldm, ldy, Yb);
         HIPCHK(ctx, hipGetLastError());
-        int cur = 0;
-        for (int c0 = 0; c0 < nsteps; c0 += cap) {
-            const int nb = std::min(cap, nsteps - c0);
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // d_tmp / host y0 may be reused
+        std::fill(ycur.begin(), ycur.begin() + gb, 0);
+        const long long rows = (long long)gb * nsteps;
+        for (long long r0 = 0; r0 < rows; r0 += cap) {
+            const int nb = (int)std::min<long long>(cap, rows - r0);
             const int T = round_up(nb, 64);
             // -- 1. monomial rows of the chunk -> complex GEMM operand (imaginary part exactly zero)
-            HIPCHK(ctx, hipMemcpy(d_mono.p, mono + ((size_t)b * nsteps + c0) * M, (size_t)nb * M * sizeof(double),
+            HIPCHK(ctx, hipMemcpy(d_mono.p, mono + ((size_t)g0 * nsteps + (size_t)r0) * M, (size_t)nb * M * sizeof(double),
                                   hipMemcpyDefault));
             hipLaunchKernelGGL(mono_operand_kernel, dim3(grid_for((size_t)T * K)), dim3(256), 0, ctx->stream,
                                d_mono.as<double>(), nb, M, e->has_const ? 1 : 0, T, K, d_A.as<double2>());
@@ -2169,31 +2173,57 @@ extern "C" int midyn_expansion_solve(midyn_expansion* e, int B, int nsteps, cons
                     std::fill(loc.begin(), loc.begin() + nb, 1);
                 }
             }
-            // -- 3. tree product of the chunk's propagators, then one application to the state
-            for (int st = 1; st < nb; st *= 2) {
-                offs.clear();
-                for (int i = 0; i + st < nb; i += 2 * st) {
-                    offs.push_back(slot(loc[i + st], i + st));  // later steps multiply from the left
-                    offs.push_back(slot(loc[i], i));
-                    offs.push_back(slot(loc[i] ^ 1, i));
-                    loc[i] ^= 1;
-                }
-                const int cnt = (int)(offs.size() / 3);
-                if (cnt == 0) continue;
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-                HIPCHK(ctx, hipMemcpy(d_offs.p, offs.data(), offs.size() * sizeof(long long), hipMemcpyHostToDevice));
-                CHK(dev_zgemm_batched(ctx, cnt, np, np, np, Xb, np, 0, Xb, np, 0, Xb, np, 0, 1.0, 0.0, nullptr,
-                                      d_offs.as<long long>()));
+            // -- 3. segments = runs of rows of one instance; tree product inside every segment, then ONE
+            //       batched application of the segment products to their instances' states.  All
+            //       offset tables of the chunk go to the device in one copy.
+            std::vector<std::pair<int, int>> segs;
+            for (int a = 0; a < nb;) {
+                const long long inst = (r0 + a) / nsteps;
+                const int eidx = (int)std::min<long long>(nb, (inst + 1) * nsteps - r0);
+                segs.emplace_back(a, eidx);
+                a = eidx;
             }
-            CHK(dev_zgemm(ctx, np, ld, np, Xb + slot(loc[0], 0), np, d_y[cur].as<double2>(), ld,
-                          d_y[cur ^ 1].as<double2>(), ld, 1.0, 0.0, nullptr));
-            cur ^= 1;
+            int longest = 0;
+            for (auto& sg : segs) longest = std::max(longest, sg.second - sg.first);
+            offs.clear();
+            level_start.clear();
+            level_cnt.clear();
+            for (int st = 1; st < longest; st *= 2) {
+                const size_t before = offs.size();
+                for (auto& sg : segs)
+                    for (int i = sg.first; i + st < sg.second; i += 2 * st) {
+                        offs.push_back(slot(loc[i + st], i + st));  // later steps multiply from the left
+                        offs.push_back(slot(loc[i], i));
+                        offs.push_back(slot(loc[i] ^ 1, i));
+                        loc[i] ^= 1;
+                    }
+                level_start.push_back((int)(before / 3));
+                level_cnt.push_back((int)((offs.size() - before) / 3));
+            }
+            const int apply_start = (int)(offs.size() / 3);
+            for (auto& sg : segs) {
+                const int bl = (int)((r0 + sg.first) / nsteps);   // instance within the group
+                offs.push_back(slot(loc[sg.first], sg.first));
+                offs.push_back(ystate(ycur[bl], bl));
+                offs.push_back(ystate(ycur[bl] ^ 1, bl));
+                ycur[bl] ^= 1;
+            }
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the previous chunk may still read d_offs
+            HIPCHK(ctx, hipMemcpy(d_offs.p, offs.data(), offs.size() * sizeof(long long), hipMemcpyHostToDevice));
+            const long long* dof = d_offs.as<long long>();
+            for (size_t lv = 0; lv < level_cnt.size(); ++lv)
+                if (level_cnt[lv] > 0)
+                    CHK(dev_zgemm_batched(ctx, level_cnt[lv], np, np, np, Xb, np, 0, Xb, np, 0, Xb, np, 0, 1.0, 0.0, nullptr,
+                                          dof + (size_t)3 * level_start[lv]));
+            CHK(dev_zgemm_batched(ctx, (int)segs.size(), np, ldm, np, Xb, np, 0, Yb, ldy, 0, Yb, ldy, 0, 1.0, 0.0, nullptr,
+                                  dof + (size_t)3 * apply_start));
         }
-        hipLaunchKernelGGL(gather_state_kernel, dim3(grid_for(inst_elems)), dim3(256), 0, ctx->stream,
-                           d_y[cur].as<double2>(), 1, n, m, ld, 1, 0, d_res.as<double2>());
+        HIPCHK(ctx, hipMemcpyAsync(d_flags.p, ycur.data(), (size_t)gb * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(gather_padded_kernel, dim3(grid_for((size_t)gb * inst_elems)), dim3(256), 0, ctx->stream, Yb,
+                           d_flags.as<int>(), half, gb, n, m, ldm, ldy, d_res.as<double2>());
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        HIPCHK(ctx, hipMemcpy(Y_out + (size_t)b * inst_elems, d_res.p, inst_elems * sizeof(double2),
+        HIPCHK(ctx, hipMemcpy(Y_out + (size_t)g0 * inst_elems, d_res.p, (size_t)gb * inst_elems * sizeof(double2),
                               hipMemcpyDeviceToHost));
     }
     return 0;

@@ -1228,6 +1228,33 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const double* src, con
     }
 }
 
+// Host batch layout [B][n][m] (or shared [n][m]) -> state pool [n_pad][ldy] with instance b in the
+// 64-aligned column block b*mpad .. b*mpad+m (every instance is its own GEMM operand), and back from
+// the ping-pong half flags[b] of the pool.
+__global__ __launch_bounds__(256) void scatter_padded_kernel(const double2* src, int shared, int B, int n, int m,
+                                                             int mpad, int ldy, double2* y) {
+    const size_t total = (size_t)B * n * m;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int b = (int)(idx / ((size_t)n * m));
+        const size_t rem = idx - (size_t)b * n * m;
+        const int i = (int)(rem / m);
+        const int j = (int)(rem - (size_t)i * m);
+        y[(size_t)i * ldy + (size_t)b * mpad + j] = shared ? src[rem] : src[idx];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_padded_kernel(const double2* y, const int* flags, size_t half, int B,
+                                                            int n, int m, int mpad, int ldy, double2* dst) {
+    const size_t total = (size_t)B * n * m;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int b = (int)(idx / ((size_t)n * m));
+        const size_t rem = idx - (size_t)b * n * m;
+        const int i = (int)(rem / m);
+        const int j = (int)(rem - (size_t)i * m);
+        dst[idx] = y[(size_t)flags[b] * half + (size_t)i * ldy + (size_t)b * mpad + j];
+    }
+}
+
 // A[t][j] = (mono[t][j], 0) for t < nb, j < M;  A[t][M] = (1, 0) when a constant term follows the
 // M expansion terms; zero padding elsewhere (row f4: GEMM operand of the polynomial evaluation)
 __global__ __launch_bounds__(256) void mono_operand_kernel(const double* mono, int nb, int M, int has_const,

@@ -399,13 +399,14 @@ class _PerturbativeSolver:
             groups.setdefault((int(nss[i]), y.shape), []).append(i)
         ident = np.eye(n, dtype=complex)
         for (steps, shape), idxs in groups.items():
-            monos, ys = [], []
-            for i in idxs:
+            mono = np.empty((len(idxs), steps, len(model.monomial_labels)), dtype=np.float64)
+            ys = []
+            for j, i in enumerate(idxs):
                 coeffs = model.approximate_signals(sgs[i], t0s[i], steps)
-                monos.append(model.monomial_table(coeffs))
+                mono[j] = compute_monomials(model.monomial_labels, coeffs).T
                 u0 = np.asarray(frame.state_out_of_frame(t0s[i], ident))
                 ys.append((u0 @ np.asarray(y0s[i], dtype=complex)).reshape(n, -1))
-            finals = model.device().solve(np.stack(monos), np.stack(ys), len(idxs), False)
+            finals = model.device().solve(mono, np.stack(ys), len(idxs), False)
             for j, i in enumerate(idxs):
                 uf = np.asarray(frame.state_into_frame(t0s[i] + steps * model.dt, ident))
                 yf = (uf @ finals[j]).reshape(shape)

@@ -1350,3 +1350,34 @@ def test_tile_boundary_shapes_rk4_and_expm(qd, n, batch, m):
             _, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff, t_span, y0s[b], method, kw["max_dt"],
                                                  magnus_order=kw.get("magnus_order", 1))
             assert_close(res[b].y, y_ref, SOLVE_TOL)
+
+
+@pytest.mark.parametrize("kind,batch,n_steps", [("magnus", 37, 50), ("dyson", 37, 50), ("magnus", 10, 500),
+                                                ("dyson", 3, 2000)])
+def test_perturbative_sweep_batched_over_instances(qd, golden, kind, batch, n_steps):
+    """List-mode sweeps of the perturbative solvers: all (instance, step) pairs are rows of one table cut
+    into device chunks (several instances per chunk; chunks that split an instance) -- against the oracle's
+    step loop instance by instance."""
+    from oracle import dynamics_oracle as orc
+
+    g = golden("perturbative")
+    r, sig_w, t_c, dt, nu = g["q1_params"]
+    cls = qd.DysonSolver if kind == "dyson" else qd.MagnusSolver
+    sol = cls(operators=g["q1_ops"], rotating_frame=g["q1_frame"], dt=dt, carrier_freqs=[nu], chebyshev_orders=[1],
+              expansion_order=6 if kind == "dyson" else 3, integration_method="DOP853", atol=1e-12, rtol=1e-12)
+    rng = np.random.default_rng(batch * 7 + n_steps)
+    amps, cents, phs = rng.uniform(0.3, 1.0, batch), rng.uniform(0.2, 3.0, batch), rng.uniform(-1, 1, batch)
+    sigs = [[qd.Signal(lambda t, a=a, c=c: a * np.exp(-((t - c) ** 2) / 0.8), carrier_freq=nu, phase=p)]
+            for a, c, p in zip(amps, cents, phs)]
+    y0s = [crand(rng, 2, 2) for _ in range(batch)]
+    res = sol.solve(t0=0.05, n_steps=n_steps, y0=y0s, signals=sigs)
+    assert len(res) == batch
+    d, basis = orc.frame_setup(g["q1_frame"])
+    terms, labels, udt = g[f"q1_{kind}_terms"], g[f"q1_{kind}_labels"], g[f"q1_{kind}_udt"]
+    for b in sorted(set([0, 1, batch // 2, batch - 1])):
+        a, c, p = amps[b], cents[b], phs[b]
+        cv = lambda t, a=a, c=c, p=p: a * np.exp(-((t - c) ** 2) / 0.8) * np.exp(1j * (2 * np.pi * nu * t + p))
+        coeffs = orc.signal_list_envelope_dct([cv], [nu], [1], 0.05, dt, n_steps)
+        want = orc.perturbative_solve(kind, terms, labels, udt, d, basis, coeffs, y0s[b], 0.05, n_steps, dt)
+        assert_close(res[b].y[-1], want, 1e-9)
+        assert_close(res[b].y[0], y0s[b], 0)

@@ -50,7 +50,19 @@ for name, cls, order in (("magnus", qd.MagnusSolver, 3), ("dyson", qd.DysonSolve
     t0 = time.perf_counter()
     y_cpu = orc.perturbative_solve(name, m.array_coefficients, labels, m.Udt, d, basis, coeffs[:, :50], y0, 0.0, 50, dt)
     t_cpu = (time.perf_counter() - t0) * n_steps / 50
+    # list-mode sweep: 256 pulse amplitudes in one call (all instance-steps are rows of one device table)
+    sweep = [[qd.Signal(lambda t, a=a: a * np.exp(-((t - 3.5 * sig_w) ** 2) / (2 * sig_w**2)), carrier_freq=5.0)] * 2
+             for a in np.linspace(0.2, 1.0, 256)]
+    sol.solve(t0=0.0, n_steps=n_steps, y0=y0, signals=sweep[:4])
+    t0 = time.perf_counter()
+    rs = sol.solve(t0=0.0, n_steps=n_steps, y0=y0, signals=sweep)
+    t_sweep = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mono = [m.monomial_table(m.approximate_signals(sg, 0.0, n_steps)) for sg in sweep]
+    t_host = time.perf_counter() - t0
     print(json.dumps({"solver": name, "order": order, "dim": dim**2, "terms": len(m.monomial_labels), "steps": n_steps,
+                      "sweep_256_instances_s": round(t_sweep, 3), "of_which_host_coefficients_s": round(t_host, 3),
+                      "sweep_instance_steps_per_s": round(256 * n_steps / t_sweep, 1),
                       "model_build_s": round(t_build, 2), "device_solve_s": round(best, 4),
                       "steps_per_s": round(n_steps / best, 1), "infidelity_vs_direct_rk4": float(fid),
                       "numpy_oracle_solve_s_extrapolated": round(t_cpu, 2)}), flush=True)
