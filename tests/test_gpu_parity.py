@@ -588,6 +588,15 @@ dist.init_process_group("nccl", rank=0, world_size=1)
 from qiskit_dynamics_amd.distributed import broadcast_stack
 s2, keep = broadcast_stack(ctx, ops, static, frame_im, n, k, src=0)
 assert np.array_equal(s2.eval_rhs(c, 0.4, y), s0.eval_rhs(c, 0.4, y))
+# the sharded form of Solver.solve list mode on the same (one-rank) NCCL group: all-gather of CUDA tensors
+from qiskit_dynamics_amd.distributed import solve_sweep
+x = np.array([[0, 1], [1, 0]], dtype=complex); z = np.diag([1.0, -1.0]).astype(complex)
+solver = qd.Solver(static_hamiltonian=5 * z, hamiltonian_operators=[x], rotating_frame=5 * z)
+sweep = [[qd.Signal(a, 5.0)] for a in (1.0, 0.5, 0.25)]
+y0 = np.array([0.0, 1.0], dtype=complex)
+got = solve_sweep(solver, [0.0, 0.4], y0, sweep, method="RK4", max_dt=0.001)
+want = solver.solve(t_span=[0.0, 0.4], y0=y0, signals=sweep, method="RK4", max_dt=0.001)
+assert len(got) == 3 and all(np.array_equal(g_.y, w_.y) and np.array_equal(g_.t, w_.t) for g_, w_ in zip(got, want))
 dist.destroy_process_group()
 print("ADOPT_OK")
 """
