@@ -116,6 +116,27 @@ def gen_signals():
     dsig2 = DiscreteSignal.from_Signal(s_gauss, dt=0.1, n_samples=20, start_time=0.0, sample_carrier=True)
     out["from_signal_carrier"] = dsig2(t)
     out["flatten_sum"] = ssum.flatten()(t)
+    # DiscreteSignalSum (signals/signals.py:612-777), add_samples (:411-439), SignalList.flatten (:805-814)
+    from qiskit_dynamics.signals import DiscreteSignalSum
+    rng = np.random.default_rng(99)
+    dss_samples = rng.normal(size=(6, 3)) + 1j * rng.normal(size=(6, 3))
+    dss = DiscreteSignalSum(dt=0.4, samples=dss_samples, start_time=-0.3, carrier_freq=np.array([0.5, 1.5, -0.7]),
+                            phase=np.array([0.1, -0.2, 0.3]))
+    out["dss_samples"] = dss_samples
+    out["dss"] = dss(t)
+    out["dss_complex"] = dss.complex_value(t)
+    out["dss_item1"] = dss[1](t)
+    out["dss_slice"] = dss[np.array([0, 2])](t)
+    dss2 = DiscreteSignalSum.from_SignalSum(ssum, dt=0.1, n_samples=20, start_time=0.0)
+    out["dss_from_sum"] = dss2(t)
+    out["dss_from_sum_samples"] = np.asarray(dss2.samples)
+    dss3 = DiscreteSignalSum.from_SignalSum(ssum, dt=0.1, n_samples=20, start_time=0.0, sample_carrier=True)
+    out["dss_from_sum_carrier"] = dss3(t)
+    d_add = DiscreteSignal(dt=0.5, samples=samples, start_time=0.25, carrier_freq=0.9, phase=0.2)
+    d_add.add_samples(6, [0.5, -0.25j])
+    out["add_samples"] = d_add(t)
+    out["add_samples_samples"] = np.asarray(d_add.samples)
+    out["list_flatten"] = SignalList([s_const, ssum, d, dss]).flatten()(t)
     save("signals", **out)
 
 

@@ -6,7 +6,7 @@ Importing the package does not touch the GPU; the first model or context does, a
 ``HipLibraryError`` if libmidyn.so or a HIP device is missing (there is no CPU fallback).
 """
 from ._lib import DynamicsError, HipLibraryError, Context, Stack, Rk4Plan, default_context
-from .signals import Signal, DiscreteSignal, SignalSum, SignalList
+from .signals import Signal, DiscreteSignal, SignalSum, DiscreteSignalSum, SignalList
 from .rotating_frame import RotatingFrame
 from .models import GeneratorModel, HamiltonianModel, LindbladModel
 from .solvers import Solver, solve_lmde, solve_ode
@@ -14,7 +14,7 @@ from .perturbative import DysonSolver, MagnusSolver, ExpansionModel
 
 __all__ = [
     "DynamicsError", "HipLibraryError", "Context", "Stack", "Rk4Plan", "default_context",
-    "Signal", "DiscreteSignal", "SignalSum", "SignalList", "RotatingFrame",
+    "Signal", "DiscreteSignal", "SignalSum", "DiscreteSignalSum", "SignalList", "RotatingFrame",
     "GeneratorModel", "HamiltonianModel", "LindbladModel", "Solver", "solve_lmde", "solve_ode",
     "DysonSolver", "MagnusSolver", "ExpansionModel",
 ]

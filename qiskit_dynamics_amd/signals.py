@@ -7,8 +7,8 @@ Mirrors the evaluation surface of the reference's ``signals/signals.py`` (``Sign
 arithmetic ORDER of the reference is kept (complex carrier argument, one ``exp``, sum over terms,
 real part) so that tables are bit-identical to ``SignalList(...)(t)`` of the reference.
 ``+``, ``-``, unary ``-``, ``*`` (the two-term product rule of the reference, :838-1000),
-``conjugate``, ``DiscreteSignal.from_Signal`` and ``flatten`` are provided so that signals can be
-built the way the reference's users build them; the composite TYPE returned by a product may differ
+``conjugate``, ``DiscreteSignal.from_Signal`` / ``add_samples``, ``DiscreteSignalSum`` (:612-777) and
+``flatten`` are provided so that signals can be built the way the reference's users build them; the composite TYPE returned by a product may differ
 from the reference's (always a ``SignalSum`` of plain ``Signal``s here), its VALUES do not.
 RWA and transfer functions are out of scope for this path.
 """
@@ -127,7 +127,7 @@ class DiscreteSignal(Signal):
                           len(self.samples))
             return self._padded_samples[idx]
 
-        super().__init__(envelope=envelope, carrier_freq=carrier_freq, phase=phase, name=name)
+        Signal.__init__(self, envelope=envelope, carrier_freq=carrier_freq, phase=phase, name=name)
 
     @classmethod
     def from_Signal(cls, signal: Signal, dt: float, n_samples: int, start_time: float = 0.0,
@@ -144,6 +144,21 @@ class DiscreteSignal(Signal):
     def conjugate(self):
         return DiscreteSignal(self._dt, np.conjugate(self.samples), start_time=self._start_time,
                               carrier_freq=-self.carrier_freq, phase=-self.phase)
+
+    def add_samples(self, start_sample: int, samples):
+        """Append ``samples`` starting at index ``start_sample``; a gap is filled with zeros
+        (signals/signals.py:411-439)."""
+        samples = np.asarray(samples)
+        if len(samples) < 1:
+            return
+        if start_sample < len(self.samples):
+            raise DynamicsError("Samples can only be added afer the last sample.")
+        zero_pad = np.expand_dims(np.zeros_like(samples[0]), 0)
+        new_samples = self.samples
+        if len(self.samples) < start_sample:
+            new_samples = np.append(new_samples, np.repeat(zero_pad, start_sample - len(self.samples)))
+        new_samples = np.append(new_samples, samples)
+        self._padded_samples = np.append(new_samples, zero_pad, axis=0)
 
     @property
     def dt(self):
@@ -223,6 +238,57 @@ class SignalSum(Signal):
         return Signal(envelope=merged, carrier_freq=ave, name=str(self))
 
 
+class DiscreteSignalSum(DiscreteSignal, SignalSum):
+    """Sum of piecewise-constant signals that share dt, number of samples and start time
+    (signals/signals.py:612-777): ``samples`` is 2-D, axis 0 = time, axis 1 = term."""
+
+    def __init__(self, dt: float, samples, start_time: float = 0.0, carrier_freq=None, phase=None,
+                 name: Optional[str] = None):
+        samples = np.asarray(samples)
+        if samples.ndim != 2:
+            raise DynamicsError("DiscreteSignalSum samples must be a 2d array (time, term).")
+        if carrier_freq is None:
+            carrier_freq = np.zeros(samples.shape[-1], dtype=float)
+        if phase is None:
+            phase = np.zeros(samples.shape[-1], dtype=float)
+        DiscreteSignal.__init__(self, dt=dt, samples=samples, start_time=start_time, carrier_freq=carrier_freq,
+                                phase=phase, name=name)
+        self._components = [
+            DiscreteSignal(dt=self.dt, samples=row, start_time=self.start_time, carrier_freq=freq, phase=phi)
+            for row, freq, phi in zip(self.samples.transpose(), np.atleast_1d(carrier_freq), np.atleast_1d(phase))]
+
+    @classmethod
+    def from_SignalSum(cls, signal_sum: SignalSum, dt: float, n_samples: int, start_time: float = 0.0,
+                       sample_carrier: bool = False):
+        """Sample every term of ``signal_sum`` at the bin mid-points (with ``sample_carrier`` the carriers
+        are folded into the samples)."""
+        times = start_time + (np.arange(n_samples) + 0.5) * dt
+        freq = signal_sum.carrier_freq
+        if sample_carrier:
+            freq = 0.0 * freq
+            samples = signal_sum.envelope(times) * np.exp(np.expand_dims(times, -1) * signal_sum._carrier_arg)
+        else:
+            samples = signal_sum.envelope(times)
+        return cls(dt, samples, start_time=start_time, carrier_freq=freq, phase=signal_sum.phase,
+                   name=signal_sum.name)
+
+    def complex_value(self, t):
+        return SignalSum.complex_value(self, t)
+
+    def conjugate(self):
+        return DiscreteSignalSum(self._dt, np.conjugate(self.samples), start_time=self._start_time,
+                                 carrier_freq=-self.carrier_freq, phase=-self.phase)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, np.integer)):
+            if idx >= len(self):
+                raise IndexError("index out of range for DiscreteSignalSum of length " + str(len(self)))
+            return self._components[idx]
+        samples = self.samples[:, idx]
+        return DiscreteSignalSum(self.dt, samples, start_time=self.start_time,
+                                 carrier_freq=np.asarray(self.carrier_freq)[idx], phase=np.asarray(self.phase)[idx])
+
+
 def _term_product(a: Signal, b: Signal) -> SignalSum:
     """Product of two elementary signals as a sum of two signals:
     Re[f e^{i x}] Re[g e^{i y}] = Re[(f g / 2) e^{i(x+y)}] + Re[(f conj(g) / 2) e^{i(x-y)}]."""
@@ -292,6 +358,10 @@ class SignalList:
 
     def __call__(self, t):
         return np.moveaxis(np.asarray([s(t) for s in self._components]), 0, -1)
+
+    def flatten(self) -> "SignalList":
+        """SignalList with every component merged into one Signal (signals/signals.py:805-814)."""
+        return SignalList([sig.flatten() for sig in self._components])
 
     @property
     def drift(self):

@@ -239,6 +239,31 @@ def test_signal_algebra_values_match_reference(golden):
     assert (qd.Signal(2.0) * qd.Signal(3.0)).components[0].is_constant
     with pytest.raises(qd.DynamicsError):
         s_gauss * "x"
+    # DiscreteSignalSum, add_samples, SignalList.flatten
+    dss = qd.DiscreteSignalSum(dt=0.4, samples=g["dss_samples"], start_time=-0.3,
+                               carrier_freq=np.array([0.5, 1.5, -0.7]), phase=np.array([0.1, -0.2, 0.3]))
+    assert_close(dss(t), g["dss"], 1e-15)
+    assert_close(dss.complex_value(t), g["dss_complex"], 1e-15)
+    assert_close(dss[1](t), g["dss_item1"], 1e-15)
+    assert_close(dss[np.array([0, 2])](t), g["dss_slice"], 1e-15)
+    assert len(dss) == 3 and isinstance(dss[0], qd.DiscreteSignal)
+    ssum = s_const + s_gauss
+    dss2 = qd.DiscreteSignalSum.from_SignalSum(ssum, dt=0.1, n_samples=20, start_time=0.0)
+    assert_close(dss2.samples, g["dss_from_sum_samples"], 0)
+    assert_close(dss2(t), g["dss_from_sum"], 1e-15)
+    dss3 = qd.DiscreteSignalSum.from_SignalSum(ssum, dt=0.1, n_samples=20, start_time=0.0, sample_carrier=True)
+    assert_close(dss3(t), g["dss_from_sum_carrier"], 1e-15)
+    d_add = qd.DiscreteSignal(dt=dt, samples=g["disc_samples"], start_time=st, carrier_freq=cf, phase=ph)
+    d_add.add_samples(6, [0.5, -0.25j])
+    assert_close(d_add.samples, g["add_samples_samples"], 0)
+    assert_close(d_add(t), g["add_samples"], 1e-15)
+    with pytest.raises(qd.DynamicsError):
+        d_add.add_samples(2, [1.0])
+    assert_close(qd.SignalList([s_const, ssum, d, dss]).flatten()(t), g["list_flatten"], 1e-15)
+    # a DiscreteSignalSum is a sum of DiscreteSignals for the device table (row f1)
+    from qiskit_dynamics_amd.signals import discrete_term_arrays
+    tp, par, rng_, smp = discrete_term_arrays([[dss, d]])
+    assert tp.tolist() == [0, 3, 4] and par.shape == (4, 4)
 
 
 def test_discrete_term_arrays_layout():
