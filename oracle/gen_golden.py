@@ -427,6 +427,37 @@ def gen_solver_list():
 
 
 # ---------------------------------------------------------------------------------------------
+def gen_rotating_frame():
+    """a5/a6/a14: RotatingFrame maps (test_rotating_frame.py scenarios re-stated on seeded inputs)."""
+    rng = np.random.default_rng(515)
+    n = 4
+    f = herm(rng, n)
+    y = crand(rng, n, 2)
+    op = crand(rng, n, n)
+    sup = crand(rng, n * n, n * n)
+    t = 0.731
+    out = {"f": f, "y": y, "op": op, "sup": sup, "t": np.array(t)}
+    rf = RotatingFrame(f)
+    out["state_into"] = rf.state_into_frame(t, y)
+    out["state_out"] = rf.state_out_of_frame(t, y)
+    out["op_into"] = rf.operator_into_frame(t, op)
+    out["op_out"] = rf.operator_out_of_frame(t, op)
+    out["gen_into"] = rf.generator_into_frame(t, op)
+    out["gen_out"] = rf.generator_out_of_frame(t, op)
+    out["vec_map"] = rf.vectorized_map_into_frame(t, sup)
+    # diagonal frame: the frame-basis flags are gauge free
+    d = rng.normal(size=n)
+    rd = RotatingFrame(d)
+    out["d"] = d
+    out["diag_state_into"] = rd.state_into_frame(t, y)
+    out["diag_gen_into"] = rd.generator_into_frame(t, op, operator_in_frame_basis=True, return_in_frame_basis=True)
+    out["diag_gen_out"] = rd.generator_out_of_frame(t, op, operator_in_frame_basis=True, return_in_frame_basis=True)
+    out["diag_vec_map"] = rd.vectorized_map_into_frame(t, sup, operator_in_frame_basis=True, return_in_frame_basis=True)
+    out["none_gen_out"] = RotatingFrame(None).generator_out_of_frame(t, op)
+    save("rotating_frame", **out)
+
+
+# ---------------------------------------------------------------------------------------------
 def _labels_array(labels):
     """Multiset labels -> (M, max_order) int array of sorted indices, padded with -1."""
     lists = [sorted(list(lab)) for lab in labels]
@@ -521,4 +552,5 @@ if __name__ == "__main__":
     gen_solve_lmde()
     gen_lindblad()
     gen_solver_list()
+    gen_rotating_frame()
     gen_perturbative()

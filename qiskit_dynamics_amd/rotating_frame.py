@@ -160,3 +160,32 @@ class RotatingFrame:
         e = np.exp(self._frame_diag * t)
         out = out * (e.conj().reshape(self.dim, 1) * e) - np.diag(self._frame_diag)
         return out if return_in_frame_basis else self.operator_out_of_frame_basis(out)
+
+    def generator_out_of_frame(self, t, operator, operator_in_frame_basis=False,
+                               return_in_frame_basis=False):
+        """exp(tF) G exp(-tF) + F  (models/rotating_frame.py:476-508)."""
+        operator = np.asarray(operator)
+        if self._frame_operator is None:
+            return operator
+        out = operator if operator_in_frame_basis else self.operator_into_frame_basis(operator)
+        e = np.exp(self._frame_diag * (-t))
+        out = out * (e.conj().reshape(self.dim, 1) * e) + np.diag(self._frame_diag)
+        return out if return_in_frame_basis else self.operator_out_of_frame_basis(out)
+
+    def vectorized_map_into_frame(self, time, op, operator_in_frame_basis=False,
+                                  return_in_frame_basis=False):
+        """Vectorised (column-stacking) linear map of dimension dim**2 into the frame:
+        ``(Delta-bar kron Delta) o op`` in the frame basis (models/rotating_frame.py:537-582; host
+        version -- the device applies the same Hadamard factor through the vectorised frame diagonal)."""
+        op = np.asarray(op)
+        if self._frame_diag is None:
+            return op
+        if not operator_in_frame_basis and self._frame_basis is not None:
+            op = self.vectorized_frame_basis_adjoint @ (op @ self.vectorized_frame_basis)
+        expvals = np.exp(self._frame_diag * time)
+        outer = (expvals.conj().reshape(self.dim, 1) * expvals).flatten()
+        op = np.outer(outer.conj(), outer) * op
+        if not return_in_frame_basis and self._frame_basis is not None:
+            op = self.vectorized_frame_basis @ (op @ self.vectorized_frame_basis_adjoint)
+        return op
+

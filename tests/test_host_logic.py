@@ -348,3 +348,26 @@ def test_perturbative_solver_argument_errors():
         complete_labels(3, None, None)
     # closure under sub-multisets + canonical order
     assert complete_labels(3, 1, [[0, 0, 2]]) == [(0,), (1,), (2,), (0, 0), (0, 2), (0, 0, 2)]
+
+
+def test_rotating_frame_maps_match_reference(golden):
+    """RotatingFrame host maps (state / operator / generator into and out of the frame, the vectorised map)
+    against values captured from the reference (models/rotating_frame.py:225-582)."""
+    g = golden("rotating_frame")
+    t = float(g["t"])
+    rf = qd.RotatingFrame(g["f"])
+    assert_close(rf.state_into_frame(t, g["y"]), g["state_into"], 1e-13)
+    assert_close(rf.state_out_of_frame(t, g["y"]), g["state_out"], 1e-13)
+    assert_close(rf.operator_into_frame(t, g["op"]), g["op_into"], 1e-13)
+    assert_close(rf.operator_out_of_frame(t, g["op"]), g["op_out"], 1e-13)
+    assert_close(rf.generator_into_frame(t, g["op"]), g["gen_into"], 1e-13)
+    assert_close(rf.generator_out_of_frame(t, g["op"]), g["gen_out"], 1e-13)
+    assert_close(rf.vectorized_map_into_frame(t, g["sup"]), g["vec_map"], 1e-12)
+    rd = qd.RotatingFrame(g["d"])
+    assert_close(rd.state_into_frame(t, g["y"]), g["diag_state_into"], 1e-14)
+    assert_close(rd.generator_into_frame(t, g["op"], True, True), g["diag_gen_into"], 1e-14)
+    assert_close(rd.generator_out_of_frame(t, g["op"], True, True), g["diag_gen_out"], 1e-14)
+    assert_close(rd.vectorized_map_into_frame(t, g["sup"], True, True), g["diag_vec_map"], 1e-14)
+    assert_close(qd.RotatingFrame(None).generator_out_of_frame(t, g["op"]), g["none_gen_out"], 0)
+    # into then out of the frame is the identity
+    assert_close(rf.generator_out_of_frame(t, rf.generator_into_frame(t, g["op"])), g["op"], 1e-12)
