@@ -304,7 +304,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import dynamics_oracle as orc
 
-        from threadpoolctl import threadpool_limits
+        from threadpoolctl import threadpool_info, threadpool_limits
 
         a_d, a = static, ops
         d = 1j * frame_im
@@ -340,7 +340,11 @@ def main():
             "value": round(best[0], 1), "unit": "RHS evals/s", "cores": best[1], "kind": "port",
             "sample": f"{n_inst} instances x {n_steps} RK4 steps ({n_inst * n_steps * 4} RHS evals) of the same "
                       f"model with the NumPy oracle (tensordot + matvec); best of BLAS thread counts 8/32/all on a "
-                      f"{os.cpu_count()}-CPU host: {best[1]} threads, {best[2]:.1f} s"}
+                      f"{os.cpu_count()}-CPU host: {best[1]} threads, {best[2]:.1f} s",
+            "host": {"cpu_count": os.cpu_count(), "numpy": np.__version__,
+                     "blas": [f"{i.get('internal_api')} {i.get('version')} ({i.get('threading_layer') or i.get('user_api')})"
+                              for i in threadpool_info()],
+                     "OPENBLAS_NUM_THREADS": os.environ.get("OPENBLAS_NUM_THREADS")}}
     # ---- optional: the complete cfg-3 solve through the public Solver API (host work included) ----
     if args.full_solve and rank == 0:
         t0f = time.perf_counter()
