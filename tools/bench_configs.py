@@ -104,6 +104,13 @@ if "cfg4" in which:
     run_modes("cfg4 (6-qubit vectorised Lindblad, N=4096, scipy_expm m=1, no frame), 1 trajectory",
               lambda: solver.solve(t_span=[0.0, nsteps * cfg["max_dt"]], y0=cfg["rho0"].flatten(order="F"),
                                    signals=sigs, method="scipy_expm", max_dt=cfg["max_dt"]), nsteps, extra4)
+    # second run of SURVEY 8(d) cfg 4: diagonal rotating frame diag(H_d)
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       static_dissipators=cfg["static_dissipators"], rotating_frame=np.diag(cfg["h_d"]).real.copy(),
+                       vectorized=True)
+    run_modes("cfg4 with the diagonal frame diag(H_d) (N=4096, scipy_expm m=1), 1 trajectory",
+              lambda: solver.solve(t_span=[0.0, nsteps * cfg["max_dt"]], y0=cfg["rho0"].flatten(order="F"),
+                                   signals=sigs, method="scipy_expm", max_dt=cfg["max_dt"]), nsteps, extra4)
     del solver
 
 if "cfg5" in which:
