@@ -1390,3 +1390,35 @@ def test_perturbative_sweep_batched_over_instances(qd, golden, kind, batch, n_st
         want = orc.perturbative_solve(kind, terms, labels, udt, d, basis, coeffs, y0s[b], 0.05, n_steps, dt)
         assert_close(res[b].y[-1], want, 1e-9)
         assert_close(res[b].y[0], y0s[b], 0)
+
+
+def test_cfg3_full_length_solve_vs_oracle(qd, cfg2):
+    """BASELINE cfg 3 at FULL length: t_span [0, 5], max_dt 0.005 -> 1000 RK4 steps (4000 RHS evaluations per
+    instance) of the n = 1024, k = 8 model, 128 instances in one batched device solve; one instance is
+    integrated by the oracle over the same 1000 steps and compared at the final time, all of them for norm
+    conservation.  (The full sweep differs only in the number of columns.)"""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    cfg, (a_d, a, d, basis), stack = cfg2
+    B = 128
+    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _rk4_points)
+    assert len(sched.step_h) == 1000
+    table, amps, phs = _table_for(cfg, range(B), sched.times)
+    y0 = np.zeros((1024, 1), dtype=complex)
+    y0[0, 0] = 1.0
+    ys = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, y0, B, True)
+    final = ys[:, -1, :, 0]
+    assert np.max(np.abs(np.linalg.norm(final, axis=1) - 1.0)) < 1e-8
+    from threadpoolctl import threadpool_limits
+
+    b = 77
+
+    def rhs(t, y):
+        c = workloads.gaussian_coefficient_table(np.array([t]), amps[b], phs[b], cfg["carrier"], 5.0)[0]
+        return orc.generator_rhs(a_d, a, c, d, None, t, y)
+
+    with threadpool_limits(limits=8):   # the oracle's matvecs run best on a few BLAS threads (see bench.py)
+        _, yref = orc.rk4_solve(rhs, cfg["t_span"], y0[:, 0], cfg["max_dt"])
+    assert_close(final[b], yref[-1], SOLVE_TOL)
