@@ -15,24 +15,66 @@ _I2 = np.eye(2, dtype=complex)
 
 
 def embed(op, q, n_qubits):
-    """op acting on qubit q of an n_qubits register (qubit 0 = leftmost Kronecker factor)."""
-    out = np.array([[1.0 + 0j]])
-    for i in range(n_qubits):
-        out = np.kron(out, op if i == q else _I2)
+    """op acting on qubit q of an n_qubits register (qubit 0 = leftmost Kronecker factor): the same
+    matrix as the chain of Kronecker products with identities, written by index arithmetic (one pass
+    over the 2^n rows per non-zero entry of `op` instead of n dense Kronecker products)."""
+    return embed_pair(op, q, None, None, n_qubits)
+
+
+def _embed_entries(op1, q1, op2, q2, n_qubits):
+    """Non-zero entries (rows, cols, value) of (op1 on qubit q1) . (op2 on qubit q2), q1 != q2 (op2 None:
+    just op1): entry (i, j) is op1[bit_q1(i), bit_q1(j)] * op2[bit_q2(i), bit_q2(j)] when all other
+    bits of i and j agree."""
+    idx = np.arange(2**n_qubits)
+    s1 = n_qubits - 1 - q1
+    s2 = None if op2 is None else n_qubits - 1 - q2
+    two = [(0, 0)] if op2 is None else [(c, d_) for c in (0, 1) for d_ in (0, 1)]
+    for a in (0, 1):
+        for b in (0, 1):
+            v1 = op1[a, b]
+            if v1 == 0:
+                continue
+            for c, d_ in two:
+                v = v1 if op2 is None else v1 * op2[c, d_]
+                if v == 0:
+                    continue
+                sel = ((idx >> s1) & 1) == a
+                if op2 is not None:
+                    sel &= ((idx >> s2) & 1) == c
+                rows = idx[sel]
+                cols = (rows & ~(1 << s1)) | (b << s1)
+                if op2 is not None:
+                    cols = (cols & ~(1 << s2)) | (d_ << s2)
+                yield rows, cols, v
+
+
+def embed_pair(op1, q1, op2, q2, n_qubits):
+    """Dense matrix of (op1 on qubit q1) . (op2 on qubit q2)."""
+    dim = 2**n_qubits
+    out = np.zeros((dim, dim), dtype=complex)
+    for rows, cols, v in _embed_entries(op1, q1, op2, q2, n_qubits):
+        out[rows, cols] = v
     return out
 
 
 def chain_hamiltonian(n_qubits, n_drives, nu0=5.0, dnu=0.05, coupling=0.002, rabi=0.02):
     """Qubit chain of SURVEY 8(d): H_d = sum_q 2 pi nu_q Z_q/2 + sum_q 2 pi J X_q X_{q+1},
-    drives H_j = 2 pi r X_j / 2.  Returns (H_d (n,n), H_ops (k,n,n), nu (n_qubits,))."""
+    drives H_j = 2 pi r X_j / 2.  Returns (H_d (n,n), H_ops (k,n,n), nu (n_qubits,)).
+    The terms are accumulated entry by entry in the order and with the arithmetic of the dense
+    expression `h_d += c * embed(...) / 2`, without its 2^n x 2^n temporaries."""
     dim = 2**n_qubits
     nu = nu0 + dnu * np.arange(n_qubits)
     h_d = np.zeros((dim, dim), dtype=complex)
     for q in range(n_qubits):
-        h_d += 2 * np.pi * nu[q] * embed(_Z, q, n_qubits) / 2
+        for rows, cols, v in _embed_entries(_Z, q, None, None, n_qubits):
+            h_d[rows, cols] += 2 * np.pi * nu[q] * v / 2
     for q in range(n_qubits - 1):
-        h_d += 2 * np.pi * coupling * (embed(_X, q, n_qubits) @ embed(_X, q + 1, n_qubits))
-    ops = np.stack([2 * np.pi * rabi * embed(_X, j, n_qubits) / 2 for j in range(n_drives)])
+        for rows, cols, v in _embed_entries(_X, q, _X, q + 1, n_qubits):
+            h_d[rows, cols] += 2 * np.pi * coupling * v
+    ops = np.zeros((n_drives, dim, dim), dtype=complex)
+    for j in range(n_drives):
+        for rows, cols, v in _embed_entries(_X, j, None, None, n_qubits):
+            ops[j][rows, cols] = 2 * np.pi * rabi * v / 2
     return h_d, ops, nu
 
 

@@ -1422,3 +1422,88 @@ def test_cfg3_full_length_solve_vs_oracle(qd, cfg2):
     with threadpool_limits(limits=8):   # the oracle's matvecs run best on a few BLAS threads (see bench.py)
         _, yref = orc.rk4_solve(rhs, cfg["t_span"], y0[:, 0], cfg["max_dt"])
     assert_close(final[b], yref[-1], SOLVE_TOL)
+
+
+def test_cfg4_full_size_vectorised_lindblad_vs_matrix_form(qd):
+    """BASELINE cfg 4 at FULL size (6 qubits, N = 4096 superoperator, 4 dissipators, scipy_expm, no
+    frame): the vectorised device propagation against an independent CPU evaluation of the same steps
+    that never forms the superoperator -- expm(h L(t_mid)) rho as a scaled Taylor series of the n x n
+    matrix form of the Lindbladian (oracle.lindblad_rhs) -- plus trace / Hermiticity / positivity."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+
+    cfg = workloads.lindblad_config()
+    assert cfg["h_d"].shape == (64, 64)
+    amps, phases = workloads.sweep_parameters(0, 6)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       static_dissipators=cfg["static_dissipators"], vectorized=True)
+    assert solver.model.stack.n == 4096
+    h = cfg["max_dt"]
+    n_steps = 3
+    t0 = 2.4
+    res = solver.solve(t_span=[t0, t0 + n_steps * h], y0=cfg["rho0"].flatten(order="F"), signals=sigs,
+                       method="scipy_expm", max_dt=h)
+    rho_dev = res.y[-1].reshape(64, 64, order="F")
+    h_d, h_ops, n_static, l_ops, d, basis = orc.lindblad_model_build(cfg["h_d"], cfg["ops"],
+                                                                     cfg["static_dissipators"], None, None)
+    rho = cfg["rho0"].astype(complex)
+    for st in range(n_steps):
+        t_mid = t0 + st * h + h / 2          # Magnus order 1: Omega = h L(t + h/2)
+        coeffs = np.array([s(t_mid) for s in sigs])
+        scal = 64                            # ||h L|| ~ 10 -> ||h L / 64|| < 0.2
+        for _ in range(scal):
+            term = rho
+            acc = rho.copy()
+            for j in range(1, 16):
+                term = orc.lindblad_rhs(h_d, h_ops, n_static, l_ops, coeffs, None, d, t_mid, term) * (h / (scal * j))
+                acc = acc + term
+            rho = acc
+    assert_close(rho_dev, rho, SOLVE_TOL)
+    assert abs(np.trace(rho_dev) - 1.0) < 1e-12
+    assert np.linalg.norm(rho_dev - rho_dev.conj().T) < 1e-12
+    assert np.min(np.linalg.eigvalsh((rho_dev + rho_dev.conj().T) / 2)) > -1e-12
+
+
+def test_cfg5_full_size_magnus2_vs_cpu_action(qd):
+    """BASELINE cfg 5 at FULL size (12 qubits, n = 4096, k = 8, diagonal rotating frame, scipy_expm with
+    magnus_order 2, max_dt 0.25): two sweep instances, one step, in one batched device solve -- against
+    a CPU evaluation of expm(Omega_2) y0 that uses the oracle's generators G(t1), G(t2) and a
+    commutator-free Taylor series (never forming Omega or its exponential) -- plus norm conservation."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+
+    cfg = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
+    frame = np.diag(cfg["h_d"]).real.copy()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
+    assert solver.model.stack.n == 4096
+
+    def sig_list(b):
+        amps, phases = workloads.sweep_parameters(b, 8)
+        return [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+                for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+
+    sweeps = [sig_list(0), sig_list(1)]
+    t0, h = 2.25, 0.25
+    res = solver.solve(t_span=[t0, t0 + h], y0=cfg["y0"], signals=sweeps, method="scipy_expm", max_dt=h,
+                       magnus_order=2)
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
+    c1, c2 = 0.5 - np.sqrt(3) / 6, 0.5 + np.sqrt(3) / 6
+    for b in range(2):
+        g1 = orc.generator_evaluate(a_d, a, np.array([s(t0 + c1 * h) for s in sweeps[b]]), d, basis, t0 + c1 * h)
+        g2 = orc.generator_evaluate(a_d, a, np.array([s(t0 + c2 * h) for s in sweeps[b]]), d, basis, t0 + c2 * h)
+
+        def omega(v):   # fixed_step_solvers.py:348-363 applied to a vector
+            u1, u2 = g1 @ v, g2 @ v
+            return (h / 2) * (u1 + u2) + (np.sqrt(3) / 12) * h * h * (g2 @ u1 - g1 @ u2)
+
+        y = cfg["y0"].astype(complex)
+        for _ in range(4):                      # ||Omega|| ~ 0.05: four scalings, Taylor degree 12
+            term, acc = y, y.copy()
+            for j in range(1, 13):
+                term = omega(term) / (4 * j)
+                acc = acc + term
+            y = acc
+        assert_close(res[b].y[-1], y, SOLVE_TOL)
+        assert abs(np.linalg.norm(res[b].y[-1]) - 1.0) < 1e-12
