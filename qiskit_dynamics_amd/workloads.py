@@ -26,6 +26,9 @@ def _embed_entries(op1, q1, op2, q2, n_qubits):
     just op1): entry (i, j) is op1[bit_q1(i), bit_q1(j)] * op2[bit_q2(i), bit_q2(j)] when all other
     bits of i and j agree."""
     idx = np.arange(2**n_qubits)
+    if q1 >= n_qubits and op2 is None:   # no such qubit: the Kronecker chain is all identities
+        yield idx, idx, 1.0 + 0j
+        return
     s1 = n_qubits - 1 - q1
     s2 = None if op2 is None else n_qubits - 1 - q2
     two = [(0, 0)] if op2 is None else [(c, d_) for c in (0, 1) for d_ in (0, 1)]
