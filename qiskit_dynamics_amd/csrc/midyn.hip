@@ -46,6 +46,7 @@ struct midyn_ctx {
     bool expm_action = true;     // few state columns: y <- expm(Omega) y as a Taylor series of matrix-vector
                                  // products instead of forming expm(Omega) (Magnus orders 1 and 2)
     bool stream_planes = true;   // single-plane stacks: the one-column kernel streams only non-zero planes
+    bool tiny_rk4 = true;        // small systems: whole RK4 solve in one persistent launch (tiny_rk4_kernel)
     bool split_k = true;
     bool combine_first = true;
     bool plane_kernel = false;  // planar two-tiles-per-barrier variant: measured 4 % SLOWER (2.43 vs 2.33 ms), kept opt-in
@@ -186,6 +187,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     else if (n == "ablate") ctx->ablate = (int)value;
     else if (n == "stream_variant") ctx->stream_variant = (int)value;
     else if (n == "stream_planes") ctx->stream_planes = value != 0;
+    else if (n == "tiny_rk4") ctx->tiny_rk4 = value != 0;
     else if (n == "expm_degree") ctx->expm_degree = (int)value;
     else if (n == "expm_action") ctx->expm_action = value != 0;
     else if (n == "split_k") ctx->split_k = value != 0;
@@ -697,6 +699,16 @@ struct DevBuf {
     T* as() { return static_cast<T*>(p); }
 };
 
+// Copy `bytes` from a host OR device pointer into device memory, ordered on the ctx stream and
+// complete on return.  (A plain hipMemcpy from a DEVICE source may return before the copy has
+// run, and it runs on the null stream, which the non-blocking ctx stream does not wait for: kernels
+// launched next would read a half-filled table.)
+static hipError_t copy_to_device_any(midyn_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    return e;
+}
+
 // 1-norms of `batch` [np][np] matrices stored back to back (one small D2H copy + stream sync)
 static int dev_norm1(midyn_ctx* ctx, const double2* A, int np, int batch, DevBuf& scratch, std::vector<double>& norms) {
     const int nchunk = std::max(1, std::min(32, np / 128));
@@ -916,6 +928,9 @@ struct midyn_rk4_plan {
     std::vector<int> save;     // [nsteps] or empty
     int cur_yin = 0;           // which yin buffer holds the input of the next stage-1
     int next_step = 0;         // next step expected (state continuity)
+    bool tiny = false;         // small system: the whole step loop runs inside tiny_rk4_kernel
+    size_t tiny_smem = 0;
+    DevBuf d_rows, d_hs, d_save;
 };
 
 // planar copy of a single-plane stack: planes[act] = the non-zero plane of active segment `act`
@@ -1057,7 +1072,7 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
     };
     if (s->k > 0) {
         // S may live on the host or on the device (midyn_sigtable_data): hipMemcpyDefault resolves it
-        hipError_t e = hipMemcpy(p->d_S.p, S, (size_t)B * R * s->k * sizeof(double), hipMemcpyDefault);
+        hipError_t e = copy_to_device_any(ctx, p->d_S.p, S, (size_t)B * R * s->k * sizeof(double));
         if (e != hipSuccess) return bail(fail(ctx, std::string("upload S: ") + hipGetErrorString(e)));
     }
     if (int r = make_phase_rows(s, times, R, p->d_times, p->d_E)) return bail(r);
@@ -1083,6 +1098,30 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
     }
     p->cur_yin = 0;
     p->next_step = 0;
+    // Small systems (rows fit one wave, active operators fit a 64 KB LDS slice): the step loop of
+    // midyn_rk4_plan_run runs inside ONE persistent kernel instead of 4 launches per step.
+    {
+        int n_act = 0;
+        (void)stack_seg_list(s, &n_act);
+        const size_t smem = ((size_t)n_act * s->n * s->n + 4 * (size_t)s->n) * sizeof(double2);
+        // n <= 16: always (measured 2-2.5x over the batched stages for 2048-4096 instances; at n = 32 the MFMA
+        // path has caught up for large sweeps); up to 64 rows when there are few columns, where the
+        // batched path would be ~10 us of launch per stage for almost no work.
+        if (ctx->tiny_rk4 && s->n <= 64 && (s->n <= 16 || p->ncol <= 64) && n_act >= 1 && smem <= 64 * 1024 &&
+            nsteps > 0) {
+            p->tiny = true;
+            p->tiny_smem = smem;
+            int st2 = p->d_rows.alloc(ctx, (size_t)3 * nsteps * sizeof(int));
+            if (!st2) st2 = p->d_hs.alloc(ctx, (size_t)nsteps * sizeof(double));
+            if (!st2 && step_save) st2 = p->d_save.alloc(ctx, (size_t)nsteps * sizeof(int));
+            if (st2) return bail(st2);
+            hipError_t e = hipMemcpy(p->d_rows.p, step_rows, (size_t)3 * nsteps * sizeof(int), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(p->d_hs.p, step_h, (size_t)nsteps * sizeof(double), hipMemcpyHostToDevice);
+            if (e == hipSuccess && step_save)
+                e = hipMemcpy(p->d_save.p, step_save, (size_t)nsteps * sizeof(int), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return bail(fail(ctx, std::string("rk4 plan (tiny) upload: ") + hipGetErrorString(e)));
+        }
+    }
     *out = p;
     return 0;
 }
@@ -1101,6 +1140,46 @@ extern "C" int midyn_rk4_plan_run(midyn_rk4_plan* p, int step_begin, int step_en
     if (step_begin < 0 || step_end > p->nsteps || step_begin > step_end)
         return fail(ctx, "midyn_rk4_plan_run: step range out of bounds");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (p->tiny) {
+        if (step_begin == step_end) return 0;
+        if (!p->save.empty())
+            for (int st = step_begin; st < step_end; ++st)
+                if (p->save[st] >= p->P && p->P > 0) return fail(ctx, "midyn_rk4_plan_run: save slot out of range");
+        TinyArgs a{};
+        a.ops = s->ops;
+        a.seg_list = stack_seg_list(s, &a.n_act);
+        a.n = s->n;
+        a.n_pad = s->n_pad;
+        a.has_static = s->has_static;
+        a.k = s->k;
+        a.S = s->k > 0 ? p->d_S.as<double>() : nullptr;
+        a.inst_stride = (long long)p->R * s->k;
+        a.E = s->has_frame ? p->d_E.as<double2>() : nullptr;
+        a.rows = p->d_rows.as<int>();
+        a.hs = p->d_hs.as<double>();
+        a.save = (!p->save.empty() && p->P > 0) ? p->d_save.as<int>() : nullptr;
+        a.step_begin = step_begin;
+        a.step_end = step_end;
+        a.ncol = p->ncol;
+        a.m = p->m;
+        a.ld = p->ld;
+        a.P = p->P;
+        a.y = p->d_y.as<double2>();
+        a.out = p->P > 0 ? p->d_out.as<double2>() : nullptr;
+        static bool attr_set[16] = {false};
+        if (!attr_set[ctx->device & 15]) {
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_rk4_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            attr_set[ctx->device & 15] = true;
+        }
+        {
+            ProfScope ps(ctx, KC_STREAM);
+            hipLaunchKernelGGL(tiny_rk4_kernel, dim3((p->ncol + 3) / 4), dim3(256), p->tiny_smem, ctx->stream, a);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        p->next_step = step_end;
+        return 0;
+    }
     for (int st = step_begin; st < step_end; ++st) {
         const int r0 = p->rows[3 * st], r1 = p->rows[3 * st + 1], r2 = p->rows[3 * st + 2];
         if (st != p->next_step) {
@@ -1798,7 +1877,7 @@ extern "C" int midyn_expm_solve(midyn_stack* s, int B, int m, int R, const doubl
     ExpmWork w;
     if (s->k > 0) {
         CHK(d_S.alloc(ctx, (size_t)B * R * s->k * sizeof(double)));
-        HIPCHK(ctx, hipMemcpy(d_S.p, S, d_S.bytes, hipMemcpyDefault));  // host or device table
+        HIPCHK(ctx, copy_to_device_any(ctx, d_S.p, S, d_S.bytes));  // host or device table
     }
     CHK(make_phase_rows(s, times, R, d_times, d_E));
     CHK(d_y[0].alloc(ctx, chunk * stv * sizeof(double2)));
@@ -1934,7 +2013,7 @@ extern "C" int midyn_parallel_solve(midyn_stack* s, int B, int m, int R, const d
     std::vector<int> loc(cap), round_start;
     for (int b = 0; b < B; ++b) {
         if (k > 0)  // host or device table (midyn_sigtable_data)
-            HIPCHK(ctx, hipMemcpy(d_S.p, S + (size_t)b * R * k, (size_t)R * k * sizeof(double), hipMemcpyDefault));
+            HIPCHK(ctx, copy_to_device_any(ctx, d_S.p, S + (size_t)b * R * k, (size_t)R * k * sizeof(double)));
         HIPCHK(ctx, hipMemsetAsync(d_y[0].p, 0, stv * sizeof(double2), ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(d_y[1].p, 0, stv * sizeof(double2), ctx->stream));
         if (b == 0 || !y0_shared)
@@ -2156,8 +2235,8 @@ extern "C" int midyn_expansion_solve(midyn_expansion* e, int B, int nsteps, cons
             const int nb = (int)std::min<long long>(cap, rows - r0);
             const int T = round_up(nb, 64);
             // -- 1. monomial rows of the chunk -> complex GEMM operand (imaginary part exactly zero)
-            HIPCHK(ctx, hipMemcpy(d_mono.p, mono + ((size_t)g0 * nsteps + (size_t)r0) * M, (size_t)nb * M * sizeof(double),
-                                  hipMemcpyDefault));
+            HIPCHK(ctx, copy_to_device_any(ctx, d_mono.p, mono + ((size_t)g0 * nsteps + (size_t)r0) * M,
+                                           (size_t)nb * M * sizeof(double)));
             hipLaunchKernelGGL(mono_operand_kernel, dim3(grid_for((size_t)T * K)), dim3(256), 0, ctx->stream,
                                d_mono.as<double>(), nb, M, e->has_const ? 1 : 0, T, K, d_A.as<double2>());
             HIPCHK(ctx, hipGetLastError());

@@ -1305,6 +1305,106 @@ __global__ __launch_bounds__(256) void gather_state_kernel(const double2* y, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tiny_rk4_kernel: a WHOLE fixed-step RK4 solve in one launch for small systems (n <= 64 rows whose
+// operator stack fits a 64 KB LDS slice): one wave per state column (instance b = column / m), lane r
+// owns row r of the state; the operator stack sits in LDS, TRANSPOSED ([seg][col][row]) so that the
+// lanes of a wave read consecutive 16-B slots while the input element u[col] is an LDS broadcast.
+// The per-stage launches of the batched path cost ~10 us each whatever the size; here a stage of a
+// 2..4-qubit model is a few hundred cycles, and thousands of sweep instances run concurrently
+// (pulse-shape sweeps of small systems are the reference's everyday workload).
+// Same arithmetic as the fused epilogue of the batched path (EPI_RK1..4): k = conj(E) o (C (E o v)).
+// ------------------------------------------------------------------------------------------------
+struct TinyArgs {
+    const double2* ops;      // [nseg][n_pad][n_pad] device stack
+    const int* seg_list;     // active segments, (seg << 2) | mode
+    int n_act, n, n_pad, has_static, k;
+    const double* S;         // [B][R][k] coefficient table (device)
+    long long inst_stride;   // R * k
+    const double2* E;        // [R][n_pad] phases or nullptr
+    const int* rows;         // [nsteps][3] table rows of every step (device)
+    const double* hs;        // [nsteps]
+    const int* save;         // [nsteps] output slot or -1 (device) or nullptr
+    int step_begin, step_end;
+    int ncol, m, ld, P;
+    double2* y;              // [n_pad][ld] state (column block), updated in place
+    double2* out;            // [B][P][n][m] saved states or nullptr
+};
+
+__global__ __launch_bounds__(256) void tiny_rk4_kernel(TinyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char tiny_smem[];
+    double2* At = reinterpret_cast<double2*>(tiny_smem);                 // [n_act][n][n] transposed
+    const int n = a.n;
+    double2* ubuf = At + (size_t)a.n_act * n * n;                        // [4 waves][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int idx = tid; idx < a.n_act * n * n; idx += 256) {
+        const int s = idx / (n * n);
+        const int rem = idx - s * n * n;
+        const int c = rem / n, r = rem - c * n;
+        At[idx] = a.ops[((size_t)(a.seg_list[s] >> 2) * a.n_pad + r) * a.n_pad + c];
+    }
+    __syncthreads();
+    const int col = blockIdx.x * 4 + wave;
+    if (col >= a.ncol) return;                 // whole wave leaves together (no further block barriers)
+    const int inst = col / a.m;
+    const bool active = lane < n;
+    const int r = active ? lane : 0;
+    double2* u = ubuf + wave * n;
+    const double* Sb = a.S ? a.S + (size_t)inst * a.inst_stride : nullptr;
+    double2 y = active ? a.y[(size_t)r * a.ld + col] : make_double2(0.0, 0.0);
+
+    // k = G(t_row) v  for the lane's row
+    auto rhs = [&](int row, double2 v) -> double2 {
+        const double2 e = a.E ? a.E[(size_t)row * a.n_pad + r] : make_double2(1.0, 0.0);
+        if (active) u[r] = a.E ? cmul(e, v) : v;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        double2 acc = make_double2(0.0, 0.0);
+        for (int s = 0; s < a.n_act; ++s) {
+            const int seg = a.seg_list[s] >> 2;
+            const double cf = (a.has_static && seg == 0) ? 1.0 : Sb[(size_t)row * a.k + (seg - a.has_static)];
+            const double2* As = At + (size_t)s * n * n + r;
+            double2 part = make_double2(0.0, 0.0);
+            for (int c = 0; c < n; ++c) {
+                const double2 av = As[(size_t)c * n];
+                const double2 uv = u[c];
+                part.x = fma(av.x, uv.x, part.x);
+                part.x = fma(-av.y, uv.y, part.x);
+                part.y = fma(av.x, uv.y, part.y);
+                part.y = fma(av.y, uv.x, part.y);
+            }
+            acc.x = fma(cf, part.x, acc.x);
+            acc.y = fma(cf, part.y, acc.y);
+        }
+        __builtin_amdgcn_wave_barrier();   // everyone has read u before the next stage overwrites it
+        return a.E ? cmul_conj_a(e, acc) : acc;
+    };
+
+    for (int st = a.step_begin; st < a.step_end; ++st) {
+        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1], r2 = a.rows[3 * st + 2];
+        const double h = a.hs[st];
+        double2 kk = rhs(r0, y);
+        double2 acc = cfma_r(h * (1.0 / 6), kk, y);
+        double2 yt = cfma_r(0.5 * h, kk, y);
+        kk = rhs(r1, yt);
+        acc = cfma_r(h * (1.0 / 3), kk, acc);
+        yt = cfma_r(0.5 * h, kk, y);
+        kk = rhs(r1, yt);
+        acc = cfma_r(h * (1.0 / 3), kk, acc);
+        yt = cfma_r(h, kk, y);
+        kk = rhs(r2, yt);
+        y = cfma_r(h * (1.0 / 6), kk, acc);
+        if (a.out && a.save && active) {
+            const int slot = a.save[st];
+            if (slot >= 0) {
+                const int j = col - inst * a.m;
+                a.out[(((size_t)inst * a.P + slot) * n + r) * a.m + j] = y;
+            }
+        }
+    }
+    if (active) a.y[(size_t)r * a.ld + col] = y;
+}
+
 // yin = E o y  (re-phasing when a step starts from a time that is not the previous step's end)
 __global__ __launch_bounds__(256) void rephase_kernel(const double2* y, const double2* e, int n_pad, int ld,
                                                       double2* yin) {

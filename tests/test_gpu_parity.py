@@ -1507,3 +1507,40 @@ def test_cfg5_full_size_magnus2_vs_cpu_action(qd):
             y = acc
         assert_close(res[b].y[-1], y, SOLVE_TOL)
         assert abs(np.linalg.norm(res[b].y[-1]) - 1.0) < 1e-12
+
+
+def test_large_device_table_sweep_small_system(qd):
+    """4096 instances of a 3-qubit model, 2000 RK4 steps, DiscreteSignal pulses: a 393 MB coefficient
+    table evaluated on the device and handed to the solver device-to-device.  (Regression: that copy
+    used to run unordered on the null stream, so the first stages could read a half-filled table --
+    wrong by 1e-5 for late instances, not reproducibly.)  Both RK4 routes -- the persistent tiny-system
+    kernel and the batched per-stage contraction -- against each other and against the oracle."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    cfg = W.schrodinger_config(3, n_drives=3)
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+    batch, steps = 4096, 2000
+    rng = np.random.default_rng(3)
+    raw = [[(rng.uniform(0.1, 1, 20) * np.exp(1j * rng.uniform(0, 1, 20)), nu, rng.uniform(0, 1)) for nu in cfg["carrier"]]
+           for _ in range(batch)]
+    sigs = [[qd.DiscreteSignal(dt=0.1, samples=s, carrier_freq=nu, phase=ph) for s, nu, ph in inst] for inst in raw]
+    res = {}
+    try:
+        for tag, flag in (("tiny", 1), ("batched", 0)):
+            ctx.set_option("tiny_rk4", flag)
+            r = solver.solve(t_span=[0.0, 2.0], y0=cfg["y0"], signals=sigs, method="RK4", max_dt=2.0 / steps)
+            res[tag] = np.array([x.y[-1] for x in r])
+    finally:
+        ctx.set_option("tiny_rk4", 1)
+    assert_close(res["batched"], res["tiny"], 1e-12)
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], cfg["h_d"])
+    for b in (0, 2811, batch - 1):
+        def coeff(t, b=b):
+            return np.array([orc.signal_sum_value(np.array([orc.discrete_envelope(s, 0.1, 0.0, t)]), [nu], [ph], t)
+                             for s, nu, ph in raw[b]])
+
+        _, yref = orc.solve_generator_model(a_d, a, d, basis, coeff, [0.0, 2.0], cfg["y0"], "RK4", 2.0 / steps)
+        assert_close(res["tiny"][b], yref[-1], SOLVE_TOL)
+        assert_close(res["batched"][b], yref[-1], SOLVE_TOL)
