@@ -1126,6 +1126,32 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
     return 0;
 }
 
+static TinyArgs tiny_args(midyn_rk4_plan* p, int step_begin, int step_end) {
+    midyn_stack* s = p->stack;
+    TinyArgs a{};
+    a.ops = s->ops;
+    a.seg_list = stack_seg_list(s, &a.n_act);
+    a.n = s->n;
+    a.n_pad = s->n_pad;
+    a.has_static = s->has_static;
+    a.k = s->k;
+    a.S = s->k > 0 ? p->d_S.as<double>() : nullptr;
+    a.inst_stride = (long long)p->R * s->k;
+    a.E = s->has_frame ? p->d_E.as<double2>() : nullptr;
+    a.rows = p->d_rows.as<int>();
+    a.hs = p->d_hs.as<double>();
+    a.save = (!p->save.empty() && p->P > 0) ? p->d_save.as<int>() : nullptr;
+    a.step_begin = step_begin;
+    a.step_end = step_end;
+    a.ncol = p->ncol;
+    a.m = p->m;
+    a.ld = p->ld;
+    a.P = p->P;
+    a.y = p->d_y.as<double2>();
+    a.out = p->P > 0 ? p->d_out.as<double2>() : nullptr;
+    return a;
+}
+
 extern "C" int midyn_rk4_plan_create(midyn_stack* s, int B, int m, int R, const double* times,
                                      const double* S, int nsteps, const int* step_rows, const double* step_h,
                                      const midyn_complex* y0, int y0_shared, midyn_rk4_plan** out) {
@@ -1145,27 +1171,7 @@ extern "C" int midyn_rk4_plan_run(midyn_rk4_plan* p, int step_begin, int step_en
         if (!p->save.empty())
             for (int st = step_begin; st < step_end; ++st)
                 if (p->save[st] >= p->P && p->P > 0) return fail(ctx, "midyn_rk4_plan_run: save slot out of range");
-        TinyArgs a{};
-        a.ops = s->ops;
-        a.seg_list = stack_seg_list(s, &a.n_act);
-        a.n = s->n;
-        a.n_pad = s->n_pad;
-        a.has_static = s->has_static;
-        a.k = s->k;
-        a.S = s->k > 0 ? p->d_S.as<double>() : nullptr;
-        a.inst_stride = (long long)p->R * s->k;
-        a.E = s->has_frame ? p->d_E.as<double2>() : nullptr;
-        a.rows = p->d_rows.as<int>();
-        a.hs = p->d_hs.as<double>();
-        a.save = (!p->save.empty() && p->P > 0) ? p->d_save.as<int>() : nullptr;
-        a.step_begin = step_begin;
-        a.step_end = step_end;
-        a.ncol = p->ncol;
-        a.m = p->m;
-        a.ld = p->ld;
-        a.P = p->P;
-        a.y = p->d_y.as<double2>();
-        a.out = p->P > 0 ? p->d_out.as<double2>() : nullptr;
+        TinyArgs a = tiny_args(p, step_begin, step_end);
         static bool attr_set[16] = {false};
         if (!attr_set[ctx->device & 15]) {
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_rk4_kernel),
@@ -1729,10 +1735,10 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
         return 0;
     };
     const double p2 = std::sqrt(3.0) / 12;
-    for (int st = 0; st < nsteps; ++st) {
+    // norm bound of Omega over the instances for one step (triangle inequality over the segments)
+    auto step_bound = [&](int st) {
         const double h = step_h[st];
         const int* rr = step_rows + 3 * st;
-        // ---- norm bound over the instances -> (degree, scaling)
         double bound = 0.0;
         for (int b = 0; b < B; ++b) {
             double gn[2] = {0.0, 0.0};
@@ -1747,6 +1753,46 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
             const double bb = magnus_order == 1 ? ah * gn[0] : 0.5 * ah * (gn[0] + gn[1]) + 2 * p2 * ah * ah * gn[0] * gn[1];
             bound = std::max(bound, bb);
         }
+        return bound;
+    };
+    if (p->tiny) {
+        // small system: the whole solve in one persistent launch (tiny_expm_kernel), the Taylor degree and
+        // scaling of every step chosen here from the same bound
+        std::vector<int> deg(nsteps), scv(nsteps);
+        for (int st = 0; st < nsteps; ++st) {
+            const double bound = step_bound(st);
+            if (!std::isfinite(bound)) return fail(ctx, "midyn_expm_solve: non-finite generator norm");
+            action_choose(bound, &deg[st], &scv[st]);
+        }
+        DevBuf d_deg, d_sc;
+        CHK(d_deg.alloc(ctx, (size_t)nsteps * sizeof(int)));
+        CHK(d_sc.alloc(ctx, (size_t)nsteps * sizeof(int)));
+        HIPCHK(ctx, hipMemcpy(d_deg.p, deg.data(), (size_t)nsteps * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(ctx, hipMemcpy(d_sc.p, scv.data(), (size_t)nsteps * sizeof(int), hipMemcpyHostToDevice));
+        for (int st = 0; st < nsteps; ++st)
+            if (step_save && step_save[st] >= P) return fail(ctx, "midyn_expm_solve: save slot out of range");
+        static bool attr_set[16] = {false};
+        if (!attr_set[ctx->device & 15]) {
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_expm_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            attr_set[ctx->device & 15] = true;
+        }
+        TinyArgs a = tiny_args(p, 0, nsteps);
+        {
+            ProfScope ps(ctx, KC_STREAM);
+            hipLaunchKernelGGL(tiny_expm_kernel, dim3((p->ncol + 3) / 4), dim3(256), p->tiny_smem, ctx->stream, a,
+                               magnus_order, d_deg.as<int>(), d_sc.as<int>());
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy(Y_out, p->d_out.p, (size_t)B * P * s->n * m * sizeof(double2), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    for (int st = 0; st < nsteps; ++st) {
+        const double h = step_h[st];
+        const int* rr = step_rows + 3 * st;
+        // ---- norm bound over the instances -> (degree, scaling)
+        double bound = step_bound(st);
         if (one) {
             for (int i = 0; i < npts; ++i)
                 CHK(launch_gen_eval(s, s->k > 0 ? p->d_S.as<double>() + (size_t)rr[i] * s->k : nullptr, plan_E(p, rr[i]),

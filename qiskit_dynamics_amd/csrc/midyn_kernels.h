@@ -1331,76 +1331,115 @@ struct TinyArgs {
     double2* out;            // [B][P][n][m] saved states or nullptr
 };
 
-__global__ __launch_bounds__(256) void tiny_rk4_kernel(TinyArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char tiny_smem[];
-    double2* At = reinterpret_cast<double2*>(tiny_smem);                 // [n_act][n][n] transposed
-    const int n = a.n;
-    double2* ubuf = At + (size_t)a.n_act * n * n;                        // [4 waves][n]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int idx = tid; idx < a.n_act * n * n; idx += 256) {
-        const int s = idx / (n * n);
-        const int rem = idx - s * n * n;
-        const int c = rem / n, r = rem - c * n;
-        At[idx] = a.ops[((size_t)(a.seg_list[s] >> 2) * a.n_pad + r) * a.n_pad + c];
+// k = G(t_row) v for the lane's row r (all lanes of the wave call it together)
+__device__ __forceinline__ double2 tiny_rhs(const TinyArgs& a, const double2* At, double2* u, const double* Sb,
+                                            int n, int r, bool active, int row, double2 v) {
+    const double2 e = a.E ? a.E[(size_t)row * a.n_pad + r] : make_double2(1.0, 0.0);
+    if (active) u[r] = a.E ? cmul(e, v) : v;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double2 acc = make_double2(0.0, 0.0);
+    for (int s = 0; s < a.n_act; ++s) {
+        const int seg = a.seg_list[s] >> 2;
+        const double cf = (a.has_static && seg == 0) ? 1.0 : Sb[(size_t)row * a.k + (seg - a.has_static)];
+        const double2* As = At + (size_t)s * n * n + r;
+        double2 part = make_double2(0.0, 0.0);
+        for (int c = 0; c < n; ++c) {
+            const double2 av = As[(size_t)c * n];
+            const double2 uv = u[c];
+            part.x = fma(av.x, uv.x, part.x);
+            part.x = fma(-av.y, uv.y, part.x);
+            part.y = fma(av.x, uv.y, part.y);
+            part.y = fma(av.y, uv.x, part.y);
+        }
+        acc.x = fma(cf, part.x, acc.x);
+        acc.y = fma(cf, part.y, acc.y);
     }
-    __syncthreads();
-    const int col = blockIdx.x * 4 + wave;
-    if (col >= a.ncol) return;                 // whole wave leaves together (no further block barriers)
-    const int inst = col / a.m;
-    const bool active = lane < n;
-    const int r = active ? lane : 0;
-    double2* u = ubuf + wave * n;
-    const double* Sb = a.S ? a.S + (size_t)inst * a.inst_stride : nullptr;
+    __builtin_amdgcn_wave_barrier();   // everyone has read u before the next product overwrites it
+    return a.E ? cmul_conj_a(e, acc) : acc;
+}
+
+// common prologue: operator stack -> LDS (transposed), wave/column bookkeeping
+#define MIDYN_TINY_PROLOGUE                                                                       \
+    extern __shared__ __attribute__((aligned(16))) char tiny_smem[];                              \
+    double2* At = reinterpret_cast<double2*>(tiny_smem);                                          \
+    const int n = a.n;                                                                            \
+    double2* ubuf = At + (size_t)a.n_act * n * n;                                                 \
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                \
+    for (int idx = tid; idx < a.n_act * n * n; idx += 256) {                                      \
+        const int s_ = idx / (n * n);                                                             \
+        const int rem_ = idx - s_ * n * n;                                                        \
+        const int c_ = rem_ / n, r_ = rem_ - c_ * n;                                              \
+        At[idx] = a.ops[((size_t)(a.seg_list[s_] >> 2) * a.n_pad + r_) * a.n_pad + c_];           \
+    }                                                                                             \
+    __syncthreads();                                                                              \
+    const int col = blockIdx.x * 4 + wave;                                                        \
+    if (col >= a.ncol) return; /* whole wave leaves together (no further block barriers) */       \
+    const int inst = col / a.m;                                                                   \
+    const bool active = lane < n;                                                                 \
+    const int r = active ? lane : 0;                                                              \
+    double2* u = ubuf + wave * n;                                                                 \
+    const double* Sb = a.S ? a.S + (size_t)inst * a.inst_stride : nullptr;                        \
     double2 y = active ? a.y[(size_t)r * a.ld + col] : make_double2(0.0, 0.0);
 
-    // k = G(t_row) v  for the lane's row
-    auto rhs = [&](int row, double2 v) -> double2 {
-        const double2 e = a.E ? a.E[(size_t)row * a.n_pad + r] : make_double2(1.0, 0.0);
-        if (active) u[r] = a.E ? cmul(e, v) : v;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        double2 acc = make_double2(0.0, 0.0);
-        for (int s = 0; s < a.n_act; ++s) {
-            const int seg = a.seg_list[s] >> 2;
-            const double cf = (a.has_static && seg == 0) ? 1.0 : Sb[(size_t)row * a.k + (seg - a.has_static)];
-            const double2* As = At + (size_t)s * n * n + r;
-            double2 part = make_double2(0.0, 0.0);
-            for (int c = 0; c < n; ++c) {
-                const double2 av = As[(size_t)c * n];
-                const double2 uv = u[c];
-                part.x = fma(av.x, uv.x, part.x);
-                part.x = fma(-av.y, uv.y, part.x);
-                part.y = fma(av.x, uv.y, part.y);
-                part.y = fma(av.y, uv.x, part.y);
-            }
-            acc.x = fma(cf, part.x, acc.x);
-            acc.y = fma(cf, part.y, acc.y);
-        }
-        __builtin_amdgcn_wave_barrier();   // everyone has read u before the next stage overwrites it
-        return a.E ? cmul_conj_a(e, acc) : acc;
-    };
+#define MIDYN_TINY_SAVE(st_)                                                                      \
+    if (a.out && a.save && active) {                                                              \
+        const int slot_ = a.save[st_];                                                            \
+        if (slot_ >= 0) a.out[(((size_t)inst * a.P + slot_) * n + r) * a.m + (col - inst * a.m)] = y; \
+    }
 
+__global__ __launch_bounds__(256) void tiny_rk4_kernel(TinyArgs a) {
+    MIDYN_TINY_PROLOGUE
     for (int st = a.step_begin; st < a.step_end; ++st) {
         const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1], r2 = a.rows[3 * st + 2];
         const double h = a.hs[st];
-        double2 kk = rhs(r0, y);
+        double2 kk = tiny_rhs(a, At, u, Sb, n, r, active, r0, y);
         double2 acc = cfma_r(h * (1.0 / 6), kk, y);
         double2 yt = cfma_r(0.5 * h, kk, y);
-        kk = rhs(r1, yt);
+        kk = tiny_rhs(a, At, u, Sb, n, r, active, r1, yt);
         acc = cfma_r(h * (1.0 / 3), kk, acc);
         yt = cfma_r(0.5 * h, kk, y);
-        kk = rhs(r1, yt);
+        kk = tiny_rhs(a, At, u, Sb, n, r, active, r1, yt);
         acc = cfma_r(h * (1.0 / 3), kk, acc);
         yt = cfma_r(h, kk, y);
-        kk = rhs(r2, yt);
+        kk = tiny_rhs(a, At, u, Sb, n, r, active, r2, yt);
         y = cfma_r(h * (1.0 / 6), kk, acc);
-        if (a.out && a.save && active) {
-            const int slot = a.save[st];
-            if (slot >= 0) {
-                const int j = col - inst * a.m;
-                a.out[(((size_t)inst * a.P + slot) * n + r) * a.m + j] = y;
+        MIDYN_TINY_SAVE(st)
+    }
+    if (active) a.y[(size_t)r * a.ld + col] = y;
+}
+
+// The expm ACTION of the Magnus-1/2 step (see expm_action_solve) for small systems, whole solve in
+// one launch: per step the host-chosen Taylor degree deg[st] and scaling sc[st], products through
+// tiny_rhs.  order 1: Omega v = h G(t1) v;  order 2: h/2 (g1 v + g2 v) + sqrt(3)/12 h^2 (g2 g1 v - g1 g2 v).
+__global__ __launch_bounds__(256) void tiny_expm_kernel(TinyArgs a, int magnus_order, const int* deg, const int* sc) {
+    MIDYN_TINY_PROLOGUE
+    const double p2 = 0.14433756729740643;  // sqrt(3) / 12
+    for (int st = a.step_begin; st < a.step_end; ++st) {
+        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];
+        const double h = a.hs[st];
+        const int p = deg[st], s = sc[st];
+        for (int rep = 0; rep < s; ++rep) {
+            double2 acc = y, term = y;
+            for (int j = 1; j <= p; ++j) {
+                const double f = 1.0 / ((double)s * j);
+                if (magnus_order == 1) {
+                    const double2 kk = tiny_rhs(a, At, u, Sb, n, r, active, r0, term);
+                    term = make_double2(h * f * kk.x, h * f * kk.y);
+                } else {
+                    const double2 u1 = tiny_rhs(a, At, u, Sb, n, r, active, r0, term);
+                    const double2 u2 = tiny_rhs(a, At, u, Sb, n, r, active, r1, term);
+                    const double2 v1 = tiny_rhs(a, At, u, Sb, n, r, active, r1, u1);
+                    const double2 v2 = tiny_rhs(a, At, u, Sb, n, r, active, r0, u2);
+                    const double ca = 0.5 * h * f, cb = p2 * h * h * f;
+                    term = make_double2(ca * (u1.x + u2.x) + cb * (v1.x - v2.x), ca * (u1.y + u2.y) + cb * (v1.y - v2.y));
+                }
+                acc.x += term.x;
+                acc.y += term.y;
             }
+            y = acc;
         }
+        MIDYN_TINY_SAVE(st)
     }
     if (active) a.y[(size_t)r * a.ld + col] = y;
 }
