@@ -59,6 +59,11 @@ struct midyn_ctx {
     double cls_ms[KC_COUNT] = {0};
     double cls_n[KC_COUNT] = {0};
     int* d_one_seg = nullptr;  // device int {0, 1}: single-segment lists for plain zgemm (dense A / real-only A)
+    // device-memory pool: DevBuf blocks are recycled instead of hipMalloc/hipFree'd (a small solve is a
+    // few hundred microseconds of kernels; a dozen allocations per call used to cost milliseconds)
+    std::vector<std::pair<size_t, void*>> mem_pool;  // (capacity, block)
+    size_t mem_pool_bytes = 0;
+    static constexpr size_t POOL_MAX_BYTES = (size_t)2 << 30, POOL_MAX_BLOCK = (size_t)256 << 20;
     double* h_pinned = nullptr;                  // pinned host scratch for small device-to-host results (norms)
     static constexpr size_t PINNED_DOUBLES = 1 << 17;
     int num_cu = 256;
@@ -162,6 +167,8 @@ extern "C" int midyn_ctx_destroy(midyn_ctx* ctx) {
     for (auto e : ctx->pool) hipEventDestroy(e);
     if (ctx->d_one_seg) hipFree(ctx->d_one_seg);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    for (auto& blk : ctx->mem_pool) hipFree(blk.second);
+    ctx->mem_pool.clear();
     if (ctx->splitk_ws) hipFree(ctx->splitk_ws);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -683,16 +690,60 @@ static int dev_lincomb(midyn_ctx* ctx, int n, double2* out, int nterms, const do
 // simple device buffer holder
 struct DevBuf {
     void* p = nullptr;
-    size_t bytes = 0;
-    ~DevBuf() {
-        if (p) hipFree(p);
+    size_t bytes = 0;      // requested size
+    size_t cap = 0;        // capacity of the block (>= bytes)
+    midyn_ctx* owner = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (!p) return;
+        if (owner && cap <= midyn_ctx::POOL_MAX_BLOCK && owner->mem_pool_bytes + cap <= midyn_ctx::POOL_MAX_BYTES) {
+            owner->mem_pool.emplace_back(cap, p);
+            owner->mem_pool_bytes += cap;
+        } else {
+            hipFree(p);
+        }
+        p = nullptr;
+        bytes = cap = 0;
     }
     int alloc(midyn_ctx* ctx, size_t b) {
-        if (p) hipFree(p);
-        p = nullptr;
+        release();
         bytes = b;
+        owner = ctx;
         if (b == 0) return 0;
-        HIPCHK(ctx, hipMalloc(&p, b));
+        const size_t want = (b + 4095) / 4096 * 4096;
+        // best fit among cached blocks of capacity in [want, 2 want]
+        int best = -1;
+        for (int i = 0; i < (int)ctx->mem_pool.size(); ++i) {
+            const size_t c = ctx->mem_pool[i].first;
+            if (c >= want && c <= 2 * want && (best < 0 || c < ctx->mem_pool[best].first)) best = i;
+        }
+        if (best >= 0) {
+            // a recycled block may still be read by kernels queued before it was released, and the
+            // caller may fill it with a host-synchronous (null-stream) copy: drain the stream first
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            cap = ctx->mem_pool[best].first;
+            p = ctx->mem_pool[best].second;
+            ctx->mem_pool_bytes -= cap;
+            ctx->mem_pool.erase(ctx->mem_pool.begin() + best);
+            return 0;
+        }
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess && !ctx->mem_pool.empty()) {  // out of memory: give the cache back and retry
+            (void)hipGetLastError();
+            for (auto& blk : ctx->mem_pool) hipFree(blk.second);
+            ctx->mem_pool.clear();
+            ctx->mem_pool_bytes = 0;
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) {
+            p = nullptr;
+            bytes = 0;
+            return fail(ctx, std::string("hipMalloc: ") + hipGetErrorString(e));
+        }
+        cap = want;
         return 0;
     }
     template <class T>
@@ -1103,12 +1154,13 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
     {
         int n_act = 0;
         (void)stack_seg_list(s, &n_act);
-        const size_t smem = ((size_t)n_act * s->n * s->n + 4 * (size_t)s->n) * sizeof(double2);
+        const size_t smem = ((size_t)n_act * s->n * s->n + 4 * (size_t)s->n) * sizeof(double2) +
+                            (size_t)4 * 2 * 3 * std::max(1, s->k) * sizeof(double) + (size_t)n_act * sizeof(int);
         // n <= 16: always (measured 2-2.5x over the batched stages for 2048-4096 instances; at n = 32 the MFMA
         // path has caught up for large sweeps); up to 64 rows when there are few columns, where the
         // batched path would be ~10 us of launch per stage for almost no work.
         if (ctx->tiny_rk4 && s->n <= 64 && (s->n <= 16 || p->ncol <= 64) && n_act >= 1 && smem <= 64 * 1024 &&
-            nsteps > 0) {
+            s->k <= 42 && nsteps > 0) {
             p->tiny = true;
             p->tiny_smem = smem;
             int st2 = p->d_rows.alloc(ctx, (size_t)3 * nsteps * sizeof(int));

@@ -1331,40 +1331,63 @@ struct TinyArgs {
     double2* out;            // [B][P][n][m] saved states or nullptr
 };
 
-// k = G(t_row) v for the lane's row r (all lanes of the wave call it together)
-__device__ __forceinline__ double2 tiny_rhs(const TinyArgs& a, const double2* At, double2* u, const double* Sb,
-                                            int n, int r, bool active, int row, double2 v) {
-    const double2 e = a.E ? a.E[(size_t)row * a.n_pad + r] : make_double2(1.0, 0.0);
-    if (active) u[r] = a.E ? cmul(e, v) : v;
+// k = G(t) v for the lane's row r (all lanes of the wave call it together); e = E(t)[r], cf = the
+// coefficient row of that time in LDS (one double per operator, static operator excluded)
+__device__ __forceinline__ double2 tiny_rhs(bool has_e, int n_act, const int* cidx, const double2* At, double2* u,
+                                            const double* cf_row, int n, int r, bool active, double2 e, double2 v) {
+    if (active) u[r] = has_e ? cmul(e, v) : v;
+    // LDS operations of one wave execute in order, so the reads below see every lane's write; only the
+    // compiler must be kept from moving them (no fence: it would also wait for the global prefetches)
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     double2 acc = make_double2(0.0, 0.0);
-    for (int s = 0; s < a.n_act; ++s) {
-        const int seg = a.seg_list[s] >> 2;
-        const double cf = (a.has_static && seg == 0) ? 1.0 : Sb[(size_t)row * a.k + (seg - a.has_static)];
+    for (int s = 0; s < n_act; ++s) {
+        const int ci = cidx[s];                        // -1: static operator (coefficient 1)
+        const double cf = ci < 0 ? 1.0 : cf_row[ci];
         const double2* As = At + (size_t)s * n * n + r;
-        double2 part = make_double2(0.0, 0.0);
-        for (int c = 0; c < n; ++c) {
-            const double2 av = As[(size_t)c * n];
-            const double2 uv = u[c];
-            part.x = fma(av.x, uv.x, part.x);
-            part.x = fma(-av.y, uv.y, part.x);
-            part.y = fma(av.x, uv.y, part.y);
-            part.y = fma(av.y, uv.x, part.y);
+        double2 p0 = make_double2(0.0, 0.0), p1 = make_double2(0.0, 0.0);
+        int c = 0;
+        for (; c + 2 <= n; c += 2) {                   // two independent chains, loads issued together
+            const double2 a0 = As[(size_t)c * n], a1 = As[(size_t)(c + 1) * n];
+            const double2 u0 = u[c], u1 = u[c + 1];
+            p0.x = fma(a0.x, u0.x, p0.x);
+            p0.y = fma(a0.x, u0.y, p0.y);
+            p1.x = fma(a1.x, u1.x, p1.x);
+            p1.y = fma(a1.x, u1.y, p1.y);
+            p0.x = fma(-a0.y, u0.y, p0.x);
+            p0.y = fma(a0.y, u0.x, p0.y);
+            p1.x = fma(-a1.y, u1.y, p1.x);
+            p1.y = fma(a1.y, u1.x, p1.y);
         }
-        acc.x = fma(cf, part.x, acc.x);
-        acc.y = fma(cf, part.y, acc.y);
+        if (c < n) {
+            const double2 a0 = As[(size_t)c * n];
+            const double2 u0 = u[c];
+            p0.x = fma(a0.x, u0.x, p0.x);
+            p0.y = fma(a0.x, u0.y, p0.y);
+            p0.x = fma(-a0.y, u0.y, p0.x);
+            p0.y = fma(a0.y, u0.x, p0.y);
+        }
+        acc.x = fma(cf, p0.x + p1.x, acc.x);
+        acc.y = fma(cf, p0.y + p1.y, acc.y);
     }
     __builtin_amdgcn_wave_barrier();   // everyone has read u before the next product overwrites it
-    return a.E ? cmul_conj_a(e, acc) : acc;
+    return has_e ? cmul_conj_a(e, acc) : acc;
 }
 
-// common prologue: operator stack -> LDS (transposed), wave/column bookkeeping
+// common prologue: operator stack -> LDS (transposed), wave/column bookkeeping.  LDS per workgroup:
+// At [n_act][n][n] | u [4 waves][n] | coefficient rows [4 waves][2 buffers][3 rows][k]
 #define MIDYN_TINY_PROLOGUE                                                                       \
     extern __shared__ __attribute__((aligned(16))) char tiny_smem[];                              \
     double2* At = reinterpret_cast<double2*>(tiny_smem);                                          \
     const int n = a.n;                                                                            \
     double2* ubuf = At + (size_t)a.n_act * n * n;                                                 \
+    double* cbuf_all = reinterpret_cast<double*>(ubuf + 4 * n);                                   \
+    int* cidx = reinterpret_cast<int*>(cbuf_all + (size_t)4 * 2 * 3 * (a.k > 0 ? a.k : 1));        \
+    const bool has_e = a.E != nullptr;                                                            \
+    const int n_act = a.n_act;                                                                    \
+    if (threadIdx.x < a.n_act) {                                                                  \
+        const int seg_ = a.seg_list[threadIdx.x] >> 2;                                            \
+        cidx[threadIdx.x] = (a.has_static && seg_ == 0) ? -1 : seg_ - a.has_static;               \
+    }                                                                                             \
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                                \
     for (int idx = tid; idx < a.n_act * n * n; idx += 256) {                                      \
         const int s_ = idx / (n * n);                                                             \
@@ -1379,67 +1402,155 @@ __device__ __forceinline__ double2 tiny_rhs(const TinyArgs& a, const double2* At
     const bool active = lane < n;                                                                 \
     const int r = active ? lane : 0;                                                              \
     double2* u = ubuf + wave * n;                                                                 \
+    const int kk_ = a.k > 0 ? a.k : 1;                                                            \
+    double* cbuf = cbuf_all + (size_t)wave * 2 * 3 * kk_;                                         \
     const double* Sb = a.S ? a.S + (size_t)inst * a.inst_stride : nullptr;                        \
     double2 y = active ? a.y[(size_t)r * a.ld + col] : make_double2(0.0, 0.0);
 
-#define MIDYN_TINY_SAVE(st_)                                                                      \
-    if (a.out && a.save && active) {                                                              \
-        const int slot_ = a.save[st_];                                                            \
-        if (slot_ >= 0) a.out[(((size_t)inst * a.P + slot_) * n + r) * a.m + (col - inst * a.m)] = y; \
+// Software pipeline over the steps (a wave issues in order, so a load whose address depends on another
+// load would stall the whole step): iteration st issues (1) the loads of the step TABLE entries (rows,
+// h, save slot) of step st+2, (2) the phase / coefficient loads of step st+1 through the table entries
+// fetched one iteration earlier, then computes step st from registers / LDS filled an iteration ago.
+// Global-memory latency (~1 us, twice for the dependent pair) is thereby off the critical path.
+#define MIDYN_TINY_FETCH(ra_, rb_, rc_, e0_, e1_, e2_, cval_)                                     \
+    {                                                                                             \
+        if (a.E) {                                                                                \
+            e0_ = a.E[(size_t)(ra_) * a.n_pad + r];                                               \
+            e1_ = a.E[(size_t)(rb_) * a.n_pad + r];                                               \
+            e2_ = a.E[(size_t)(rc_) * a.n_pad + r];                                               \
+        }                                                                                         \
+        for (int q_ = 0; q_ < TINY_CQ; ++q_) {                                                    \
+            const int i_ = lane + 64 * q_;                                                        \
+            const int which_ = i_ / kk_;                                                          \
+            const int row_ = which_ == 0 ? (ra_) : (which_ == 1 ? (rb_) : (rc_));                 \
+            cval_[q_] = (Sb && i_ < 3 * a.k) ? Sb[(size_t)row_ * a.k + (i_ - which_ * kk_)] : 0.0; \
+        }                                                                                         \
+    }
+struct TinyStep {
+    int r0, r1, r2, save;
+    double h;
+};
+__device__ __forceinline__ TinyStep tiny_step_entry(const TinyArgs& a, int st) {
+    TinyStep t;
+    t.r0 = a.rows[3 * st];
+    t.r1 = a.rows[3 * st + 1];
+    t.r2 = a.rows[3 * st + 2];
+    t.h = a.hs[st];
+    t.save = a.save ? a.save[st] : -1;
+    return t;
+}
+#define MIDYN_TINY_STASH(buf_, cval_)                                                             \
+    {                                                                                             \
+        for (int q_ = 0; q_ < TINY_CQ; ++q_) {                                                    \
+            const int i_ = lane + 64 * q_;                                                        \
+            if (i_ < 3 * a.k) cbuf[(size_t)(buf_) * 3 * kk_ + i_] = cval_[q_];                    \
+        }                                                                                         \
+        __builtin_amdgcn_wave_barrier();                                                          \
+    }
+
+#define MIDYN_TINY_SAVE(slot_)                                                                    \
+    if (a.out && active && (slot_) >= 0)                                                          \
+        a.out[(((size_t)inst * a.P + (slot_)) * n + r) * a.m + (col - inst * a.m)] = y;
+
+constexpr int TINY_CQ = 2;  // coefficient values fetched per lane: supports 3 k <= 128 (k <= 42 operators)
+
+// pipeline prologue shared by the two kernels: cur = entry of the first step (its data fetched and
+// stashed), nxt = entry of the second step
+#define MIDYN_TINY_PIPE_PROLOGUE                                                                  \
+    const double2 one = make_double2(1.0, 0.0);                                                   \
+    double2 e0 = one, e1 = one, e2 = one, f0 = one, f1 = one, f2 = one;                           \
+    double cv[TINY_CQ], cn[TINY_CQ];                                                              \
+    TinyStep cur{0, 0, 0, -1, 0.0}, nxt{0, 0, 0, -1, 0.0}, nn{0, 0, 0, -1, 0.0};                  \
+    if (a.step_begin < a.step_end) {                                                              \
+        cur = tiny_step_entry(a, a.step_begin);                                                   \
+        if (a.step_begin + 1 < a.step_end) nxt = tiny_step_entry(a, a.step_begin + 1);            \
+        MIDYN_TINY_FETCH(cur.r0, cur.r1, cur.r2, e0, e1, e2, cv)                                  \
+        MIDYN_TINY_STASH(0, cv)                                                                   \
+    }                                                                                             \
+    int cb = 0;
+#define MIDYN_TINY_PIPE_ISSUE(st_)                                                                \
+    if ((st_) + 2 < a.step_end) nn = tiny_step_entry(a, (st_) + 2);                               \
+    if ((st_) + 1 < a.step_end) MIDYN_TINY_FETCH(nxt.r0, nxt.r1, nxt.r2, f0, f1, f2, cn)
+#define MIDYN_TINY_PIPE_ROTATE(st_)                                                               \
+    if ((st_) + 1 < a.step_end) {                                                                 \
+        MIDYN_TINY_STASH(cb ^ 1, cn)                                                              \
+        e0 = f0;                                                                                  \
+        e1 = f1;                                                                                  \
+        e2 = f2;                                                                                  \
+        cb ^= 1;                                                                                  \
+        cur = nxt;                                                                                \
+        nxt = nn;                                                                                 \
     }
 
 __global__ __launch_bounds__(256) void tiny_rk4_kernel(TinyArgs a) {
     MIDYN_TINY_PROLOGUE
+    MIDYN_TINY_PIPE_PROLOGUE
     for (int st = a.step_begin; st < a.step_end; ++st) {
-        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1], r2 = a.rows[3 * st + 2];
-        const double h = a.hs[st];
-        double2 kk = tiny_rhs(a, At, u, Sb, n, r, active, r0, y);
+        MIDYN_TINY_PIPE_ISSUE(st)
+        const double* c0 = cbuf + (size_t)cb * 3 * kk_;
+        const double *c1 = c0 + kk_, *c2 = c0 + 2 * kk_;
+        const double h = cur.h;
+        double2 kk = tiny_rhs(has_e, n_act, cidx, At, u, c0, n, r, active, e0, y);
         double2 acc = cfma_r(h * (1.0 / 6), kk, y);
         double2 yt = cfma_r(0.5 * h, kk, y);
-        kk = tiny_rhs(a, At, u, Sb, n, r, active, r1, yt);
+        kk = tiny_rhs(has_e, n_act, cidx, At, u, c1, n, r, active, e1, yt);
         acc = cfma_r(h * (1.0 / 3), kk, acc);
         yt = cfma_r(0.5 * h, kk, y);
-        kk = tiny_rhs(a, At, u, Sb, n, r, active, r1, yt);
+        kk = tiny_rhs(has_e, n_act, cidx, At, u, c1, n, r, active, e1, yt);
         acc = cfma_r(h * (1.0 / 3), kk, acc);
         yt = cfma_r(h, kk, y);
-        kk = tiny_rhs(a, At, u, Sb, n, r, active, r2, yt);
+        kk = tiny_rhs(has_e, n_act, cidx, At, u, c2, n, r, active, e2, yt);
         y = cfma_r(h * (1.0 / 6), kk, acc);
-        MIDYN_TINY_SAVE(st)
+        MIDYN_TINY_SAVE(cur.save)
+        MIDYN_TINY_PIPE_ROTATE(st)
     }
     if (active) a.y[(size_t)r * a.ld + col] = y;
 }
 
 // The expm ACTION of the Magnus-1/2 step (see expm_action_solve) for small systems, whole solve in
-// one launch: per step the host-chosen Taylor degree deg[st] and scaling sc[st], products through
-// tiny_rhs.  order 1: Omega v = h G(t1) v;  order 2: h/2 (g1 v + g2 v) + sqrt(3)/12 h^2 (g2 g1 v - g1 g2 v).
+// one launch: per step the host-chosen Taylor degree and scaling (packed as deg | sc << 8 in the
+// third row slot of the step table, which Magnus orders 1 and 2 do not use), products through tiny_rhs.
+// order 1: Omega v = h G(t1) v;  order 2: h/2 (g1 v + g2 v) + sqrt(3)/12 h^2 (g2 g1 v - g1 g2 v).
 __global__ __launch_bounds__(256) void tiny_expm_kernel(TinyArgs a, int magnus_order, const int* deg, const int* sc) {
     MIDYN_TINY_PROLOGUE
     const double p2 = 0.14433756729740643;  // sqrt(3) / 12
+    MIDYN_TINY_PIPE_PROLOGUE
+    int p_cur = a.step_begin < a.step_end ? deg[a.step_begin] : 0, s_cur = a.step_begin < a.step_end ? sc[a.step_begin] : 0;
+    int p_nxt = 0, s_nxt = 0;
     for (int st = a.step_begin; st < a.step_end; ++st) {
-        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];
-        const double h = a.hs[st];
-        const int p = deg[st], s = sc[st];
+        if (st + 1 < a.step_end) {
+            p_nxt = deg[st + 1];
+            s_nxt = sc[st + 1];
+        }
+        MIDYN_TINY_PIPE_ISSUE(st)
+        const double* c0 = cbuf + (size_t)cb * 3 * kk_;
+        const double* c1 = c0 + kk_;
+        const double h = cur.h;
+        const int p = p_cur, s = s_cur;
         for (int rep = 0; rep < s; ++rep) {
             double2 acc = y, term = y;
             for (int j = 1; j <= p; ++j) {
                 const double f = 1.0 / ((double)s * j);
                 if (magnus_order == 1) {
-                    const double2 kk = tiny_rhs(a, At, u, Sb, n, r, active, r0, term);
+                    const double2 kk = tiny_rhs(has_e, n_act, cidx, At, u, c0, n, r, active, e0, term);
                     term = make_double2(h * f * kk.x, h * f * kk.y);
                 } else {
-                    const double2 u1 = tiny_rhs(a, At, u, Sb, n, r, active, r0, term);
-                    const double2 u2 = tiny_rhs(a, At, u, Sb, n, r, active, r1, term);
-                    const double2 v1 = tiny_rhs(a, At, u, Sb, n, r, active, r1, u1);
-                    const double2 v2 = tiny_rhs(a, At, u, Sb, n, r, active, r0, u2);
-                    const double ca = 0.5 * h * f, cb = p2 * h * h * f;
-                    term = make_double2(ca * (u1.x + u2.x) + cb * (v1.x - v2.x), ca * (u1.y + u2.y) + cb * (v1.y - v2.y));
+                    const double2 u1 = tiny_rhs(has_e, n_act, cidx, At, u, c0, n, r, active, e0, term);
+                    const double2 u2 = tiny_rhs(has_e, n_act, cidx, At, u, c1, n, r, active, e1, term);
+                    const double2 v1 = tiny_rhs(has_e, n_act, cidx, At, u, c1, n, r, active, e1, u1);
+                    const double2 v2 = tiny_rhs(has_e, n_act, cidx, At, u, c0, n, r, active, e0, u2);
+                    const double ca = 0.5 * h * f, cb2 = p2 * h * h * f;
+                    term = make_double2(ca * (u1.x + u2.x) + cb2 * (v1.x - v2.x), ca * (u1.y + u2.y) + cb2 * (v1.y - v2.y));
                 }
                 acc.x += term.x;
                 acc.y += term.y;
             }
             y = acc;
         }
-        MIDYN_TINY_SAVE(st)
+        MIDYN_TINY_SAVE(cur.save)
+        MIDYN_TINY_PIPE_ROTATE(st)
+        p_cur = p_nxt;
+        s_cur = s_nxt;
     }
     if (active) a.y[(size_t)r * a.ld + col] = y;
 }

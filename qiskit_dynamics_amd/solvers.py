@@ -116,6 +116,28 @@ class FixedStepSchedule:
         return self.t_list, y
 
 
+_SCHEDULE_CACHE: "dict" = {}
+_SCHEDULE_CACHE_MAX = 16
+
+
+def _cached_schedule(t_span, t_eval, max_dt, tag, points) -> FixedStepSchedule:
+    """Schedules are pure functions of (t_span, t_eval, max_dt, method points): repeated solves of the
+    same time grid (optimisation loops) reuse them instead of re-walking thousands of steps in Python."""
+    try:
+        key = (tuple(np.asarray(t_span, dtype=float).ravel().tolist()),
+               None if t_eval is None else tuple(np.asarray(t_eval, dtype=float).ravel().tolist()),
+               float(max_dt), tag)
+    except (TypeError, ValueError):
+        return FixedStepSchedule(t_span, t_eval, max_dt, points)
+    sched = _SCHEDULE_CACHE.get(key)
+    if sched is None:
+        sched = FixedStepSchedule(t_span, t_eval, max_dt, points)
+        if len(_SCHEDULE_CACHE) >= _SCHEDULE_CACHE_MAX:
+            _SCHEDULE_CACHE.pop(next(iter(_SCHEDULE_CACHE)))
+        _SCHEDULE_CACHE[key] = sched
+    return sched
+
+
 def _rk4_points(t, h):
     h2 = 0.5 * h
     return [t, t + h2, t + h]
@@ -305,10 +327,13 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
         if kind == "lindblad":
             raise DynamicsError(
                 "LMDE-specific methods with LindbladModel requires setting a vectorized=True.")
-        points = _rk4_points if method in RK4_PARALLEL_METHODS else _magnus_points(magnus_order)
-        sched = FixedStepSchedule(t_span, t_eval, max_dt, points)
+        if method in RK4_PARALLEL_METHODS:
+            sched = _cached_schedule(t_span, t_eval, max_dt, "rk4", _rk4_points)
+        else:
+            sched = _cached_schedule(t_span, t_eval, max_dt, ("magnus", int(magnus_order)),
+                                     _magnus_points(magnus_order))
     elif method in RK4_METHODS:
-        sched = FixedStepSchedule(t_span, t_eval, max_dt, _rk4_points)
+        sched = _cached_schedule(t_span, t_eval, max_dt, "rk4", _rk4_points)
     else:
         raise DynamicsError(f"Method {method} not supported by solve_lmde.")
     batch = len(y0_list)
