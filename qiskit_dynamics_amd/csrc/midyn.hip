@@ -1159,7 +1159,10 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
         // n <= 16: always (measured 2-2.5x over the batched stages for 2048-4096 instances; at n = 32 the MFMA
         // path has caught up for large sweeps); up to 64 rows when there are few columns, where the
         // batched path would be ~10 us of launch per stage for almost no work.
-        if (ctx->tiny_rk4 && s->n <= 64 && (s->n <= 16 || p->ncol <= 64) && n_act >= 1 && smem <= 64 * 1024 &&
+        // LDS: 64 KB slices (two or more workgroups per CU) for big sweeps, up to 152 KB of the 160 KB when
+        // there are at most 1024 columns (<= 256 workgroups: one per CU anyway)
+        const size_t smem_max = p->ncol <= 1024 ? (size_t)152 * 1024 : (size_t)64 * 1024;
+        if (ctx->tiny_rk4 && s->n <= 64 && (s->n <= 16 || p->ncol <= 64) && n_act >= 1 && smem <= smem_max &&
             s->k <= 42 && nsteps > 0) {
             p->tiny = true;
             p->tiny_smem = smem;
@@ -1227,7 +1230,7 @@ extern "C" int midyn_rk4_plan_run(midyn_rk4_plan* p, int step_begin, int step_en
         static bool attr_set[16] = {false};
         if (!attr_set[ctx->device & 15]) {
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_rk4_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
             attr_set[ctx->device & 15] = true;
         }
         {
@@ -1826,7 +1829,7 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
         static bool attr_set[16] = {false};
         if (!attr_set[ctx->device & 15]) {
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_expm_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
             attr_set[ctx->device & 15] = true;
         }
         TinyArgs a = tiny_args(p, 0, nsteps);

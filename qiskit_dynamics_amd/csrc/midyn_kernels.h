@@ -1346,7 +1346,28 @@ __device__ __forceinline__ double2 tiny_rhs(bool has_e, int n_act, const int* ci
         const double2* As = At + (size_t)s * n * n + r;
         double2 p0 = make_double2(0.0, 0.0), p1 = make_double2(0.0, 0.0);
         int c = 0;
-        for (; c + 2 <= n; c += 2) {                   // two independent chains, loads issued together
+        // 8 columns per round: all 16 LDS reads are issued before the first FMA needs one (the loop is
+        // otherwise bound by LDS latency, one dependent read per iteration), two accumulation chains
+        for (; c + 8 <= n; c += 8) {
+            double2 av[8], uv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                av[q] = As[(size_t)(c + q) * n];
+                uv[q] = u[c + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                p0.x = fma(av[q].x, uv[q].x, p0.x);
+                p0.y = fma(av[q].x, uv[q].y, p0.y);
+                p1.x = fma(av[q + 1].x, uv[q + 1].x, p1.x);
+                p1.y = fma(av[q + 1].x, uv[q + 1].y, p1.y);
+                p0.x = fma(-av[q].y, uv[q].y, p0.x);
+                p0.y = fma(av[q].y, uv[q].x, p0.y);
+                p1.x = fma(-av[q + 1].y, uv[q + 1].y, p1.x);
+                p1.y = fma(av[q + 1].y, uv[q + 1].x, p1.y);
+            }
+        }
+        for (; c + 2 <= n; c += 2) {
             const double2 a0 = As[(size_t)c * n], a1 = As[(size_t)(c + 1) * n];
             const double2 u0 = u[c], u1 = u[c + 1];
             p0.x = fma(a0.x, u0.x, p0.x);
