@@ -47,6 +47,7 @@ struct midyn_ctx {
                                  // products instead of forming expm(Omega) (Magnus orders 1 and 2)
     bool stream_planes = true;   // single-plane stacks: the one-column kernel streams only non-zero planes
     bool tiny_rk4 = true;        // small systems: whole RK4 solve in one persistent launch (tiny_rk4_kernel)
+    bool multi_stream = true;    // 2..8 state columns at n >= 256: multi-column streaming kernel
     bool split_k = true;
     bool combine_first = true;
     bool plane_kernel = false;  // planar two-tiles-per-barrier variant: measured 4 % SLOWER (2.43 vs 2.33 ms), kept opt-in
@@ -195,6 +196,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     else if (n == "stream_variant") ctx->stream_variant = (int)value;
     else if (n == "stream_planes") ctx->stream_planes = value != 0;
     else if (n == "tiny_rk4") ctx->tiny_rk4 = value != 0;
+    else if (n == "multi_stream") ctx->multi_stream = value != 0;
     else if (n == "expm_degree") ctx->expm_degree = (int)value;
     else if (n == "expm_action") ctx->expm_action = value != 0;
     else if (n == "split_k") ctx->split_k = value != 0;
@@ -617,6 +619,22 @@ static int launch_stream(midyn_ctx* ctx, const StreamArgs& a, const double* plan
     return 0;
 }
 
+static int launch_stream_multi(midyn_ctx* ctx, const StreamArgs& a, int ncol, int m_cols, long long inst_stride) {
+    ProfScope ps(ctx, KC_STREAM);
+    const dim3 grid(a.n_pad), block(256);
+#define MIDYN_MULTI(C_)                                                                                        \
+    if (a.n_pad >= 512)                                                                                        \
+        hipLaunchKernelGGL((rhs_stream_multi_kernel<C_, 2>), grid, block, 0, ctx->stream, a, ncol, m_cols, inst_stride); \
+    else                                                                                                       \
+        hipLaunchKernelGGL((rhs_stream_multi_kernel<C_, 1>), grid, block, 0, ctx->stream, a, ncol, m_cols, inst_stride)
+    if (ncol <= 2) { MIDYN_MULTI(2); }
+    else if (ncol <= 4) { MIDYN_MULTI(4); }
+    else { MIDYN_MULTI(8); }
+#undef MIDYN_MULTI
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
 // plain zgemm on device buffers: C = alpha * A.B + beta * Z; `batch` independent problems whose
 // operands are `sa`, `sb`, `sc` elements apart (C and Z share the stride)
 static int dev_zgemm_batched(midyn_ctx* ctx, int batch, int M, int N, int K, const double2* A, int lda, long long sa,
@@ -974,6 +992,7 @@ struct midyn_rk4_plan {
     bool stream_path = false;
     DevBuf d_S, d_times, d_E, d_y, d_acc, d_yin[2], d_out, d_tmp, d_G, d_eval_out, d_eval_tmp;
     bool combine_first = false;  // one instance, many columns: form C(t) once, then ONE n^3 zgemm
+    bool multi_stream = false;   // 2..8 columns, large n: multi-column streaming kernel instead of a padded MFMA tile
     std::vector<int> rows;     // [nsteps][3]
     std::vector<double> hs;    // [nsteps]
     std::vector<int> save;     // [nsteps] or empty
@@ -1019,6 +1038,18 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
             planes = s->planes;
         }
         return launch_stream(ctx, a, planes);
+    }
+    if (p->multi_stream) {
+        // 2..8 columns at a size where the padded MFMA tile would mostly multiply zeros
+        StreamArgs a{};
+        a.ops = s->ops;
+        a.seg_list = stack_seg_list(s, &a.n_act);
+        a.n_pad = s->n_pad;
+        a.has_static = s->has_static;
+        a.coeff = s->k > 0 ? p->d_S.as<double>() + (size_t)row * s->k : nullptr;
+        a.yin = yin;
+        a.epi = epi;
+        return launch_stream_multi(ctx, a, p->ncol, p->m, (long long)p->R * s->k);
     }
     if (p->combine_first) {
         // All columns share the coefficients (B == 1): C(t) = sum_seg c_seg A_seg costs nseg*n^2
@@ -1113,7 +1144,8 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
     const size_t y0_elems = (size_t)(y0_shared ? 1 : B) * s->n * m;
     guard(p->d_tmp.alloc(ctx, y0_elems * sizeof(double2)));
     if (P > 0) guard(p->d_out.alloc(ctx, (size_t)B * P * s->n * m * sizeof(double2)));
-    p->combine_first = (B == 1 && m >= 8 && s->nseg > 1 && ctx->combine_first);
+    p->multi_stream = (!p->stream_path && p->ncol <= 8 && s->n_pad >= 256 && s->nseg <= 64 && ctx->multi_stream);
+    p->combine_first = (B == 1 && m >= 8 && s->nseg > 1 && ctx->combine_first && !p->multi_stream);
     if (p->combine_first) guard(p->d_G.alloc(ctx, (size_t)s->n_pad * s->n_pad * sizeof(double2)));
     if (st) {
         delete p;

@@ -268,6 +268,90 @@ __global__ __launch_bounds__(256) void rhs_stream_kernel(StreamArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// rhs_stream_multi_kernel<C>: the streaming contraction for 2..C state columns (C = 2, 4, 8) that may
+// belong to DIFFERENT instances (own coefficient vectors): the operator rows are read ONCE for all
+// columns -- the MFMA path would pad to a 64-column tile and take ~58 us at n = 1024 where this takes
+// about as long as the one-column kernel (HBM-bound: 2 nseg C + 4 C FMAs per 16 nseg bytes).
+// Per lane: g[c] = sum_seg coeff[inst(c)][seg] A_seg[row][col] for each column c, then acc[c] += g[c] y[col][c].
+// ------------------------------------------------------------------------------------------------
+template <int C, int UNROLL>
+__global__ __launch_bounds__(256) void rhs_stream_multi_kernel(StreamArgs a, int ncol, int m_cols, long long inst_stride) {
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = a.n_pad;
+    const size_t plane = (size_t)n * n;
+    const int ld = a.epi.ld;
+    __shared__ double cf_s[64 * C];       // [seg][column] coefficients (<= 64 active segments)
+    __shared__ double2 part[4][C];
+    for (int i = tid; i < a.n_act * C; i += 256) {
+        const int s = i / C, c = i - s * C;
+        const int seg = a.seg_list[s] >> 2;
+        double v = 0.0;
+        if (c < ncol) v = (a.has_static && seg == 0) ? 1.0 : a.coeff[(size_t)(c / m_cols) * inst_stride + (seg - a.has_static)];
+        cf_s[i] = v;
+    }
+    __syncthreads();
+    double2 acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = make_double2(0.0, 0.0);
+    for (int c0 = tid; c0 < n; c0 += 256 * UNROLL) {
+        double2 g[UNROLL][C];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int c = 0; c < C; ++c) g[u][c] = make_double2(0.0, 0.0);
+        for (int s = 0; s < a.n_act; ++s) {
+            const double2* p = a.ops + (size_t)(a.seg_list[s] >> 2) * plane + (size_t)row * n;
+            double2 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int col = c0 + u * 256;
+                v[u] = col < n ? p[col] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double cf = cf_s[s * C + c];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    g[u][c].x = fma(cf, v[u].x, g[u][c].x);
+                    g[u][c].y = fma(cf, v[u].y, g[u][c].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int col = c0 + u * 256;
+            if (col < n) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double2 yv = a.yin[(size_t)col * ld + c];
+                    acc[c].x = fma(g[u][c].x, yv.x, acc[c].x);
+                    acc[c].x = fma(-g[u][c].y, yv.y, acc[c].x);
+                    acc[c].y = fma(g[u][c].x, yv.y, acc[c].y);
+                    acc[c].y = fma(g[u][c].y, yv.x, acc[c].y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            acc[c].x += __shfl_down(acc[c].x, off, 64);
+            acc[c].y += __shfl_down(acc[c].y, off, 64);
+        }
+        if ((tid & 63) == 0) part[tid >> 6][c] = acc[c];
+    }
+    __syncthreads();
+    if (tid < C && tid < ncol) {
+        double2 r = part[0][tid];
+        r.x += part[1][tid].x + part[2][tid].x + part[3][tid].x;
+        r.y += part[1][tid].y + part[2][tid].y + part[3][tid].y;
+        apply_epilogue(a.epi, row, tid, r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // rhs_stream_plane_kernel: the same contraction for stacks whose active operators are ALL purely real
 // or purely imaginary (-iH of a real-symmetric H is purely imaginary: cfg 2/3).  The exactly-zero
 // plane of every operator is not stored at all (`planes[act][n][n]` doubles, built once by

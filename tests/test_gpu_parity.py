@@ -1544,3 +1544,47 @@ def test_large_device_table_sweep_small_system(qd):
         _, yref = orc.solve_generator_model(a_d, a, d, basis, coeff, [0.0, 2.0], cfg["y0"], "RK4", 2.0 / steps)
         assert_close(res["tiny"][b], yref[-1], SOLVE_TOL)
         assert_close(res["batched"][b], yref[-1], SOLVE_TOL)
+
+
+@pytest.mark.parametrize("batch,m", [(2, 1), (3, 1), (5, 1), (8, 1), (1, 2), (2, 3), (1, 8), (4, 2)])
+def test_multi_column_streaming_kernel(qd, cfg2, batch, m):
+    """2..8 state columns at n = 1024 take the multi-column streaming kernel (operator rows read once for
+    all columns, own coefficients per instance): against the MFMA path and the oracle, RK4 and expm action."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    cfg, (a_d, a, d, basis), stack = cfg2
+    rng = np.random.default_rng(batch * 10 + m)
+    sched = FixedStepSchedule([2.4, 2.42], None, cfg["max_dt"], _rk4_points)
+    table, amps, phs = _table_for(cfg, range(batch), sched.times)
+    y0 = crand(rng, batch, 1024, m)
+    outs = {}
+    try:
+        for flag in (1, 0):
+            stack.ctx.set_option("multi_stream", flag)
+            outs[flag] = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
+                                         sched.n_save, y0, batch, False)
+    finally:
+        stack.ctx.set_option("multi_stream", 1)
+    assert_close(outs[1], outs[0], 1e-12)
+    b = batch - 1
+
+    def rhs(t, y):
+        c = workloads.gaussian_coefficient_table(np.array([t]), amps[b], phs[b], cfg["carrier"], 5.0)[0]
+        return orc.generator_rhs(a_d, a, c, d, None, t, y)
+
+    _, yref = orc.rk4_solve(rhs, [2.4, 2.42], y0[b], cfg["max_dt"])
+    assert_close(outs[1][b, -1], yref[-1], SOLVE_TOL)
+    # single evaluation with m columns (one instance)
+    c = rng.normal(size=8)
+    ym = crand(rng, 1024, max(m, 2))
+    try:
+        stack.ctx.set_option("multi_stream", 1)
+        got = stack.eval_rhs(c, 0.37, ym)
+        stack.ctx.set_option("multi_stream", 0)
+        want = stack.eval_rhs(c, 0.37, ym)
+    finally:
+        stack.ctx.set_option("multi_stream", 1)
+    assert_close(got, want, 1e-12)
+    assert_close(got, orc.generator_rhs(a_d, a, c, d, None, 0.37, ym), EVAL_TOL)

@@ -21,8 +21,10 @@ for B in sizes:
     table = workloads.gaussian_coefficient_table(sched.times[:nr], amps, phs, cfg["carrier"], 5.0)
     res = {}
     ref = None
-    for tag, opts in (("splitk", {"split_k": 1, "force_tile": 0}), ("nosplit", {"split_k": 0, "force_tile": 0}),
-                      ("splitk64", {"split_k": 1, "force_tile": 64})):
+    for tag, opts in (("splitk", {"split_k": 1, "force_tile": 0, "multi_stream": 0}),
+                      ("nosplit", {"split_k": 0, "force_tile": 0, "multi_stream": 0}),
+                      ("splitk64", {"split_k": 1, "force_tile": 64, "multi_stream": 0}),
+                      ("multi_stream", {"split_k": 1, "force_tile": 0, "multi_stream": 1})):
         for k_, v_ in opts.items():
             ctx.set_option(k_, v_)
         p = qd.Rk4Plan(stack, sched.times[:nr], table, rows, sched.step_h[:S], y0, B, True)
@@ -33,6 +35,6 @@ for B in sizes:
         if ref is None: ref = out
         err = float(np.max(np.abs(out - ref)))
         res[tag] = (dt / (4 * (S - 2)) * 1e6, err)
-    ctx.set_option("split_k", 1); ctx.set_option("force_tile", 0)
+    ctx.set_option("split_k", 1); ctx.set_option("force_tile", 0); ctx.set_option("multi_stream", 1)
     print(B, {k: (round(v[0], 1), f"{v[1]:.1e}") for k, v in res.items()}, "us per batched eval;",
-          f"{B / res['splitk'][0] * 1e6:.0f} evals/s", flush=True)
+          f"{B / min(res['splitk'][0], res['multi_stream'][0]) * 1e6:.0f} evals/s", flush=True)
