@@ -45,7 +45,18 @@ int midyn_ctx_destroy(midyn_ctx* ctx);
 int midyn_ctx_synchronize(midyn_ctx* ctx);
 /* Text of the last error on this ctx (or of the last ctx-less failure when ctx == NULL). */
 const char* midyn_last_error(midyn_ctx* ctx);
-/* 0: skip exact-zero real/imaginary planes of operators in the MFMA contraction (default 1). */
+/* Options (defaults in brackets; all of them select between paths that give the same results):
+ *   skip_zero_planes [1]  skip exact-zero real/imaginary planes of operators (MFMA contraction and, for
+ *                         single-plane stacks, the planar streaming kernel `stream_planes` [1])
+ *   complex_3m [1]        dense complex products with 3 real MFMAs instead of 4
+ *   split_k [1], force_splits [0], force_tile [0 | 64 | 128 | 12864]   tile / split-K choice of the zgemm
+ *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage
+ *   multi_stream [1]      2..8 state columns at n >= 256: multi-column streaming kernel
+ *   tiny_rk4 [1]          small systems: whole fixed-step solve in one persistent launch
+ *   expm_action [1]       few columns, Magnus order <= 2: expm(Omega) y by matrix-vector products
+ *   expm_degree [0]       0: Taylor degree of the dense expm chosen from the norm; else 2|4|6|9|12|16
+ *   profile [0]           record HIP-event kernel times (midyn_get_counters)
+ *   stream_variant, plane_kernel, prefer_duo, ablate          A/B and profiling switches */
 int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long value);
 
 /* ---- operator stack ----------------------------------------------------------------------
