@@ -619,9 +619,25 @@ static int launch_stream(midyn_ctx* ctx, const StreamArgs& a, const double* plan
     return 0;
 }
 
-static int launch_stream_multi(midyn_ctx* ctx, const StreamArgs& a, int ncol, int m_cols, long long inst_stride) {
+static int launch_stream_multi(midyn_ctx* ctx, const StreamArgs& a, int ncol, int m_cols, long long inst_stride,
+                               const double* planes = nullptr) {
     ProfScope ps(ctx, KC_STREAM);
     const dim3 grid(a.n_pad), block(256);
+    if (planes) {  // single-plane stack: stream only the non-zero planes
+#define MIDYN_MULTI_P(C_)                                                                                       \
+    if (a.n_pad >= 1024)                                                                                        \
+        hipLaunchKernelGGL((rhs_stream_multi_plane_kernel<C_, 2>), grid, block, 0, ctx->stream, a, planes, ncol, m_cols, \
+                           inst_stride);                                                                        \
+    else                                                                                                        \
+        hipLaunchKernelGGL((rhs_stream_multi_plane_kernel<C_, 1>), grid, block, 0, ctx->stream, a, planes, ncol, m_cols, \
+                           inst_stride)
+        if (ncol <= 2) { MIDYN_MULTI_P(2); }
+        else if (ncol <= 4) { MIDYN_MULTI_P(4); }
+        else { MIDYN_MULTI_P(8); }
+#undef MIDYN_MULTI_P
+        HIPCHK(ctx, hipGetLastError());
+        return 0;
+    }
 #define MIDYN_MULTI(C_)                                                                                        \
     if (a.n_pad >= 512)                                                                                        \
         hipLaunchKernelGGL((rhs_stream_multi_kernel<C_, 2>), grid, block, 0, ctx->stream, a, ncol, m_cols, inst_stride); \
@@ -1049,7 +1065,12 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
         a.coeff = s->k > 0 ? p->d_S.as<double>() + (size_t)row * s->k : nullptr;
         a.yin = yin;
         a.epi = epi;
-        return launch_stream_multi(ctx, a, p->ncol, p->m, (long long)p->R * s->k);
+        const double* planes = nullptr;
+        if (ctx->skip_zero_planes && ctx->stream_planes && s->all_single_plane) {
+            CHK(stack_planes(s));
+            planes = s->planes;
+        }
+        return launch_stream_multi(ctx, a, p->ncol, p->m, (long long)p->R * s->k, planes);
     }
     if (p->combine_first) {
         // All columns share the coefficients (B == 1): C(t) = sum_seg c_seg A_seg costs nseg*n^2

@@ -351,6 +351,95 @@ __global__ __launch_bounds__(256) void rhs_stream_multi_kernel(StreamArgs a, int
     }
 }
 
+// Planar variant of rhs_stream_multi_kernel for single-plane stacks (see rhs_stream_plane_kernel): only
+// the non-zero plane of every operator is streamed (8 B per element); a real-only operator feeds the
+// real part of g_c, an imaginary-only one its imaginary part.
+template <int C, int UNROLL>
+__global__ __launch_bounds__(256) void rhs_stream_multi_plane_kernel(StreamArgs a, const double* planes, int ncol,
+                                                                     int m_cols, long long inst_stride) {
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n = a.n_pad;
+    const size_t plane = (size_t)n * n;
+    const int ld = a.epi.ld;
+    __shared__ double cr_s[64 * C], ci_s[64 * C];   // [seg][column]: coefficient on the real / imaginary part
+    __shared__ double2 part[4][C];
+    for (int i = tid; i < a.n_act * C; i += 256) {
+        const int s = i / C, c = i - s * C;
+        const int packed = a.seg_list[s];
+        const int seg = packed >> 2;
+        double v = 0.0;
+        if (c < ncol) v = (a.has_static && seg == 0) ? 1.0 : a.coeff[(size_t)(c / m_cols) * inst_stride + (seg - a.has_static)];
+        cr_s[i] = (packed & 3) == 2 ? 0.0 : v;
+        ci_s[i] = (packed & 3) == 2 ? v : 0.0;
+    }
+    __syncthreads();
+    double2 acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = make_double2(0.0, 0.0);
+    for (int c0 = 2 * tid; c0 < n; c0 += 512 * UNROLL) {
+        double2 g0[UNROLL][C], g1[UNROLL][C];     // complex g of column pair (col, col + 1)
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int c = 0; c < C; ++c) g0[u][c] = g1[u][c] = make_double2(0.0, 0.0);
+        for (int s = 0; s < a.n_act; ++s) {
+            const double* p = planes + (size_t)s * plane + (size_t)row * n;
+            double2 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int col = c0 + u * 512;
+                v[u] = col < n ? *reinterpret_cast<const double2*>(p + col) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double cr = cr_s[s * C + c], ci = ci_s[s * C + c];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    g0[u][c].x = fma(cr, v[u].x, g0[u][c].x);
+                    g0[u][c].y = fma(ci, v[u].x, g0[u][c].y);
+                    g1[u][c].x = fma(cr, v[u].y, g1[u][c].x);
+                    g1[u][c].y = fma(ci, v[u].y, g1[u][c].y);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int col = c0 + u * 512;
+            if (col < n) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double2 y0 = a.yin[(size_t)col * ld + c], y1 = a.yin[(size_t)(col + 1) * ld + c];
+                    acc[c].x = fma(g0[u][c].x, y0.x, acc[c].x);
+                    acc[c].x = fma(-g0[u][c].y, y0.y, acc[c].x);
+                    acc[c].y = fma(g0[u][c].x, y0.y, acc[c].y);
+                    acc[c].y = fma(g0[u][c].y, y0.x, acc[c].y);
+                    acc[c].x = fma(g1[u][c].x, y1.x, acc[c].x);
+                    acc[c].x = fma(-g1[u][c].y, y1.y, acc[c].x);
+                    acc[c].y = fma(g1[u][c].x, y1.y, acc[c].y);
+                    acc[c].y = fma(g1[u][c].y, y1.x, acc[c].y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            acc[c].x += __shfl_down(acc[c].x, off, 64);
+            acc[c].y += __shfl_down(acc[c].y, off, 64);
+        }
+        if ((tid & 63) == 0) part[tid >> 6][c] = acc[c];
+    }
+    __syncthreads();
+    if (tid < C && tid < ncol) {
+        double2 r = part[0][tid];
+        r.x += part[1][tid].x + part[2][tid].x + part[3][tid].x;
+        r.y += part[1][tid].y + part[2][tid].y + part[3][tid].y;
+        apply_epilogue(a.epi, row, tid, r);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // rhs_stream_plane_kernel: the same contraction for stacks whose active operators are ALL purely real
 // or purely imaginary (-iH of a real-symmetric H is purely imaginary: cfg 2/3).  The exactly-zero

@@ -1561,13 +1561,16 @@ def test_multi_column_streaming_kernel(qd, cfg2, batch, m):
     y0 = crand(rng, batch, 1024, m)
     outs = {}
     try:
-        for flag in (1, 0):
-            stack.ctx.set_option("multi_stream", flag)
+        for flag in (1, 2, 0):   # 1: planar multi-column kernel (single-plane stack), 2: interleaved one, 0: MFMA
+            stack.ctx.set_option("multi_stream", 1 if flag else 0)
+            stack.ctx.set_option("stream_planes", 0 if flag == 2 else 1)
             outs[flag] = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                                          sched.n_save, y0, batch, False)
     finally:
         stack.ctx.set_option("multi_stream", 1)
+        stack.ctx.set_option("stream_planes", 1)
     assert_close(outs[1], outs[0], 1e-12)
+    assert_close(outs[2], outs[0], 1e-12)
     b = batch - 1
 
     def rhs(t, y):
