@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The tests bind libmidyn.so: build it when it is missing or older than its sources (a fresh
+    checkout has no binary -- *.so is git-ignored; hipcc cross-compiles gfx950 without a GPU)."""
+    lib = os.path.join(ROOT, "qiskit_dynamics_amd", "libmidyn.so")
+    srcs = [os.path.join(ROOT, "qiskit_dynamics_amd", "csrc", f) for f in ("midyn.hip", "midyn_kernels.h")]
+    srcs.append(os.path.join(ROOT, "include", "midyn.h"))
+    stale = not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in srcs if os.path.exists(f))
+    if stale:
+        import importlib
+
+        try:
+            importlib.import_module("__graft_entry__").build()
+        except Exception as err:  # pylint: disable=broad-except
+            print(f"[conftest] could not build libmidyn.so: {err}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}
