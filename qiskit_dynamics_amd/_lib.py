@@ -485,9 +485,11 @@ class Rk4Plan:
         return out
 
     def close(self):
-        if getattr(self, "handle", None) is not None and self.handle:
+        # the plan points into its stack and context: only destroy it while both are alive
+        if (getattr(self, "handle", None) is not None and self.handle and self.stack.handle
+                and self.stack.ctx.handle):
             self.stack.ctx.lib.midyn_rk4_plan_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
