@@ -21,7 +21,9 @@
  *     B instances is [B][n][m].  Vectorised density matrices are column stacked (caller's job).
  *   - Every function returns 0 on success, non-zero on failure; `midyn_last_error` gives the text.
  *   - A ctx owns one HIP stream and is single threaded.  One ctx per device / per process rank.
- *   - Handles are opaque; the library never keeps a host pointer after a call returns.
+ *   - Handles are opaque; the library never keeps a host pointer after a call returns.  Objects
+ *     created from a ctx (stacks, plans, tables, expansions, ...) must be destroyed BEFORE that ctx, and
+ *     a plan / Lindblad handle before the stacks it was created from.
  */
 #ifndef MIDYN_H
 #define MIDYN_H
