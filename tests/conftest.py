@@ -16,19 +16,16 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """The tests bind libmidyn.so: build it when it is missing or older than its sources (a fresh
+    """The tests bind libmidyn.so: build it when it is missing or was built from other sources (a fresh
     checkout has no binary -- *.so is git-ignored; hipcc cross-compiles gfx950 without a GPU)."""
-    lib = os.path.join(ROOT, "qiskit_dynamics_amd", "libmidyn.so")
-    srcs = [os.path.join(ROOT, "qiskit_dynamics_amd", "csrc", f) for f in ("midyn.hip", "midyn_kernels.h")]
-    srcs.append(os.path.join(ROOT, "include", "midyn.h"))
-    stale = not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in srcs if os.path.exists(f))
-    if stale:
-        import importlib
+    import importlib
 
-        try:
-            importlib.import_module("__graft_entry__").build()
-        except Exception as err:  # pylint: disable=broad-except
-            print(f"[conftest] could not build libmidyn.so: {err}", file=sys.stderr)
+    try:
+        entry = importlib.import_module("__graft_entry__")
+        if not entry.library_is_current():   # content hash of the sources vs the stamp written by build()
+            entry.build()
+    except Exception as err:  # pylint: disable=broad-except
+        print(f"[conftest] could not build libmidyn.so: {err}", file=sys.stderr)
 
 
 @pytest.fixture(scope="session")

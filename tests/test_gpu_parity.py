@@ -1591,3 +1591,48 @@ def test_multi_column_streaming_kernel(qd, cfg2, batch, m):
         stack.ctx.set_option("multi_stream", 1)
     assert_close(got, want, 1e-12)
     assert_close(got, orc.generator_rhs(a_d, a, c, d, None, 0.37, ym), EVAL_TOL)
+
+
+def test_repeated_solves_are_bitwise_identical(qd, monkeypatch):
+    """No atomics, no unordered copies: the same solve must give the same bits every time (a data race
+    shows up as irreproducibility long before it shows up as a wrong answer).  Sweeps with a device
+    coefficient table through the batched RK4 stages, the tiny kernel, the expm action, the
+    parallel-in-time method, and a mid-size model through split-K and the multi-column kernel."""
+    from qiskit_dynamics_amd import solvers as S
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    monkeypatch.setattr(S, "DEVICE_SIGNAL_TABLE_MIN", 0)
+    rng = np.random.default_rng(17)
+
+    def sweep(cfg, batch):
+        return [[qd.DiscreteSignal(dt=0.05, samples=rng.uniform(0.1, 1, 40) * np.exp(1j * rng.uniform(0, 1, 40)),
+                                   carrier_freq=nu, phase=rng.uniform(0, 1)) for nu in cfg["carrier"]]
+                for _ in range(batch)]
+
+    cases = []
+    cfg = W.schrodinger_config(3, n_drives=3)
+    s3 = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+    sig3 = sweep(cfg, 1500)
+    for method, kw, opts in (("RK4", {}, {"tiny_rk4": 1}), ("RK4", {}, {"tiny_rk4": 0}),
+                             ("scipy_expm", {"magnus_order": 2}, {"tiny_rk4": 0}),
+                             ("scipy_expm", {"magnus_order": 1}, {"tiny_rk4": 1})):
+        cases.append((s3, dict(t_span=[0.0, 2.0], y0=cfg["y0"], signals=sig3, method=method, max_dt=0.002, **kw), opts))
+    cases.append((s3, dict(t_span=[0.0, 2.0], y0=cfg["y0"], signals=sig3[0], method="hip_expm_parallel", max_dt=0.002,
+                           magnus_order=2), {}))
+    cfg = W.schrodinger_config(8)
+    s8 = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+    for batch in (5, 200):
+        cases.append((s8, dict(t_span=[0.0, 0.1], y0=cfg["y0"], signals=sweep(cfg, batch), method="RK4", max_dt=0.005), {}))
+    for solver, kw, opts in cases:
+        try:
+            for k_, v_ in opts.items():
+                ctx.set_option(k_, v_)
+            runs = []
+            for _ in range(3):
+                r = solver.solve(**kw)
+                r = r if isinstance(r, list) else [r]
+                runs.append(np.array([x.y for x in r]))
+        finally:
+            ctx.set_option("tiny_rk4", 1)
+        assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), (kw["method"], opts)
