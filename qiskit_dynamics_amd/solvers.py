@@ -315,6 +315,16 @@ def _batch_table(model, signals_list, times, batch, n_coeff):
     return np.stack([_signal_table(model, s, times) for s in signals_list])
 
 
+# One small trajectory with many steps is launch-bound when advanced step by step.  The fixed-step
+# methods are linear maps per step, so the same numbers (to rounding: products are re-associated) come
+# out of the parallel-in-time route -- all step propagators at once, tree product (row f3) -- at a
+# fraction of the latency.  "RK4" / "scipy_expm" solves of ONE instance with at most this many rows and
+# at least this many steps are routed there; set AUTO_PARALLEL_IN_TIME = False to keep them sequential.
+AUTO_PARALLEL_IN_TIME = True
+AUTO_PARALLEL_MAX_ROWS = 64
+AUTO_PARALLEL_MIN_STEPS = 256
+
+
 def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_dt=None,
                  magnus_order=1, **unknown):
     """Solve ``len(y0_list)`` instances that share t_span/t_eval in one device call."""
@@ -343,7 +353,13 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     y0_dev, tag = _prepare_y0_batch(model, kind, y0_list, shared_y0)
     stack = model.stack
     table = _batch_table(model, signals_list, sched.times, batch, stack.k)
-    if method in RK4_METHODS:
+    auto_parallel = (AUTO_PARALLEL_IN_TIME and batch == 1 and stack.n <= AUTO_PARALLEL_MAX_ROWS
+                     and len(sched.step_h) >= AUTO_PARALLEL_MIN_STEPS and y0_dev.shape[-1] <= 64
+                     and method in RK4_METHODS + EXPM_METHODS)
+    if auto_parallel:
+        ys = stack.parallel_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save,
+                                  0 if method in RK4_METHODS else magnus_order, y0_dev, batch, shared_y0)
+    elif method in RK4_METHODS:
         ys = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                              sched.n_save, y0_dev, batch, shared_y0)
     elif method in RK4_PARALLEL_METHODS + EXPM_PARALLEL_METHODS:

@@ -1636,3 +1636,43 @@ def test_repeated_solves_are_bitwise_identical(qd, monkeypatch):
         finally:
             ctx.set_option("tiny_rk4", 1)
         assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), (kw["method"], opts)
+
+
+@pytest.mark.parametrize("n,method,mo", [(4, "RK4", 1), (27, "RK4", 1), (64, "scipy_expm", 2), (9, "scipy_expm", 1)])
+def test_auto_parallel_in_time_routing(qd, monkeypatch, n, method, mo):
+    """One small trajectory with many steps is routed to the parallel-in-time implementation of the SAME
+    method (all step propagators at once + tree product); the numbers must agree with the sequential
+    route to rounding, and the switch must bring the sequential route back."""
+    from qiskit_dynamics_amd import solvers as S
+
+    rng = np.random.default_rng(n)
+
+    def herm(s_=1.0):
+        a_ = crand(rng, n, n)
+        return s_ * (a_ + a_.conj().T) / 2
+
+    h0 = np.diag(rng.normal(size=n) * 20.0).astype(complex)
+    ops = np.array([herm(0.3) for _ in range(3)])
+    solver = qd.Solver(static_hamiltonian=h0, hamiltonian_operators=ops, rotating_frame=h0)
+    sigs = [qd.Signal(lambda t, j=j: 0.3 * np.cos(0.5 * t + j) + 0j, 3.0 + 0.2 * j, 0.1 * j) for j in range(3)]
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    kw = dict(t_span=[0.0, 1.0], y0=y0, signals=sigs, method=method, max_dt=1.0 / 600, t_eval=[0.0, 0.37, 1.0])
+    if method == "scipy_expm":
+        kw["magnus_order"] = mo
+    calls = []
+    orig = qd.Stack.parallel_solve
+
+    def spy(self, *a_, **k_):
+        calls.append(1)
+        return orig(self, *a_, **k_)
+
+    monkeypatch.setattr(qd.Stack, "parallel_solve", spy)
+    auto = solver.solve(**kw)
+    assert len(calls) == 1, "the parallel-in-time route was not taken"
+    monkeypatch.setattr(S, "AUTO_PARALLEL_IN_TIME", False)
+    seq = solver.solve(**kw)
+    assert len(calls) == 1, "the switch did not disable the routing"
+    assert_close(auto.t, seq.t, 0)
+    assert_close(auto.y, seq.y, 1e-11)
+    assert abs(np.linalg.norm(auto.y[-1]) - 1.0) < 1e-8
