@@ -321,7 +321,7 @@ def _batch_table(model, signals_list, times, batch, n_coeff):
 # fraction of the latency.  "RK4" / "scipy_expm" solves of ONE instance with at most this many rows and
 # at least this many steps are routed there; set AUTO_PARALLEL_IN_TIME = False to keep them sequential.
 AUTO_PARALLEL_IN_TIME = True
-AUTO_PARALLEL_MAX_ROWS = 64
+AUTO_PARALLEL_MAX_ROWS = 128
 AUTO_PARALLEL_MIN_STEPS = 256
 
 
