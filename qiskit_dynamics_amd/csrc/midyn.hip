@@ -1212,12 +1212,13 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
         const size_t smem = ((size_t)n_act * s->n * s->n + 4 * (size_t)s->n) * sizeof(double2) +
                             (size_t)4 * 2 * 3 * std::max(1, s->k) * sizeof(double) + (size_t)n_act * sizeof(int);
         // n <= 16: always (measured 2-2.5x over the batched stages for 2048-4096 instances; at n = 32 the MFMA
-        // path has caught up for large sweeps); up to 64 rows when there are few columns, where the
-        // batched path would be ~10 us of launch per stage for almost no work.
+        // path has caught up for large sweeps); up to 32 rows when there are few columns, where the
+        // batched path would be ~10 us of launch per stage for almost no work (at 64 rows the one-wave
+        // product is LDS-bound and loses: 131 vs 40 ms for 8 instances x 2000 steps).
         // LDS: 64 KB slices (two or more workgroups per CU) for big sweeps, up to 152 KB of the 160 KB when
         // there are at most 1024 columns (<= 256 workgroups: one per CU anyway)
         const size_t smem_max = p->ncol <= 1024 ? (size_t)152 * 1024 : (size_t)64 * 1024;
-        if (ctx->tiny_rk4 && s->n <= 64 && (s->n <= 16 || p->ncol <= 64) && n_act >= 1 && smem <= smem_max &&
+        if (ctx->tiny_rk4 && s->n <= 32 && (s->n <= 16 || p->ncol <= 64) && n_act >= 1 && smem <= smem_max &&
             s->k <= 42 && nsteps > 0) {
             p->tiny = true;
             p->tiny_smem = smem;

@@ -318,8 +318,9 @@ def _batch_table(model, signals_list, times, batch, n_coeff):
 # One small trajectory with many steps is launch-bound when advanced step by step.  The fixed-step
 # methods are linear maps per step, so the same numbers (to rounding: products are re-associated) come
 # out of the parallel-in-time route -- all step propagators at once, tree product (row f3) -- at a
-# fraction of the latency.  "RK4" / "scipy_expm" solves of ONE instance with at most this many rows and
-# at least this many steps are routed there; set AUTO_PARALLEL_IN_TIME = False to keep them sequential.
+# fraction of the latency.  "RK4" / "scipy_expm" solves of one (or a handful of) instances with at most
+# this many rows and at least this many steps are routed there; AUTO_PARALLEL_IN_TIME = False keeps them
+# sequential.
 AUTO_PARALLEL_IN_TIME = True
 AUTO_PARALLEL_MAX_ROWS = 128
 AUTO_PARALLEL_MIN_STEPS = 256
@@ -353,7 +354,10 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     y0_dev, tag = _prepare_y0_batch(model, kind, y0_list, shared_y0)
     stack = model.stack
     table = _batch_table(model, signals_list, sched.times, batch, stack.k)
-    auto_parallel = (AUTO_PARALLEL_IN_TIME and batch == 1 and stack.n <= AUTO_PARALLEL_MAX_ROWS
+    # a few instances are still cheaper one after the other in parallel-in-time form (~2 ms each) than in
+    # lock-step through thousands of launches (35-40 ms) or, for n <= 16, the persistent kernel (6-9 ms)
+    max_batch = 3 if stack.n <= 16 else 16
+    auto_parallel = (AUTO_PARALLEL_IN_TIME and batch <= max_batch and stack.n <= AUTO_PARALLEL_MAX_ROWS
                      and len(sched.step_h) >= AUTO_PARALLEL_MIN_STEPS and y0_dev.shape[-1] <= 64
                      and method in RK4_METHODS + EXPM_METHODS)
     if auto_parallel:
