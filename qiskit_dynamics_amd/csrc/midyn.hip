@@ -2230,8 +2230,12 @@ extern "C" int midyn_parallel_solve(midyn_stack* s, int B, int m, int R, const d
             auto slot = [&](int which, int i) { return (long long)((size_t)which * cap + i) * (long long)mat; };
             int longest = 0;
             for (auto& sg : segs) longest = std::max(longest, sg.second - sg.first);
+            // all levels' offset tables go to the device in ONE copy (a level has at most half the entries of
+            // the one before: fewer than nb products in total)
+            offs.clear();
+            round_start.clear();
             for (int st = 1; st < longest; st *= 2) {
-                offs.clear();
+                round_start.push_back((int)(offs.size() / 3));
                 for (auto& sg : segs)
                     for (int i = sg.first; i + st < sg.second; i += 2 * st) {
                         offs.push_back(slot(loc[i + st], i + st));  // later steps multiply from the left
@@ -2239,12 +2243,17 @@ extern "C" int midyn_parallel_solve(midyn_stack* s, int B, int m, int R, const d
                         offs.push_back(slot(loc[i] ^ 1, i));
                         loc[i] ^= 1;
                     }
-                const int cnt = (int)(offs.size() / 3);
-                if (cnt == 0) continue;
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the previous level may still read d_offs
+            }
+            round_start.push_back((int)(offs.size() / 3));
+            if (!offs.empty()) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the previous chunk may still read d_offs
                 HIPCHK(ctx, hipMemcpy(d_offs.p, offs.data(), offs.size() * sizeof(long long), hipMemcpyHostToDevice));
-                CHK(dev_zgemm_batched(ctx, cnt, np, np, np, Xb, np, 0, Xb, np, 0, Xb, np, 0, 1.0, 0.0, nullptr,
-                                      d_offs.as<long long>()));
+                for (size_t lv = 0; lv + 1 < round_start.size(); ++lv) {
+                    const int cnt = round_start[lv + 1] - round_start[lv];
+                    if (cnt > 0)
+                        CHK(dev_zgemm_batched(ctx, cnt, np, np, np, Xb, np, 0, Xb, np, 0, Xb, np, 0, 1.0, 0.0, nullptr,
+                                              d_offs.as<long long>() + (size_t)3 * round_start[lv]));
+                }
             }
             // -- 3. apply the interval propagators in time order, store the states at the output times
             for (auto& sg : segs) {
