@@ -1749,6 +1749,112 @@ __global__ __launch_bounds__(256) void tiny_expm_kernel(TinyArgs a, int magnus_o
     if (active) a.y[(size_t)r * a.ld + col] = y;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Krylov (Arnoldi) pieces for the expm action of ONE large-norm generator on ONE vector (see
+// krylov_expm_step in midyn.hip).  V holds the orthonormal basis, row i = vector v_i of length n
+// (leading dimension ldv); Hm is the (m+1) x m Hessenberg matrix in a 64 x 64 row-major block.
+// ------------------------------------------------------------------------------------------------
+// hc[i] = v_i^H w for i < cnt (one workgroup per i); add != 0 accumulates into Hm[i][j] instead of setting it
+__global__ __launch_bounds__(256) void krylov_dot_kernel(const double2* V, int ldv, const double2* w, int n, int j,
+                                                         int add, double2* hc, double2* Hm) {
+    const int i = blockIdx.x;
+    const double2* v = V + (size_t)i * ldv;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const double2 a = v[r], b = w[r];
+        acc.x = fma(a.x, b.x, acc.x);
+        acc.x = fma(a.y, b.y, acc.x);
+        acc.y = fma(a.x, b.y, acc.y);
+        acc.y = fma(-a.y, b.x, acc.y);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        acc.x += __shfl_down(acc.x, off, 64);
+        acc.y += __shfl_down(acc.y, off, 64);
+    }
+    __shared__ double2 part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double2 t = part[0];
+        t.x += part[1].x + part[2].x + part[3].x;
+        t.y += part[1].y + part[2].y + part[3].y;
+        hc[i] = t;
+        double2* h = Hm + (size_t)i * 64 + j;
+        if (add) *h = make_double2(h->x + t.x, h->y + t.y);
+        else *h = t;
+    }
+}
+
+// out[r] = base[r] + sign * sum_{i < cnt} coef[i * cstride] v_i[r]     (base may be out itself or nullptr)
+__global__ __launch_bounds__(256) void krylov_axpy_kernel(const double2* V, int ldv, const double2* coef, int cstride,
+                                                          int cnt, double sign, const double2* base, int n,
+                                                          double2* out) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+        double2 acc = base ? base[r] : make_double2(0.0, 0.0);
+        for (int i = 0; i < cnt; ++i) {
+            const double2 c = coef[(size_t)i * cstride];
+            const double2 v = V[(size_t)i * ldv + r];
+            acc.x += sign * (c.x * v.x - c.y * v.y);
+            acc.y += sign * (c.x * v.y + c.y * v.x);
+        }
+        out[r] = acc;
+    }
+}
+
+// nrm = ||w||_2 (one workgroup); stores it to *nrm_out and, when Hm != nullptr, to Hm[j+1][j]; then
+// vnext = w / nrm (nrm == 0: vnext = 0, the subspace is invariant)
+__global__ __launch_bounds__(1024) void krylov_norm_scale_kernel(const double2* w, int n, int j, double2* Hm,
+                                                                 double* nrm_out, double2* vnext) {
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < n; r += 1024) {
+        const double2 a = w[r];
+        acc = fma(a.x, a.x, acc);
+        acc = fma(a.y, a.y, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double part[16];
+    __shared__ double nrm_s;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += part[i];
+        nrm_s = sqrt(t);
+        *nrm_out = nrm_s;
+        if (Hm) Hm[(size_t)(j + 1) * 64 + j] = make_double2(nrm_s, 0.0);
+    }
+    __syncthreads();
+    const double inv = nrm_s > 0.0 ? 1.0 / nrm_s : 0.0;
+    for (int r = threadIdx.x; r < n; r += 1024) vnext[r] = make_double2(w[r].x * inv, w[r].y * inv);
+}
+
+// small = h * Hm[0..m)[0..m), zero elsewhere (64 x 64 block that dev_expm_inplace exponentiates)
+__global__ __launch_bounds__(256) void krylov_small_kernel(const double2* Hm, int m, double h, double2* small) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 64 * 64; idx += gridDim.x * 256) {
+        const int i = idx >> 6, j = idx & 63;
+        const double2 v = (i < m && j < m) ? Hm[idx] : make_double2(0.0, 0.0);
+        small[idx] = make_double2(h * v.x, h * v.y);
+    }
+}
+
+// Saad's a-posteriori estimate  beta * |h h_{m+1,m}| * |e_m^T expm(h H_m) e_1|  -> err[0]; err[1] = beta
+__global__ void krylov_err_kernel(const double2* E, const double2* Hm, int m, double h, const double* beta, double* err) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double2 e = E[(size_t)(m - 1) * 64];
+        const double hn = Hm[(size_t)m * 64 + (m - 1)].x;
+        err[0] = beta[0] * fabs(h) * hn * hypot(e.x, e.y);
+        err[1] = beta[0];
+    }
+}
+
+// coef[i] = beta * E[i][0]
+__global__ void krylov_coef_kernel(const double2* E, int m, const double* beta, double2* coef) {
+    const int i = threadIdx.x;
+    if (i < m) coef[i] = make_double2(beta[0] * E[(size_t)i * 64].x, beta[0] * E[(size_t)i * 64].y);
+}
+
 // yin = E o y  (re-phasing when a step starts from a time that is not the previous step's end)
 __global__ __launch_bounds__(256) void rephase_kernel(const double2* y, const double2* e, int n_pad, int ld,
                                                       double2* yin) {

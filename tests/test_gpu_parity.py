@@ -1676,3 +1676,52 @@ def test_auto_parallel_in_time_routing(qd, monkeypatch, n, method, mo):
     assert_close(auto.t, seq.t, 0)
     assert_close(auto.y, seq.y, 1e-11)
     assert abs(np.linalg.norm(auto.y[-1]) - 1.0) < 1e-8
+
+
+@pytest.mark.parametrize("n,magn", [(200, 9.0), (300, 25.0)])
+def test_krylov_expm_action_matches_taylor(qd, n, magn):
+    """One column, no rotating frame, ||h G||_1 of order 10..50: the expm action runs as an Arnoldi process
+    (CGS2 on the device, small expm of the Hessenberg block, Saad's estimate) instead of ~15 products per
+    unit of norm -- against the scaled Taylor series (krylov = 0), the dense expm and the oracle."""
+    from oracle import dynamics_oracle as orc
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(n)
+    evals = rng.uniform(-magn, magn, n) * 20.0          # spectral radius of h G about magn at h = 0.05
+    q_, _ = np.linalg.qr(crand(rng, n, n))
+    h_static = (q_ * evals) @ q_.conj().T
+    h_static = (h_static + h_static.conj().T) / 2
+    a_ = crand(rng, n, n)
+    h_ops = np.array([(a_ + a_.conj().T) / 2 * 0.3])
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops)
+    sig = [qd.Signal(lambda t: 0.5 * np.cos(t) + 0j, 1.0, 0.2)]
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    kw = dict(t_span=[0.0, 0.15], y0=y0, signals=sig, method="scipy_expm", max_dt=0.05)
+    res = {}
+    try:
+        for tag, opts in (("krylov", {}), ("taylor", {"krylov": 0}), ("dense", {"expm_action": 0})):
+            for k_, v_ in opts.items():
+                ctx.set_option(k_, v_)
+            ctx.reset_counters()
+            ctx.set_option("profile", 1)
+            res[tag] = solver.solve(**kw).y
+            counters = {c: ctx.counters(c)["launches"] for c in ("rhs_stream", "zgemm")}
+            ctx.set_option("profile", 0)
+            ctx.set_option("krylov", 1)
+            ctx.set_option("expm_action", 1)
+            if tag == "krylov":
+                assert counters["zgemm"] > 0 and counters["rhs_stream"] < 3 * 64, counters   # Arnoldi was used
+            if tag == "taylor":
+                assert counters["zgemm"] == 0 and counters["rhs_stream"] >= 3 * 64, counters
+    finally:
+        ctx.set_option("profile", 0)
+        ctx.set_option("krylov", 1)
+        ctx.set_option("expm_action", 1)
+    assert_close(res["krylov"], res["taylor"], 1e-11)
+    assert_close(res["krylov"], res["dense"], 1e-11)
+    a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, None)
+    coeff = lambda t: np.array([orc.signal_sum_value(np.array([0.5 * np.cos(t) + 0j]), [1.0], [0.2], t)])
+    _, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff, [0.0, 0.15], y0, "scipy_expm", 0.05)
+    assert_close(res["krylov"], y_ref, SOLVE_TOL)
+    assert abs(np.linalg.norm(res["krylov"][-1]) - 1.0) < 1e-12
