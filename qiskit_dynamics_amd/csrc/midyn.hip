@@ -1929,7 +1929,7 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
         HIPCHK(ctx, hipMemsetAsync(kH.p, 0, kH.bytes, ctx->stream));
         hipLaunchKernelGGL(krylov_norm_scale_kernel, dim3(1), dim3(1024), 0, ctx->stream, ycur, np, 0, (double2*)nullptr,
                            kbeta.as<double>(), Vb);
-        int next_check = std::min(KM, std::max(8, (int)(1.2 * bound) + 12));
+        int next_check = std::min(KM, std::max(8, (int)(1.5 * bound) + 14));
         int m = 0;
         bool done = false;
         for (int j = 0; j < KM && !done; ++j) {
