@@ -583,7 +583,10 @@ ref = (np.tensordot(c, ops, axes=1) + static) * (e.conj()[:, None] * e[None, :])
 assert np.max(np.abs(s1.eval_generator(c, 0.4) - ref)) < 1e-12
 # a world-size-1 NCCL (= RCCL) broadcast of the packed buffer through torch.distributed
 import os, torch.distributed as dist
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+import socket
+with socket.socket() as _s:
+    _s.bind(("127.0.0.1", 0)); _port = _s.getsockname()[1]
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_port))
 dist.init_process_group("nccl", rank=0, world_size=1)
 from qiskit_dynamics_amd.distributed import broadcast_stack
 s2, keep = broadcast_stack(ctx, ops, static, frame_im, n, k, src=0)
