@@ -1728,3 +1728,35 @@ def test_krylov_expm_action_matches_taylor(qd, n, magn):
     _, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff, [0.0, 0.15], y0, "scipy_expm", 0.05)
     assert_close(res["krylov"], y_ref, SOLVE_TOL)
     assert abs(np.linalg.norm(res["krylov"][-1]) - 1.0) < 1e-12
+
+
+def test_dyson_magnus_two_transmon_reference_scenario(qd):
+    """The reference's own acceptance scenario (test_dyson_magnus_solvers.py:142-330): two coupled 5-level
+    transmons (dim 25), Gaussian drives on both, DysonSolver with expansion_order 6 (3002 terms) and
+    MagnusSolver with order 3, 1000 steps of dt = 0.01; criterion = the reference's fidelity test against
+    the direct solution, |1 - |<U_pert, U_direct>|^2 / dim^4| < 1e-6."""
+    w_c, w_t = 2 * np.pi * 5.033, 2 * np.pi * 4.067
+    alpha_c, alpha_t, coupling = 2 * np.pi * (-0.33534), 2 * np.pi * (-0.33834), 2 * np.pi * 0.002
+    dim = 5
+    a = np.diag(np.sqrt(np.arange(1, dim)), 1)
+    num = np.diag(np.arange(dim)).astype(float)
+    i1, i2 = np.eye(dim), np.eye(dim**2)
+    a0, a1 = np.kron(a, i1), np.kron(i1, a)
+    n0, n1 = np.kron(num, i1), np.kron(i1, num)
+    h0 = (w_c * n0 + 0.5 * alpha_c * n0 @ (n0 - i2) + w_t * n1 + 0.5 * alpha_t * n1 @ (n1 - i2)
+          + coupling * (a0 @ a1.T + a0.T @ a1))
+    hdc, hdt = 2 * np.pi * (a0 + a0.T), 2 * np.pi * (a1 + a1.T)
+    r = 0.2
+    sig_w = 0.399128 / r
+    gauss = qd.Signal(lambda t: np.exp(-((t - 3.5 * sig_w) ** 2) / (2 * sig_w**2)), carrier_freq=5.0)
+    dt, n_steps = 0.01, 1000
+    y0 = np.eye(dim**2, dtype=complex)
+    direct = qd.Solver(static_hamiltonian=h0, hamiltonian_operators=[hdc, hdt], rotating_frame=h0).solve(
+        t_span=[0.0, dt * n_steps], y0=y0, signals=[gauss, gauss], method="RK4", max_dt=dt / 20).y[-1]
+    assert np.linalg.norm(direct.conj().T @ direct - y0) < 1e-8
+    for cls, order in ((qd.DysonSolver, 6), (qd.MagnusSolver, 3)):
+        sol = cls(operators=[-1j * hdc, -1j * hdt], rotating_frame=-1j * h0, dt=dt, carrier_freqs=[5.0, 5.0],
+                  chebyshev_orders=[1, 1], expansion_order=order, integration_method="DOP853", atol=1e-10, rtol=1e-10)
+        yf = sol.solve(t0=0.0, n_steps=n_steps, y0=y0, signals=[gauss, gauss]).y[-1]
+        infidelity = abs(1.0 - abs((yf.conj() * direct).sum()) ** 2 / dim**4)
+        assert infidelity < 1e-6, (cls.__name__, infidelity)
