@@ -2706,6 +2706,10 @@ extern "C" int midyn_lindblad_rhs(midyn_lindblad* L, const double* coeffs, doubl
     return 0;
 }
 
+// RK4 for a sweep of density matrices: the instances of a chunk advance TOGETHER -- per RHS evaluation
+// two batched generator evaluations (own coefficient rows), 2 + 2 n_diss batched zgemms, two batched
+// frame masks, whatever the number of instances; coefficient table and phase rows are device resident
+// (no host round trip per evaluation).
 extern "C" int midyn_lindblad_rk4_solve(midyn_lindblad* L, int B, int R, const double* times, const double* S,
                                         int nsteps, const int* step_rows, const double* step_h, const int* step_save,
                                         int P, const midyn_complex* rho0, int rho0_shared, midyn_complex* out) {
@@ -2716,73 +2720,121 @@ extern "C" int midyn_lindblad_rk4_solve(midyn_lindblad* L, int B, int R, const d
     if (L->k > 0 && !S) return fail(ctx, "midyn_lindblad_rk4_solve: S is NULL");
     for (int i = 0; i < 3 * nsteps; ++i)
         if (step_rows[i] < 0 || step_rows[i] >= R) return fail(ctx, "midyn_lindblad_rk4_solve: step_rows out of range");
+    for (int i = 0; i < nsteps; ++i)
+        if (step_save && step_save[i] >= P) return fail(ctx, "midyn_lindblad_rk4_solve: save slot out of range");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const int np = L->np;
-    const size_t nn = (size_t)L->n * L->n;
-    double2 *Y = L->Y.as<double2>(), *Yt = L->Yt.as<double2>();
-    double2* K[4] = {L->K[0].as<double2>(), L->K[1].as<double2>(), L->K[2].as<double2>(), L->K[3].as<double2>()};
-    std::vector<double> zero(std::max(1, L->k), 0.0);
-    std::vector<double> s_host;
-    if (L->k > 0) {
-        // the per-evaluation coefficient vectors are read on the host: bring a device table over
-        hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, S) == hipSuccess && at.type == hipMemoryTypeDevice) {
-            s_host.resize((size_t)B * R * L->k);
-            HIPCHK(ctx, hipMemcpy(s_host.data(), S, s_host.size() * sizeof(double), hipMemcpyDeviceToHost));
-            S = s_host.data();
-        } else {
-            (void)hipGetLastError();
-        }
+    const int np = L->np, n = L->n, k = L->k;
+    const size_t nn = (size_t)n * n, mat = (size_t)np * np;
+    const bool framed = L->left->has_frame;
+    const int nd = L->n_static + L->n_dyn;
+    // instances per chunk: 11 matrices each, ~2 GB of scratch, at most 4096
+    const int chunk = (int)std::max<long long>(1, std::min<long long>(std::min(B, 4096), ((long long)2 << 30) / (long long)(mat * 16 * 11)));
+    DevBuf d_S, d_times, d_E, ML, MR, Xp, T, Rb, Y, Yt, K[4], d_in, d_out;
+    if (k > 0) {
+        CHK(d_S.alloc(ctx, (size_t)B * R * k * sizeof(double)));
+        HIPCHK(ctx, copy_to_device_any(ctx, d_S.p, S, d_S.bytes));
     }
-    for (int b = 0; b < B; ++b) {
-        const midyn_complex* r0 = rho0 + (rho0_shared ? 0 : (size_t)b * nn);
-        midyn_complex* ob = out + (size_t)b * P * nn;
-        HIPCHK(ctx, hipMemsetAsync(L->Y.p, 0, L->Y.bytes, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        CHK(upload_padded(ctx, r0, L->n, L->n, Y, np));
-        memcpy(ob, r0, nn * sizeof(midyn_complex));
-        auto cf = [&](int row) { return L->k > 0 ? S + ((size_t)b * R + row) * L->k : zero.data(); };
+    CHK(make_phase_rows(L->left, times, R, d_times, d_E));
+    for (DevBuf* bp : {&ML, &MR, &Xp, &T, &Rb, &Y, &Yt, &K[0], &K[1], &K[2], &K[3]}) CHK(bp->alloc(ctx, (size_t)chunk * mat * sizeof(double2)));
+    CHK(d_in.alloc(ctx, (size_t)chunk * nn * sizeof(double2)));
+    CHK(d_out.alloc(ctx, (size_t)chunk * P * nn * sizeof(double2)));
+    const long long cstride = (long long)R * k;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        // initial states -> padded device matrices (one strided copy per instance block via a staging buffer)
+        HIPCHK(ctx, hipMemsetAsync(Y.p, 0, (size_t)nb * mat * sizeof(double2), ctx->stream));
+        if (rho0_shared) {
+            for (int b = 0; b < nb; ++b) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                CHK(upload_padded(ctx, rho0, n, n, Y.as<double2>() + (size_t)b * mat, np));
+            }
+        } else {
+            HIPCHK(ctx, hipMemcpyAsync(d_in.p, rho0 + (size_t)b0 * nn, (size_t)nb * nn * sizeof(double2), hipMemcpyHostToDevice,
+                                       ctx->stream));
+            for (int b = 0; b < nb; ++b)
+                hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_in.as<double2>() + (size_t)b * nn,
+                                   n, Y.as<double2>() + (size_t)b * mat, np, n, n);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(save_density_kernel, dim3(grid_for((size_t)nb * nn)), dim3(256), 0, ctx->stream, Y.as<double2>(), np,
+                           n, nb, P, 0, d_out.as<double2>());
+        const double* Sc = k > 0 ? d_S.as<double>() + (size_t)b0 * cstride : nullptr;
+        // rhs of the whole chunk at table row `row`
+        auto rhs = [&](int row, const double2* X, double2* dst) -> int {
+            const double2* Erow = framed ? d_E.as<double2>() + (size_t)row * np : nullptr;
+            const double2* Xin = X;
+            if (framed) {
+                hipLaunchKernelGGL(frame_mask_batch_kernel, dim3(grid_for((size_t)nb * mat)), dim3(256), 0, ctx->stream, X, Erow,
+                                   np, +1, nb, Xp.as<double2>());
+                Xin = Xp.as<double2>();
+            }
+            const double* cf = Sc ? Sc + (size_t)row * k : nullptr;
+            CHK(launch_gen_eval(L->left, cf, nullptr, 1.0, ML.as<double2>(), nb, cstride));
+            CHK(launch_gen_eval(L->right, cf, nullptr, 1.0, MR.as<double2>(), nb, cstride));
+            double2* Rr = Rb.as<double2>();
+            CHK(dev_sqgemm(ctx, nb, np, ML.as<double2>(), Xin, Rr, 1.0, 0.0, nullptr));
+            CHK(dev_sqgemm(ctx, nb, np, Xin, MR.as<double2>(), Rr, 1.0, 1.0, Rr));
+            for (int j = 0; j < nd; ++j) {
+                // T_b = N_j X_b (shared left operand), [T_b *= gamma_b,j], R_b += T_b N_j^+ (shared right operand)
+                CHK(dev_zgemm_batched(ctx, nb, np, np, np, L->diss.as<double2>() + (size_t)j * mat, np, 0, Xin, np, (long long)mat,
+                                      T.as<double2>(), np, (long long)mat, 1.0, 0.0, nullptr));
+                if (j >= L->n_static) {
+                    hipLaunchKernelGGL(scale_batch_kernel, dim3(grid_for((size_t)nb * mat)), dim3(256), 0, ctx->stream,
+                                       T.as<double2>(), mat, nb, cf + L->k_h + (j - L->n_static), cstride);
+                }
+                CHK(dev_zgemm_batched(ctx, nb, np, np, np, T.as<double2>(), np, (long long)mat,
+                                      L->diss_adj.as<double2>() + (size_t)j * mat, np, 0, Rr, np, (long long)mat, 1.0, 1.0, Rr));
+            }
+            if (framed)
+                hipLaunchKernelGGL(frame_mask_batch_kernel, dim3(grid_for((size_t)nb * mat)), dim3(256), 0, ctx->stream, Rr, Erow,
+                                   np, -1, nb, dst);
+            else
+                HIPCHK(ctx, hipMemcpyAsync(dst, Rr, (size_t)nb * mat * sizeof(double2), hipMemcpyDeviceToDevice, ctx->stream));
+            HIPCHK(ctx, hipGetLastError());
+            return 0;
+        };
+        double2 *y = Y.as<double2>(), *yt = Yt.as<double2>();
+        double2* kk[4] = {K[0].as<double2>(), K[1].as<double2>(), K[2].as<double2>(), K[3].as<double2>()};
         for (int st = 0; st < nsteps; ++st) {
             const double h = step_h[st];
             const int* rr = step_rows + 3 * st;
             // fixed_step_solvers.py:62-73
-            CHK(lindblad_rhs_dev(L, cf(rr[0]), times[rr[0]], Y, K[0]));
+            CHK(rhs(rr[0], y, kk[0]));
             {
-                const double2* xs[2] = {Y, K[0]};
+                const double2* xs[2] = {y, kk[0]};
                 double al[2] = {1.0, 0.5 * h};
-                CHK(dev_lincomb(ctx, np, Yt, 2, xs, al, 0.0));
+                CHK(dev_lincomb(ctx, np, yt, 2, xs, al, 0.0, nb));
             }
-            CHK(lindblad_rhs_dev(L, cf(rr[1]), times[rr[1]], Yt, K[1]));
+            CHK(rhs(rr[1], yt, kk[1]));
             {
-                const double2* xs[2] = {Y, K[1]};
+                const double2* xs[2] = {y, kk[1]};
                 double al[2] = {1.0, 0.5 * h};
-                CHK(dev_lincomb(ctx, np, Yt, 2, xs, al, 0.0));
+                CHK(dev_lincomb(ctx, np, yt, 2, xs, al, 0.0, nb));
             }
-            CHK(lindblad_rhs_dev(L, cf(rr[1]), times[rr[1]], Yt, K[2]));
+            CHK(rhs(rr[1], yt, kk[2]));
             {
-                const double2* xs[2] = {Y, K[2]};
+                const double2* xs[2] = {y, kk[2]};
                 double al[2] = {1.0, h};
-                CHK(dev_lincomb(ctx, np, Yt, 2, xs, al, 0.0));
+                CHK(dev_lincomb(ctx, np, yt, 2, xs, al, 0.0, nb));
             }
-            CHK(lindblad_rhs_dev(L, cf(rr[2]), times[rr[2]], Yt, K[3]));
+            CHK(rhs(rr[2], yt, kk[3]));
             {
-                const double2* xs[4] = {K[0], K[1], K[2], K[3]};
+                const double2* xs[4] = {kk[0], kk[1], kk[2], kk[3]};
                 double al[4] = {1.0, 2.0, 2.0, 1.0};
-                CHK(dev_lincomb(ctx, np, Yt, 4, xs, al, 0.0));
-                const double2* ys[2] = {Y, Yt};
+                CHK(dev_lincomb(ctx, np, yt, 4, xs, al, 0.0, nb));
+                const double2* ys[2] = {y, yt};
                 double bl[2] = {1.0, (1.0 / 6) * h};
-                CHK(dev_lincomb(ctx, np, Y, 2, ys, bl, 0.0));
+                CHK(dev_lincomb(ctx, np, y, 2, ys, bl, 0.0, nb));
             }
             if (step_save && step_save[st] >= 0) {
-                if (step_save[st] >= P) return fail(ctx, "midyn_lindblad_rk4_solve: save slot out of range");
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-                HIPCHK(ctx, hipMemcpy2D(ob + (size_t)step_save[st] * nn, (size_t)L->n * sizeof(double2), Y,
-                                        (size_t)np * sizeof(double2), (size_t)L->n * sizeof(double2), L->n,
-                                        hipMemcpyDeviceToHost));
+                hipLaunchKernelGGL(save_density_kernel, dim3(grid_for((size_t)nb * nn)), dim3(256), 0, ctx->stream, y, np, n, nb,
+                                   P, step_save[st], d_out.as<double2>());
+                HIPCHK(ctx, hipGetLastError());
             }
         }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy(out + (size_t)b0 * P * nn, d_out.p, (size_t)nb * P * nn * sizeof(double2), hipMemcpyDeviceToHost));
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -1951,6 +1951,41 @@ __global__ __launch_bounds__(256) void frame_mask_kernel(const double2* src, con
     }
 }
 
+// Batched forms for a chunk of instances (matrices back to back, one phase row shared by the chunk):
+// frame mask of every matrix, and T_b *= gamma_b (gamma_b = coeff[b * stride + j]: a dynamic dissipator's rate)
+__global__ __launch_bounds__(256) void frame_mask_batch_kernel(const double2* src, const double2* e, int n_pad, int dir,
+                                                               int batch, double2* dst) {
+    const size_t plane = (size_t)n_pad * n_pad, total = plane * batch;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const size_t idx = g % plane;
+        const int a = (int)(idx / n_pad);
+        const int b = (int)(idx - (size_t)a * n_pad);
+        const double2 ea = e[a], eb = e[b];
+        const double2 ph = dir > 0 ? cmul_conj_a(eb, ea) : cmul_conj_a(ea, eb);
+        dst[g] = cmul(ph, src[g]);
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_batch_kernel(double2* x, size_t plane, int batch, const double* coeff,
+                                                          long long stride) {
+    const size_t total = plane * batch;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const double s = coeff[(size_t)(g / plane) * stride];
+        x[g] = make_double2(s * x[g].x, s * x[g].y);
+    }
+}
+
+// out[b][slot][i][j] = Y[b][i][j] (padded [np][np] -> [n][n]) for a chunk of instances
+__global__ __launch_bounds__(256) void save_density_kernel(const double2* Y, int np, int n, int batch, int P, int slot,
+                                                           double2* out) {
+    const size_t nn = (size_t)n * n, total = nn * batch;
+    for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
+        const size_t b = g / nn, rem = g - b * nn;
+        const int i = (int)(rem / n), j = (int)(rem - (size_t)i * n);
+        out[(b * P + slot) * nn + rem] = Y[b * (size_t)np * np + (size_t)i * np + j];
+    }
+}
+
 // ---- micro-benchmarks: the ceilings the roofline fractions are quoted against -------------------
 // 8 independent fp64 MFMA accumulators per wave (all in VGPRs), `iters` rounds, 4 waves per SIMD:
 // pure matrix-pipe throughput.

@@ -178,6 +178,31 @@ if "lind1024" in which:
                       "trace": float(abs(np.trace(rho))), "hermiticity": float(np.linalg.norm(rho - rho.conj().T))}),
           flush=True)
 
+if "lindsweep" in which:
+    # sweep of small open systems, non-vectorised (n x n density matrices): every instance advances in the same
+    # batched launches (two generator evaluations + 2 + 2 n_diss batched zgemms per RHS evaluation)
+    for nq, B, nsteps in ((4, 256, 1000), (6, 256, 400), (8, 64, 200)):
+        cfg = workloads.lindblad_config(n_qubits=nq, n_drives=min(nq, 8), n_diss=nq, gamma=1e-2, t_final=nsteps * 0.005,
+                                        max_dt=0.005)
+        solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                           static_dissipators=cfg["static_dissipators"], rotating_frame=np.diag(cfg["h_d"]).real.copy(),
+                           vectorized=False)
+        sweeps = []
+        for b in range(B):
+            amps, phases = workloads.sweep_parameters(b, len(cfg["ops"]))
+            sweeps.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+                           for a, nu, ph in zip(amps, cfg["carrier"], phases)])
+        solver.solve(t_span=[0, 4 * 0.005], y0=cfg["rho0"], signals=sweeps[:2], method="RK4", max_dt=0.005)
+        res, dt = timed(lambda: solver.solve(t_span=[0, nsteps * 0.005], y0=cfg["rho0"], signals=sweeps, method="RK4",
+                                             max_dt=0.005))
+        rho = res[-1].y[-1]
+        print(json.dumps({"what": f"{nq}-qubit non-vectorised Lindblad sweep (n={2**nq}, {nq} dissipators), RK4",
+                          "instances": B, "steps": nsteps, "wall_s": round(dt, 3),
+                          "us_per_instance_rhs_eval": round(dt / (4.0 * nsteps * B) * 1e6, 3),
+                          "trace": float(abs(np.trace(rho))),
+                          "hermiticity": float(np.linalg.norm(rho - rho.conj().T))}), flush=True)
+        del solver
+
 if "unitary1024" in which:
     from bench import build_frame_basis_stack
     from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
