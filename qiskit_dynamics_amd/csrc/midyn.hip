@@ -24,8 +24,9 @@ using namespace midyn;
 // -------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
-enum KClass { KC_STREAM = 0, KC_RHS_GEMM, KC_ZGEMM, KC_GEN, KC_ELEM, KC_COUNT };
-static const char* kclass_names[KC_COUNT] = {"rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise"};
+enum KClass { KC_STREAM = 0, KC_RHS_GEMM, KC_ZGEMM, KC_GEN, KC_ELEM, KC_BLOCKS, KC_BLOCKS_GEMM, KC_COUNT };
+static const char* kclass_names[KC_COUNT] = {"rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise",
+                                             "rhs_blocks", "rhs_blocks_gemm"};  // the last two: block-sparse routes
 
 struct EventPair {
     hipEvent_t a, b;
@@ -37,6 +38,7 @@ struct midyn_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool skip_zero_planes = true;
+    bool skip_zero_blocks = true;  // block-sparse stacks: contract only the 16 x 16 operator blocks that hold a non-zero
     bool profile = false;
     int force_tile = 0;  // 0 auto, 64, 128, 12864
     bool prefer_duo = false;
@@ -188,6 +190,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     if (!ctx || !name) return fail(ctx, "midyn_ctx_set_option: NULL argument");
     std::string n(name);
     if (n == "skip_zero_planes") ctx->skip_zero_planes = value != 0;
+    else if (n == "skip_zero_blocks") ctx->skip_zero_blocks = value != 0;
     else if (n == "profile") {
         if (!value) drain_events(ctx);
         ctx->profile = value != 0;
@@ -260,6 +263,15 @@ struct midyn_stack {
     std::vector<int> h_flags;
     std::vector<int> h_modes;   // per segment: 0 full, 1 real only, 2 imaginary only, 3 zero
     std::vector<double> seg_norm1;  // ||A_seg||_1 per segment (lazy; norm bounds of the expm action)
+    // block occupancy (lazy, stack_block_lists): which 16 x 16 blocks of the active segments hold a non-zero
+    int blk_state = 0;              // 0 not examined, 1 lists built, -1 not applicable
+    double blk_density = 1.0;       // non-zero 16 x 16 blocks / all blocks of the active segments
+    int* blk_ptr = nullptr;         // streaming lists per group of 16 rows: [n_pad/16 + 1]
+    int* blk_idx = nullptr;         // entry = (active index << 16) | column chunk
+    int* gw_ptr[2] = {nullptr, nullptr};  // MFMA tile lists per row panel of 64 / 128 rows: [M/BM + 1]
+    int* gw_idx[2] = {nullptr, nullptr};  // entry = (K tile << 8) | (seg << 2 | mode)
+    double gw_density[2] = {1.0, 1.0};    // listed tiles / all (panel, K tile, active segment) tiles
+    double gw_avg[2] = {0.0, 0.0};        // average list length per row panel
 };
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -415,6 +427,8 @@ extern "C" int midyn_stack_destroy(midyn_stack* s) {
     s->eval_plan = nullptr;
     if (s->planes) hipFree(s->planes);
     s->planes = nullptr;
+    for (int* q : {s->blk_ptr, s->blk_idx, s->gw_ptr[0], s->gw_idx[0], s->gw_ptr[1], s->gw_idx[1]})
+        if (q) hipFree(q);
     if (s->owns && s->buf) hipFree(s->buf);
     delete s;
     return 0;
@@ -442,12 +456,12 @@ extern "C" int midyn_stack_segment_modes(midyn_stack* s, int* modes) {
 // -------------------------------------------------------------------------------------------------
 // kernel launch helpers
 // -------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2>
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2, bool SPARSE = false>
 static int launch_gemm_mode(midyn_ctx* ctx, const GemmArgs& g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr size_t SMEM = (size_t)2 * BK * (BM + BN) * sizeof(double2);
     static bool attr_set[16] = {false};
-    auto kern = zgemm_seg_kernel<BM, BN, WM, WN, BK, MODE, MINW>;
+    auto kern = zgemm_seg_kernel<BM, BN, WM, WN, BK, MODE, MINW, SPARSE>;
     if (!attr_set[ctx->device & 15]) {
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
@@ -463,6 +477,14 @@ static int launch_gemm_mode(midyn_ctx* ctx, const GemmArgs& g) {
 // kernel), 3 when the stack is mixed (per-segment run-time flags)
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_gemm_cfg(midyn_ctx* ctx, const GemmArgs& g, int uniform_mode) {
+    if (g.work_ptr) {  // block-sparse stack: tile lists instead of the full (K tile, segment) loop
+        switch (uniform_mode) {
+            case 1: return launch_gemm_mode<BM, BN, WM, WN, BK, 1, 2, true>(ctx, g);
+            case 2: return launch_gemm_mode<BM, BN, WM, WN, BK, 2, 2, true>(ctx, g);
+            case 0: return launch_gemm_mode<BM, BN, WM, WN, BK, 0, 2, true>(ctx, g);
+            default: return launch_gemm_mode<BM, BN, WM, WN, BK, 3, 2, true>(ctx, g);
+        }
+    }
     switch (uniform_mode) {
         case 0: return launch_gemm_mode<BM, BN, WM, WN, BK, 0>(ctx, g);
         case 1: return launch_gemm_mode<BM, BN, WM, WN, BK, 1>(ctx, g);
@@ -512,14 +534,16 @@ static int launch_reduce(midyn_ctx* ctx, const GemmArgs& g) {
 }
 
 // tile choice: 128x128 (8 waves) when that still gives >= 1 block per CU, else 64x64 (4 waves)
-static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int uniform_mode = 0) {
+static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int uniform_mode = 0,
+                       const midyn_stack* sparse = nullptr) {
     const GemmArgs& g0 = g_in;
     if (g0.M % 64 || g0.N % 64 || g0.K % GEMM_BK)
         return fail(ctx, "launch_gemm: dimensions must be padded to 64/64/16");
     if (g0.n_act > 64)
         return fail(ctx, "more than 64 non-zero operator segments are not supported by the MFMA contraction yet");
     GemmArgs g = g_in;
-    if (uniform_mode == 0 && ctx->complex_3m) uniform_mode = 4;  // dense complex: 3 real MFMAs per product
+    if (uniform_mode == 0 && ctx->complex_3m && !sparse) uniform_mode = 4;  // dense complex: 3 real MFMAs per product
+    g.work_ptr = g.work_idx = nullptr;
     g.ablate = ctx->ablate;
     g.splits = 1;
     g.partial = nullptr;
@@ -548,7 +572,18 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     else if (ctx->force_tile == 64) t128 = false;
     else if (uniform_mode == 4) t128 = false;  // 3M: three accumulator sets only fit the 32x32 wave tile
     else t128 = can128;  // measured: 128-tile + split-K beats 64-tile without split (n=1024: 49.9 vs 46.4 TF)
-    const int splits = best_splits(t128 ? tiles128 : tiles64);
+    int splits = best_splits(t128 ? tiles128 : tiles64);
+    if (sparse) {
+        // the list of a row panel is shared out by COUNT: split while a share keeps >= 4 tiles
+        const int t = t128 ? 1 : 0;
+        g.work_ptr = sparse->gw_ptr[t];
+        g.work_idx = sparse->gw_idx[t];
+        const long long tiles = t128 ? tiles128 : tiles64;
+        splits = 1;
+        if (ctx->split_k)
+            while ((long long)splits * 2 * tiles <= 2 * ctx->num_cu && sparse->gw_avg[t] / (splits * 2) >= 4.0) splits *= 2;
+        if (ctx->force_splits > 0) splits = ctx->force_splits;
+    }
     CHK(setup_splits(ctx, g, splits));
     int st = t128 ? launch_gemm_cfg<128, 128, 2, 4, 16>(ctx, g, uniform_mode)
                   : launch_gemm_cfg<64, 64, 2, 2, 16>(ctx, g, uniform_mode);
@@ -649,6 +684,22 @@ static int launch_stream_multi(midyn_ctx* ctx, const StreamArgs& a, int ncol, in
     else if (ncol <= 4) { MIDYN_MULTI(4); }
     else { MIDYN_MULTI(8); }
 #undef MIDYN_MULTI
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// block-sparse stack, 1..8 columns: only the listed 16 x 16 operator blocks are read
+static int launch_blocks(midyn_ctx* ctx, const StreamArgs& a, const midyn_stack* s, int ncol, int m_cols,
+                         long long inst_stride) {
+    ProfScope ps(ctx, KC_BLOCKS);
+    const dim3 grid(a.n_pad / 16), block(256);
+#define MIDYN_BLOCKS(C_) \
+    hipLaunchKernelGGL((rhs_blocks_kernel<C_>), grid, block, 0, ctx->stream, a, s->blk_ptr, s->blk_idx, ncol, m_cols, inst_stride)
+    if (ncol <= 1) { MIDYN_BLOCKS(1); }
+    else if (ncol <= 2) { MIDYN_BLOCKS(2); }
+    else if (ncol <= 4) { MIDYN_BLOCKS(4); }
+    else { MIDYN_BLOCKS(8); }
+#undef MIDYN_BLOCKS
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -1011,6 +1062,7 @@ struct midyn_rk4_plan {
     DevBuf d_S, d_times, d_E, d_y, d_acc, d_yin[2], d_out, d_tmp, d_G, d_eval_out, d_eval_tmp;
     bool combine_first = false;  // one instance, many columns: form C(t) once, then ONE n^3 zgemm
     bool multi_stream = false;   // 2..8 columns, large n: multi-column streaming kernel instead of a padded MFMA tile
+    bool blocks = false;         // block-sparse stack: work-list kernels (rhs_blocks_kernel / SPARSE zgemm_seg_kernel)
     std::vector<int> rows;     // [nsteps][3]
     std::vector<double> hs;    // [nsteps]
     std::vector<int> save;     // [nsteps] or empty
@@ -1020,6 +1072,78 @@ struct midyn_rk4_plan {
     size_t tiny_smem = 0;
     DevBuf d_rows, d_hs, d_save;
 };
+
+// Block occupancy of the stack (once per stack): the 16 x 16 map of every segment comes from
+// block_map_kernel; the host turns it into the work lists of rhs_blocks_kernel (per 16 rows) and of the
+// SPARSE zgemm_seg_kernel (per row panel of 64 / 128 rows, K tile outer / segment inner).
+static int stack_block_lists(midyn_stack* s) {
+    if (s->blk_state) return 0;
+    midyn_ctx* ctx = s->ctx;
+    s->blk_state = -1;
+    const int np = s->n_pad, nb = np / 16;
+    if (s->n_act < 1 || s->n_act > 64 || np < 256 || nb > 0xffff) return 0;
+    const size_t map_bytes = (size_t)s->nseg * nb * nb;
+    DevBuf d_map;
+    CHK(d_map.alloc(ctx, map_bytes));
+    HIPCHK(ctx, hipMemsetAsync(d_map.p, 0, map_bytes, ctx->stream));
+    hipLaunchKernelGGL(block_map_kernel, dim3(nb, s->nseg), dim3(256), 0, ctx->stream, s->ops, np,
+                       d_map.as<unsigned char>());
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<unsigned char> map(map_bytes);
+    HIPCHK(ctx, hipMemcpyAsync(map.data(), d_map.p, map_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> act;  // packed (seg << 2 | mode), the order of seg_act
+    for (int seg = 0; seg < s->nseg; ++seg)
+        if (s->h_modes[seg] != 3) act.push_back((seg << 2) | s->h_modes[seg]);
+    size_t nz = 0;
+    for (int a : act) {
+        const unsigned char* m = map.data() + (size_t)(a >> 2) * nb * nb;
+        for (size_t i = 0; i < (size_t)nb * nb; ++i) nz += m[i];
+    }
+    s->blk_density = (double)nz / ((double)act.size() * nb * nb);
+    if (s->blk_density > 0.5) return 0;  // dense enough: the dense kernels are the right ones
+    auto upload = [&](const std::vector<int>& h, int** d) -> int {
+        HIPCHK(ctx, hipMalloc(d, std::max<size_t>(h.size(), 1) * sizeof(int)));
+        if (!h.empty()) HIPCHK(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice));
+        return 0;
+    };
+    {   // streaming lists: per 16-row group, segment outer / chunk inner
+        std::vector<int> ptr(nb + 1, 0), idx;
+        idx.reserve(nz);
+        for (int rb = 0; rb < nb; ++rb) {
+            for (size_t ai = 0; ai < act.size(); ++ai) {
+                const unsigned char* m = map.data() + ((size_t)(act[ai] >> 2) * nb + rb) * nb;
+                for (int cb = 0; cb < nb; ++cb)
+                    if (m[cb]) idx.push_back(((int)ai << 16) | cb);
+            }
+            ptr[rb + 1] = (int)idx.size();
+        }
+        CHK(upload(ptr, &s->blk_ptr));
+        CHK(upload(idx, &s->blk_idx));
+    }
+    for (int t = 0; t < 2; ++t) {  // MFMA tile lists: BM = 64, 128 (K tile = GEMM_BK = 16 columns = one chunk)
+        const int BM = t == 0 ? 64 : 128;
+        if (np % BM) continue;
+        const int panels = np / BM, rpb = BM / 16;
+        std::vector<int> ptr(panels + 1, 0), idx;
+        for (int pm = 0; pm < panels; ++pm) {
+            for (int kt = 0; kt < nb; ++kt)
+                for (int a : act) {
+                    const unsigned char* m = map.data() + ((size_t)(a >> 2) * nb + (size_t)pm * rpb) * nb + kt;
+                    bool any = false;
+                    for (int r = 0; r < rpb && !any; ++r) any = m[(size_t)r * nb] != 0;
+                    if (any) idx.push_back((kt << 8) | a);
+                }
+            ptr[pm + 1] = (int)idx.size();
+        }
+        s->gw_density[t] = (double)idx.size() / ((double)panels * nb * act.size());
+        s->gw_avg[t] = (double)idx.size() / panels;
+        CHK(upload(ptr, &s->gw_ptr[t]));
+        CHK(upload(idx, &s->gw_idx[t]));
+    }
+    s->blk_state = 1;
+    return 0;
+}
 
 // planar copy of a single-plane stack: planes[act] = the non-zero plane of active segment `act`
 static int stack_planes(midyn_stack* s) {
@@ -1041,6 +1165,18 @@ static const double2* plan_E(midyn_rk4_plan* p, int row) {
 static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, const double2* yin) {
     midyn_stack* s = p->stack;
     midyn_ctx* ctx = s->ctx;
+    if (p->blocks && p->ncol <= 8) {
+        StreamArgs a{};
+        a.ops = s->ops;
+        a.seg_list = s->seg_act;
+        a.n_act = s->n_act;
+        a.n_pad = s->n_pad;
+        a.has_static = s->has_static;
+        a.coeff = s->k > 0 ? p->d_S.as<double>() + (size_t)row * s->k : nullptr;
+        a.yin = yin;
+        a.epi = epi;
+        return launch_blocks(ctx, a, s, p->ncol, p->m, (long long)p->R * s->k);
+    }
     if (p->stream_path) {
         StreamArgs a{};
         a.ops = s->ops;
@@ -1121,7 +1257,8 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
         CHK(stack_planes(s));
         return launch_gemm_plane(ctx, g, s->planes, (long long)s->n_pad * s->n_pad);
     }
-    return launch_gemm(ctx, g, KC_RHS_GEMM, ctx->skip_zero_planes ? s->uniform_mode : 0);
+    return launch_gemm(ctx, g, p->blocks ? KC_BLOCKS_GEMM : KC_RHS_GEMM, ctx->skip_zero_planes ? s->uniform_mode : 0,
+                       p->blocks ? s : nullptr);
 }
 
 extern "C" int midyn_rk4_plan_destroy(midyn_rk4_plan* p) {
@@ -1169,6 +1306,15 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
     if (P > 0) guard(p->d_out.alloc(ctx, (size_t)B * P * s->n * m * sizeof(double2)));
     p->multi_stream = (!p->stream_path && p->ncol <= 8 && s->n_pad >= 256 && s->nseg <= 64 && ctx->multi_stream);
     p->combine_first = (B == 1 && m >= 8 && s->nseg > 1 && ctx->combine_first && !p->multi_stream);
+    if (ctx->skip_zero_blocks && ctx->skip_zero_planes && s->n_pad >= 256 && !st) {
+        guard(stack_block_lists(s));
+        if (s->blk_state == 1) {
+            const int t = (s->n_pad % 128 == 0 && p->ld % 128 == 0) ? 1 : 0;
+            if (p->ncol <= 8) p->blocks = s->blk_density <= 0.25;
+            else p->blocks = s->gw_ptr[t] && s->gw_density[t] <= 0.5 && ctx->force_tile == 0;
+        }
+        if (p->blocks) p->combine_first = false;
+    }
     if (p->combine_first) guard(p->d_G.alloc(ctx, (size_t)s->n_pad * s->n_pad * sizeof(double2)));
     if (st) {
         delete p;
@@ -1789,7 +1935,9 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
     } guard{p};
     const int np = s->n_pad, ld = p->ld;
     const size_t stv = (size_t)np * ld, state_bytes = stv * sizeof(double2);
-    const bool one = (B == 1);  // one instance: explicit G(t_i), products on a single matrix
+    // one instance: explicit G(t_i), products on a single matrix -- unless the stack is block sparse, where
+    // the per-segment work lists touch far fewer bytes than one dense n x n matrix
+    const bool one = (B == 1) && !p->blocks;
     const int npts = magnus_order;
     DevBuf Gx[2], U[2], V[2], W, d_cs;
     std::vector<double> h_cs;
@@ -1937,7 +2085,14 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
             e.mode = EPI_RHS;
             e.ld = ld;
             e.out = wv;
-            CHK(product(0, row, Vb + (size_t)j * np, Vb + (size_t)j * np, e));   // w = G v_j
+            const double2* vj = Vb + (size_t)j * np;
+            const double2* vj_phased = vj;
+            if (!one && plan_E(p, row)) {  // products through the plan: phased input, conjugate phase on output
+                CHK(rephase(vj, row, yin[0]));
+                vj_phased = yin[0];
+                e.e_cur = plan_E(p, row);
+            }
+            CHK(product(0, row, vj, vj_phased, e));   // w = G v_j
             for (int pass = 0; pass < 2; ++pass) {                                 // CGS + re-orthogonalisation
                 hipLaunchKernelGGL(krylov_dot_kernel, dim3(j + 1), dim3(256), 0, ctx->stream, Vb, np, wv, np, j, pass,
                                    khc.as<double2>(), Hm);
@@ -1999,7 +2154,7 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
         int deg = 2, sc = 1;
         action_choose(bound, &deg, &sc);
         bool stepped = false;
-        if (one && p->stream_path && magnus_order == 1 && ctx->krylov && (long long)deg * sc >= 64) {
+        if ((one || p->blocks) && p->stream_path && magnus_order == 1 && ctx->krylov && (long long)deg * sc >= 64) {
             bool conv = false;
             CHK(krylov_step(h, rr[0], bound, y, acc, &conv));
             if (conv) {

@@ -441,6 +441,111 @@ __global__ __launch_bounds__(256) void rhs_stream_multi_plane_kernel(StreamArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
+// rhs_blocks_kernel<C>: the streaming contraction (1..C columns, own coefficients per column) for
+// BLOCK-SPARSE stacks -- operators in a computational or diagonal-frame basis (Pauli strings, Kronecker
+// superoperators) are dense arrays in the reference but almost all of their 16 x 16 blocks are exactly
+// zero.  The stack keeps, per group of 16 rows, the list of (segment, column chunk) blocks that hold a
+// non-zero (`idx[ptr[g] .. ptr[g+1])`, entry = (active index << 16) | chunk, built once per stack from
+// block_map_kernel); only those blocks are read, straight from the dense arrays.  The skipped products
+// are exact zeros, so the result equals the dense kernels' up to the summation order.
+// One workgroup (4 waves) per row group; wave w takes entries w, w+4, ...; a lane owns row (lane >> 2)
+// and the four columns 4 (lane & 3) .. +3 of a chunk (64 contiguous bytes), four blocks in flight.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void rhs_blocks_kernel(StreamArgs a, const int* __restrict__ ptr,
+                                                         const int* __restrict__ idx, int ncol, int m_cols,
+                                                         long long inst_stride) {
+    constexpr int U = 4;
+    const int rg = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = a.n_pad;
+    const size_t plane = (size_t)n * n;
+    const int ld = a.epi.ld;
+    __shared__ double cf_s[64 * C];  // [active segment][column]
+    __shared__ int seg_s[64];
+    __shared__ double2 part[4][16][C];
+    for (int i = tid; i < a.n_act * C; i += 256) {
+        const int s = i / C, c = i - s * C;
+        const int seg = a.seg_list[s] >> 2;
+        double v = 0.0;
+        if (c < ncol)
+            v = (a.has_static && seg == 0) ? 1.0 : a.coeff[(size_t)(c / m_cols) * inst_stride + (seg - a.has_static)];
+        cf_s[i] = v;
+    }
+    if (tid < a.n_act) seg_s[tid] = a.seg_list[tid] >> 2;
+    __syncthreads();
+    const int r = lane >> 2, q = lane & 3;
+    const size_t row_off = (size_t)(rg * 16 + r) * n + 4 * q;
+    const int e1 = ptr[rg + 1];
+    double2 acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = make_double2(0.0, 0.0);
+    auto block_fma = [&](int s, int col0, const double2 (&v)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double cf = cf_s[s * C + c];
+                const double2 yv = a.yin[(size_t)(col0 + j) * ld + c];
+                const double gx = cf * v[j].x, gy = cf * v[j].y;
+                acc[c].x = fma(gx, yv.x, acc[c].x);
+                acc[c].x = fma(-gy, yv.y, acc[c].x);
+                acc[c].y = fma(gx, yv.y, acc[c].y);
+                acc[c].y = fma(gy, yv.x, acc[c].y);
+            }
+        }
+    };
+    int e = ptr[rg] + wave;
+    for (; e + 4 * (U - 1) < e1; e += 4 * U) {
+        int s[U], col0[U];
+        double2 v[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ent = idx[e + 4 * u];
+            s[u] = ent >> 16;
+            col0[u] = (ent & 0xffff) * 16 + 4 * q;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double2* p = a.ops + (size_t)seg_s[s[u]] * plane + row_off + (col0[u] - 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[u][j] = p[j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) block_fma(s[u], col0[u], v[u]);
+    }
+    for (; e < e1; e += 4) {
+        const int ent = idx[e];
+        const int s = ent >> 16, col0 = (ent & 0xffff) * 16 + 4 * q;
+        const double2* p = a.ops + (size_t)seg_s[s] * plane + row_off + (col0 - 4 * q);
+        double2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = p[j];
+        block_fma(s, col0, v);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        acc[c].x += __shfl_xor(acc[c].x, 1, 64);
+        acc[c].y += __shfl_xor(acc[c].y, 1, 64);
+        acc[c].x += __shfl_xor(acc[c].x, 2, 64);
+        acc[c].y += __shfl_xor(acc[c].y, 2, 64);
+        if (q == 0) part[wave][r][c] = acc[c];
+    }
+    __syncthreads();
+    if (tid < 16 * C) {
+        const int rr = tid / C, c = tid - rr * C;
+        if (c < ncol) {
+            double2 t = part[0][rr][c];
+            t.x += part[1][rr][c].x + part[2][rr][c].x + part[3][rr][c].x;
+            t.y += part[1][rr][c].y + part[2][rr][c].y + part[3][rr][c].y;
+            apply_epilogue(a.epi, rg * 16 + rr, c, t);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // rhs_stream_plane_kernel: the same contraction for stacks whose active operators are ALL purely real
 // or purely imaginary (-iH of a real-symmetric H is purely imaginary: cfg 2/3).  The exactly-zero
 // plane of every operator is not stored at all (`planes[act][n][n]` doubles, built once by
@@ -575,6 +680,11 @@ struct GemmArgs {
     int splits;              // split-K: gridDim = tiles * splits; split z handles K tiles [z*KT/splits, ...)
     double2* partial;        // [splits][M][N] raw partial sums when splits > 1 (epilogue runs in
                              // splitk_reduce_kernel), nullptr otherwise
+    // block-sparse stacks (SPARSE instantiation): the tiles of row panel bm that hold a non-zero, K tile
+    // outer / segment inner like the dense loop: work_idx[work_ptr[bm] .. work_ptr[bm+1]) with
+    // entry = (K tile << 8) | (seg << 2 | mode); split z of `splits` takes an equal share of the LIST
+    const int* work_ptr;
+    const int* work_idx;
     int ablate;              // profiling only (midyn_ctx_set_option "ablate"): 1 no barrier, 2 no DMA,
                              // 4 no epilogue, 8 no fragment reads -- results are WRONG when non-zero
     Epilogue epi;
@@ -681,7 +791,7 @@ __device__ __forceinline__ void read_frags(const double2* __restrict__ Ab, const
 
 // second launch-bound argument = waves per SIMD the register allocation must allow: the 4-wave
 // configurations are meant to run two workgroups per CU (2 waves per SIMD -> <= 256 registers).
-template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2>
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2, bool SPARSE = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs g) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int NWAVE = WM * WN;
@@ -721,8 +831,17 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
     // split-K: this workgroup contracts K tiles [kt0, kt0 + KT) of every active segment
     const int KT_all = g.K / BK;
     const int KT = KT_all / g.splits;
-    const int kt0 = split * KT;
-    const int total = g.n_act * KT;
+    int kt0 = split * KT;
+    int total = g.n_act * KT;
+    // SPARSE: this workgroup's share [w0, w0 + total) of the row panel's tile list (K tiles absolute)
+    int w0 = 0;
+    if (SPARSE) {
+        const int l0 = g.work_ptr[bm], len = g.work_ptr[bm + 1] - l0;
+        const int a0 = (int)((long long)len * split / g.splits), a1 = (int)((long long)len * (split + 1) / g.splits);
+        w0 = l0 + a0;
+        total = a1 - a0;
+        kt0 = 0;
+    }
 
     // per-lane column bookkeeping for the coefficient scaling
     const int lcol = lane & 15;
@@ -803,9 +922,18 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
 
     double sc[NT], sc_next[NT];
     int packed = __builtin_amdgcn_readlane(seg_vec, 0);
+    // SPARSE: 64 list entries per VGPR (lane l holds entry 64 blk + l), read with v_readlane; the next
+    // 64 are fetched one iteration into a block, so no memory load sits on the per-tile path
+    int wvec = 0, wvec_next = 0, kt_first = 0;
+    if (SPARSE) {
+        wvec = lane < total ? g.work_idx[w0 + lane] : 0;
+        const int ent = __builtin_amdgcn_readlane(wvec, 0);
+        packed = ent & 255;
+        kt_first = ent >> 8;
+    }
     if (total > 0) {
-        dma_a(0, packed >> 2, 0);
-        dma_b(0, 0);
+        dma_a(kt_first, packed >> 2, 0);
+        dma_b(kt_first, 0);
         load_sc(packed >> 2, sc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -827,25 +955,37 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
     const int b_lane_off = wn * TN + lcol;
     if (total > 0) read_frags<BK, BN, MT, NT>(As + a_lane_off, Bs + b_lane_off, 0, lk, lcol, fa[0], fb[0]);
 
-    int kt = 0, s = 0;
+    int kt = SPARSE ? kt_first : 0, s = 0;
+    int bb = 0;  // SPARSE: LDS buffer of the current B tile (toggles whenever the K tile changes)
     for (int it = 0; it < total; ++it) {
         int s_n = s + 1, kt_n = kt;
-        if (s_n == g.n_act) {
+        int packed_n = 0, bb_n = bb, ent_n = 0;
+        if (SPARSE) {
+            const int j = it + 1;
+            if ((j & 63) == 0) wvec = wvec_next;
+            ent_n = j < total ? __builtin_amdgcn_readlane(wvec, j & 63) : ((kt << 8) | packed);
+            if ((j & 63) == 1 && (j | 63) + 1 < total) {
+                const int e = (j | 63) + 1 + lane;
+                wvec_next = e < total ? g.work_idx[w0 + e] : 0;
+            }
+            kt_n = ent_n >> 8;
+            s_n = kt_n != kt ? 0 : 1;  // 0 = a new B tile is needed
+            bb_n = bb ^ (kt_n != kt ? 1 : 0);
+        } else if (s_n == g.n_act) {
             s_n = 0;
             kt_n = kt + 1;
         }
-        int packed_n = 0;
         const double2* Ab = As + (it & 1) * BK * BM + a_lane_off;
-        const double2* Bb = Bs + (kt & 1) * BK * BN + b_lane_off;
+        const double2* Bb = Bs + (SPARSE ? bb : (kt & 1)) * BK * BN + b_lane_off;
         const double2* Ab_n = As + ((it + 1) & 1) * BK * BM + a_lane_off;
-        const double2* Bb_n = Bs + (kt_n & 1) * BK * BN + b_lane_off;
+        const double2* Bb_n = Bs + (SPARSE ? bb_n : (kt_n & 1)) * BK * BN + b_lane_off;
         const int mode = packed & 3;
         auto issue_next_tile = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            packed_n = __builtin_amdgcn_readlane(seg_vec, s_n);
+            packed_n = SPARSE ? (ent_n & 255) : __builtin_amdgcn_readlane(seg_vec, s_n);
             if (it + 1 < total && !MIDYN_ABL(g, 2)) {
                 dma_a(kt_n, packed_n >> 2, (it + 1) & 1);
-                if (s_n == 0) dma_b(kt_n, kt_n & 1);
+                if (s_n == 0) dma_b(kt_n, SPARSE ? bb_n : (kt_n & 1));
             }
             load_sc(packed_n >> 2, sc_next);
             __builtin_amdgcn_sched_barrier(0);
@@ -902,6 +1042,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
         for (int nt = 0; nt < NT; ++nt) sc[nt] = sc_next[nt];
         s = s_n;
         kt = kt_n;
+        bb = bb_n;
         packed = packed_n;
     }
 
@@ -1904,6 +2045,20 @@ __global__ __launch_bounds__(256) void plane_flags_kernel(const double2* ops, si
     if (seg_of >= 0) {
         if (fr) flags[2 * seg_of] = 1;
         if (fi) flags[2 * seg_of + 1] = 1;
+    }
+}
+
+// map[(seg * nrb + rb) * ncb + cb] = 1 when the 16 x 16 block (rb, cb) of operator segment seg holds a
+// non-zero entry (nrb = ncb = n_pad / 16; the map is zeroed by the caller; every writer stores 1).
+// grid (nrb, nseg): one workgroup per 16-row strip.
+__global__ __launch_bounds__(256) void block_map_kernel(const double2* ops, int n_pad, unsigned char* map) {
+    const int rb = blockIdx.x, seg = blockIdx.y;
+    const int nb = n_pad / 16;
+    const double2* base = ops + (size_t)seg * n_pad * n_pad + (size_t)rb * 16 * n_pad;
+    unsigned char* out = map + ((size_t)seg * nb + rb) * nb;
+    for (int idx = threadIdx.x; idx < 16 * n_pad; idx += 256) {
+        const double2 v = base[idx];
+        if (v.x != 0.0 || v.y != 0.0) out[(idx % n_pad) / 16] = 1;
     }
 }
 

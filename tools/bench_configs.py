@@ -63,13 +63,16 @@ if "expm" in which:
                           "unitarity_per_n": unit}), flush=True)
 
 def all_counters():
-    return {k_: ctx.counters(k_) for k_ in ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise")}
+    return {k_: ctx.counters(k_) for k_ in ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", "rhs_blocks",
+                                            "rhs_blocks_gemm")}
 
 
 def run_modes(label, fn, nsteps, extra):
     """Time `fn` with the expm-action path (default for few columns) and with the dense expm path."""
-    for mode, flag in (("action", 1), ("dense_expm", 0)):
+    modes = (("action", 1, 1), ("action, dense kernels (skip_zero_blocks=0)", 1, 0), ("dense_expm", 0, 1))
+    for mode, flag, blocks in modes:
         ctx.set_option("expm_action", flag)
+        ctx.set_option("skip_zero_blocks", blocks)
         fn()  # warm (allocations, lazy norms)
         ctx.reset_counters()
         ctx.set_option("profile", 1)
@@ -83,6 +86,7 @@ def run_modes(label, fn, nsteps, extra):
         out.update(extra(r))
         print(json.dumps(out), flush=True)
     ctx.set_option("expm_action", 1)
+    ctx.set_option("skip_zero_blocks", 1)
 
 
 if "cfg4" in which:
