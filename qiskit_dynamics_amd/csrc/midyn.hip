@@ -574,14 +574,15 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     else t128 = can128;  // measured: 128-tile + split-K beats 64-tile without split (n=1024: 49.9 vs 46.4 TF)
     int splits = best_splits(t128 ? tiles128 : tiles64);
     if (sparse) {
-        // the list of a row panel is shared out by COUNT: split while a share keeps >= 4 tiles
+        // the list of a row panel is shared out by COUNT: one workgroup per CU at most, a share keeps >= 4 tiles
+        // (measured, n = 4096, 112 tiles per panel: 32 panels x 8 splits 87 us, x 16 107 us, x 4 133 us)
         const int t = t128 ? 1 : 0;
         g.work_ptr = sparse->gw_ptr[t];
         g.work_idx = sparse->gw_idx[t];
         const long long tiles = t128 ? tiles128 : tiles64;
         splits = 1;
         if (ctx->split_k)
-            while ((long long)splits * 2 * tiles <= 2 * ctx->num_cu && sparse->gw_avg[t] / (splits * 2) >= 4.0) splits *= 2;
+            while ((long long)splits * 2 * tiles <= ctx->num_cu && sparse->gw_avg[t] / (splits * 2) >= 4.0) splits *= 2;
         if (ctx->force_splits > 0) splits = ctx->force_splits;
     }
     CHK(setup_splits(ctx, g, splits));
@@ -1162,9 +1163,12 @@ static const double2* plan_E(midyn_rk4_plan* p, int row) {
     return p->d_E.as<double2>() + (size_t)row * p->stack->n_pad;
 }
 
-static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, const double2* yin) {
+// e_in (block-sparse streaming route only): `yin` is NOT pre-phased, the kernel applies this phase row on load
+static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, const double2* yin,
+                           const double2* e_in = nullptr) {
     midyn_stack* s = p->stack;
     midyn_ctx* ctx = s->ctx;
+    if (e_in && !(p->blocks && p->ncol <= 8)) return fail(ctx, "plan_rhs_launch: fused input phase needs the block route");
     if (p->blocks && p->ncol <= 8) {
         StreamArgs a{};
         a.ops = s->ops;
@@ -1174,6 +1178,7 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
         a.has_static = s->has_static;
         a.coeff = s->k > 0 ? p->d_S.as<double>() + (size_t)row * s->k : nullptr;
         a.yin = yin;
+        a.e_in = e_in;
         a.epi = epi;
         return launch_blocks(ctx, a, s, p->ncol, p->m, (long long)p->R * s->k);
     }
@@ -1995,6 +2000,16 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
         HIPCHK(ctx, hipGetLastError());
         return 0;
     };
+    // out = conj-phase(G(row) . w) for an UN-phased w: explicit G (one), the block kernels' fused input phase, or
+    // a rephase pass into `scratch` followed by the plan's contraction
+    const bool fuse_phase = !one && p->blocks && p->ncol <= 8;
+    auto product_plain = [&](int i, int row, const double2* w, double2* scratch, Epilogue epi) -> int {
+        if (one) return product(i, row, w, w, epi);
+        epi.e_cur = plan_E(p, row);
+        if (fuse_phase || !plan_E(p, row)) return plan_rhs_launch(p, row, epi, w, fuse_phase ? plan_E(p, row) : nullptr);
+        CHK(rephase(w, row, scratch));
+        return plan_rhs_launch(p, row, epi, scratch);
+    };
     const double p2 = std::sqrt(3.0) / 12;
     // norm bound of Omega over the instances for one step (triangle inequality over the segments)
     auto step_bound = [&](int st) {
@@ -2085,14 +2100,7 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
             e.mode = EPI_RHS;
             e.ld = ld;
             e.out = wv;
-            const double2* vj = Vb + (size_t)j * np;
-            const double2* vj_phased = vj;
-            if (!one && plan_E(p, row)) {  // products through the plan: phased input, conjugate phase on output
-                CHK(rephase(vj, row, yin[0]));
-                vj_phased = yin[0];
-                e.e_cur = plan_E(p, row);
-            }
-            CHK(product(0, row, vj, vj_phased, e));   // w = G v_j
+            CHK(product_plain(0, row, Vb + (size_t)j * np, yin[0], e));   // w = G v_j
             for (int pass = 0; pass < 2; ++pass) {                                 // CGS + re-orthogonalisation
                 hipLaunchKernelGGL(krylov_dot_kernel, dim3(j + 1), dim3(256), 0, ctx->stream, Vb, np, wv, np, j, pass,
                                    khc.as<double2>(), Hm);
@@ -2189,23 +2197,15 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
                     e.mode = EPI_RHS;
                     e.ld = ld;
                     // u1 = g1 term, u2 = g2 term
-                    if (!one) CHK(rephase(term, rr[0], yin[0]));
-                    e.e_cur = plan_E(p, rr[0]);
                     e.out = u1;
-                    CHK(product(0, rr[0], term, yin[0], e));
-                    if (!one) CHK(rephase(term, rr[1], yin[1]));
-                    e.e_cur = plan_E(p, rr[1]);
+                    CHK(product_plain(0, rr[0], term, yin[0], e));
                     e.out = u2;
-                    CHK(product(1, rr[1], term, yin[1], e));
+                    CHK(product_plain(1, rr[1], term, yin[1], e));
                     // v1 = g2 u1, v2 = g1 u2
-                    if (!one) CHK(rephase(u1, rr[1], yin[0]));
-                    e.e_cur = plan_E(p, rr[1]);
                     e.out = v1;
-                    CHK(product(1, rr[1], u1, yin[0], e));
-                    if (!one) CHK(rephase(u2, rr[0], yin[1]));
-                    e.e_cur = plan_E(p, rr[0]);
+                    CHK(product_plain(1, rr[1], u1, yin[0], e));
                     e.out = v2;
-                    CHK(product(0, rr[0], u2, yin[1], e));
+                    CHK(product_plain(0, rr[0], u2, yin[1], e));
                     const double f = 1.0 / ((double)sc * j);
                     hipLaunchKernelGGL(magnus2_term_kernel, dim3(grid_for(stv)), dim3(256), 0, ctx->stream, u1, u2, v1, v2,
                                        0.5 * h * f, p2 * h * h * f, stv, w, acc);

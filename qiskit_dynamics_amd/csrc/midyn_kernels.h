@@ -181,6 +181,7 @@ struct StreamArgs {
     int has_static;
     const double* coeff;     // [k] coefficients of this evaluation (device) or nullptr
     const double2* yin;      // [n_pad * ld] pre-phased input, column 0 used
+    const double2* e_in;     // rhs_blocks_kernel only: phase row applied to yin on load (input NOT pre-phased), or nullptr
     Epilogue epi;
 };
 
@@ -488,7 +489,8 @@ __global__ __launch_bounds__(256) void rhs_blocks_kernel(StreamArgs a, const int
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const double cf = cf_s[s * C + c];
-                const double2 yv = a.yin[(size_t)(col0 + j) * ld + c];
+                double2 yv = a.yin[(size_t)(col0 + j) * ld + c];
+                if (a.e_in) yv = cmul(a.e_in[col0 + j], yv);
                 const double gx = cf * v[j].x, gy = cf * v[j].y;
                 acc[c].x = fma(gx, yv.x, acc[c].x);
                 acc[c].x = fma(-gy, yv.y, acc[c].x);
