@@ -50,6 +50,10 @@ const char* midyn_last_error(midyn_ctx* ctx);
 /* Options (defaults in brackets; all of them select between paths that give the same results):
  *   skip_zero_planes [1]  skip exact-zero real/imaginary planes of operators (MFMA contraction and, for
  *                         single-plane stacks, the planar streaming kernel `stream_planes` [1])
+ *   skip_zero_blocks [1]  stacks whose 16 x 16 operator blocks are mostly exactly zero (operators in a
+ *                         computational / diagonal-frame basis): contract only the occupied blocks
+ *                         (work-list kernels; the skipped products are exact zeros)
+ *   krylov [1]            one column, Magnus order 1, large norm: Arnoldi instead of the scaled Taylor series
  *   complex_3m [1]        dense complex products with 3 real MFMAs instead of 4
  *   split_k [1], force_splits [0], force_tile [0 | 64 | 128 | 12864]   tile / split-K choice of the zgemm
  *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage
@@ -217,7 +221,8 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
 
 /* ---- counters ----------------------------------------------------------------------------------
  * Kernel-time accounting measured with HIP events on the ctx stream.
- * names: "rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise".
+ * names: "rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", and for the block-sparse routes
+ * "rhs_blocks" (1..8 columns) and "rhs_blocks_gemm" (MFMA tiles over work lists).
  * out[0] = launches, out[1] = total ms (events are only recorded when profiling is enabled with
  * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch). */
 int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);
