@@ -1899,3 +1899,62 @@ def test_block_sparse_vectorised_lindblad(qd):
         assert_close(out[(1, 1)], out[key], 1e-12)
     rho = out[(1, 1)].reshape(16, 16, order="F")
     assert abs(np.trace(rho) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("nb", [24, 130])
+def test_block_sparse_mfma_route_mixed_and_complex_planes(qd, nb):
+    """The SPARSE MFMA instantiations other than the single-plane ones: (a) a sweep of 5-qubit vectorised
+    Lindbladians without a frame (N = 1024; imaginary Hamiltonian part, real dissipator part: per-segment
+    run-time plane modes), (b) a 9-qubit chain driven through Y operators in the lab frame, where every
+    drive operator -iY is purely real and the static one purely imaginary (mixed), and (c) drives
+    X + Y with both planes occupied (dense complex mode).  Work lists against the dense kernels."""
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+
+    def both_routes(fn):
+        out = {}
+        for flag in (1, 0):
+            ctx.set_option("skip_zero_blocks", flag)
+            ctx.reset_counters()
+            ctx.set_option("profile", 1)
+            try:
+                r = fn()
+            finally:
+                ctx.set_option("profile", 0)
+                ctx.set_option("skip_zero_blocks", 1)
+            assert (ctx.counters("rhs_blocks_gemm")["launches"] > 0) == bool(flag)
+            out[flag] = np.stack([x.y[-1] for x in r])
+        return out
+
+    # (a) vectorised Lindblad sweep
+    cfg = W.lindblad_config(n_qubits=5, n_drives=5, n_diss=5, gamma=1e-2, t_final=0.2, max_dt=0.05)
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       static_dissipators=cfg["static_dissipators"], vectorized=True)
+    sweeps = []
+    for b in range(nb):
+        amps, phases = W.sweep_parameters(b, 5)
+        sweeps.append([qd.Signal(float(a), nu, ph) for a, nu, ph in zip(amps, cfg["carrier"], phases)])
+    y0 = cfg["rho0"].flatten(order="F")
+    for method, kw in (("RK4", {"max_dt": 0.01}), ("scipy_expm", {"max_dt": 0.05})):
+        out = both_routes(lambda: solver.solve(t_span=[0.0, 0.2], y0=y0, signals=sweeps, method=method, **kw))
+        assert_close(out[1], out[0], 1e-12)
+        tr = [abs(np.trace(v.reshape(32, 32, order="F")) - 1.0) for v in out[1]]
+        assert max(tr) < 1e-10
+
+    # (b), (c) Hamiltonians with Y and X + iY-type drives, lab frame (no rotating frame)
+    nq = 9
+    h_d, ops_x, nu = W.chain_hamiltonian(nq, 4)
+    y_mat = np.array([[0, -1j], [1j, 0]])
+    ops_y = np.stack([2 * np.pi * 0.02 * W.embed(y_mat, q, nq) / 2 for q in range(4)])
+    rng = np.random.default_rng(8)
+    y0 = rng.normal(size=2**nq) + 1j * rng.normal(size=2**nq)
+    y0 /= np.linalg.norm(y0)
+    for ops in (ops_y, ops_x + ops_y):
+        solver = qd.Solver(static_hamiltonian=h_d, hamiltonian_operators=ops)
+        sweeps = []
+        for b in range(nb):
+            amps, phases = W.sweep_parameters(b, 4)
+            sweeps.append([qd.Signal(float(a), f, ph) for a, f, ph in zip(amps, nu[:4], phases)])
+        out = both_routes(lambda: solver.solve(t_span=[0.0, 0.02], y0=y0, signals=sweeps, method="RK4", max_dt=0.002))
+        assert_close(out[1], out[0], 1e-12)
