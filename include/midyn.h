@@ -53,7 +53,8 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   skip_zero_blocks [1]  stacks whose 16 x 16 operator blocks are mostly exactly zero (operators in a
  *                         computational / diagonal-frame basis): contract only the occupied blocks
  *                         (work-list kernels; the skipped products are exact zeros)
- *   krylov [1]            one column, Magnus order 1, large norm: Arnoldi instead of the scaled Taylor series
+ *   krylov [1]            one column, Magnus order 1: Arnoldi instead of the scaled Taylor series when the
+ *                         series is long enough to pay for it (2: always, 0: never)
  *   complex_3m [1]        dense complex products with 3 real MFMAs instead of 4
  *   split_k [1], force_splits [0], force_tile [0 | 64 | 128 | 12864]   tile / split-K choice of the zgemm
  *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage

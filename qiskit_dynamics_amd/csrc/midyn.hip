@@ -45,7 +45,8 @@ struct midyn_ctx {
     int ablate = 0;
     int stream_variant = 0;
     int expm_degree = 0;         // 0: Taylor degree chosen from the norm; else forced (2,4,6,9,12,16)
-    bool krylov = true;          // one column, Magnus order 1, large norm: Arnoldi instead of the scaled Taylor series
+    int krylov = 1;              // one column, Magnus order 1: Arnoldi instead of the scaled Taylor series
+                                 // (1: when the series is long enough to pay for it, 2: always, 0: never)
     bool expm_action = true;     // few state columns: y <- expm(Omega) y as a Taylor series of matrix-vector
                                  // products instead of forming expm(Omega) (Magnus orders 1 and 2)
     bool stream_planes = true;   // single-plane stacks: the one-column kernel streams only non-zero planes
@@ -203,7 +204,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     else if (n == "multi_stream") ctx->multi_stream = value != 0;
     else if (n == "expm_degree") ctx->expm_degree = (int)value;
     else if (n == "expm_action") ctx->expm_action = value != 0;
-    else if (n == "krylov") ctx->krylov = value != 0;
+    else if (n == "krylov") ctx->krylov = (int)value;
     else if (n == "split_k") ctx->split_k = value != 0;
     else if (n == "combine_first") ctx->combine_first = value != 0;
     else if (n == "complex_3m") ctx->complex_3m = value != 0;
@@ -2162,7 +2163,12 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
         int deg = 2, sc = 1;
         action_choose(bound, &deg, &sc);
         bool stepped = false;
-        if ((one || p->blocks) && p->stream_path && magnus_order == 1 && ctx->krylov && (long long)deg * sc >= 64) {
+        // Arnoldi pays ~6 launches per vector (product, two Gram-Schmidt passes, normalisation) against one per
+        // Taylor term: with the microsecond products of a block-sparse stack both are launch bound and the
+        // series wins unless it is several times longer (cfg 4, 100 steps: Taylor 160 terms 0.100 s, Arnoldi 28
+        // vectors 0.113 s); with dense streamed products (tens of microseconds each) Arnoldi wins from 64 terms
+        const long long krylov_min = ctx->krylov >= 2 ? 0 : (p->blocks ? (long long)(6.0 * (1.5 * bound + 20.0)) : 64);
+        if ((one || p->blocks) && p->stream_path && magnus_order == 1 && ctx->krylov && (long long)deg * sc >= krylov_min) {
             bool conv = false;
             CHK(krylov_step(h, rr[0], bound, y, acc, &conv));
             if (conv) {
