@@ -268,7 +268,7 @@ struct midyn_stack {
     int blk_state = 0;              // 0 not examined, 1 lists built, -1 not applicable
     double blk_density = 1.0;       // non-zero 16 x 16 blocks / all blocks of the active segments
     int* blk_ptr = nullptr;         // streaming lists per group of 16 rows: [n_pad/16 + 1]
-    int* blk_idx = nullptr;         // entry = (active index << 16) | column chunk
+    int* blk_idx = nullptr;         // entry = (segment << 16) | column chunk
     int* gw_ptr[2] = {nullptr, nullptr};  // MFMA tile lists per row panel of 64 / 128 rows: [M/BM + 1]
     int* gw_idx[2] = {nullptr, nullptr};  // entry = (K tile << 8) | (seg << 2 | mode)
     double gw_density[2] = {1.0, 1.0};    // listed tiles / all (panel, K tile, active segment) tiles
@@ -1083,7 +1083,7 @@ static int stack_block_lists(midyn_stack* s) {
     midyn_ctx* ctx = s->ctx;
     s->blk_state = -1;
     const int np = s->n_pad, nb = np / 16;
-    if (s->n_act < 1 || s->n_act > 64 || np < 256 || nb > 0xffff) return 0;
+    if (s->n_act < 1 || s->nseg > 64 || np < 256 || nb > 0xffff) return 0;
     const size_t map_bytes = (size_t)s->nseg * nb * nb;
     DevBuf d_map;
     CHK(d_map.alloc(ctx, map_bytes));
@@ -1116,7 +1116,7 @@ static int stack_block_lists(midyn_stack* s) {
             for (size_t ai = 0; ai < act.size(); ++ai) {
                 const unsigned char* m = map.data() + ((size_t)(act[ai] >> 2) * nb + rb) * nb;
                 for (int cb = 0; cb < nb; ++cb)
-                    if (m[cb]) idx.push_back(((int)ai << 16) | cb);
+                    if (m[cb]) idx.push_back(((act[ai] >> 2) << 16) | cb);
             }
             ptr[rb + 1] = (int)idx.size();
         }
@@ -1173,8 +1173,8 @@ static int plan_rhs_launch(midyn_rk4_plan* p, int row, const Epilogue& epi, cons
     if (p->blocks && p->ncol <= 8) {
         StreamArgs a{};
         a.ops = s->ops;
-        a.seg_list = s->seg_act;
-        a.n_act = s->n_act;
+        a.seg_list = nullptr;
+        a.n_act = s->nseg;  // the block lists carry segment numbers: coefficients are staged for every segment
         a.n_pad = s->n_pad;
         a.has_static = s->has_static;
         a.coeff = s->k > 0 ? p->d_S.as<double>() + (size_t)row * s->k : nullptr;

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void rhs_stream_multi_plane_kernel(StreamArgs 
 // BLOCK-SPARSE stacks -- operators in a computational or diagonal-frame basis (Pauli strings, Kronecker
 // superoperators) are dense arrays in the reference but almost all of their 16 x 16 blocks are exactly
 // zero.  The stack keeps, per group of 16 rows, the list of (segment, column chunk) blocks that hold a
-// non-zero (`idx[ptr[g] .. ptr[g+1])`, entry = (active index << 16) | chunk, built once per stack from
+// non-zero (`idx[ptr[g] .. ptr[g+1])`, entry = (segment << 16) | chunk, built once per stack from
 // block_map_kernel); only those blocks are read, straight from the dense arrays.  The skipped products
 // are exact zeros, so the result equals the dense kernels' up to the summation order.
 // One workgroup (4 waves) per row group; wave w takes entries w, w+4, ...; a lane owns row (lane >> 2)
@@ -456,7 +456,7 @@ template <int C>
 __global__ __launch_bounds__(256) void rhs_blocks_kernel(StreamArgs a, const int* __restrict__ ptr,
                                                          const int* __restrict__ idx, int ncol, int m_cols,
                                                          long long inst_stride) {
-    constexpr int U = 4;
+    constexpr int U = C <= 2 ? 8 : 4;  // blocks in flight per wave
     const int rg = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -464,68 +464,70 @@ __global__ __launch_bounds__(256) void rhs_blocks_kernel(StreamArgs a, const int
     const int n = a.n_pad;
     const size_t plane = (size_t)n * n;
     const int ld = a.epi.ld;
-    __shared__ double cf_s[64 * C];  // [active segment][column]
-    __shared__ int seg_s[64];
+    __shared__ double cf_s[64 * C];  // [segment][column]   (a.n_act = number of SEGMENTS here, <= 64)
     __shared__ double2 part[4][16][C];
-    for (int i = tid; i < a.n_act * C; i += 256) {
-        const int s = i / C, c = i - s * C;
-        const int seg = a.seg_list[s] >> 2;
-        double v = 0.0;
-        if (c < ncol)
-            v = (a.has_static && seg == 0) ? 1.0 : a.coeff[(size_t)(c / m_cols) * inst_stride + (seg - a.has_static)];
-        cf_s[i] = v;
-    }
-    if (tid < a.n_act) seg_s[tid] = a.seg_list[tid] >> 2;
-    __syncthreads();
     const int r = lane >> 2, q = lane & 3;
-    const size_t row_off = (size_t)(rg * 16 + r) * n + 4 * q;
-    const int e1 = ptr[rg + 1];
+    const size_t row_off = (size_t)(rg * 16 + r) * n;
+    // The wave's entries (e0 + wave + 4 i) are fetched 64 at a time into one VGPR and handed out with
+    // v_readlane: block addresses are scalars, and the first group of block loads is in flight while the
+    // coefficients are staged (a row group holds a few dozen blocks: the kernel is a latency chain).
+    const int e0 = ptr[rg], e1 = ptr[rg + 1];
+    const int nw = (e1 - e0 - wave + 3) >> 2;  // entries of this wave
     double2 acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = make_double2(0.0, 0.0);
-    auto block_fma = [&](int s, int col0, const double2 (&v)[4]) {
+    bool staged = false;
+    for (int base = 0; base < nw || !staged; base += 64) {
+        const int mine = base + lane < nw ? idx[e0 + wave + 4 * (base + lane)] : 0;
+        const int m = nw - base < 64 ? nw - base : 64;   // <= 0 for a wave without entries
+        for (int i = 0; i < m || !staged; i += U) {
+            int seg[U], col0[U];
+            double2 v[U][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+            for (int u = 0; u < U; ++u) {
+                const int ent = __builtin_amdgcn_readlane(mine, i + u < m ? i + u : 0);
+                seg[u] = i + u < m ? ent >> 16 : -1;
+                col0[u] = (ent & 0xffff) * 16 + 4 * q;
+            }
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const double cf = cf_s[s * C + c];
-                double2 yv = a.yin[(size_t)(col0 + j) * ld + c];
-                if (a.e_in) yv = cmul(a.e_in[col0 + j], yv);
-                const double gx = cf * v[j].x, gy = cf * v[j].y;
-                acc[c].x = fma(gx, yv.x, acc[c].x);
-                acc[c].x = fma(-gy, yv.y, acc[c].x);
-                acc[c].y = fma(gx, yv.y, acc[c].y);
-                acc[c].y = fma(gy, yv.x, acc[c].y);
+            for (int u = 0; u < U; ++u) {
+                if (seg[u] >= 0) {
+                    const double2* p = a.ops + (size_t)seg[u] * plane + row_off + col0[u];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[u][j] = p[j];
+                }
+            }
+            if (!staged) {  // once, behind the first block loads
+                for (int t = tid; t < a.n_act * C; t += 256) {
+                    const int sg = t / C, c = t - sg * C;
+                    double cv = 0.0;
+                    if (c < ncol)
+                        cv = (a.has_static && sg == 0) ? 1.0
+                                                       : a.coeff[(size_t)(c / m_cols) * inst_stride + (sg - a.has_static)];
+                    cf_s[t] = cv;
+                }
+                __syncthreads();
+                staged = true;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (seg[u] < 0) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const double cf = cf_s[seg[u] * C + c];
+                        double2 yv = a.yin[(size_t)(col0[u] + j) * ld + c];
+                        if (a.e_in) yv = cmul(a.e_in[col0[u] + j], yv);
+                        const double gx = cf * v[u][j].x, gy = cf * v[u][j].y;
+                        acc[c].x = fma(gx, yv.x, acc[c].x);
+                        acc[c].x = fma(-gy, yv.y, acc[c].x);
+                        acc[c].y = fma(gx, yv.y, acc[c].y);
+                        acc[c].y = fma(gy, yv.x, acc[c].y);
+                    }
+                }
             }
         }
-    };
-    int e = ptr[rg] + wave;
-    for (; e + 4 * (U - 1) < e1; e += 4 * U) {
-        int s[U], col0[U];
-        double2 v[U][4];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ent = idx[e + 4 * u];
-            s[u] = ent >> 16;
-            col0[u] = (ent & 0xffff) * 16 + 4 * q;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double2* p = a.ops + (size_t)seg_s[s[u]] * plane + row_off + (col0[u] - 4 * q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[u][j] = p[j];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) block_fma(s[u], col0[u], v[u]);
-    }
-    for (; e < e1; e += 4) {
-        const int ent = idx[e];
-        const int s = ent >> 16, col0 = (ent & 0xffff) * 16 + 4 * q;
-        const double2* p = a.ops + (size_t)seg_s[s] * plane + row_off + (col0 - 4 * q);
-        double2 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = p[j];
-        block_fma(s, col0, v);
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
