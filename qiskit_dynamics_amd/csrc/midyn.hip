@@ -1318,6 +1318,9 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
             const int t = (s->n_pad % 128 == 0 && p->ld % 128 == 0) ? 1 : 0;
             if (p->ncol <= 8) p->blocks = s->blk_density <= 0.25;
             else p->blocks = s->gw_ptr[t] && s->gw_density[t] <= 0.5 && ctx->force_tile == 0;
+            // one instance, many columns: forming C(t) first contracts ONE dense operator; the per-segment tile
+            // lists only win when they hold less than that in total
+            if (p->blocks && p->combine_first && s->gw_density[t] * s->n_act >= 0.8) p->blocks = false;
         }
         if (p->blocks) p->combine_first = false;
     }

@@ -1843,6 +1843,14 @@ def test_block_sparse_routes_match_dense_routes(qd, nq, nb):
             out[flag] = np.stack([x.y[-1] for x in r]) if nb > 1 else r.y[-1][None]
         assert_close(out[1], out[0], 1e-13)
         assert np.max(np.abs(np.linalg.norm(out[1], axis=1) - 1.0)) < 1e-8
+        if nb > 8 and method == "RK4":
+            # unsplit work lists: more than 64 entries per workgroup (the list vector is refilled in flight)
+            ctx.set_option("force_splits", 1)
+            try:
+                r = solver.solve(t_span=[0.0, 0.2], y0=y0, signals=sig, method=method, max_dt=0.01, **kw)
+            finally:
+                ctx.set_option("force_splits", 0)
+            assert_close(np.stack([x.y[-1] for x in r]), out[0], 1e-13)
 
 
 def test_block_sparse_against_oracle(qd):
