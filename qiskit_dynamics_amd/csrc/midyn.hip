@@ -555,12 +555,13 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     //    workspace, summed + epilogue in splitk_reduce_kernel) so that the whole chip contracts.
     //  force_tile (64 | 128 | 12864) pins the tile for A/B runs; 12864 = 128x64x8 two-per-CU variant.
     const int KT = g.K / GEMM_BK;
-    auto best_splits = [&](long long tiles) {
+    // `fill`: workgroups per CU the split may create (the 64-tile keeps two workgroups per CU busy)
+    auto best_splits = [&](long long tiles, int fill) {
         int sp = 1;
         if (g.batch > 1 || g.batch_offs) return 1;  // the batch dimension already fills the chip
-        tiles *= 1;
-        if (ctx->split_k && tiles < ctx->num_cu)
-            while ((long long)sp * 2 * tiles <= ctx->num_cu && KT % (sp * 2) == 0 && KT / (sp * 2) >= 2) sp *= 2;
+        const long long cap = (long long)fill * ctx->num_cu;
+        if (ctx->split_k && tiles < cap)
+            while ((long long)sp * 2 * tiles <= cap && KT % (sp * 2) == 0 && KT / (sp * 2) >= 2) sp *= 2;
         if (ctx->force_splits > 0 && KT % ctx->force_splits == 0) sp = ctx->force_splits;
         return sp;
     };
@@ -573,7 +574,11 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     else if (ctx->force_tile == 64) t128 = false;
     else if (uniform_mode == 4) t128 = false;  // 3M: three accumulator sets only fit the 32x32 wave tile
     else t128 = can128;  // measured: 128-tile + split-K beats 64-tile without split (n=1024: 49.9 vs 46.4 TF)
-    int splits = best_splits(t128 ? tiles128 : tiles64);
+    // narrow state blocks (<= 256 columns) of the dense RHS contraction: 64-tiles split to two workgroups per CU
+    // (n = 1024, k = 8: 128 columns 92.0 vs 99.4 us, 256 columns 169.7 vs 176.7 us; from 384 columns the 128-tile wins)
+    if (t128 && !sparse && cls == KC_RHS_GEMM && g.N <= 256 && ctx->force_tile == 0 && g.batch <= 1 && !g.batch_offs)
+        t128 = false;
+    int splits = best_splits(t128 ? tiles128 : tiles64, (!t128 && cls == KC_RHS_GEMM) ? 2 : 1);
     if (sparse) {
         // the list of a row panel is shared out by COUNT: one workgroup per CU at most, a share keeps >= 4 tiles
         // (measured, n = 4096, 112 tiles per panel: 32 panels x 8 splits 87 us, x 16 107 us, x 4 133 us)
