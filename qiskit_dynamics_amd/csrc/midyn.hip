@@ -534,6 +534,14 @@ static int launch_reduce(midyn_ctx* ctx, const GemmArgs& g) {
     return 0;
 }
 
+// Block-sparse stacks: which tile lists to run on (0: 64-row panels, 1: 128-row panels).  A 128-row panel
+// lists every K tile that any of its 8 row groups touches, a 64-row panel far fewer for scattered patterns
+// (cfg 5, 128 / 256 / 512 instances: 55.6 / 91.6 / 152.6 us per contraction on 64-row panels against
+// 86.5 / 142.8 / 256.7 us on 128-row panels): the big tile only when it lists (almost) no extra zeros.
+static int sparse_tile(const midyn_stack* s, bool can128) {
+    return (can128 && s->gw_ptr[1] && s->gw_density[1] <= 1.15 * s->gw_density[0]) ? 1 : 0;
+}
+
 // tile choice: 128x128 (8 waves) when that still gives >= 1 block per CU, else 64x64 (4 waves)
 static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int uniform_mode = 0,
                        const midyn_stack* sparse = nullptr) {
@@ -574,14 +582,13 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     else if (ctx->force_tile == 64) t128 = false;
     else if (uniform_mode == 4) t128 = false;  // 3M: three accumulator sets only fit the 32x32 wave tile
     else t128 = can128;  // measured: 128-tile + split-K beats 64-tile without split (n=1024: 49.9 vs 46.4 TF)
-    // narrow state blocks (<= 256 columns) of the dense RHS contraction: 64-tiles split to two workgroups per CU
-    // (n = 1024, k = 8: 128 columns 92.0 vs 99.4 us, 256 columns 169.7 vs 176.7 us; from 384 columns the 128-tile wins)
-    if (t128 && !sparse && cls == KC_RHS_GEMM && g.N <= 256 && ctx->force_tile == 0 && g.batch <= 1 && !g.batch_offs)
-        t128 = false;
-    int splits = best_splits(t128 ? tiles128 : tiles64, (!t128 && cls == KC_RHS_GEMM) ? 2 : 1);
+    // (tried: 64-tiles with two workgroups per CU for narrow state blocks -- n = 1024: 128 columns 92 vs 99 us,
+    //  but n = 4096, 128 columns 41.1 vs 37.1 ms: not a rule)
+    if (sparse) t128 = sparse_tile(sparse, can128) == 1;
+    int splits = best_splits(t128 ? tiles128 : tiles64, 1);
     if (sparse) {
         // the list of a row panel is shared out by COUNT: one workgroup per CU at most, a share keeps >= 4 tiles
-        // (measured, n = 4096, 112 tiles per panel: 32 panels x 8 splits 87 us, x 16 107 us, x 4 133 us)
+        // (measured on 128-row panels, n = 4096, 112 tiles per panel: 32 panels x 8 splits 87 us, x 16 107 us, x 4 133 us)
         const int t = t128 ? 1 : 0;
         g.work_ptr = sparse->gw_ptr[t];
         g.work_idx = sparse->gw_idx[t];
@@ -1320,9 +1327,9 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
     if (ctx->skip_zero_blocks && ctx->skip_zero_planes && s->n_pad >= 256 && !st) {
         guard(stack_block_lists(s));
         if (s->blk_state == 1) {
-            const int t = (s->n_pad % 128 == 0 && p->ld % 128 == 0) ? 1 : 0;
+            const int t = sparse_tile(s, s->n_pad % 128 == 0 && p->ld % 128 == 0 && ctx->force_tile != 64);
             if (p->ncol <= 8) p->blocks = s->blk_density <= 0.25;
-            else p->blocks = s->gw_ptr[t] && s->gw_density[t] <= 0.5 && ctx->force_tile == 0;
+            else p->blocks = s->gw_ptr[t] && s->gw_density[t] <= 0.5 && (ctx->force_tile == 0 || ctx->force_tile == 64);
             // one instance, many columns: forming C(t) first contracts ONE dense operator; the per-segment tile
             // lists only win when they hold less than that in total
             if (p->blocks && p->combine_first && s->gw_density[t] * s->n_act >= 0.8) p->blocks = false;
