@@ -38,6 +38,7 @@ struct midyn_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool skip_zero_planes = true;
+    int sparse_bm = 0;             // A/B: pin the row panels of the sparse MFMA route (32 | 64 | 128; 0 = by list density)
     bool skip_zero_blocks = true;  // block-sparse stacks: contract only the 16 x 16 operator blocks that hold a non-zero
     bool profile = false;
     int force_tile = 0;  // 0 auto, 64, 128, 12864
@@ -192,6 +193,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     std::string n(name);
     if (n == "skip_zero_planes") ctx->skip_zero_planes = value != 0;
     else if (n == "skip_zero_blocks") ctx->skip_zero_blocks = value != 0;
+    else if (n == "sparse_bm") ctx->sparse_bm = (int)value;
     else if (n == "profile") {
         if (!value) drain_events(ctx);
         ctx->profile = value != 0;
@@ -269,10 +271,10 @@ struct midyn_stack {
     double blk_density = 1.0;       // non-zero 16 x 16 blocks / all blocks of the active segments
     int* blk_ptr = nullptr;         // streaming lists per group of 16 rows: [n_pad/16 + 1]
     int* blk_idx = nullptr;         // entry = (segment << 16) | column chunk
-    int* gw_ptr[2] = {nullptr, nullptr};  // MFMA tile lists per row panel of 64 / 128 rows: [M/BM + 1]
-    int* gw_idx[2] = {nullptr, nullptr};  // entry = (K tile << 8) | (seg << 2 | mode)
-    double gw_density[2] = {1.0, 1.0};    // listed tiles / all (panel, K tile, active segment) tiles
-    double gw_avg[2] = {0.0, 0.0};        // average list length per row panel
+    int* gw_ptr[3] = {nullptr, nullptr, nullptr};  // MFMA tile lists per row panel of 64 / 128 / 32 rows: [M/BM + 1]
+    int* gw_idx[3] = {nullptr, nullptr, nullptr};  // entry = (K tile << 8) | (seg << 2 | mode)
+    double gw_density[3] = {1.0, 1.0, 1.0};        // listed tiles / all (panel, K tile, active segment) tiles
+    double gw_avg[3] = {0.0, 0.0, 0.0};            // average list length per row panel
 };
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -428,7 +430,7 @@ extern "C" int midyn_stack_destroy(midyn_stack* s) {
     s->eval_plan = nullptr;
     if (s->planes) hipFree(s->planes);
     s->planes = nullptr;
-    for (int* q : {s->blk_ptr, s->blk_idx, s->gw_ptr[0], s->gw_idx[0], s->gw_ptr[1], s->gw_idx[1]})
+    for (int* q : {s->blk_ptr, s->blk_idx, s->gw_ptr[0], s->gw_idx[0], s->gw_ptr[1], s->gw_idx[1], s->gw_ptr[2], s->gw_idx[2]})
         if (q) hipFree(q);
     if (s->owns && s->buf) hipFree(s->buf);
     delete s;
@@ -534,12 +536,23 @@ static int launch_reduce(midyn_ctx* ctx, const GemmArgs& g) {
     return 0;
 }
 
-// Block-sparse stacks: which tile lists to run on (0: 64-row panels, 1: 128-row panels).  A 128-row panel
-// lists every K tile that any of its 8 row groups touches, a 64-row panel far fewer for scattered patterns
-// (cfg 5, 128 / 256 / 512 instances: 55.6 / 91.6 / 152.6 us per contraction on 64-row panels against
-// 86.5 / 142.8 / 256.7 us on 128-row panels): the big tile only when it lists (almost) no extra zeros.
-static int sparse_tile(const midyn_stack* s, bool can128) {
-    return (can128 && s->gw_ptr[1] && s->gw_density[1] <= 1.15 * s->gw_density[0]) ? 1 : 0;
+// Block-sparse stacks: which tile lists to run on -- 0: 64-row panels (64 x 64 tiles), 1: 128-row panels
+// (128 x 128), 2: 32-row panels (32 x 128).  A tall panel lists every K tile that ANY of its 16-row groups
+// touches, so for scattered patterns the short panels execute far fewer zero tiles (cfg 5, 128 / 256 / 512
+// instances, microseconds per contraction: 128 rows 86.5 / 142.8 / 256.7, 64 rows 55.6 / 91.6 / 152.6,
+// 32 rows 38.1 / 56.9 / 94.1).  Executed work is proportional to the list density; the weights stand for the
+// lower MFMA efficiency of the smaller tiles, so block-dense patterns keep the big tile.
+static int sparse_tile(const midyn_ctx* ctx, const midyn_stack* s, int M, int N) {
+    const bool ok[3] = {true, M % 128 == 0 && N % 128 == 0 && s->gw_ptr[1] != nullptr,
+                        M % 32 == 0 && N % 128 == 0 && s->gw_ptr[2] != nullptr};
+    if (ctx->sparse_bm == 64 || ctx->force_tile == 64) return 0;
+    if (ctx->sparse_bm == 128 && ok[1]) return 1;
+    if (ctx->sparse_bm == 32 && ok[2]) return 2;
+    static const double weight[3] = {1.15, 1.0, 1.3};
+    int best = 0;
+    for (int t = 1; t < 3; ++t)
+        if (ok[t] && s->gw_density[t] * weight[t] < s->gw_density[best] * weight[best]) best = t;
+    return best;
 }
 
 // tile choice: 128x128 (8 waves) when that still gives >= 1 block per CU, else 64x64 (4 waves)
@@ -584,19 +597,26 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
     else t128 = can128;  // measured: 128-tile + split-K beats 64-tile without split (n=1024: 49.9 vs 46.4 TF)
     // (tried: 64-tiles with two workgroups per CU for narrow state blocks -- n = 1024: 128 columns 92 vs 99 us,
     //  but n = 4096, 128 columns 41.1 vs 37.1 ms: not a rule)
-    if (sparse) t128 = sparse_tile(sparse, can128) == 1;
     int splits = best_splits(t128 ? tiles128 : tiles64, 1);
     if (sparse) {
         // the list of a row panel is shared out by COUNT: one workgroup per CU at most, a share keeps >= 4 tiles
         // (measured on 128-row panels, n = 4096, 112 tiles per panel: 32 panels x 8 splits 87 us, x 16 107 us, x 4 133 us)
-        const int t = t128 ? 1 : 0;
+        const int t = sparse_tile(ctx, sparse, g.M, g.N);
+        static const int bm_of[3] = {64, 128, 32}, bn_of[3] = {64, 128, 128};
         g.work_ptr = sparse->gw_ptr[t];
         g.work_idx = sparse->gw_idx[t];
-        const long long tiles = t128 ? tiles128 : tiles64;
+        const long long tiles = (long long)(g.M / bm_of[t]) * (g.N / bn_of[t]);
         splits = 1;
         if (ctx->split_k)
             while ((long long)splits * 2 * tiles <= ctx->num_cu && sparse->gw_avg[t] / (splits * 2) >= 4.0) splits *= 2;
         if (ctx->force_splits > 0) splits = ctx->force_splits;
+        CHK(setup_splits(ctx, g, splits));
+        int sts;
+        if (t == 1) sts = launch_gemm_cfg<128, 128, 2, 4, 16>(ctx, g, uniform_mode);
+        else if (t == 2) sts = launch_gemm_cfg<32, 128, 1, 4, 16>(ctx, g, uniform_mode);
+        else sts = launch_gemm_cfg<64, 64, 2, 2, 16>(ctx, g, uniform_mode);
+        if (sts) return sts;
+        return launch_reduce(ctx, g);
     }
     CHK(setup_splits(ctx, g, splits));
     int st = t128 ? launch_gemm_cfg<128, 128, 2, 4, 16>(ctx, g, uniform_mode)
@@ -1135,8 +1155,8 @@ static int stack_block_lists(midyn_stack* s) {
         CHK(upload(ptr, &s->blk_ptr));
         CHK(upload(idx, &s->blk_idx));
     }
-    for (int t = 0; t < 2; ++t) {  // MFMA tile lists: BM = 64, 128 (K tile = GEMM_BK = 16 columns = one chunk)
-        const int BM = t == 0 ? 64 : 128;
+    for (int t = 0; t < 3; ++t) {  // MFMA tile lists: BM = 64, 128, 32 (K tile = GEMM_BK = 16 columns = one chunk)
+        const int BM = t == 0 ? 64 : (t == 1 ? 128 : 32);
         if (np % BM) continue;
         const int panels = np / BM, rpb = BM / 16;
         std::vector<int> ptr(panels + 1, 0), idx;
@@ -1327,7 +1347,7 @@ static int plan_create_impl(midyn_stack* s, int B, int m, int R, const double* t
     if (ctx->skip_zero_blocks && ctx->skip_zero_planes && s->n_pad >= 256 && !st) {
         guard(stack_block_lists(s));
         if (s->blk_state == 1) {
-            const int t = sparse_tile(s, s->n_pad % 128 == 0 && p->ld % 128 == 0 && ctx->force_tile != 64);
+            const int t = sparse_tile(ctx, s, s->n_pad, p->ld);
             if (p->ncol <= 8) p->blocks = s->blk_density <= 0.25;
             else p->blocks = s->gw_ptr[t] && s->gw_density[t] <= 0.5 && (ctx->force_tile == 0 || ctx->force_tile == 64);
             // one instance, many columns: forming C(t) first contracts ONE dense operator; the per-segment tile
