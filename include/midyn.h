@@ -53,7 +53,7 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   skip_zero_blocks [1]  stacks whose 16 x 16 operator blocks are mostly exactly zero (operators in a
  *                         computational / diagonal-frame basis): contract only the occupied blocks
  *                         (work-list kernels; the skipped products are exact zeros)
- *   sparse_bm [0]         row-panel height of the sparse MFMA route: 0 by list density, or 32 | 64 | 128
+ *   sparse_bm [0]         row-panel height of the sparse MFMA route: 0 by list density, or 16 | 32 | 64 | 128
  *   krylov [1]            one column, Magnus order 1: Arnoldi instead of the scaled Taylor series when the
  *                         series is long enough to pay for it (2: always, 0: never)
  *   complex_3m [1]        dense complex products with 3 real MFMAs instead of 4

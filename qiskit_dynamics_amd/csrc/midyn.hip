@@ -38,7 +38,7 @@ struct midyn_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool skip_zero_planes = true;
-    int sparse_bm = 0;             // A/B: pin the row panels of the sparse MFMA route (32 | 64 | 128; 0 = by list density)
+    int sparse_bm = 0;             // A/B: pin the row panels of the sparse MFMA route (16 | 32 | 64 | 128; 0 = by list density)
     bool skip_zero_blocks = true;  // block-sparse stacks: contract only the 16 x 16 operator blocks that hold a non-zero
     bool profile = false;
     int force_tile = 0;  // 0 auto, 64, 128, 12864
@@ -271,10 +271,10 @@ struct midyn_stack {
     double blk_density = 1.0;       // non-zero 16 x 16 blocks / all blocks of the active segments
     int* blk_ptr = nullptr;         // streaming lists per group of 16 rows: [n_pad/16 + 1]
     int* blk_idx = nullptr;         // entry = (segment << 16) | column chunk
-    int* gw_ptr[3] = {nullptr, nullptr, nullptr};  // MFMA tile lists per row panel of 64 / 128 / 32 rows: [M/BM + 1]
-    int* gw_idx[3] = {nullptr, nullptr, nullptr};  // entry = (K tile << 8) | (seg << 2 | mode)
-    double gw_density[3] = {1.0, 1.0, 1.0};        // listed tiles / all (panel, K tile, active segment) tiles
-    double gw_avg[3] = {0.0, 0.0, 0.0};            // average list length per row panel
+    int* gw_ptr[4] = {nullptr, nullptr, nullptr, nullptr};  // MFMA tile lists per row panel of 64 / 128 / 32 / 16 rows: [M/BM + 1]
+    int* gw_idx[4] = {nullptr, nullptr, nullptr, nullptr};  // entry = (K tile << 8) | (seg << 2 | mode)
+    double gw_density[4] = {1.0, 1.0, 1.0, 1.0};            // listed tiles / all (panel, K tile, active segment) tiles
+    double gw_avg[4] = {0.0, 0.0, 0.0, 0.0};                // average list length per row panel
 };
 
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -430,7 +430,8 @@ extern "C" int midyn_stack_destroy(midyn_stack* s) {
     s->eval_plan = nullptr;
     if (s->planes) hipFree(s->planes);
     s->planes = nullptr;
-    for (int* q : {s->blk_ptr, s->blk_idx, s->gw_ptr[0], s->gw_idx[0], s->gw_ptr[1], s->gw_idx[1], s->gw_ptr[2], s->gw_idx[2]})
+    for (int* q : {s->blk_ptr, s->blk_idx, s->gw_ptr[0], s->gw_idx[0], s->gw_ptr[1], s->gw_idx[1], s->gw_ptr[2], s->gw_idx[2],
+                   s->gw_ptr[3], s->gw_idx[3]})
         if (q) hipFree(q);
     if (s->owns && s->buf) hipFree(s->buf);
     delete s;
@@ -537,20 +538,24 @@ static int launch_reduce(midyn_ctx* ctx, const GemmArgs& g) {
 }
 
 // Block-sparse stacks: which tile lists to run on -- 0: 64-row panels (64 x 64 tiles), 1: 128-row panels
-// (128 x 128), 2: 32-row panels (32 x 128).  A tall panel lists every K tile that ANY of its 16-row groups
-// touches, so for scattered patterns the short panels execute far fewer zero tiles (cfg 5, 128 / 256 / 512
-// instances, microseconds per contraction: 128 rows 86.5 / 142.8 / 256.7, 64 rows 55.6 / 91.6 / 152.6,
-// 32 rows 38.1 / 56.9 / 94.1).  Executed work is proportional to the list density; the weights stand for the
-// lower MFMA efficiency of the smaller tiles, so block-dense patterns keep the big tile.
+// (128 x 128), 2: 32-row panels (32 x 128), 3: 16-row panels (16 x 128).  A tall panel lists every K tile that
+// ANY of its 16-row groups touches, so for scattered patterns the short panels execute far fewer zero tiles:
+// cfg 5 (n = 4096, 9 operators), 128 instances -- listed tiles 3584 / 3840 / 4096 / 4352 for 128 / 64 / 32 / 16
+// rows, i.e. the listed WORK halves with the panel height; microseconds per contraction for 128 / 512
+// instances: 86.5 / 256.7, 55.6 / 152.6, 38.1 / 94.1, 28.2 / 77.0.  Time per unit of listed density relative to
+// the 128 x 128 tile (from those runs): 64 rows 1.2, 32 rows 1.55, 16 rows 2.15 -- the weights below, so that
+// block-dense patterns keep the big tile.
 static int sparse_tile(const midyn_ctx* ctx, const midyn_stack* s, int M, int N) {
-    const bool ok[3] = {true, M % 128 == 0 && N % 128 == 0 && s->gw_ptr[1] != nullptr,
-                        M % 32 == 0 && N % 128 == 0 && s->gw_ptr[2] != nullptr};
+    const bool ok[4] = {true, M % 128 == 0 && N % 128 == 0 && s->gw_ptr[1] != nullptr,
+                        M % 32 == 0 && N % 128 == 0 && s->gw_ptr[2] != nullptr,
+                        N % 128 == 0 && s->gw_ptr[3] != nullptr};
     if (ctx->sparse_bm == 64 || ctx->force_tile == 64) return 0;
     if (ctx->sparse_bm == 128 && ok[1]) return 1;
     if (ctx->sparse_bm == 32 && ok[2]) return 2;
-    static const double weight[3] = {1.15, 1.0, 1.3};
+    if (ctx->sparse_bm == 16 && ok[3]) return 3;
+    static const double weight[4] = {1.2, 1.0, 1.55, 2.15};
     int best = 0;
-    for (int t = 1; t < 3; ++t)
+    for (int t = 1; t < 4; ++t)
         if (ok[t] && s->gw_density[t] * weight[t] < s->gw_density[best] * weight[best]) best = t;
     return best;
 }
@@ -602,7 +607,7 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
         // the list of a row panel is shared out by COUNT: one workgroup per CU at most, a share keeps >= 4 tiles
         // (measured on 128-row panels, n = 4096, 112 tiles per panel: 32 panels x 8 splits 87 us, x 16 107 us, x 4 133 us)
         const int t = sparse_tile(ctx, sparse, g.M, g.N);
-        static const int bm_of[3] = {64, 128, 32}, bn_of[3] = {64, 128, 128};
+        static const int bm_of[4] = {64, 128, 32, 16}, bn_of[4] = {64, 128, 128, 128};
         g.work_ptr = sparse->gw_ptr[t];
         g.work_idx = sparse->gw_idx[t];
         const long long tiles = (long long)(g.M / bm_of[t]) * (g.N / bn_of[t]);
@@ -614,6 +619,7 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
         int sts;
         if (t == 1) sts = launch_gemm_cfg<128, 128, 2, 4, 16>(ctx, g, uniform_mode);
         else if (t == 2) sts = launch_gemm_cfg<32, 128, 1, 4, 16>(ctx, g, uniform_mode);
+        else if (t == 3) sts = launch_gemm_cfg<16, 128, 1, 4, 16>(ctx, g, uniform_mode);
         else sts = launch_gemm_cfg<64, 64, 2, 2, 16>(ctx, g, uniform_mode);
         if (sts) return sts;
         return launch_reduce(ctx, g);
@@ -1155,8 +1161,8 @@ static int stack_block_lists(midyn_stack* s) {
         CHK(upload(ptr, &s->blk_ptr));
         CHK(upload(idx, &s->blk_idx));
     }
-    for (int t = 0; t < 3; ++t) {  // MFMA tile lists: BM = 64, 128, 32 (K tile = GEMM_BK = 16 columns = one chunk)
-        const int BM = t == 0 ? 64 : (t == 1 ? 128 : 32);
+    for (int t = 0; t < 4; ++t) {  // MFMA tile lists: BM = 64, 128, 32, 16 (K tile = GEMM_BK = 16 columns = one chunk)
+        const int BM = t == 0 ? 64 : (t == 1 ? 128 : (t == 2 ? 32 : 16));
         if (np % BM) continue;
         const int panels = np / BM, rpb = BM / 16;
         std::vector<int> ptr(panels + 1, 0), idx;
