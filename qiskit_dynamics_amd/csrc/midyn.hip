@@ -546,9 +546,9 @@ static int launch_reduce(midyn_ctx* ctx, const GemmArgs& g) {
 // the 128 x 128 tile (from those runs): 64 rows 1.2, 32 rows 1.55, 16 rows 2.15 -- the weights below, so that
 // block-dense patterns keep the big tile.
 static int sparse_tile(const midyn_ctx* ctx, const midyn_stack* s, int M, int N) {
+    // (the 32- and 16-row panels run 128 columns wide, or 64 wide when the state block is not a multiple of 128)
     const bool ok[4] = {true, M % 128 == 0 && N % 128 == 0 && s->gw_ptr[1] != nullptr,
-                        M % 32 == 0 && N % 128 == 0 && s->gw_ptr[2] != nullptr,
-                        N % 128 == 0 && s->gw_ptr[3] != nullptr};
+                        M % 32 == 0 && s->gw_ptr[2] != nullptr, s->gw_ptr[3] != nullptr};
     if (ctx->sparse_bm == 64 || ctx->force_tile == 64) return 0;
     if (ctx->sparse_bm == 128 && ok[1]) return 1;
     if (ctx->sparse_bm == 32 && ok[2]) return 2;
@@ -607,7 +607,8 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
         // the list of a row panel is shared out by COUNT: one workgroup per CU at most, a share keeps >= 4 tiles
         // (measured on 128-row panels, n = 4096, 112 tiles per panel: 32 panels x 8 splits 87 us, x 16 107 us, x 4 133 us)
         const int t = sparse_tile(ctx, sparse, g.M, g.N);
-        static const int bm_of[4] = {64, 128, 32, 16}, bn_of[4] = {64, 128, 128, 128};
+        const int wide = g.N % 128 == 0 ? 128 : 64;
+        const int bm_of[4] = {64, 128, 32, 16}, bn_of[4] = {64, 128, wide, wide};
         g.work_ptr = sparse->gw_ptr[t];
         g.work_idx = sparse->gw_idx[t];
         const long long tiles = (long long)(g.M / bm_of[t]) * (g.N / bn_of[t]);
@@ -618,8 +619,10 @@ static int launch_gemm(midyn_ctx* ctx, const GemmArgs& g_in, int cls, int unifor
         CHK(setup_splits(ctx, g, splits));
         int sts;
         if (t == 1) sts = launch_gemm_cfg<128, 128, 2, 4, 16>(ctx, g, uniform_mode);
-        else if (t == 2) sts = launch_gemm_cfg<32, 128, 1, 4, 16>(ctx, g, uniform_mode);
-        else if (t == 3) sts = launch_gemm_cfg<16, 128, 1, 4, 16>(ctx, g, uniform_mode);
+        else if (t == 2 && wide == 128) sts = launch_gemm_cfg<32, 128, 1, 4, 16>(ctx, g, uniform_mode);
+        else if (t == 2) sts = launch_gemm_cfg<32, 64, 1, 2, 16>(ctx, g, uniform_mode);
+        else if (t == 3 && wide == 128) sts = launch_gemm_cfg<16, 128, 1, 4, 16>(ctx, g, uniform_mode);
+        else if (t == 3) sts = launch_gemm_cfg<16, 64, 1, 2, 16>(ctx, g, uniform_mode);
         else sts = launch_gemm_cfg<64, 64, 2, 2, 16>(ctx, g, uniform_mode);
         if (sts) return sts;
         return launch_reduce(ctx, g);
