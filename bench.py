@@ -382,6 +382,32 @@ def main():
                 "what": "same sweep with Python-callable Gaussian envelopes: coefficient table evaluated on the host",
                 "solve_s": round(t_solve, 2), "rhs_evals_per_s_end_to_end": round(b_loc * 4000 / t_solve, 1),
                 "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(yf, axis=1) - 1.0)))}
+    # ---- informational (NOT the BASELINE config): the same sweep set up in the diagonal frame diag(H_d) --
+    #      same physics out of the frame, but the operators stay block sparse and the contraction runs on
+    #      the work-list kernels.  Same table, same steps, timed like `value`.
+    if rank == 0 and world == 1 and not args.no_end_to_end and not args.dense:
+        try:
+            from qiskit_dynamics_amd.rotating_frame import RotatingFrame
+
+            fr = RotatingFrame(np.diag(cfg["h_d"]).real.copy())
+            stack_d = qd.Stack(ctx, -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag)
+            plan_d = qd.Rk4Plan(stack_d, times, table, rows, sched.step_h[:total], y0, b_loc, True)
+            plan_d.run(0, args.warmup)
+            ctx.synchronize()
+            t0d = time.perf_counter()
+            plan_d.run(args.warmup, total)
+            ctx.synchronize()
+            dtd = time.perf_counter() - t0d
+            fin_d = plan_d.fetch()[:, :, 0]
+            plan_d.close()
+            out["diagonal_frame_variant"] = {
+                "what": "same model, sweep and steps with rotating_frame=diag(H_d) (NOT the BASELINE config, which "
+                        "rotates into the eigenbasis of H_d): block-sparse operators, work-list kernels",
+                "rhs_evals_per_s": round(b_loc * 4 * args.steps / dtd, 1), "ms_per_step": round(dtd / args.steps * 1e3, 4),
+                "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(fin_d, axis=1) - 1.0)))}
+            del stack_d
+        except Exception as exc:  # pylint: disable=broad-except
+            out["diagonal_frame_variant"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
