@@ -1993,6 +1993,10 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
     std::vector<double> h_cs;
     if (one)
         for (int i = 0; i < npts; ++i) CHK(Gx[i].alloc(ctx, (size_t)np * np * sizeof(double2)));
+    // Magnus 2 with a frame, products through the plan and no fused input phase (sweeps, MFMA routes): the
+    // producers write the phased copies of their results (see the term loop)
+    const bool chain_phases = magnus_order == 2 && !one && s->has_frame && !(p->blocks && p->ncol <= 8);
+    DevBuf TP[4];
     if (magnus_order == 2) {
         for (int i = 0; i < 2; ++i) {
             CHK(U[i].alloc(ctx, state_bytes));
@@ -2000,6 +2004,11 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
         }
         CHK(W.alloc(ctx, state_bytes));
         HIPCHK(ctx, hipMemsetAsync(W.p, 0, state_bytes, ctx->stream));
+        if (chain_phases)
+            for (int i = 0; i < 4; ++i) {
+                CHK(TP[i].alloc(ctx, state_bytes));
+                HIPCHK(ctx, hipMemsetAsync(TP[i].p, 0, state_bytes, ctx->stream));
+            }
     }
     double2* y = p->d_y.as<double2>();
     double2* acc = p->d_acc.as<double2>();
@@ -2242,25 +2251,65 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
                 const double2* term = y;
                 double2 *u1 = U[0].as<double2>(), *u2 = U[1].as<double2>(), *v1 = V[0].as<double2>(),
                         *v2 = V[1].as<double2>(), *w = W.as<double2>();
-                for (int j = 1; j <= deg; ++j) {
-                    Epilogue e{};
-                    e.mode = EPI_RHS;
-                    e.ld = ld;
-                    // u1 = g1 term, u2 = g2 term
-                    e.out = u1;
-                    CHK(product_plain(0, rr[0], term, yin[0], e));
-                    e.out = u2;
-                    CHK(product_plain(1, rr[1], term, yin[1], e));
-                    // v1 = g2 u1, v2 = g1 u2
-                    e.out = v1;
-                    CHK(product_plain(1, rr[1], u1, yin[0], e));
-                    e.out = v2;
-                    CHK(product_plain(0, rr[0], u2, yin[1], e));
-                    const double f = 1.0 / ((double)sc * j);
-                    hipLaunchKernelGGL(magnus2_term_kernel, dim3(grid_for(stv)), dim3(256), 0, ctx->stream, u1, u2, v1, v2,
-                                       0.5 * h * f, p2 * h * h * f, stv, w, acc);
-                    HIPCHK(ctx, hipGetLastError());
-                    term = w;
+                if (chain_phases) {
+                    // Frames, products through the plan, no fused input phase: every product input must be
+                    // pre-phased.  The producers write the phased copies themselves -- the EPI_RHS epilogue's
+                    // second output for u1, u2, the combination kernel for the next term -- so a term is
+                    // 4 products + 1 combination instead of 4 re-phasing passes on top.
+                    double2 *tp0 = TP[0].as<double2>(), *tp1 = TP[1].as<double2>(), *u1p = TP[2].as<double2>(),
+                            *u2p = TP[3].as<double2>();
+                    const double2 *E0 = plan_E(p, rr[0]), *E1 = plan_E(p, rr[1]);
+                    CHK(rephase(y, rr[0], tp0));
+                    CHK(rephase(y, rr[1], tp1));
+                    for (int j = 1; j <= deg; ++j) {
+                        Epilogue e{};
+                        e.mode = EPI_RHS;
+                        e.ld = ld;
+                        e.e_cur = E0;  // u1 = g1 term, and E1 o u1 for v1
+                        e.out = u1;
+                        e.e_next = E1;
+                        e.yin_next = u1p;
+                        CHK(plan_rhs_launch(p, rr[0], e, tp0));
+                        e.e_cur = E1;  // u2 = g2 term, and E0 o u2 for v2
+                        e.out = u2;
+                        e.e_next = E0;
+                        e.yin_next = u2p;
+                        CHK(plan_rhs_launch(p, rr[1], e, tp1));
+                        e.e_next = nullptr;
+                        e.yin_next = nullptr;
+                        e.e_cur = E1;  // v1 = g2 u1
+                        e.out = v1;
+                        CHK(plan_rhs_launch(p, rr[1], e, u1p));
+                        e.e_cur = E0;  // v2 = g1 u2
+                        e.out = v2;
+                        CHK(plan_rhs_launch(p, rr[0], e, u2p));
+                        const double f = 1.0 / ((double)sc * j);
+                        hipLaunchKernelGGL(magnus2_term_kernel, dim3(grid_for(stv)), dim3(256), 0, ctx->stream, u1, u2, v1,
+                                           v2, 0.5 * h * f, p2 * h * h * f, stv, w, acc, E0, E1, ld, tp0, tp1);
+                        HIPCHK(ctx, hipGetLastError());
+                    }
+                } else {
+                    for (int j = 1; j <= deg; ++j) {
+                        Epilogue e{};
+                        e.mode = EPI_RHS;
+                        e.ld = ld;
+                        // u1 = g1 term, u2 = g2 term
+                        e.out = u1;
+                        CHK(product_plain(0, rr[0], term, yin[0], e));
+                        e.out = u2;
+                        CHK(product_plain(1, rr[1], term, yin[1], e));
+                        // v1 = g2 u1, v2 = g1 u2
+                        e.out = v1;
+                        CHK(product_plain(1, rr[1], u1, yin[0], e));
+                        e.out = v2;
+                        CHK(product_plain(0, rr[0], u2, yin[1], e));
+                        const double f = 1.0 / ((double)sc * j);
+                        hipLaunchKernelGGL(magnus2_term_kernel, dim3(grid_for(stv)), dim3(256), 0, ctx->stream, u1, u2, v1,
+                                           v2, 0.5 * h * f, p2 * h * h * f, stv, w, acc, (const double2*)nullptr,
+                                           (const double2*)nullptr, ld, (double2*)nullptr, (double2*)nullptr);
+                        HIPCHK(ctx, hipGetLastError());
+                        term = w;
+                    }
                 }
             }
             std::swap(y, acc);

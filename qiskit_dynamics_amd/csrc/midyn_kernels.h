@@ -94,6 +94,9 @@ __device__ __forceinline__ void apply_epilogue_t(const Epilogue& e, int row, int
     if (e.e_cur) k = cmul_conj_a(e.e_cur[row], c);
     if (EMODE == EPI_RHS) {
         e.out[idx] = k;
+        // optional second output: the same result already phased for the product that consumes it next
+        // (saves a separate re-phasing pass over the state block)
+        if (e.yin_next) e.yin_next[idx] = e.e_next ? cmul(e.e_next[row], k) : k;
         return;
     }
     const double2 en = e.e_next ? e.e_next[row] : make_double2(1.0, 0.0);
@@ -2013,15 +2016,22 @@ __global__ __launch_bounds__(256) void rephase_kernel(const double2* y, const do
 
 // One Taylor term of the commutator-free Magnus-2 action (fixed_step_solvers.py:348-363 applied to a
 // vector):  w = a (u1 + u2) + b (v1 - v2),  u_i = g_i term, v1 = g2 u1, v2 = g1 u2;  acc += w.
+// Optionally also writes the two phased copies of w the next term's products read (wp0 = e0 o w, wp1 = e1 o w).
 __global__ __launch_bounds__(256) void magnus2_term_kernel(const double2* u1, const double2* u2, const double2* v1,
                                                            const double2* v2, double a, double b, size_t total,
-                                                           double2* w, double2* acc) {
+                                                           double2* w, double2* acc, const double2* e0,
+                                                           const double2* e1, int ld, double2* wp0, double2* wp1) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const double2 p = u1[idx], q = u2[idx], r = v1[idx], t = v2[idx];
         const double2 o = make_double2(a * (p.x + q.x) + b * (r.x - t.x), a * (p.y + q.y) + b * (r.y - t.y));
         w[idx] = o;
         const double2 c = acc[idx];
         acc[idx] = make_double2(c.x + o.x, c.y + o.y);
+        if (wp0) {
+            const size_t i = idx / ld;
+            wp0[idx] = cmul(e0[i], o);
+            wp1[idx] = cmul(e1[i], o);
+        }
     }
 }
 
