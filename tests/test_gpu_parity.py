@@ -1966,3 +1966,34 @@ def test_block_sparse_mfma_route_mixed_and_complex_planes(qd, nb):
             sweeps.append([qd.Signal(float(a), f, ph) for a, f, ph in zip(amps, nu[:4], phases)])
         out = both_routes(lambda: solver.solve(t_span=[0.0, 0.02], y0=y0, signals=sweeps, method="RK4", max_dt=0.002))
         assert_close(out[1], out[0], 1e-12)
+
+
+@pytest.mark.parametrize("bm", [16, 32, 64, 128])
+@pytest.mark.parametrize("nb", [24, 130])
+def test_block_sparse_every_panel_height(qd, bm, nb):
+    """The automatic rule picks the row-panel height with the least listed work (16 rows for scattered
+    patterns); `sparse_bm` pins each of the compiled tiles (16x64, 16x128, 32x64, 32x128, 64x64, 128x128 with
+    work lists) so that all of them are checked against the dense kernels, RK4 and Magnus-2 action."""
+    ctx = qd.default_context()
+    cfg, sweeps = _chain_sweep(qd, 9, nb, 0.1)
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       rotating_frame=np.diag(cfg["h_d"]).real.copy())
+    rng = np.random.default_rng(6)
+    y0 = rng.normal(size=512) + 1j * rng.normal(size=512)
+    y0 /= np.linalg.norm(y0)
+    for method, kw in (("RK4", {}), ("scipy_expm", {"magnus_order": 2})):
+        out = {}
+        for flag in (1, 0):
+            ctx.set_option("skip_zero_blocks", flag)
+            ctx.set_option("sparse_bm", bm if flag else 0)
+            ctx.reset_counters()
+            ctx.set_option("profile", 1)
+            try:
+                r = solver.solve(t_span=[0.0, 0.1], y0=y0, signals=sweeps, method=method, max_dt=0.01, **kw)
+            finally:
+                ctx.set_option("profile", 0)
+                ctx.set_option("skip_zero_blocks", 1)
+                ctx.set_option("sparse_bm", 0)
+            assert (ctx.counters("rhs_blocks_gemm")["launches"] > 0) == bool(flag)
+            out[flag] = np.stack([x.y[-1] for x in r])
+        assert_close(out[1], out[0], 1e-13)
