@@ -118,6 +118,28 @@ if "cfg4" in which:
                                    signals=sigs, method="scipy_expm", max_dt=cfg["max_dt"]), nsteps, extra4)
     del solver
 
+if "cfg4sweep" in which:
+    # sweeps of the cfg-4 model (N = 4096 superoperators): every Taylor term is one MFMA contraction over the
+    # tile lists for all instances
+    cfg = workloads.lindblad_config()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], static_dissipators=cfg["static_dissipators"], vectorized=True)
+    y0 = cfg["rho0"].flatten(order="F")
+    for nb in (16, 64, 256):
+        sweeps = []
+        for b in range(nb):
+            amps, phases = workloads.sweep_parameters(b, 6)
+            sweeps.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph) for a, nu, ph in zip(amps, cfg["carrier"], phases)])
+        res = {}
+        for blocks, nst in ((1, 100), (0, 4)):
+            ctx.set_option("skip_zero_blocks", blocks)
+            fn = lambda: solver.solve(t_span=[0.0, nst * 0.05], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.05)
+            fn()
+            ctx.synchronize(); t0 = time.perf_counter(); r = fn(); ctx.synchronize(); dt = time.perf_counter() - t0
+            rho = r[-1].y[-1].reshape(64, 64, order="F")
+            res["work_lists" if blocks else "dense_kernels"] = {"steps": nst, "ms_per_step": round(dt / nst * 1e3, 3), "ms_per_instance_step": round(dt / nst / nb * 1e3, 4), "trace": float(abs(np.trace(rho)))}
+        print(json.dumps({"what": f"cfg4 model (N=4096 vectorised Lindbladian, no frame), sweep of {nb} instances, scipy_expm m=1 (expm action)", **res}), flush=True)
+    ctx.set_option("skip_zero_blocks", 1)
+
 if "cfg5" in which:
     t0 = time.time()
     cfg = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
