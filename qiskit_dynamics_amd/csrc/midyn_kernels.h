@@ -14,8 +14,13 @@
 //   zgemm_seg_kernel    many columns: fp64 MFMA 16x16x4 complex GEMM over the K = nseg*n axis with
 //                       the real signal coefficient applied to the B fragment (+ RK4 epilogue);
 //                       also the plain zgemm of the expm pipeline
+//                       SPARSE instantiation: the (K tile, segment) loop runs over per-row-panel work
+//                       lists of the tiles that hold a non-zero (block-sparse stacks; tiles 16x64 .. 128x128)
+//   rhs_stream_multi_*  2..8 columns with own coefficients, operator rows read once
+//   rhs_blocks_kernel   1..8 columns of a block-sparse stack: only the listed 16x16 operator blocks are read
+//   tiny_rk4/expm       small systems: the whole fixed-step solve in one persistent launch
 //   gen_eval_kernel     G = scale * Delta(t) o (A_d + sum c_j A_j)
-//   small elementwise kernels (lincomb, phase table, transposes, norms)
+//   small elementwise kernels (lincomb, phase table, transposes, norms, block map, Krylov bookkeeping)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,6 +49,7 @@ __device__ __forceinline__ double2 cfma_r(double s, double2 a, double2 c) {  // 
 // ------------------------------------------------------------------------------------------------
 // Epilogue shared by the stream and the MFMA kernels.
 //   EPI_RHS    out = conj(Ecur[row]) * C                         (GeneratorModel.evaluate_rhs)
+//              optionally also yin_next = Enext * out  (the result pre-phased for its consumer)
 //   EPI_RK1..4 classic RK4 stages, fixed_step_solvers.py:62-73, fused:
 //              k = conj(Ecur) * C
 //              1: acc = y + h/6 k         ; yin_next = Enext * (y + h/2 k)
