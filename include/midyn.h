@@ -53,6 +53,8 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   skip_zero_blocks [1]  stacks whose 16 x 16 operator blocks are mostly exactly zero (operators in a
  *                         computational / diagonal-frame basis): contract only the occupied blocks
  *                         (work-list kernels; the skipped products are exact zeros)
+ *   chebyshev [1]         expm action, Magnus order 1, nearly skew-Hermitian generator: Chebyshev series instead of
+ *                         the scaled Taylor series when shorter (2: always, 0: never)
  *   sparse_bm [0]         row-panel height of the sparse MFMA route: 0 by list density, or 16 | 32 | 64 | 128
  *   krylov [1]            one column, Magnus order 1: Arnoldi instead of the scaled Taylor series when the
  *                         series is long enough to pay for it (2: always, 0: never)

@@ -38,6 +38,8 @@ struct midyn_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool skip_zero_planes = true;
+    int chebyshev = 1;             // expm action, Magnus order 1, nearly skew-Hermitian generator: Chebyshev series
+                                   // instead of the scaled Taylor series (1: when shorter, 2: always, 0: never)
     int sparse_bm = 0;             // A/B: pin the row panels of the sparse MFMA route (16 | 32 | 64 | 128; 0 = by list density)
     bool skip_zero_blocks = true;  // block-sparse stacks: contract only the 16 x 16 operator blocks that hold a non-zero
     bool profile = false;
@@ -194,6 +196,7 @@ extern "C" int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long 
     if (n == "skip_zero_planes") ctx->skip_zero_planes = value != 0;
     else if (n == "skip_zero_blocks") ctx->skip_zero_blocks = value != 0;
     else if (n == "sparse_bm") ctx->sparse_bm = (int)value;
+    else if (n == "chebyshev") ctx->chebyshev = (int)value;
     else if (n == "profile") {
         if (!value) drain_events(ctx);
         ctx->profile = value != 0;
@@ -266,6 +269,7 @@ struct midyn_stack {
     std::vector<int> h_flags;
     std::vector<int> h_modes;   // per segment: 0 full, 1 real only, 2 imaginary only, 3 zero
     std::vector<double> seg_norm1;  // ||A_seg||_1 per segment (lazy; norm bounds of the expm action)
+    std::vector<double> seg_norminf, seg_herm1;  // ||A_seg||_inf and ||(A_seg + A_seg^dagger)/2||_1 (lazy; Chebyshev action)
     // block occupancy (lazy, stack_block_lists): which 16 x 16 blocks of the active segments hold a non-zero
     int blk_state = 0;              // 0 not examined, 1 lists built, -1 not applicable
     double blk_density = 1.0;       // non-zero 16 x 16 blocks / all blocks of the active segments
@@ -530,6 +534,7 @@ static int launch_reduce(midyn_ctx* ctx, const GemmArgs& g) {
         case EPI_RK3: MIDYN_REDUCE(EPI_RK3); break;
         case EPI_RK4: MIDYN_REDUCE(EPI_RK4); break;
         case EPI_TAYLOR: MIDYN_REDUCE(EPI_TAYLOR); break;
+        case EPI_CHEB: MIDYN_REDUCE(EPI_CHEB); break;
         default: MIDYN_REDUCE(EPI_PLAIN); break;
     }
 #undef MIDYN_REDUCE
@@ -891,12 +896,18 @@ static hipError_t copy_to_device_any(midyn_ctx* ctx, void* dst, const void* src,
 }
 
 // 1-norms of `batch` [np][np] matrices stored back to back (one small D2H copy + stream sync)
-static int dev_norm1(midyn_ctx* ctx, const double2* A, int np, int batch, DevBuf& scratch, std::vector<double>& norms) {
+// mode 0: 1-norms; 1: infinity norms; 2: 1-norms of the Hermitian parts (A + A^dagger) / 2
+static int dev_norm1(midyn_ctx* ctx, const double2* A, int np, int batch, DevBuf& scratch, std::vector<double>& norms,
+                     int mode = 0) {
     const int nchunk = std::max(1, std::min(32, np / 128));
     const size_t cnt = (size_t)batch * nchunk * np;
     if (scratch.bytes < cnt * sizeof(double)) CHK(scratch.alloc(ctx, cnt * sizeof(double)));
-    hipLaunchKernelGGL(colsum_kernel, dim3((np + 255) / 256, batch, nchunk), dim3(256), 0, ctx->stream, A, np, nchunk,
-                       scratch.as<double>());
+    if (mode == 0)
+        hipLaunchKernelGGL(colsum_kernel, dim3((np + 255) / 256, batch, nchunk), dim3(256), 0, ctx->stream, A, np, nchunk,
+                           scratch.as<double>());
+    else
+        hipLaunchKernelGGL(colsum_mode_kernel, dim3((np + 255) / 256, batch, nchunk), dim3(256), 0, ctx->stream, A, np,
+                           nchunk, mode, scratch.as<double>());
     HIPCHK(ctx, hipGetLastError());
     std::vector<double> h_pageable;
     double* h = ctx->h_pinned;
@@ -1971,6 +1982,33 @@ static int stack_seg_norms(midyn_stack* s) {
     return 0;
 }
 
+static int stack_seg_aux_norms(midyn_stack* s) {
+    if (!s->seg_herm1.empty()) return 0;
+    midyn_ctx* ctx = s->ctx;
+    DevBuf cs;
+    CHK(dev_norm1(ctx, s->ops, s->n_pad, s->nseg, cs, s->seg_norminf, 1));
+    CHK(dev_norm1(ctx, s->ops, s->n_pad, s->nseg, cs, s->seg_herm1, 2));
+    return 0;
+}
+
+// Bessel functions J_0..J_K of the first kind at x > 0 by Miller's backward recurrence (normalised with
+// J_0 + 2 sum J_2k = 1); K is chosen by the caller, the recurrence starts far enough above it.
+static std::vector<double> bessel_j(double x, int K) {
+    const int M = 2 * ((std::max(K, (int)std::ceil(x)) + 40) / 2 + 8);
+    std::vector<double> j(M + 2, 0.0);
+    j[M] = 1e-280;
+    for (int k = M; k >= 1; --k) {
+        j[k - 1] = (2.0 * k / x) * j[k] - j[k + 1];
+        if (std::fabs(j[k - 1]) > 1e250)
+            for (int q = k - 1; q <= M; ++q) j[q] *= 1e-250;
+    }
+    double norm = j[0];
+    for (int k = 2; k <= M; k += 2) norm += 2.0 * j[k];
+    j.resize(K + 1);
+    for (double& v : j) v /= norm;
+    return j;
+}
+
 static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* times, const double* S_host,
                              const double* S_any, int nsteps, const int* step_rows, const double* step_h,
                              const int* step_save, int P, int magnus_order, const midyn_complex* y0, int y0_shared,
@@ -2085,6 +2123,20 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
         }
         return bound;
     };
+    // the same triangle bound with another per-segment norm table (infinity norms, Hermitian parts), order 1
+    auto step_bound_with = [&](int st, const std::vector<double>& seg_norm) {
+        const double ah = std::fabs(step_h[st]);
+        const int row = step_rows[3 * st];
+        double bound = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const double* c = s->k > 0 ? S_host + ((size_t)b * R + row) * s->k : nullptr;
+            double g = 0.0;
+            for (int seg = 0; seg < s->nseg; ++seg)
+                g += ((s->has_static && seg == 0) ? 1.0 : std::fabs(c[seg - s->has_static])) * seg_norm[seg];
+            bound = std::max(bound, ah * g);
+        }
+        return bound;
+    };
     if (p->tiny) {
         // small system: the whole solve in one persistent launch (tiny_expm_kernel), the Taylor degree and
         // scaling of every step chosen here from the same bound
@@ -2124,7 +2176,7 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
     // batched-expm machinery) and Saad's a-posteriori estimate beta h_{m+1,m} |e_m^T expm(h H_m) e_1|;
     // y <- beta V_m expm(h H_m) e_1.  The scaled Taylor series needs ~15 products per unit of ||h G||_1,
     // Arnoldi about 1.5 x the spectral radius + 20 in total (cfg 4, no frame: 160 -> ~40 products).
-    DevBuf kV, kH, kE, kw, khc, kbeta, kerr, kcoef;
+    DevBuf kV, kH, kE, kw, khc, kbeta, kerr, kcoef, cheb_buf[2];
     ExpmWork kwork;
     const int KM = 60;
     auto krylov_step = [&](double h, int row, double bound, const double2* ycur, double2* ynew, bool* converged) -> int {
@@ -2216,12 +2268,68 @@ static int expm_action_solve(midyn_stack* s, int B, int m, int R, const double* 
         int deg = 2, sc = 1;
         action_choose(bound, &deg, &sc);
         bool stepped = false;
+        // ---- Chebyshev series for a nearly skew-Hermitian Omega = h G (Hamiltonian models exactly, Lindbladians
+        // with weak dissipation): with B = Omega / rho, rho >= the numerical radius,
+        //     expm(Omega) y = J_0(rho) phi_0 + 2 sum_k J_k(rho) phi_k,   phi_0 = y, phi_1 = B y,
+        //     phi_{k+1} = 2 B phi_k + phi_{k-1}          (phi_k = i^k T_k(B / i) y, Bessel J_k),
+        // which needs about rho + 10 rho^(1/3) + 10 products where the scaled Taylor series needs ~15 rho
+        // (cfg 4 without a frame, rho = 10.8: 39 products instead of 160), no orthogonalisation, one launch per
+        // term (EPI_CHEB epilogue), sweeps included.  The series is only used when the Hermitian part is small
+        // enough that the polynomials cannot grow:  K sqrt(2 ||herm(Omega)|| / rho) <= 0.7.
+        if (magnus_order == 1 && ctx->chebyshev && ctx->krylov < 2) {
+            CHK(stack_seg_aux_norms(s));
+            double rho = std::max(bound, step_bound_with(st, s->seg_norminf));
+            if (one) rho = std::max(step_bound(st), rho);  // `bound` may have been tightened to the exact 1-norm
+            const double herm = step_bound_with(st, s->seg_herm1);
+            const int reps = std::max(1, (int)std::ceil(rho / 128.0));  // Bessel table accurate to a few 1e-15 up to here
+            const double rr_ = rho / reps;
+            int K = 0;
+            std::vector<double> coef;
+            if (rr_ > 0.0 && std::isfinite(rr_)) {
+                const int kmax = (int)(rr_ + 10.0 * std::cbrt(rr_) + 40.0);
+                coef = bessel_j(rr_, kmax);
+                K = kmax;
+                while (K > 1 && std::fabs(coef[K]) < 1e-18) --K;
+            }
+            const bool stable = K > 0 && (double)K * std::sqrt(2.0 * herm / std::max(rho, 1e-300)) <= 0.7;
+            const bool shorter = (long long)reps * (K + 1) * 10 < (long long)deg * sc * 8;
+            if (K > 0 && K < (int)coef.size() - 1 && stable && (shorter || ctx->chebyshev >= 2)) {
+                if (!cheb_buf[0].p)
+                    for (int i = 0; i < 2; ++i) CHK(cheb_buf[i].alloc(ctx, state_bytes));
+                double2* P2[2] = {cheb_buf[0].as<double2>(), cheb_buf[1].as<double2>()};
+                for (int rep = 0; rep < reps; ++rep) {
+                    hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_for(stv)), dim3(256), 0, ctx->stream, y, coef[0], stv, acc);
+                    HIPCHK(ctx, hipGetLastError());
+                    int cur = 0;
+                    if (one) HIPCHK(ctx, hipMemcpyAsync(yin[0], y, state_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                    else CHK(rephase(y, rr[0], yin[0]));
+                    for (int k = 0; k < K; ++k) {
+                        Epilogue e{};
+                        e.mode = EPI_CHEB;
+                        e.ld = ld;
+                        e.alpha = (k == 0 ? 1.0 : 2.0) * h / (rr_ * reps);
+                        e.beta = 2.0 * coef[k + 1];
+                        e.z = k == 0 ? nullptr : (k == 1 ? y : P2[k & 1]);
+                        e.out = P2[k & 1];
+                        e.e_cur = plan_E(p, rr[0]);
+                        e.e_next = plan_E(p, rr[0]);
+                        e.acc = acc;
+                        e.yin_next = yin[cur ^ 1];
+                        CHK(product(0, rr[0], yin[cur], yin[cur], e));
+                        cur ^= 1;
+                    }
+                    std::swap(y, acc);
+                }
+                stepped = true;
+            }
+        }
         // Arnoldi pays ~6 launches per vector (product, two Gram-Schmidt passes, normalisation) against one per
         // Taylor term: with the microsecond products of a block-sparse stack both are launch bound and the
         // series wins unless it is several times longer (cfg 4, 100 steps: Taylor 160 terms 0.100 s, Arnoldi 28
         // vectors 0.113 s); with dense streamed products (tens of microseconds each) Arnoldi wins from 64 terms
         const long long krylov_min = ctx->krylov >= 2 ? 0 : (p->blocks ? (long long)(6.0 * (1.5 * bound + 20.0)) : 64);
-        if ((one || p->blocks) && p->stream_path && magnus_order == 1 && ctx->krylov && (long long)deg * sc >= krylov_min) {
+        if (!stepped && (one || p->blocks) && p->stream_path && magnus_order == 1 && ctx->krylov &&
+            (long long)deg * sc >= krylov_min) {
             bool conv = false;
             CHK(krylov_step(h, rr[0], bound, y, acc, &conv));
             if (conv) {

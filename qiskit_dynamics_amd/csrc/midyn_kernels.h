@@ -59,11 +59,13 @@ __device__ __forceinline__ double2 cfma_r(double s, double2 a, double2 c) {  // 
 //   EPI_PLAIN  out = alpha * C + beta * Z                          (expm pipeline zgemm)
 //   EPI_TAYLOR one term of the Taylor series of the ACTION expm(Omega) y (Omega = h G(t)):
 //              k = conj(Ecur) * C ; term = h * k ; acc += term ; yin_next = Enext * term
+//   EPI_CHEB   one step of the Chebyshev recurrence of the same action (phi_{k+1} = 2 B phi_k + phi_{k-1}):
+//              k = conj(Ecur) * C ; term = alpha * k + Z ; out = term ; acc += beta * term ; yin_next = Enext * term
 // The stage input is kept PRE-PHASED (yin = exp(d t_stage) o y_stage) so the contraction kernels
 // never touch the frame; yin ping-pongs between two buffers because other workgroups still read
 // the current one while this one already writes the next.
 // ------------------------------------------------------------------------------------------------
-enum { EPI_RHS = 0, EPI_RK1 = 1, EPI_RK2 = 2, EPI_RK3 = 3, EPI_RK4 = 4, EPI_PLAIN = 5, EPI_TAYLOR = 6 };
+enum { EPI_RHS = 0, EPI_RK1 = 1, EPI_RK2 = 2, EPI_RK3 = 3, EPI_RK4 = 4, EPI_PLAIN = 5, EPI_TAYLOR = 6, EPI_CHEB = 7 };
 
 struct Epilogue {
     int mode;
@@ -114,6 +116,18 @@ __device__ __forceinline__ void apply_epilogue_t(const Epilogue& e, int row, int
         e.yin_next[idx] = cmul(en, term);
         return;
     }
+    if (EMODE == EPI_CHEB) {
+        double2 term = make_double2(e.alpha * k.x, e.alpha * k.y);
+        if (e.z) {
+            const double2 z = e.z[idx];
+            term.x += z.x;
+            term.y += z.y;
+        }
+        e.out[idx] = term;
+        e.acc[idx] = cfma_r(e.beta, term, e.acc[idx]);
+        e.yin_next[idx] = cmul(en, term);
+        return;
+    }
     if (EMODE == EPI_RK1) {
         const double2 y = e.y[idx];
         e.acc[idx] = cfma_r(h * (1.0 / 6), k, y);
@@ -142,6 +156,7 @@ __device__ __forceinline__ void apply_epilogue(const Epilogue& e, int row, int c
         case EPI_RK3: apply_epilogue_t<EPI_RK3>(e, row, col, c); break;
         case EPI_RK4: apply_epilogue_t<EPI_RK4>(e, row, col, c); break;
         case EPI_TAYLOR: apply_epilogue_t<EPI_TAYLOR>(e, row, col, c); break;
+        case EPI_CHEB: apply_epilogue_t<EPI_CHEB>(e, row, col, c); break;
         default: apply_epilogue_t<EPI_PLAIN>(e, row, col, c); break;
     }
 }
@@ -170,6 +185,7 @@ __device__ __forceinline__ void store_tile(const Epilogue& e, int row0, int col0
         case EPI_RK3: store_tile_t<EPI_RK3, MT, NT>(e, row0, col0, cre, cim); break;
         case EPI_RK4: store_tile_t<EPI_RK4, MT, NT>(e, row0, col0, cre, cim); break;
         case EPI_TAYLOR: store_tile_t<EPI_TAYLOR, MT, NT>(e, row0, col0, cre, cim); break;
+        case EPI_CHEB: store_tile_t<EPI_CHEB, MT, NT>(e, row0, col0, cre, cim); break;
         default: store_tile_t<EPI_PLAIN, MT, NT>(e, row0, col0, cre, cim); break;
     }
 }
@@ -2020,6 +2036,14 @@ __global__ __launch_bounds__(256) void rephase_kernel(const double2* y, const do
     }
 }
 
+// dst = a * src (state blocks)
+__global__ __launch_bounds__(256) void scale_copy_kernel(const double2* src, double a, size_t total, double2* dst) {
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const double2 v = src[idx];
+        dst[idx] = make_double2(a * v.x, a * v.y);
+    }
+}
+
 // One Taylor term of the commutator-free Magnus-2 action (fixed_step_solvers.py:348-363 applied to a
 // vector):  w = a (u1 + u2) + b (v1 - v2),  u_i = g_i term, v1 = g2 u1, v2 = g1 u2;  acc += w.
 // Optionally also writes the two phased copies of w the next term's products read (wp0 = e0 o w, wp1 = e1 o w).
@@ -2095,6 +2119,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const double2* A, int n, in
     for (int r = r0; r < r1; ++r) {
         const double2 v = Ab[(size_t)r * n + c];
         s += hypot(v.x, v.y);
+    }
+    sums[((size_t)blockIdx.y * nchunk + blockIdx.z) * n + c] = s;
+}
+
+// The same partial column sums for |A^T| (mode 1: the infinity norm of A as the 1-norm of A^T) and for the
+// Hermitian part |A + A^dagger| / 2 (mode 2); one-off per operator stack, so the strided transposed reads are fine.
+__global__ __launch_bounds__(256) void colsum_mode_kernel(const double2* A, int n, int nchunk, int mode, double* sums) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const double2* Ab = A + (size_t)blockIdx.y * n * n;
+    const int rows = (n + nchunk - 1) / nchunk;
+    const int r0 = blockIdx.z * rows, r1 = min(n, r0 + rows);
+    double s = 0.0;
+    for (int r = r0; r < r1; ++r) {
+        const double2 t = Ab[(size_t)c * n + r];
+        if (mode == 1) {
+            s += hypot(t.x, t.y);
+        } else {
+            const double2 v = Ab[(size_t)r * n + c];
+            s += 0.5 * hypot(v.x + t.x, v.y - t.y);
+        }
     }
     sums[((size_t)blockIdx.y * nchunk + blockIdx.z) * n + c] = s;
 }

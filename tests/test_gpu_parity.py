@@ -1717,9 +1717,10 @@ def test_auto_parallel_in_time_routing(qd, monkeypatch, n, method, mo):
 
 @pytest.mark.parametrize("n,magn", [(200, 9.0), (300, 25.0)])
 def test_krylov_expm_action_matches_taylor(qd, n, magn):
-    """One column, no rotating frame, ||h G||_1 of order 10..50: the expm action runs as an Arnoldi process
-    (CGS2 on the device, small expm of the Hessenberg block, Saad's estimate) instead of ~15 products per
-    unit of norm -- against the scaled Taylor series (krylov = 0), the dense expm and the oracle."""
+    """One column, no rotating frame, ||h G||_1 of order 10..50: the expm action as a Chebyshev series (default
+    for nearly skew-Hermitian generators), as an Arnoldi process (krylov = 2: CGS2 on the device, small expm of
+    the Hessenberg block, Saad's estimate) and as the scaled Taylor series (~15 products per unit of norm),
+    against each other, the dense expm and the oracle."""
     from oracle import dynamics_oracle as orc
 
     ctx = qd.default_context()
@@ -1735,9 +1736,10 @@ def test_krylov_expm_action_matches_taylor(qd, n, magn):
     y0 = crand(rng, n)
     y0 /= np.linalg.norm(y0)
     kw = dict(t_span=[0.0, 0.15], y0=y0, signals=sig, method="scipy_expm", max_dt=0.05)
-    res = {}
+    res, products = {}, {}
     try:
-        for tag, opts in (("krylov", {}), ("taylor", {"krylov": 0}), ("dense", {"expm_action": 0})):
+        for tag, opts in (("chebyshev", {}), ("krylov", {"krylov": 2}), ("taylor", {"krylov": 0, "chebyshev": 0}),
+                          ("dense", {"expm_action": 0})):
             for k_, v_ in opts.items():
                 ctx.set_option(k_, v_)
             ctx.reset_counters()
@@ -1746,7 +1748,11 @@ def test_krylov_expm_action_matches_taylor(qd, n, magn):
             counters = {c: ctx.counters(c)["launches"] for c in ("rhs_stream", "zgemm")}
             ctx.set_option("profile", 0)
             ctx.set_option("krylov", 1)
+            ctx.set_option("chebyshev", 1)
             ctx.set_option("expm_action", 1)
+            products[tag] = counters["rhs_stream"]
+            if tag == "chebyshev":   # the default: about rho + 10 rho^(1/3) + 10 products per step (rho = the norm
+                assert counters["zgemm"] == 0, counters   # BOUND of h G, several times the spectral radius here)
             if tag == "krylov":
                 assert counters["zgemm"] > 0 and counters["rhs_stream"] < 3 * 64, counters   # Arnoldi was used
             if tag == "taylor":
@@ -1754,7 +1760,12 @@ def test_krylov_expm_action_matches_taylor(qd, n, magn):
     finally:
         ctx.set_option("profile", 0)
         ctx.set_option("krylov", 1)
+        ctx.set_option("chebyshev", 1)
         ctx.set_option("expm_action", 1)
+    assert products["chebyshev"] < 0.85 * products["taylor"], products
+    assert_close(res["chebyshev"], res["taylor"], 1e-11)
+    assert_close(res["chebyshev"], res["dense"], 1e-11)
+    assert_close(res["krylov"], res["dense"], 1e-11)
     assert_close(res["krylov"], res["taylor"], 1e-11)
     assert_close(res["krylov"], res["dense"], 1e-11)
     a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, None)
