@@ -48,21 +48,42 @@ def _as_signal_list(signals, n_ops, what="Signals"):
     return signals
 
 
+def _kron_eye_left(a):
+    """kron(I, a) for a (..., n, n): a on the diagonal blocks, written block by block (np.kron would multiply
+    every entry of a with every entry of the identity: n^4 products, seconds at n = 64)."""
+    n = a.shape[-1]
+    out = np.zeros(a.shape[:-2] + (n, n, n, n), dtype=complex)
+    for i in range(n):
+        out[..., i, :, i, :] = a
+    return out.reshape(a.shape[:-2] + (n * n, n * n))
+
+
+def _kron_eye_right(b):
+    """kron(b, I) for b (..., n, n): entry b[i, j] on the diagonal of block (i, j)."""
+    n = b.shape[-1]
+    out = np.zeros(b.shape[:-2] + (n, n, n, n), dtype=complex)
+    for k in range(n):
+        out[..., :, k, :, k] = b
+    return out.reshape(b.shape[:-2] + (n * n, n * n))
+
+
 def vec_commutator(a):
-    """-i (I (x) A - A^T (x) I): column-stacking matrix of X -> -i[A, X]."""
-    a = np.asarray(a)
-    iden = np.eye(a.shape[-1])
-    return -1j * (np.kron(iden, a) - np.kron(np.swapaxes(a, -1, -2), iden))
+    """-i (I (x) A - A^T (x) I): column-stacking matrix of X -> -i[A, X]  (models/model_utils.py:31-71).
+    Same entries as the Kronecker-product expression, assembled without its n^4 multiplications by the identity."""
+    a = np.asarray(a, dtype=complex)
+    return -1j * (_kron_eye_left(a) - _kron_eye_right(np.swapaxes(a, -1, -2)))
 
 
 def vec_dissipator(l):
-    """conj(L) (x) L - (I (x) L^+L + (L^+L)^T (x) I)/2: column-stacking Lindblad dissipator."""
-    l = np.asarray(l)
-    iden = np.eye(l.shape[-1])
+    """conj(L) (x) L - (I (x) L^+L + (L^+L)^T (x) I)/2: column-stacking Lindblad dissipator
+    (models/model_utils.py:74-118).  (conj(L) (x) I)(I (x) L) = conj(L) (x) L entry for entry (every product
+    of the matrix form has exactly one non-zero term), so the n^2 x n^2 matrix product is not needed."""
+    l = np.asarray(l, dtype=complex)
+    n = l.shape[-1]
     lc = l.conj()
     ldl = np.swapaxes(lc, -1, -2) @ l
-    return np.kron(lc, iden) @ np.kron(iden, l) - 0.5 * (
-        np.kron(iden, ldl) + np.kron(np.swapaxes(ldl, -1, -2), iden))
+    outer = np.einsum("...ij,...km->...ikjm", lc, l).reshape(l.shape[:-2] + (n * n, n * n))
+    return outer - 0.5 * (_kron_eye_left(ldl) + _kron_eye_right(np.swapaxes(ldl, -1, -2)))
 
 
 class BaseGeneratorModel:
