@@ -82,6 +82,16 @@ int midyn_stack_create(midyn_ctx* ctx, int n, int k, const midyn_complex* ops,
                        midyn_stack** out);
 int midyn_stack_adopt(midyn_ctx* ctx, int n, int k, int has_static, int has_frame,
                       void* dev_buffer, midyn_stack** out);
+/* Vectorised Lindblad model: the n^2 x n^2 column-stacking superoperators are built ON THE DEVICE from the
+ * n x n operators (all in the frame basis), replacing the host Kronecker products of
+ * models/operator_collections.py:851-1061 / models/model_utils.py:31-118:
+ *   static    = vec_commutator(h_d) + sum_j vec_dissipator(n_static[j])        (h_d NULL / n_s = 0: part absent)
+ *   operators = [vec_commutator(h_ops[j]), j < k_h ; vec_dissipator(l_ops[j]), j < k_l]
+ * h_d (n,n), h_ops (k_h,n,n), n_static (n_s,n,n), l_ops (k_l,n,n) host arrays; frame_im (n^2) or NULL
+ * (rotating_frame.py:510-582 vectorised frame diagonal).  The stack has dimension n^2 and k_h + k_l operators. */
+int midyn_stack_create_lindblad(midyn_ctx* ctx, int n, const midyn_complex* h_d, int k_h,
+                                const midyn_complex* h_ops, int n_s, const midyn_complex* n_static, int k_l,
+                                const midyn_complex* l_ops, const double* frame_im, midyn_stack** out);
 int midyn_stack_destroy(midyn_stack* stack);
 /* info[0..7] = n, n_pad, k, has_static, has_frame, n_segments, n_active_segments, packed_bytes>>20 */
 int midyn_stack_info(midyn_stack* stack, long long* info);

@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libmidyn.so")
 # every symbol include/midyn.h declares (tests/test_abi.py checks the .so exports all of them)
 ABI_SYMBOLS = [
     "midyn_ctx_create", "midyn_ctx_destroy", "midyn_ctx_synchronize", "midyn_last_error",
-    "midyn_ctx_set_option", "midyn_stack_packed_bytes", "midyn_stack_create", "midyn_stack_adopt",
+    "midyn_ctx_set_option", "midyn_stack_packed_bytes", "midyn_stack_create", "midyn_stack_create_lindblad",
+    "midyn_stack_adopt",
     "midyn_stack_destroy", "midyn_stack_info", "midyn_stack_segment_modes", "midyn_eval_generator", "midyn_eval_rhs",
     "midyn_rk4_solve", "midyn_expm", "midyn_expm_solve", "midyn_zgemm", "midyn_rk4_plan_create",
     "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_get_counters",
@@ -100,6 +101,7 @@ def load():
         lib.midyn_stack_packed_bytes.argtypes = [_ci, _ci, _ci, P(ctypes.c_size_t)]
         lib.midyn_stack_create.argtypes = [_vp, _ci, _ci, _vp, _vp, _vp, _vp, P(_vp)]
         lib.midyn_stack_adopt.argtypes = [_vp, _ci, _ci, _ci, _ci, _vp, P(_vp)]
+        lib.midyn_stack_create_lindblad.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, P(_vp)]
         lib.midyn_stack_destroy.argtypes = [_vp]
         lib.midyn_stack_info.argtypes = [_vp, P(_cll)]
         lib.midyn_stack_segment_modes.argtypes = [_vp, P(_ci)]
@@ -248,11 +250,21 @@ class Stack:
     ops (k,n,n) | None, static (n,n) | None, frame_im (n,) | None -- all in the frame basis.
     """
 
-    def __init__(self, ctx: Context, ops, static, frame_im, dev_buffer_ptr=None, _adopt=None):
+    def __init__(self, ctx: Context, ops, static, frame_im, dev_buffer_ptr=None, _adopt=None, _lindblad=None):
         self.ctx = ctx
         lib = ctx.lib
         h = _vp()
-        if _adopt is not None:
+        if _lindblad is not None:
+            # superoperators of the vectorised Lindblad model built on the device from the n x n operators
+            h_d, h_ops, n_static, l_ops = _lindblad
+            arrs = [None if x is None else c128(x) for x in (h_d, h_ops, n_static, l_ops)]
+            n = next(x.shape[-1] for x in arrs if x is not None)
+            counts = [0 if x is None else x.shape[0] for x in arrs[1:]]
+            fr_a = None if frame_im is None else f64(frame_im)
+            ctx.check(lib.midyn_stack_create_lindblad(ctx.handle, n, _ptr(arrs[0]), counts[0], _ptr(arrs[1]), counts[1],
+                                                      _ptr(arrs[2]), counts[2], _ptr(arrs[3]), _ptr(fr_a),
+                                                      ctypes.byref(h)))
+        elif _adopt is not None:
             n, k, has_static, has_frame = _adopt
             ctx.check(lib.midyn_stack_adopt(ctx.handle, n, k, has_static, has_frame,
                                             _vp(dev_buffer_ptr), ctypes.byref(h)))
@@ -275,6 +287,12 @@ class Stack:
         modes = (ctypes.c_int * max(self.n_segments, 1))()
         ctx.check(lib.midyn_stack_segment_modes(h, modes))
         self.segment_modes = [int(modes[i]) for i in range(self.n_segments)]
+
+    @classmethod
+    def from_lindblad(cls, ctx, h_d, h_ops, n_static, l_ops, frame_im):
+        """Vectorised Lindblad stack (dimension n^2) from the n x n operators in the frame basis: h_d (n,n) | None,
+        h_ops (k_h,n,n) | None, n_static (n_s,n,n) | None, l_ops (k_l,n,n) | None, frame_im (n^2,) | None."""
+        return cls(ctx, None, None, frame_im, _lindblad=(h_d, h_ops, n_static, l_ops))
 
     @staticmethod
     def packed_bytes(n, k, has_static):

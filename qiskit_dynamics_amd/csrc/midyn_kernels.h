@@ -2065,6 +2065,47 @@ __global__ __launch_bounds__(256) void magnus2_term_kernel(const double2* u1, co
     }
 }
 
+// Column-stacking superoperators of the vectorised Lindblad model, written straight into the operator stack
+// from the n x n operators (models/model_utils.py:31-118; N = n^2, row r = i n + k, column c = j n + m):
+//   kind 0:  -i (I (x) A - A^T (x) I)                                    (vec_commutator)
+//   kind 1:  conj(L) (x) L - (I (x) L^+L + (L^+L)^T (x) I) / 2           (vec_dissipator; ldl = L^+L)
+// accumulate != 0 adds to what `out` holds.  Plain multiplies and adds in numpy's order (no contraction).
+__global__ __launch_bounds__(256) void vec_lindblad_kernel(int n, int ld, const double2* a, int kind, const double2* ldl,
+                                                           double2* out, int accumulate) {
+#pragma clang fp contract(off)
+    const size_t N = (size_t)n * n, total = N * N;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / N), c = (int)(idx - (size_t)r * N);
+        const int i = r / n, k = r - i * n, j = c / n, m = c - j * n;
+        double2 val;
+        if (kind == 0) {
+            const double2 x = i == j ? a[k * n + m] : make_double2(0.0, 0.0);
+            const double2 y = k == m ? a[j * n + i] : make_double2(0.0, 0.0);
+            const double2 d = make_double2(x.x - y.x, x.y - y.y);
+            val = make_double2(d.y, -d.x);  // -i d
+        } else {
+            const double2 lc = a[i * n + j], l2 = a[k * n + m];  // conj(lc) * l2
+            const double2 outer = make_double2(lc.x * l2.x + lc.y * l2.y, lc.x * l2.y - lc.y * l2.x);
+            const double2 x = i == j ? ldl[k * n + m] : make_double2(0.0, 0.0);
+            const double2 y = k == m ? ldl[j * n + i] : make_double2(0.0, 0.0);
+            val = make_double2(outer.x - 0.5 * (x.x + y.x), outer.y - 0.5 * (x.y + y.y));
+        }
+        double2* o = out + (size_t)r * ld + c;
+        if (accumulate) val = make_double2(o->x + val.x, o->y + val.y);
+        *o = val;
+    }
+}
+
+// a += b over [rows][cols] blocks of leading dimension ld (static superoperator = commutator part + dissipator sum)
+__global__ __launch_bounds__(256) void add_padded_kernel(double2* a, const double2* b, int rows, int cols, int ld) {
+#pragma clang fp contract(off)
+    const size_t total = (size_t)rows * cols;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t r = idx / cols, off = r * ld + (idx - r * cols);
+        a[off] = make_double2(a[off].x + b[off].x, a[off].y + b[off].y);
+    }
+}
+
 // flags[2*seg + 0/1] = 1 if any real / imaginary part of segment seg is non zero
 __global__ __launch_bounds__(256) void plane_flags_kernel(const double2* ops, size_t plane, int nseg,
                                                           int* flags) {

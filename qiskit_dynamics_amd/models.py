@@ -320,22 +320,11 @@ class LindbladModel(BaseGeneratorModel):
             self.signals = (hamiltonian_signals, dissipator_signals)
             return
         # superoperator stack (column stacking): static = vec_comm(H_d) + sum vec_diss(N_j),
-        # operators = [vec_comm(H_j) ; vec_diss(L_j)]
-        s_d = None
-        if self._h_d is not None:
-            s_d = vec_commutator(self._h_d)
-        if self._n_static is not None:
-            nd = np.sum(vec_dissipator(self._n_static), axis=0)
-            s_d = nd if s_d is None else s_d + nd
-        parts = []
-        if self._h_ops is not None:
-            parts.append(vec_commutator(self._h_ops))
-        if self._l_ops is not None:
-            parts.append(vec_dissipator(self._l_ops))
-        s_ops = None
-        if parts:
-            s_ops = parts[0] if len(parts) == 1 else np.append(parts[0], parts[1], axis=0)
-        self._stack = _lib.Stack(self._ctx, s_ops, s_d, frame.vectorized_frame_diag_imag())
+        # operators = [vec_comm(H_j) ; vec_diss(L_j)] -- assembled on the device from the n x n operators
+        # (the host never holds the n^2 x n^2 arrays; `vec_commutator` / `vec_dissipator` above are the same
+        # formulas on the host, kept for the getters and the tests)
+        self._stack = _lib.Stack.from_lindblad(self._ctx, self._h_d, self._h_ops, self._n_static, self._l_ops,
+                                               frame.vectorized_frame_diag_imag())
         self.signals = (hamiltonian_signals, dissipator_signals)
 
     def _build_unvectorized(self):

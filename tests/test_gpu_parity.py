@@ -2008,3 +2008,41 @@ def test_block_sparse_every_panel_height(qd, bm, nb):
             assert (ctx.counters("rhs_blocks_gemm")["launches"] > 0) == bool(flag)
             out[flag] = np.stack([x.y[-1] for x in r])
         assert_close(out[1], out[0], 1e-13)
+
+
+@pytest.mark.parametrize("n,with_hd,n_s,k_h,k_l,framed", [(5, True, 2, 2, 1, True), (8, False, 3, 0, 2, False),
+                                                            (4, True, 0, 3, 0, True), (16, True, 4, 4, 2, False)])
+def test_lindblad_superoperators_built_on_device(qd, n, with_hd, n_s, k_h, k_l, framed):
+    """a13: the vectorised Lindblad stack assembled on the device from the n x n operators
+    (midyn_stack_create_lindblad) against the stack uploaded from the host Kronecker formulas
+    (models.vec_commutator / vec_dissipator), entry for entry through the generator evaluation, with every
+    combination of absent parts."""
+    from qiskit_dynamics_amd import models as M
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(100 * n + n_s)
+
+    def herm(k):
+        a = crand(rng, k, n, n)
+        return (a + np.swapaxes(a.conj(), -1, -2)) / 2
+
+    h_d = herm(1)[0] if with_hd else None
+    h_ops = herm(k_h) if k_h else None
+    n_static = crand(rng, n_s, n, n) if n_s else None
+    l_ops = crand(rng, k_l, n, n) if k_l else None
+    fim = rng.normal(size=n * n) if framed else None
+    dev = qd.Stack.from_lindblad(ctx, h_d, h_ops, n_static, l_ops, fim)
+    s_d = None
+    if h_d is not None:
+        s_d = M.vec_commutator(h_d)
+    if n_static is not None:
+        nd = np.sum(M.vec_dissipator(n_static), axis=0)
+        s_d = nd if s_d is None else s_d + nd
+    parts = ([M.vec_commutator(h_ops)] if h_ops is not None else []) + ([M.vec_dissipator(l_ops)] if l_ops is not None else [])
+    s_ops = None if not parts else np.concatenate(parts, axis=0)
+    host = qd.Stack(ctx, s_ops, s_d, fim)
+    assert (dev.n, dev.k, dev.has_static, dev.has_frame) == (host.n, host.k, host.has_static, host.has_frame)
+    for t in (0.0, 0.7):
+        c = rng.normal(size=k_h + k_l)
+        g_dev, g_host = dev.eval_generator(c, t), host.eval_generator(c, t)
+        assert_close(g_dev, g_host, 1e-14)
