@@ -2046,3 +2046,69 @@ def test_lindblad_superoperators_built_on_device(qd, n, with_hd, n_s, k_h, k_l, 
         c = rng.normal(size=k_h + k_l)
         g_dev, g_host = dev.eval_generator(c, t), host.eval_generator(c, t)
         assert_close(g_dev, g_host, 1e-14)
+
+
+def _count_products(ctx, fn):
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    try:
+        r = fn()
+    finally:
+        ctx.set_option("profile", 0)
+    n = sum(ctx.counters(c)["launches"] for c in ("rhs_stream", "rhs_gemm", "rhs_blocks", "rhs_blocks_gemm"))
+    return r, n
+
+
+def test_chebyshev_action_sweep_with_frame_and_fallbacks(qd):
+    """Chebyshev expm action (default for nearly skew-Hermitian generators): (a) a sweep of 12 instances of a
+    7-qubit chain without a frame (large ||hG||) and in the full frame, against the Taylor series
+    (chebyshev = 0) with fewer products; (b) a strongly dissipative Lindbladian, where the stability check
+    must reject the series (same products as with chebyshev = 0, same results); (c) the series forced on a
+    small norm (chebyshev = 2)."""
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    cfg = W.schrodinger_config(7, 4, 1.0, 0.05)
+    sweeps = []
+    for b in range(12):
+        amps, phases = W.sweep_parameters(b, 4)
+        sweeps.append([qd.Signal(lambda t, a=a: a * np.cos(0.3 * t) + 0j, nu, ph) for a, nu, ph in zip(amps, cfg["carrier"], phases)])
+    rng = np.random.default_rng(4)
+    y0 = crand(rng, 128)
+    y0 /= np.linalg.norm(y0)
+    try:
+        for frame, expect_fewer in ((None, True), (cfg["h_d"], None)):
+            solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
+            fn = lambda: solver.solve(t_span=[0.0, 0.2], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.05)
+            ctx.set_option("chebyshev", 1)
+            r1, n1 = _count_products(ctx, fn)
+            ctx.set_option("chebyshev", 0)
+            r0, n0 = _count_products(ctx, fn)
+            a1, a0 = np.stack([x.y[-1] for x in r1]), np.stack([x.y[-1] for x in r0])
+            assert_close(a1, a0, 1e-12)
+            assert np.max(np.abs(np.linalg.norm(a1, axis=1) - 1.0)) < 1e-12
+            if expect_fewer:
+                assert n1 < 0.6 * n0, (n1, n0)
+            # (c) forced on whatever norm this is
+            ctx.set_option("chebyshev", 2)
+            r2, _ = _count_products(ctx, fn)
+            assert_close(np.stack([x.y[-1] for x in r2]), a0, 1e-12)
+        # (b) strong dissipation: Hermitian part comparable to the norm -> the series must not be used
+        lc = W.lindblad_config(n_qubits=3, n_drives=3, n_diss=3, gamma=40.0, t_final=1.0, max_dt=0.05)
+        sig = [qd.Signal(0.4, nu, 0.1) for nu in lc["carrier"]]
+        m = qd.LindbladModel(static_hamiltonian=lc["h_d"], hamiltonian_operators=lc["ops"], hamiltonian_signals=sig,
+                             static_dissipators=lc["static_dissipators"], vectorized=True)
+        yv = lc["rho0"].flatten(order="F")
+        fn = lambda: qd.solve_lmde(m, [0.0, 0.2], yv, method="scipy_expm", max_dt=0.05)
+        ctx.set_option("chebyshev", 1)
+        r1, n1 = _count_products(ctx, fn)
+        ctx.set_option("chebyshev", 0)
+        r0, n0 = _count_products(ctx, fn)
+        assert n1 == n0, (n1, n0)
+        assert_close(r1.y[-1], r0.y[-1], 1e-14)
+        ctx.set_option("expm_action", 0)
+        rd = fn()
+        assert_close(r1.y[-1], rd.y[-1], 1e-11)
+    finally:
+        ctx.set_option("chebyshev", 1)
+        ctx.set_option("expm_action", 1)
