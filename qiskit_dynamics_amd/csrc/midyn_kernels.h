@@ -1875,7 +1875,10 @@ __global__ __launch_bounds__(256) void tiny_rk4_kernel(TinyArgs a) {
 // one launch: per step the host-chosen Taylor degree and scaling (packed as deg | sc << 8 in the
 // third row slot of the step table, which Magnus orders 1 and 2 do not use), products through tiny_rhs.
 // order 1: Omega v = h G(t1) v;  order 2: h/2 (g1 v + g2 v) + sqrt(3)/12 h^2 (g2 g1 v - g1 g2 v).
-__global__ __launch_bounds__(256) void tiny_expm_kernel(TinyArgs a, int magnus_order, const int* deg, const int* sc) {
+// deg[st] < 0: Chebyshev series with K = -deg[st] terms in sc[st] repetitions, rho[st] the norm bound of Omega and
+// cheb[st * cheb_stride + k] = J_k(rho / sc) (see the Chebyshev paragraph of expm_action_solve).
+__global__ __launch_bounds__(256) void tiny_expm_kernel(TinyArgs a, int magnus_order, const int* deg, const int* sc,
+                                                        const double* rho, const double* cheb, int cheb_stride) {
     MIDYN_TINY_PROLOGUE
     const double p2 = 0.14433756729740643;  // sqrt(3) / 12
     MIDYN_TINY_PIPE_PROLOGUE
@@ -1891,7 +1894,39 @@ __global__ __launch_bounds__(256) void tiny_expm_kernel(TinyArgs a, int magnus_o
         const double* c1 = c0 + kk_;
         const double h = cur.h;
         const int p = p_cur, s = s_cur;
-        for (int rep = 0; rep < s; ++rep) {
+        if (p < 0) {
+            // Omega phi for the current step (Magnus 1: h G(t1); Magnus 2: commutator free), scaled by w
+            auto omega = [&](double2 v, double w) -> double2 {
+                if (magnus_order == 1) {
+                    const double2 kk = tiny_rhs(has_e, n_act, cidx, At, u, c0, n, r, active, e0, v);
+                    return make_double2(w * h * kk.x, w * h * kk.y);
+                }
+                const double2 u1 = tiny_rhs(has_e, n_act, cidx, At, u, c0, n, r, active, e0, v);
+                const double2 u2 = tiny_rhs(has_e, n_act, cidx, At, u, c1, n, r, active, e1, v);
+                const double2 v1 = tiny_rhs(has_e, n_act, cidx, At, u, c1, n, r, active, e1, u1);
+                const double2 v2 = tiny_rhs(has_e, n_act, cidx, At, u, c0, n, r, active, e0, u2);
+                const double ca = 0.5 * h * w, cb2 = p2 * h * h * w;
+                return make_double2(ca * (u1.x + u2.x) + cb2 * (v1.x - v2.x), ca * (u1.y + u2.y) + cb2 * (v1.y - v2.y));
+            };
+            const int K = -p;
+            const double* cj = cheb + (size_t)st * cheb_stride;
+            const double w = 1.0 / rho[st];
+            for (int rep = 0; rep < s; ++rep) {
+                double2 prev = y;
+                double2 phi = omega(y, w);                         // phi_1 = B y
+                double2 acc = make_double2(cj[0] * y.x + 2.0 * cj[1] * phi.x, cj[0] * y.y + 2.0 * cj[1] * phi.y);
+                for (int k = 1; k < K; ++k) {                      // phi_{k+1} = 2 B phi_k + phi_{k-1}
+                    const double2 t = omega(phi, 2.0 * w);
+                    const double2 nxt = make_double2(t.x + prev.x, t.y + prev.y);
+                    acc.x += 2.0 * cj[k + 1] * nxt.x;
+                    acc.y += 2.0 * cj[k + 1] * nxt.y;
+                    prev = phi;
+                    phi = nxt;
+                }
+                y = acc;
+            }
+        }
+        for (int rep = 0; rep < s && p >= 0; ++rep) {
             double2 acc = y, term = y;
             for (int j = 1; j <= p; ++j) {
                 const double f = 1.0 / ((double)s * j);

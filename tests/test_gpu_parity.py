@@ -2112,3 +2112,47 @@ def test_chebyshev_action_sweep_with_frame_and_fallbacks(qd):
     finally:
         ctx.set_option("chebyshev", 1)
         ctx.set_option("expm_action", 1)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_tiny_kernel_chebyshev_lab_frame(qd, order):
+    """Small systems without a rotating frame have ||h G|| of several units (2 pi nu h per qubit): the
+    persistent one-launch solver then runs the Chebyshev recurrence in registers (negative degree in its step
+    table) for Magnus 1 and 2.  Against the Taylor series in the same kernel (chebyshev = 0), the dense expm
+    route and the oracle; a sweep of 40 instances of a 3-qubit chain (n = 8)."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    cfg = W.schrodinger_config(3, 3, 1.0, 0.04)
+    sweeps, params = [], []
+    for b in range(40):
+        amps, phases = W.sweep_parameters(b, 3)
+        params.append((amps, phases))
+        sweeps.append([qd.Signal(float(a), nu, ph) for a, nu, ph in zip(amps, cfg["carrier"], phases)])
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"])
+    rng = np.random.default_rng(12)
+    y0 = crand(rng, 8)
+    y0 /= np.linalg.norm(y0)
+    fn = lambda: solver.solve(t_span=[0.0, 0.4], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.04,
+                              magnus_order=order)
+    out = {}
+    try:
+        for tag, opts in (("cheb", {"chebyshev": 1}), ("taylor", {"chebyshev": 0}), ("dense", {"expm_action": 0})):
+            for k_, v_ in opts.items():
+                ctx.set_option(k_, v_)
+            out[tag] = np.stack([x.y[-1] for x in fn()])
+            ctx.set_option("chebyshev", 1)
+            ctx.set_option("expm_action", 1)
+    finally:
+        ctx.set_option("chebyshev", 1)
+        ctx.set_option("expm_action", 1)
+    assert_close(out["cheb"], out["taylor"], 1e-12)
+    assert_close(out["cheb"], out["dense"], 1e-11)
+    assert np.max(np.abs(np.linalg.norm(out["cheb"], axis=1) - 1.0)) < 1e-12
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], None)
+    for b in (0, 39):
+        amps, phases = params[b]
+        coeff = lambda t: np.array([np.real(s_(t)) for s_ in sweeps[b]])
+        _, yref = orc.solve_generator_model(a_d, a, d, basis, coeff, [0.0, 0.4], y0, "scipy_expm", 0.04, magnus_order=order)
+        assert_close(out["cheb"][b], yref[-1], SOLVE_TOL)
