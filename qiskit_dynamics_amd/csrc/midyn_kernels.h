@@ -2082,16 +2082,24 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const double2* src, dou
 // One Taylor term of the commutator-free Magnus-2 action (fixed_step_solvers.py:348-363 applied to a
 // vector):  w = a (u1 + u2) + b (v1 - v2),  u_i = g_i term, v1 = g2 u1, v2 = g1 u2;  acc += w.
 // Optionally also writes the two phased copies of w the next term's products read (wp0 = e0 o w, wp1 = e1 o w).
+// z / beta: the Chebyshev recurrence of the same action, w = (...) + z (phi_{k+1} = 2 B phi_k + phi_{k-1}; z may alias
+// w), acc += beta w; the Taylor series passes z = nullptr, beta = 1.
 __global__ __launch_bounds__(256) void magnus2_term_kernel(const double2* u1, const double2* u2, const double2* v1,
                                                            const double2* v2, double a, double b, size_t total,
                                                            double2* w, double2* acc, const double2* e0,
-                                                           const double2* e1, int ld, double2* wp0, double2* wp1) {
+                                                           const double2* e1, int ld, double2* wp0, double2* wp1,
+                                                           const double2* z, double beta) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const double2 p = u1[idx], q = u2[idx], r = v1[idx], t = v2[idx];
-        const double2 o = make_double2(a * (p.x + q.x) + b * (r.x - t.x), a * (p.y + q.y) + b * (r.y - t.y));
+        double2 o = make_double2(a * (p.x + q.x) + b * (r.x - t.x), a * (p.y + q.y) + b * (r.y - t.y));
+        if (z) {
+            const double2 zz = z[idx];
+            o.x += zz.x;
+            o.y += zz.y;
+        }
         w[idx] = o;
         const double2 c = acc[idx];
-        acc[idx] = make_double2(c.x + o.x, c.y + o.y);
+        acc[idx] = make_double2(c.x + beta * o.x, c.y + beta * o.y);
         if (wp0) {
             const size_t i = idx / ld;
             wp0[idx] = cmul(e0[i], o);

@@ -2093,6 +2093,19 @@ def test_chebyshev_action_sweep_with_frame_and_fallbacks(qd):
             ctx.set_option("chebyshev", 2)
             r2, _ = _count_products(ctx, fn)
             assert_close(np.stack([x.y[-1] for x in r2]), a0, 1e-12)
+        # Magnus 2 on the large-norm generator (sweep, with and without a frame; one trajectory on the streaming path)
+        for frame, sig in ((None, sweeps), (np.diag(cfg["h_d"]).real.copy(), sweeps), (None, sweeps[0])):
+            solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
+            fn = lambda: solver.solve(t_span=[0.0, 0.2], y0=y0, signals=sig, method="scipy_expm", max_dt=0.05,
+                                      magnus_order=2)
+            ctx.set_option("chebyshev", 1)
+            r1, n1 = _count_products(ctx, fn)
+            ctx.set_option("chebyshev", 0)
+            r0, n0 = _count_products(ctx, fn)
+            as_arr = lambda r: np.stack([x.y[-1] for x in r]) if isinstance(r, list) else r.y[-1][None]
+            assert_close(as_arr(r1), as_arr(r0), 1e-12)
+            if frame is None:
+                assert n1 < 0.7 * n0, (n1, n0)
         # (b) strong dissipation: Hermitian part comparable to the norm -> the series must not be used
         lc = W.lindblad_config(n_qubits=3, n_drives=3, n_diss=3, gamma=40.0, t_final=1.0, max_dt=0.05)
         sig = [qd.Signal(0.4, nu, 0.1) for nu in lc["carrier"]]
