@@ -540,10 +540,68 @@ def gen_perturbative():
     save("perturbative", **out)
 
 
+# ---------------------------------------------------------------------------------------------
+def lab_frame_signals(n_drives, carrier, instance):
+    """Constant-envelope drives of sweep instance `instance` (amplitude, carrier, phase per drive)."""
+    amps, phases = workloads.sweep_parameters(instance, n_drives)
+    return [(float(a), float(nu), float(ph)) for a, nu, ph in zip(amps, carrier, phases)]
+
+
+def gen_lab_frame():
+    """Large ||h G||: models WITHOUT a rotating frame, `scipy_expm` with Magnus orders 1 and 2
+    (fixed_step_solvers.py:80-108,308-403 through solve_lmde / Solver list mode).  These are the inputs on which
+    the device takes the Chebyshev expm action, the work-list kernels (8 qubits: block-sparse computational
+    basis), the persistent small-system kernel (3 qubits) and the device-built Lindblad superoperators."""
+    out = {}
+    # (a) 8-qubit chain, n = 256, lab frame: a sweep of 3 instances
+    cfg = workloads.schrodinger_config(n_qubits=8, n_drives=4, t_final=1.0, max_dt=0.05)
+    rng = np.random.default_rng(808)
+    y0 = crand(rng, 256)
+    y0 /= np.linalg.norm(y0)
+    out["q8_y0"] = y0
+    solver = Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"])
+    sig_lists = [[Signal(a, nu, ph) for a, nu, ph in lab_frame_signals(4, cfg["carrier"], b)] for b in range(3)]
+    for mo in (1, 2):
+        res = solver.solve(t_span=[0.0, 0.2], y0=y0, signals=sig_lists, method="scipy_expm", max_dt=0.05,
+                           magnus_order=mo)
+        out[f"q8_expm{mo}_y"] = np.array([r.y[-1] for r in res])
+    # the same model in the diagonal frame (block sparse, small norm): the frame handling on the same inputs
+    solver_d = Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                      rotating_frame=np.diag(cfg["h_d"]).real.copy())
+    res = solver_d.solve(t_span=[0.0, 0.2], y0=y0, signals=sig_lists, method="scipy_expm", max_dt=0.05, magnus_order=1)
+    out["q8_diag_expm1_y"] = np.array([r.y[-1] for r in res])
+    # (b) 3-qubit chain, n = 8, lab frame, sweep of 6 instances
+    cfg3 = workloads.schrodinger_config(n_qubits=3, n_drives=3, t_final=1.0, max_dt=0.04)
+    y3 = crand(rng, 8)
+    y3 /= np.linalg.norm(y3)
+    out["q3_y0"] = y3
+    solver3 = Solver(static_hamiltonian=cfg3["h_d"], hamiltonian_operators=cfg3["ops"])
+    sig3 = [[Signal(a, nu, ph) for a, nu, ph in lab_frame_signals(3, cfg3["carrier"], b)] for b in range(6)]
+    for mo in (1, 2):
+        res = solver3.solve(t_span=[0.0, 0.4], y0=y3, signals=sig3, method="scipy_expm", max_dt=0.04, magnus_order=mo)
+        out[f"q3_expm{mo}_y"] = np.array([r.y[-1] for r in res])
+    # (c) 3-qubit vectorised Lindbladian (N = 64), no frame, weak dissipation
+    lc = workloads.lindblad_config(n_qubits=3, n_drives=3, n_diss=3, gamma=1e-2, t_final=1.0, max_dt=0.05)
+    sigl = [Signal(a, nu, ph) for a, nu, ph in lab_frame_signals(3, lc["carrier"], 0)]
+    m = LindbladModel(static_hamiltonian=lc["h_d"], hamiltonian_operators=lc["ops"], hamiltonian_signals=sigl,
+                      static_dissipators=lc["static_dissipators"], vectorized=True)
+    rho0 = crand(rng, 8, 8)
+    rho0 = rho0 @ rho0.conj().T
+    rho0 /= np.trace(rho0)
+    out["l3_rho0"] = rho0
+    r = solve_lmde(m, [0.0, 0.2], rho0.flatten(order="F"), method="scipy_expm", max_dt=0.05)
+    out["l3_expm1_y"] = np.asarray(r.y[-1])
+    save("lab_frame", **out)
+
+
+# ---------------------------------------------------------------------------------------------
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "perturbative":
         gen_perturbative()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lab_frame":
+        gen_lab_frame()
         sys.exit(0)
     gen_collection()
     gen_signals()
@@ -554,3 +612,4 @@ if __name__ == "__main__":
     gen_solver_list()
     gen_rotating_frame()
     gen_perturbative()
+    gen_lab_frame()

@@ -2169,3 +2169,47 @@ def test_tiny_kernel_chebyshev_lab_frame(qd, order):
         coeff = lambda t: np.array([np.real(s_(t)) for s_ in sweeps[b]])
         _, yref = orc.solve_generator_model(a_d, a, d, basis, coeff, [0.0, 0.4], y0, "scipy_expm", 0.04, magnus_order=order)
         assert_close(out["cheb"][b], yref[-1], SOLVE_TOL)
+
+
+def test_lab_frame_expm_routes_against_reference_golden(qd, golden):
+    """The reference's own results (tests/golden/lab_frame.npz) for models WITHOUT a rotating frame, where the
+    device takes its newest routes: Chebyshev expm action on the work-list kernels (8 qubits, lab frame), the
+    persistent small-system kernel with the Chebyshev recurrence (3 qubits), the diagonal-frame twin, and a
+    vectorised Lindbladian whose superoperators are assembled on the device -- Magnus orders 1 and 2."""
+    from qiskit_dynamics_amd import workloads as W
+
+    g = golden("lab_frame")
+
+    def sigs(n_drives, carrier, b):
+        amps, phases = W.sweep_parameters(b, n_drives)
+        return [qd.Signal(float(a), float(nu), float(ph)) for a, nu, ph in zip(amps, carrier, phases)]
+
+    cfg = W.schrodinger_config(n_qubits=8, n_drives=4, t_final=1.0, max_dt=0.05)
+    sweeps = [sigs(4, cfg["carrier"], b) for b in range(3)]
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"])
+    for mo in (1, 2):
+        res = solver.solve(t_span=[0.0, 0.2], y0=g["q8_y0"], signals=sweeps, method="scipy_expm", max_dt=0.05,
+                           magnus_order=mo)
+        assert_close(np.stack([r.y[-1] for r in res]), g[f"q8_expm{mo}_y"], SOLVE_TOL)
+        one = solver.solve(t_span=[0.0, 0.2], y0=g["q8_y0"], signals=sweeps[2], method="scipy_expm", max_dt=0.05,
+                           magnus_order=mo)
+        assert_close(one.y[-1], g[f"q8_expm{mo}_y"][2], SOLVE_TOL)
+    solver_d = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                         rotating_frame=np.diag(cfg["h_d"]).real.copy())
+    res = solver_d.solve(t_span=[0.0, 0.2], y0=g["q8_y0"], signals=sweeps, method="scipy_expm", max_dt=0.05)
+    assert_close(np.stack([r.y[-1] for r in res]), g["q8_diag_expm1_y"], SOLVE_TOL)
+
+    cfg3 = W.schrodinger_config(n_qubits=3, n_drives=3, t_final=1.0, max_dt=0.04)
+    solver3 = qd.Solver(static_hamiltonian=cfg3["h_d"], hamiltonian_operators=cfg3["ops"])
+    sweeps3 = [sigs(3, cfg3["carrier"], b) for b in range(6)]
+    for mo in (1, 2):
+        res = solver3.solve(t_span=[0.0, 0.4], y0=g["q3_y0"], signals=sweeps3, method="scipy_expm", max_dt=0.04,
+                            magnus_order=mo)
+        assert_close(np.stack([r.y[-1] for r in res]), g[f"q3_expm{mo}_y"], SOLVE_TOL)
+
+    lc = W.lindblad_config(n_qubits=3, n_drives=3, n_diss=3, gamma=1e-2, t_final=1.0, max_dt=0.05)
+    m = qd.LindbladModel(static_hamiltonian=lc["h_d"], hamiltonian_operators=lc["ops"],
+                         hamiltonian_signals=sigs(3, lc["carrier"], 0), static_dissipators=lc["static_dissipators"],
+                         vectorized=True)
+    r = qd.solve_lmde(m, [0.0, 0.2], g["l3_rho0"].flatten(order="F"), method="scipy_expm", max_dt=0.05)
+    assert_close(r.y[-1], g["l3_expm1_y"], SOLVE_TOL)
