@@ -591,6 +591,22 @@ def gen_lab_frame():
     out["l3_rho0"] = rho0
     r = solve_lmde(m, [0.0, 0.2], rho0.flatten(order="F"), method="scipy_expm", max_dt=0.05)
     out["l3_expm1_y"] = np.asarray(r.y[-1])
+    # (d) sweep of non-vectorised open systems through Solver list mode (RK4 on n x n density matrices):
+    # 3 instances of a 3-qubit chain in the diagonal frame, static + one dynamic dissipator, own initial states
+    frame3 = np.diag(lc["h_d"]).real.copy()
+    sm = lc["static_dissipators"]
+    solver_nv = Solver(static_hamiltonian=lc["h_d"], hamiltonian_operators=lc["ops"], static_dissipators=sm[:2],
+                       dissipator_operators=sm[2:3], rotating_frame=frame3, vectorized=False)
+    rhos, sweeps = [], []
+    for b in range(3):
+        x = crand(rng, 8, 8)
+        x = x @ x.conj().T
+        rhos.append(x / np.trace(x))
+        sweeps.append(([Signal(a, nu, ph) for a, nu, ph in lab_frame_signals(3, lc["carrier"], b)],
+                       [Signal(0.5 + 0.25 * b, 0.0)]))
+    out["nv_rho0"] = np.array(rhos)
+    res = solver_nv.solve(t_span=[0.0, 0.2], y0=rhos, signals=sweeps, method="RK4", max_dt=0.01)
+    out["nv_rk4_y"] = np.array([r.y[-1] for r in res])
     save("lab_frame", **out)
 
 

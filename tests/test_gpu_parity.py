@@ -2213,3 +2213,23 @@ def test_lab_frame_expm_routes_against_reference_golden(qd, golden):
                          vectorized=True)
     r = qd.solve_lmde(m, [0.0, 0.2], g["l3_rho0"].flatten(order="F"), method="scipy_expm", max_dt=0.05)
     assert_close(r.y[-1], g["l3_expm1_y"], SOLVE_TOL)
+
+
+def test_unvectorized_lindblad_sweep_against_reference_golden(qd, golden):
+    """Row f2 in sweep form against the reference itself (tests/golden/lab_frame.npz, `nv_*`): Solver list
+    mode with `vectorized=False`, per-instance Hamiltonian and dissipator signals and initial states -- the
+    instances advance together in the batched launches of midyn_lindblad_rk4_solve."""
+    from qiskit_dynamics_amd import workloads as W
+
+    g = golden("lab_frame")
+    lc = W.lindblad_config(n_qubits=3, n_drives=3, n_diss=3, gamma=1e-2, t_final=1.0, max_dt=0.05)
+    sm = lc["static_dissipators"]
+    solver = qd.Solver(static_hamiltonian=lc["h_d"], hamiltonian_operators=lc["ops"], static_dissipators=sm[:2],
+                       dissipator_operators=sm[2:3], rotating_frame=np.diag(lc["h_d"]).real.copy(), vectorized=False)
+    sweeps = []
+    for b in range(3):
+        amps, phases = W.sweep_parameters(b, 3)
+        sweeps.append(([qd.Signal(float(a), float(nu), float(ph)) for a, nu, ph in zip(amps, lc["carrier"], phases)],
+                       [qd.Signal(0.5 + 0.25 * b, 0.0)]))
+    res = solver.solve(t_span=[0.0, 0.2], y0=list(g["nv_rho0"]), signals=sweeps, method="RK4", max_dt=0.01)
+    assert_close(np.stack([r.y[-1] for r in res]), g["nv_rk4_y"], SOLVE_TOL)
