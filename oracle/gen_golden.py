@@ -570,6 +570,11 @@ def gen_lab_frame():
                       rotating_frame=np.diag(cfg["h_d"]).real.copy())
     res = solver_d.solve(t_span=[0.0, 0.2], y0=y0, signals=sig_lists, method="scipy_expm", max_dt=0.05, magnus_order=1)
     out["q8_diag_expm1_y"] = np.array([r.y[-1] for r in res])
+    # RK4 on the same block-sparse stacks (lab frame and diagonal frame)
+    res = solver.solve(t_span=[0.0, 0.1], y0=y0, signals=sig_lists, method="RK4", max_dt=0.002)
+    out["q8_rk4_y"] = np.array([r.y[-1] for r in res])
+    res = solver_d.solve(t_span=[0.0, 0.1], y0=y0, signals=sig_lists, method="RK4", max_dt=0.002)
+    out["q8_diag_rk4_y"] = np.array([r.y[-1] for r in res])
     # (b) 3-qubit chain, n = 8, lab frame, sweep of 6 instances
     cfg3 = workloads.schrodinger_config(n_qubits=3, n_drives=3, t_final=1.0, max_dt=0.04)
     y3 = crand(rng, 8)

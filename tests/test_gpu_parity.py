@@ -2198,6 +2198,11 @@ def test_lab_frame_expm_routes_against_reference_golden(qd, golden):
                          rotating_frame=np.diag(cfg["h_d"]).real.copy())
     res = solver_d.solve(t_span=[0.0, 0.2], y0=g["q8_y0"], signals=sweeps, method="scipy_expm", max_dt=0.05)
     assert_close(np.stack([r.y[-1] for r in res]), g["q8_diag_expm1_y"], SOLVE_TOL)
+    for slv, key in ((solver, "q8_rk4_y"), (solver_d, "q8_diag_rk4_y")):   # RK4 on the work-list kernels
+        res = slv.solve(t_span=[0.0, 0.1], y0=g["q8_y0"], signals=sweeps, method="RK4", max_dt=0.002)
+        assert_close(np.stack([r.y[-1] for r in res]), g[key], SOLVE_TOL)
+        one = slv.solve(t_span=[0.0, 0.1], y0=g["q8_y0"], signals=sweeps[1], method="RK4", max_dt=0.002)
+        assert_close(one.y[-1], g[key][1], SOLVE_TOL)
 
     cfg3 = W.schrodinger_config(n_qubits=3, n_drives=3, t_final=1.0, max_dt=0.04)
     solver3 = qd.Solver(static_hamiltonian=cfg3["h_d"], hamiltonian_operators=cfg3["ops"])
