@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
                 }
     }
     // epilogue: D[row = (lane>>4) + 4*reg][col = lane & 15]
-    if (g.splits > 1) {
+    if (g.partial) {   // raw partial sums (split-K, or one of several launches over chunks of the segment list)
         double2* P = g.partial + (size_t)split * g.M * g.N;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)

@@ -2238,3 +2238,37 @@ def test_unvectorized_lindblad_sweep_against_reference_golden(qd, golden):
                        [qd.Signal(0.5 + 0.25 * b, 0.0)]))
     res = solver.solve(t_span=[0.0, 0.2], y0=list(g["nv_rho0"]), signals=sweeps, method="RK4", max_dt=0.01)
     assert_close(np.stack([r.y[-1] for r in res]), g["nv_rk4_y"], SOLVE_TOL)
+
+
+def test_more_than_64_operators(qd):
+    """A model with 70 drive operators + a static one (the MFMA contraction keeps a 64-entry segment table in one
+    VGPR: longer lists run as chunked launches whose raw partial sums are reduced together).  Sweep of 12
+    instances (MFMA route) and one trajectory (streaming route), RK4 and scipy_expm, against the oracle."""
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(70)
+    n, k = 64, 70
+    h_static = crand(rng, n, n)
+    h_static = (h_static + h_static.conj().T) / 2
+    a_ = crand(rng, k, n, n)
+    h_ops = (a_ + np.swapaxes(a_.conj(), -1, -2)) / 2 * 0.2
+    frame = crand(rng, n, n)
+    frame = (frame + frame.conj().T) / 2
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=frame)
+    par = [(rng.uniform(0.2, 1.0, k), rng.uniform(0.0, 2.0, k), rng.uniform(-3, 3, k)) for _ in range(12)]
+    sweeps = [[qd.Signal(float(a), float(f), float(p)) for a, f, p in zip(*pb)] for pb in par]
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
+
+    def coeff(b):
+        amp, fr, ph = par[b]
+        return lambda t: np.array([orc.signal_sum_value(np.array([amp[j] + 0j]), [fr[j]], [ph[j]], t) for j in range(k)])
+
+    for method, kw in (("RK4", {"max_dt": 0.01}), ("scipy_expm", {"max_dt": 0.05})):
+        res = solver.solve(t_span=[0.0, 0.1], y0=y0, signals=sweeps, method=method, **kw)
+        one = solver.solve(t_span=[0.0, 0.1], y0=y0, signals=sweeps[3], method=method, **kw)
+        for b in (0, 3, 11):
+            _, yref = orc.solve_generator_model(a_d, a, d, basis, coeff(b), [0.0, 0.1], y0, method, kw["max_dt"])
+            assert_close(res[b].y[-1], yref[-1], SOLVE_TOL)
+        assert_close(one.y[-1], res[3].y[-1], 1e-11)
