@@ -612,6 +612,20 @@ def gen_lab_frame():
     out["nv_rho0"] = np.array(rhos)
     res = solver_nv.solve(t_span=[0.0, 0.2], y0=rhos, signals=sweeps, method="RK4", max_dt=0.01)
     out["nv_rk4_y"] = np.array([r.y[-1] for r in res])
+    # (e) LindbladModel.from_hamiltonian (lindblad_model.py:214-260) on framed Hamiltonian models
+    rngf = np.random.default_rng(2140)
+    hs, hops = herm(rngf, 4), np.array([herm(rngf, 4), herm(rngf, 4)])
+    frm = herm(rngf, 4)
+    ldis = crand(rngf, 1, 4, 4)
+    rho = herm(rngf, 4)
+    out["fh_hs"], out["fh_hops"], out["fh_frame"], out["fh_l"], out["fh_rho"] = hs, hops, frm, ldis, rho
+    for tag, frame in (("nofr", None), ("fr", frm), ("diag", np.diag(frm).real.copy())):
+        hm = HamiltonianModel(static_operator=hs, operators=hops, signals=[Signal(0.5, 1.0), Signal(0.3, 2.0, 0.4)],
+                              rotating_frame=frame)
+        for vec in (False, True):
+            lm = LindbladModel.from_hamiltonian(hm, static_dissipators=ldis, vectorized=vec)
+            yin = rho.flatten(order="F") if vec else rho
+            out[f"fh_{tag}_{'vec' if vec else 'mat'}_rhs"] = np.array([lm.evaluate_rhs(t, yin) for t in (0.0, 0.3)])
     save("lab_frame", **out)
 
 

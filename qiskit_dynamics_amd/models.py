@@ -342,6 +342,25 @@ class LindbladModel(BaseGeneratorModel):
                                                frame.vectorized_frame_diag_imag())
         self.signals = (hamiltonian_signals, dissipator_signals)
 
+    @classmethod
+    def from_hamiltonian(cls, hamiltonian, static_dissipators=None, dissipator_operators=None,
+                         dissipator_signals=None, array_library: Optional[str] = None, vectorized: bool = False):
+        """Construct from a :class:`HamiltonianModel` (models/lindblad_model.py:214-260): its operators are read
+        out of the frame basis through the model's own getters and handed to the constructor together with its
+        signals, rotating frame and ``in_frame_basis`` flag -- exactly what the reference does, including that
+        ``static_operator`` of a framed Hamiltonian model is the static Hamiltonian with the frame already
+        subtracted."""
+        in_frame_basis = hamiltonian.in_frame_basis
+        hamiltonian.in_frame_basis = False
+        static_hamiltonian = hamiltonian.static_operator
+        hamiltonian_operators = hamiltonian.operators
+        hamiltonian.in_frame_basis = in_frame_basis
+        return cls(static_hamiltonian=static_hamiltonian, hamiltonian_operators=hamiltonian_operators,
+                   hamiltonian_signals=hamiltonian.signals, static_dissipators=static_dissipators,
+                   dissipator_operators=dissipator_operators, dissipator_signals=dissipator_signals,
+                   rotating_frame=hamiltonian.rotating_frame, in_frame_basis=hamiltonian.in_frame_basis,
+                   array_library=array_library, vectorized=vectorized, context=getattr(hamiltonian, "_ctx", None))
+
     def _build_unvectorized(self):
         """Operator stacks of the non-vectorised RHS (operator_collections.py:451-567):
         left = A + B, right = A - B with B = -iH, A = -1/2 sum N^+N - 1/2 sum gamma_j L_j^+L_j; both

@@ -2272,3 +2272,19 @@ def test_more_than_64_operators(qd):
             _, yref = orc.solve_generator_model(a_d, a, d, basis, coeff(b), [0.0, 0.1], y0, method, kw["max_dt"])
             assert_close(res[b].y[-1], yref[-1], SOLVE_TOL)
         assert_close(one.y[-1], res[3].y[-1], 1e-11)
+
+
+def test_lindblad_from_hamiltonian_golden(qd, golden):
+    """`LindbladModel.from_hamiltonian` (lindblad_model.py:214-260) on Hamiltonian models without a frame, in a
+    Hermitian frame and in a diagonal frame, vectorised and not, against the reference's RHS evaluations (the
+    getters of a framed Hamiltonian model return the frame-subtracted static operator: reproduced as is)."""
+    g = golden("lab_frame")
+    for tag, frame in (("nofr", None), ("fr", g["fh_frame"]), ("diag", np.diag(g["fh_frame"]).real.copy())):
+        hm = qd.HamiltonianModel(static_operator=g["fh_hs"], operators=g["fh_hops"],
+                                 signals=[qd.Signal(0.5, 1.0), qd.Signal(0.3, 2.0, 0.4)], rotating_frame=frame)
+        for vec in (False, True):
+            lm = qd.LindbladModel.from_hamiltonian(hm, static_dissipators=g["fh_l"], vectorized=vec)
+            yin = g["fh_rho"].flatten(order="F") if vec else g["fh_rho"]
+            for i, t in enumerate((0.0, 0.3)):
+                assert_close(lm.evaluate_rhs(t, yin), g[f"fh_{tag}_{'vec' if vec else 'mat'}_rhs"][i], EVAL_TOL)
+        assert hm.in_frame_basis is False
