@@ -225,12 +225,24 @@ def _basis_matrix(model, kind):
     return frame.frame_basis
 
 
+try:  # optional: keeps a host matvec from waking a whole BLAS thread pool (see _apply_basis)
+    from threadpoolctl import threadpool_limits as _threadpool_limits
+except ImportError:  # pragma: no cover
+    _threadpool_limits = None
+
+
 def _apply_basis(ctx, mat, cols):
     """mat @ cols for a (rows, ncols) block: one device zgemm for wide blocks (a sweep's states),
-    a host matvec for a handful of columns."""
+    a host matvec for a handful of columns.  The matvec runs on ONE BLAS thread: a pool of 64 OpenBLAS
+    threads spins for milliseconds after the call, and under a CPU quota (16 CPUs on the measurement boxes) that
+    throttles the thread which then launches thousands of kernels -- a 1000-step single-trajectory solve at
+    n = 1024 took 100 ms instead of 61 ms."""
     if cols.shape[1] >= 16:
         return ctx.zgemm(mat, cols)
-    return mat @ cols
+    if _threadpool_limits is None:
+        return mat @ cols
+    with _threadpool_limits(limits=1, user_api="blas"):
+        return mat @ cols
 
 
 def _prepare_y0_batch(model, kind, y0_list, shared):
