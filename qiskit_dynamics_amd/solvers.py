@@ -401,7 +401,10 @@ def _rotate_density(model, mats, into_frame_basis):
     a, b = (basis.conj().T, basis) if into_frame_basis else (basis, basis.conj().T)
     n = basis.shape[0]
     if n < 128:
-        return a @ mats @ b
+        if _threadpool_limits is None:
+            return a @ mats @ b
+        with _threadpool_limits(limits=1, user_api="blas"):  # see _apply_basis
+            return a @ mats @ b
     return np.stack([ctx.zgemm(ctx.zgemm(a, m), b) for m in mats.reshape(-1, n, n)]).reshape(mats.shape)
 
 
