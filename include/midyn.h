@@ -92,6 +92,10 @@ int midyn_stack_adopt(midyn_ctx* ctx, int n, int k, int has_static, int has_fram
 int midyn_stack_create_lindblad(midyn_ctx* ctx, int n, const midyn_complex* h_d, int k_h,
                                 const midyn_complex* h_ops, int n_s, const midyn_complex* n_static, int k_l,
                                 const midyn_complex* l_ops, const double* frame_im, midyn_stack** out);
+/* defect[seg] = || A_seg + A_seg^dagger ||_F for seg < n_segments: zero for anti-Hermitian generators.  For a
+ * Hamiltonian model (A = -iH) this is || H - H^dagger ||_F, the quantity the reference's constructor validates
+ * (models/hamiltonian_model.py:98-104, is_hermitian :196-222), evaluated on the device. */
+int midyn_stack_antiherm_defect(midyn_stack* stack, double* defect);
 int midyn_stack_destroy(midyn_stack* stack);
 /* info[0..7] = n, n_pad, k, has_static, has_frame, n_segments, n_active_segments, packed_bytes>>20 */
 int midyn_stack_info(midyn_stack* stack, long long* info);

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libmidyn.so")
 ABI_SYMBOLS = [
     "midyn_ctx_create", "midyn_ctx_destroy", "midyn_ctx_synchronize", "midyn_last_error",
     "midyn_ctx_set_option", "midyn_stack_packed_bytes", "midyn_stack_create", "midyn_stack_create_lindblad",
-    "midyn_stack_adopt",
+    "midyn_stack_adopt", "midyn_stack_antiherm_defect",
     "midyn_stack_destroy", "midyn_stack_info", "midyn_stack_segment_modes", "midyn_eval_generator", "midyn_eval_rhs",
     "midyn_rk4_solve", "midyn_expm", "midyn_expm_solve", "midyn_zgemm", "midyn_rk4_plan_create",
     "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_get_counters",
@@ -102,6 +102,7 @@ def load():
         lib.midyn_stack_create.argtypes = [_vp, _ci, _ci, _vp, _vp, _vp, _vp, P(_vp)]
         lib.midyn_stack_adopt.argtypes = [_vp, _ci, _ci, _ci, _ci, _vp, P(_vp)]
         lib.midyn_stack_create_lindblad.argtypes = [_vp, _ci, _vp, _ci, _vp, _ci, _vp, _ci, _vp, _vp, P(_vp)]
+        lib.midyn_stack_antiherm_defect.argtypes = [_vp, P(_cd)]
         lib.midyn_stack_destroy.argtypes = [_vp]
         lib.midyn_stack_info.argtypes = [_vp, P(_cll)]
         lib.midyn_stack_segment_modes.argtypes = [_vp, P(_ci)]
@@ -293,6 +294,12 @@ class Stack:
         """Vectorised Lindblad stack (dimension n^2) from the n x n operators in the frame basis: h_d (n,n) | None,
         h_ops (k_h,n,n) | None, n_static (n_s,n,n) | None, l_ops (k_l,n,n) | None, frame_im (n^2,) | None."""
         return cls(ctx, None, None, frame_im, _lindblad=(h_d, h_ops, n_static, l_ops))
+
+    def antiherm_defect(self) -> np.ndarray:
+        """|| A_seg + A_seg^dagger ||_F per segment (static operator first when present), computed on the device."""
+        out = (ctypes.c_double * max(self.n_segments, 1))()
+        self.ctx.check(self.ctx.lib.midyn_stack_antiherm_defect(self.handle, out))
+        return np.array([out[i] for i in range(self.n_segments)])
 
     @staticmethod
     def packed_bytes(n, k, has_static):

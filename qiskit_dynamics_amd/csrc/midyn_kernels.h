@@ -2228,6 +2228,29 @@ __global__ __launch_bounds__(256) void colsum_mode_kernel(const double2* A, int 
     sums[((size_t)blockIdx.y * nchunk + blockIdx.z) * n + c] = s;
 }
 
+// partial[(seg * nchunk + z)] = sum over the rows of chunk z of |A_seg[r][c] + conj(A_seg[c][r])|^2: the squared
+// Frobenius norm of A + A^dagger in fixed-order pieces (the host adds them).  For the generators -iH of a
+// Hamiltonian model this is || H - H^dagger ||_F^2, i.e. the reference's Hermiticity validation
+// (models/hamiltonian_model.py:98-104) evaluated where the operators already are.
+__global__ __launch_bounds__(256) void antiherm_defect_kernel(const double2* A, int n, int nchunk, double* partial) {
+    const double2* Ab = A + (size_t)blockIdx.y * n * n;
+    const int rows = (n + nchunk - 1) / nchunk;
+    const int r0 = blockIdx.x * rows, r1 = min(n, r0 + rows);
+    double acc = 0.0;
+    for (size_t idx = (size_t)r0 * n + threadIdx.x; idx < (size_t)r1 * n; idx += 256) {
+        const int r = (int)(idx / n), c = (int)(idx - (size_t)r * n);
+        const double2 v = Ab[idx], t = Ab[(size_t)c * n + r];
+        const double dx = v.x + t.x, dy = v.y - t.y;
+        acc += dx * dx + dy * dy;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * nchunk + blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // pad copy: src [rows][cols] (ld src_ld) -> dst (ld dst_ld), both complex
 __global__ __launch_bounds__(256) void copy2d_kernel(const double2* src, int src_ld, double2* dst, int dst_ld,
                                                      int rows, int cols) {

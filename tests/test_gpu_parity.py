@@ -2288,3 +2288,42 @@ def test_lindblad_from_hamiltonian_golden(qd, golden):
             for i, t in enumerate((0.0, 0.3)):
                 assert_close(lm.evaluate_rhs(t, yin), g[f"fh_{tag}_{'vec' if vec else 'mat'}_rhs"][i], EVAL_TOL)
         assert hm.in_frame_basis is False
+
+
+def test_hermiticity_validation_on_device(qd):
+    """Large operators with no / a diagonal frame are validated on the device (|| H - H^dagger ||_F from the
+    uploaded -iH, tolerance 1e-10 as hamiltonian_model.py:98-104,196-222): same verdicts and the same errors as
+    the host check, including the order static operator -> operators and the tolerance boundary."""
+    from qiskit_dynamics_amd import _lib
+    from qiskit_dynamics_amd.models import is_hermitian
+
+    rng = np.random.default_rng(21)
+    n = 1280
+    a = crand(rng, n, n)
+    h_d = (a + a.conj().T) / 2
+    b = crand(rng, 2, n, n)
+    h_ops = (b + np.swapaxes(b.conj(), -1, -2)) / 2
+    frame = np.diag(h_d).real.copy()
+    m = qd.HamiltonianModel(static_operator=h_d, operators=h_ops, rotating_frame=frame)
+    d = m.stack.antiherm_defect()
+    assert d.shape == (3,) and np.all(d < 1e-10)
+    bad = h_d.copy()
+    bad[7, 900] += 3e-10
+    assert not is_hermitian(bad)
+    with pytest.raises(_lib.DynamicsError, match="static_operator must be Hermitian"):
+        qd.HamiltonianModel(static_operator=bad, operators=h_ops, rotating_frame=frame)
+    ok = h_d.copy()
+    ok[7, 900] += 5e-11          # inside the tolerance: accepted by both checks
+    assert is_hermitian(ok)
+    qd.HamiltonianModel(static_operator=ok, operators=h_ops, rotating_frame=None)
+    bad_ops = h_ops.copy()
+    bad_ops[1, 3, 4] += 1e-6
+    with pytest.raises(_lib.DynamicsError, match="operators must be Hermitian"):
+        qd.HamiltonianModel(static_operator=h_d, operators=bad_ops)
+    with pytest.raises(_lib.DynamicsError, match="operators must be Hermitian"):
+        qd.HamiltonianModel(operators=bad_ops, rotating_frame=frame)   # no user static operator, frame segment present
+    qd.HamiltonianModel(static_operator=bad, operators=bad_ops, validate=False)
+    # the defect itself against numpy
+    m2 = qd.HamiltonianModel(static_operator=bad, operators=bad_ops, validate=False)
+    ref = [np.linalg.norm(x.conj().T - x) for x in (bad, bad_ops[0], bad_ops[1])]
+    assert np.allclose(m2.stack.antiherm_defect(), ref, rtol=1e-9, atol=1e-13)
