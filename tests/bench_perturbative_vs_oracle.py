@@ -1,6 +1,6 @@
 """Row f4: DysonSolver / MagnusSolver on the two-transmon model of the reference's test
 (test_dyson_magnus_solvers.py:142-219; dim 25, two drives) -- device solve vs the NumPy oracle loop.
-    python tools/bench_perturbative.py        (on the GPU box)"""
+    python tests/bench_perturbative_vs_oracle.py        (on the GPU box)"""
 import json
 import os
 import sys
@@ -10,7 +10,8 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import qiskit_dynamics_amd as qd  # noqa: E402
-from oracle import dynamics_oracle as orc  # noqa: E402  (CPU comparison leg only)
+from oracle import dynamics_oracle as orc  # noqa: E402  (CPU comparison leg; lives under tests/: only tests, smoke()
+#                                                and bench.py's cpu_baseline leg may use the oracle)
 
 w_c, w_t = 2 * np.pi * 5.033, 2 * np.pi * 4.067
 alpha_c, alpha_t, J = 2 * np.pi * (-0.33534), 2 * np.pi * (-0.33834), 2 * np.pi * 0.002
