@@ -2327,3 +2327,30 @@ def test_hermiticity_validation_on_device(qd):
     m2 = qd.HamiltonianModel(static_operator=bad, operators=bad_ops, validate=False)
     ref = [np.linalg.norm(x.conj().T - x) for x in (bad, bad_ops[0], bad_ops[1])]
     assert np.allclose(m2.stack.antiherm_defect(), ref, rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("nq", [3, 8])
+def test_chebyshev_action_backwards_in_time(qd, nq):
+    """Negative step sizes through the Chebyshev action (persistent small-system kernel at 3 qubits, work-list
+    kernels at 8): integrating forwards and then backwards over the same grid returns the initial state, and
+    the backward solve agrees with the Taylor route (chebyshev = 0)."""
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    cfg = W.schrodinger_config(nq, 3, 1.0, 0.05)
+    amps, phases = W.sweep_parameters(1, 3)
+    sig = [qd.Signal(float(a), float(nu), float(ph)) for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"])
+    rng = np.random.default_rng(nq)
+    y0 = crand(rng, 2**nq)
+    y0 /= np.linalg.norm(y0)
+    for mo in (1, 2):
+        fw = solver.solve(t_span=[0.0, 0.3], y0=y0, signals=sig, method="scipy_expm", max_dt=0.05, magnus_order=mo)
+        bw = solver.solve(t_span=[0.3, 0.0], y0=fw.y[-1], signals=sig, method="scipy_expm", max_dt=0.05, magnus_order=mo)
+        assert_close(bw.y[-1], y0, 1e-11)
+        ctx.set_option("chebyshev", 0)
+        try:
+            bw0 = solver.solve(t_span=[0.3, 0.0], y0=fw.y[-1], signals=sig, method="scipy_expm", max_dt=0.05, magnus_order=mo)
+        finally:
+            ctx.set_option("chebyshev", 1)
+        assert_close(bw.y[-1], bw0.y[-1], 1e-12)
