@@ -58,7 +58,8 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   sparse_bm [0]         row-panel height of the sparse MFMA route: 0 by list density, or 16 | 32 | 64 | 128
  *   krylov [1]            one column, Magnus order 1: Arnoldi instead of the scaled Taylor series when the
  *                         series is long enough to pay for it (2: always, 0: never)
- *   complex_3m [1]        dense complex products with 3 real MFMAs instead of 4
+ *   complex_3m [1]        dense complex products with 3 real MFMAs instead of 4 (normwise error bound): 0 never,
+ *                         1 in solver loops / expm only (midyn_eval_rhs, midyn_zgemm stay 4M), 2 everywhere
  *   split_k [1], force_splits [0], force_tile [0 | 64 | 128 | 12864]   tile / split-K choice of the zgemm
  *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage
  *   multi_stream [1]      2..8 state columns at n >= 256: multi-column streaming kernel

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmidyn.so")
 
-# every symbol include/midyn.h declares (tests/test_abi.py checks the .so exports all of them)
+# every symbol include/midyn.h declares (__graft_entry__.build() and tests/test_host_logic.py check the .so exports all of them; tests/abi_probe.c compiles the header as plain C)
 ABI_SYMBOLS = [
     "midyn_ctx_create", "midyn_ctx_destroy", "midyn_ctx_synchronize", "midyn_last_error",
     "midyn_ctx_set_option", "midyn_stack_packed_bytes", "midyn_stack_create", "midyn_stack_create_lindblad",

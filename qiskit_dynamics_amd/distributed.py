@@ -35,8 +35,23 @@ def init_process_group_from_env(backend: str = "nccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
+    if backend == "nccl":
+        # one process per GPU: every RCCL collective of this process must run on ITS device, not on
+        # cuda:0 (two ranks on one device = RCCL "duplicate GPU" error or a hang)
+        import torch
+
+        torch.cuda.set_device(local_device())
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
+
+
+def local_device() -> int:
+    """Device ordinal of this rank: LOCAL_RANK (torchrun / bench.py's own spawner), modulo the visible devices."""
+    import torch
+
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    return local % n_dev if n_dev else 0
 
 
 def broadcast_stack(ctx, ops, static, frame_im, n, k, src: int = 0):
@@ -74,15 +89,19 @@ def broadcast_stack(ctx, ops, static, frame_im, n, k, src: int = 0):
     return stack, buf
 
 
-def gather_sweep_results(local: np.ndarray, n_total: int):
+def gather_sweep_results(local: np.ndarray, n_total: int, device=None):
     """All-gather per-rank result blocks (shape (b_loc, ...)) into the full (n_total, ...) array on
-    every rank.  Not on the timed path; used by tests and for returning sweep results."""
+    every rank.  Not on the timed path; used by tests and for returning sweep results.  `device` is the
+    ordinal of the GPU this rank computes on (the solver context's); RCCL needs the staging tensors there."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size()
     backend = dist.get_backend()
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+    else:
+        dev = torch.device("cpu")
     sizes = [shard_bounds(n_total, r, world) for r in range(world)]
     max_b = max(hi - lo for lo, hi in sizes)
     pad = np.zeros((max_b,) + local.shape[1:], dtype=np.complex128)
@@ -121,11 +140,17 @@ def solve_sweep(solver, t_span, y0, signals, **kwargs):
         local_t = np.asarray(res[0].t, dtype=float)
         local_y = np.stack([np.asarray(r.y, dtype=np.complex128) for r in res])
     # ranks with an empty shard (B < world) learn the result shape from the others
+    ctx = getattr(getattr(solver, "model", None), "_ctx", None)
+    device = getattr(ctx, "device", None)
+    if dist.get_backend() == "nccl" and device is not None:
+        import torch
+
+        torch.cuda.set_device(int(device))  # all_gather_object stages on the current device
     shapes = [None] * world
     dist.all_gather_object(shapes, None if local_y is None else (local_y.shape[1:], local_t.tolist()))
     known = next(s_ for s_ in shapes if s_ is not None)
     if local_y is None:
         local_y = np.zeros((0,) + tuple(known[0]), dtype=np.complex128)
-    full = gather_sweep_results(local_y, n_total)
+    full = gather_sweep_results(local_y, n_total, device=device)
     t_out = np.asarray(known[1], dtype=float)
     return [OdeResult(t=t_out, y=full[b]) for b in range(n_total)]

@@ -248,6 +248,11 @@ class HamiltonianModel(GeneratorModel):
         # uploaded -iH, one pass at HBM rate instead of a transposed walk over host memory (0.35 s per 4096 x 4096
         # operator) -- with the same tolerance and the same errors.
         user_static = static_operator is not None
+        if static_operator is None and operators is None:
+            # hamiltonian_model.py:63-120 defers to the base class, which raises this (generator_model.py:125-140)
+            raise DynamicsError(
+                f"{type(self).__name__} requires at least one of static_operator or operators to be "
+                "specified at construction.")
         dim = np.shape(static_operator if user_static else operators)[-1]
         frame_is_diagonal = rotating_frame is None or (
             isinstance(rotating_frame, RotatingFrame) and rotating_frame.frame_basis is None) or (
@@ -465,35 +470,7 @@ class LindbladModel(BaseGeneratorModel):
 
     @signals.setter
     def signals(self, new_signals):
-        ham, dis = new_signals
-        if ham is None:
-            self._hamiltonian_signals = None
-        elif self._h_ops is None:
-            raise DynamicsError("Hamiltonian signals must be None if hamiltonian_operators is None.")
-        else:
-            self._hamiltonian_signals = _as_signal_list(ham, self._h_ops.shape[0],
-                                                        "Hamiltonian signals")
-        if dis is None:
-            self._dissipator_signals = None
-        elif self._l_ops is None:
-            raise DynamicsError("Dissipator signals must be None if dissipator_operators is None.")
-        else:
-            self._dissipator_signals = _as_signal_list(dis, self._l_ops.shape[0],
-                                                       "Dissipator signals")
-
-    @classmethod
-    def from_hamiltonian(cls, hamiltonian: HamiltonianModel, static_dissipators=None,
-                         dissipator_operators=None, dissipator_signals=None,
-                         array_library: Optional[str] = None, vectorized: bool = False):
-        saved = hamiltonian.in_frame_basis
-        hamiltonian.in_frame_basis = False
-        h_static, h_ops = hamiltonian.static_operator, hamiltonian.operators
-        hamiltonian.in_frame_basis = saved
-        return cls(static_hamiltonian=h_static, hamiltonian_operators=h_ops,
-                   hamiltonian_signals=hamiltonian.signals, static_dissipators=static_dissipators,
-                   dissipator_operators=dissipator_operators, dissipator_signals=dissipator_signals,
-                   rotating_frame=hamiltonian.rotating_frame, in_frame_basis=saved,
-                   array_library=array_library, vectorized=vectorized)
+        self._hamiltonian_signals, self._dissipator_signals = self._checked_signals(new_signals)
 
     # -- evaluation -----------------------------------------------------------------------------
     def _coefficients(self, time):
@@ -515,14 +492,33 @@ class LindbladModel(BaseGeneratorModel):
             return None
         return np.concatenate(parts, axis=-1)
 
-    def _signal_table(self, times):
-        """(R, k_h + k_d) table for an array of times (used by the solvers)."""
-        parts = []
-        if self._hamiltonian_signals is not None:
-            parts.append(self._hamiltonian_signals.table(times))
-        if self._dissipator_signals is not None:
-            parts.append(self._dissipator_signals.table(times))
-        self._coefficients(times[0] if len(times) else 0.0)  # raises if signals are missing
+    def _checked_signals(self, new_signals):
+        """(ham SignalList | None, dis SignalList | None) from a user pair, validated like the setter."""
+        ham, dis = new_signals
+        if ham is not None:
+            if self._h_ops is None:
+                raise DynamicsError("Hamiltonian signals must be None if hamiltonian_operators is None.")
+            ham = _as_signal_list(ham, self._h_ops.shape[0], "Hamiltonian signals")
+        if dis is not None:
+            if self._l_ops is None:
+                raise DynamicsError("Dissipator signals must be None if dissipator_operators is None.")
+            dis = _as_signal_list(dis, self._l_ops.shape[0], "Dissipator signals")
+        return ham, dis
+
+    def _signal_table(self, times, signals=None):
+        """(R, k_h + k_d) table for an array of times (used by the solvers).  ``signals`` (a
+        (ham, dis) pair) replaces the model's own for this call only; the model is not modified."""
+        ham, dis = (self._hamiltonian_signals, self._dissipator_signals) if signals is None \
+            else self._checked_signals(signals)
+        if ham is None and self._h_ops is not None:
+            raise DynamicsError(
+                f"{type(self).__name__} with non-empty hamiltonian operators cannot be evaluated "
+                "without hamiltonian signals.")
+        if dis is None and self._l_ops is not None:
+            raise DynamicsError(
+                f"{type(self).__name__} with non-empty dissipator operators cannot be evaluated "
+                "without dissipator signals.")
+        parts = [sl.table(times) for sl in (ham, dis) if sl is not None]
         if not parts:
             return np.zeros((len(times), 0))
         return np.ascontiguousarray(np.concatenate(parts, axis=-1))

@@ -173,14 +173,10 @@ def _model_kind(model) -> str:
 def _signal_table(model, signals, times) -> np.ndarray:
     """(R, k) float64 table of ``signals`` (model's own signals when None) at ``times``."""
     if isinstance(model, LindbladModel):
-        if signals is not None:
-            saved = model.signals
-            try:
-                model.signals = signals if isinstance(signals, tuple) else (signals, None)
-                return model._signal_table(times)
-            finally:
-                model.signals = saved
-        return model._signal_table(times)
+        if signals is None:
+            return model._signal_table(times)
+        # the passed signals are validated and tabulated WITHOUT touching model.signals (functional path)
+        return model._signal_table(times, signals if isinstance(signals, tuple) else (signals, None))
     n_ops = 0 if model._ops_fb is None else model._ops_fb.shape[0]
     sl = model.signals if signals is None else signals
     if sl is None:
@@ -333,9 +329,21 @@ def _batch_table(model, signals_list, times, batch, n_coeff):
 # fraction of the latency.  "RK4" / "scipy_expm" solves of one (or a handful of) instances with at most
 # this many rows and at least this many steps are routed there; AUTO_PARALLEL_IN_TIME = False keeps them
 # sequential.
+#
+# The route taken is recorded in ``OdeResult.route`` ("sequential", "parallel_in_time(auto)", "parallel_in_time").
+# Automatic routing is limited to HamiltonianModels (anti-Hermitian generators: every step propagator is unitary
+# to rounding, so products of propagators are as accurate as stepping the state).  Dissipative models (a general
+# GeneratorModel, a vectorised LindbladModel) are stepped sequentially unless AUTO_PARALLEL_IN_TIME == "all" or
+# the user names a *_parallel method.
 AUTO_PARALLEL_IN_TIME = True
 AUTO_PARALLEL_MAX_ROWS = 128
 AUTO_PARALLEL_MIN_STEPS = 256
+
+
+def _auto_parallel_allowed(model) -> bool:
+    if AUTO_PARALLEL_IN_TIME == "all":
+        return True
+    return bool(AUTO_PARALLEL_IN_TIME) and isinstance(model, HamiltonianModel)
 
 
 def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_dt=None,
@@ -365,30 +373,47 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
         return _solve_batch_lindblad(model, sched, y0_list, signals_list, shared_y0)
     y0_dev, tag = _prepare_y0_batch(model, kind, y0_list, shared_y0)
     stack = model.stack
+    # Instances that share their signals share the generator: they are just more COLUMNS of one problem
+    # (the reference would loop them, solver_classes.py:568-586).  One coefficient table instead of B
+    # copies of it on host and device, one generator evaluation per stage instead of nseg contractions.
+    folded = batch > 1 and all(s is signals_list[0] for s in signals_list)
+    n_inst, m_cols = batch, y0_dev.shape[-1]
+    if folded:
+        if shared_y0:
+            y0_dev = np.ascontiguousarray(np.tile(y0_dev, (1, batch)))
+        else:
+            y0_dev = np.ascontiguousarray(y0_dev.transpose(1, 0, 2).reshape(y0_dev.shape[1], batch * m_cols))
+        signals_list, batch, shared_y0 = signals_list[:1], 1, True
     table = _batch_table(model, signals_list, sched.times, batch, stack.k)
     # a few instances are still cheaper one after the other in parallel-in-time form (~2 ms each) than in
     # lock-step through thousands of launches (35-40 ms) or, for n <= 16, the persistent kernel (6-9 ms)
     max_batch = 3 if stack.n <= 16 else 16
-    auto_parallel = (AUTO_PARALLEL_IN_TIME and batch <= max_batch and stack.n <= AUTO_PARALLEL_MAX_ROWS
+    auto_parallel = (_auto_parallel_allowed(model) and batch <= max_batch and stack.n <= AUTO_PARALLEL_MAX_ROWS
                      and len(sched.step_h) >= AUTO_PARALLEL_MIN_STEPS and y0_dev.shape[-1] <= 64
                      and method in RK4_METHODS + EXPM_METHODS)
+    route = "sequential"
     if auto_parallel:
+        route = "parallel_in_time(auto)"
         ys = stack.parallel_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save,
                                   0 if method in RK4_METHODS else magnus_order, y0_dev, batch, shared_y0)
     elif method in RK4_METHODS:
         ys = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                              sched.n_save, y0_dev, batch, shared_y0)
     elif method in RK4_PARALLEL_METHODS + EXPM_PARALLEL_METHODS:
+        route = "parallel_in_time"
         ys = stack.parallel_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                                   sched.n_save, 0 if method in RK4_PARALLEL_METHODS else magnus_order,
                                   y0_dev, batch, shared_y0)
     else:
         ys = stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                               sched.n_save, magnus_order, y0_dev, batch, shared_y0)
+    if folded:  # (1, P, rows, B*m) -> (B, P, rows, m)
+        _, p, rows, _ = ys.shape
+        ys = ys.reshape(p, rows, n_inst, m_cols).transpose(2, 0, 1, 3)
     results = []
     for y_b in _restore_batch(model, kind, tag, ys):
         t_out, y_out = sched.trim(y_b)
-        results.append(OdeResult(t=t_out, y=y_out))
+        results.append(OdeResult(t=t_out, y=y_out, route=route))
     return results
 
 
@@ -425,7 +450,7 @@ def _solve_batch_lindblad(model, sched, y0_list, signals_list, shared_y0):
     results = []
     for b in range(batch):
         t_out, y_out = sched.trim(ys[b])
-        results.append(OdeResult(t=t_out, y=y_out))
+        results.append(OdeResult(t=t_out, y=y_out, route="sequential"))
     return results
 
 

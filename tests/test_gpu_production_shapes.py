@@ -1,0 +1,295 @@
+"""Parity of the PRODUCTION routes at BASELINE shapes, directly against the CPU oracle (not against another
+device route):
+
+  * cfg 5 shard (n = 4096, k = 8, diagonal frame, Magnus-2, 128 instances, all 20 steps, dense random y0): the
+    SPARSE MFMA work-list contraction (`zgemm_seg_kernel<..., SPARSE>`, counter "rhs_blocks_gemm");
+  * cfg 4 sweep (N = 4096 vectorised Lindbladian, 64 instances): the same route through the Chebyshev action;
+  * expm at n = 1024 / 2048 against scipy.linalg.expm (the function the reference calls,
+    solvers/fixed_step_solvers.py:22,104);
+  * 3M vs 4M complex products on badly scaled operators (entries spanning 1e-8 ... 1).
+
+All of them need a real MI355X (`pytest -m gpu`).
+"""
+import numpy as np
+import pytest
+import scipy.linalg
+import scipy.sparse as sp
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+SOLVE_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def qd():
+    import qiskit_dynamics_amd as q
+
+    q.default_context()
+    return q
+
+
+def crand(rng, *shape):
+    return rng.uniform(-1, 1, shape) + 1j * rng.uniform(-1, 1, shape)
+
+
+def _gauss_signals(qd, cfg, b, k, t_mid):
+    from qiskit_dynamics_amd import workloads
+
+    amps, phases = workloads.sweep_parameters(b, k)
+    return [qd.Signal(lambda t, a=a: a * np.exp(-((t - t_mid) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+
+
+def _profiled(ctx, fn):
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    try:
+        return fn()
+    finally:
+        ctx.set_option("profile", 0)
+
+
+def test_cfg5_shard_sparse_mfma_route_vs_oracle(qd):
+    """BASELINE cfg 5, the per-GPU shard of the 8-GPU run: 12 qubits (n = 4096), k = 8, diagonal rotating frame,
+    scipy_expm with magnus_order = 2, max_dt = 0.25, T = 5 -> ALL 20 steps, 128 instances in ONE batched device
+    solve, dense random y0.  The launch counters must show the SPARSE MFMA work-list contraction.  Instances
+    0, 63 and 127 are compared with a CPU evaluation of the same 20 steps that uses the ORACLE's generators
+    (oracle.generator_evaluate: G(t) = Delta(t) o (A_d + sum c_j A_j), dense, checked entry by entry against the
+    CSR copy used for the matrix-vector products) and a commutator-free Taylor series of expm(Omega_2)
+    (fixed_step_solvers.py:345-363 applied to a vector); all 128 instances are checked for norm conservation."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+
+    ctx = qd.default_context()
+    cfg = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
+    frame = np.diag(cfg["h_d"]).real.copy()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
+    assert solver.model.stack.n == 4096
+    nb, n = 128, 4096
+    sweeps = [_gauss_signals(qd, cfg, b, 8, 2.5) for b in range(nb)]
+    rng = np.random.default_rng(12)
+    y0 = rng.normal(size=n) + 1j * rng.normal(size=n)
+    y0 /= np.linalg.norm(y0)
+    h, t_final = 0.25, 5.0
+    res = _profiled(ctx, lambda: solver.solve(t_span=[0.0, t_final], y0=y0, signals=sweeps, method="scipy_expm",
+                                              max_dt=h, magnus_order=2))
+    assert ctx.counters("rhs_blocks_gemm")["launches"] > 0, "the SPARSE MFMA work-list route did not run"
+    assert ctx.counters("rhs_gemm")["launches"] == 0, "a dense contraction ran"
+    assert all(r.route == "sequential" for r in res)
+    finals = np.stack([r.y[-1] for r in res])
+    assert np.max(np.abs(np.linalg.norm(finals, axis=1) - 1.0)) < 1e-11
+
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
+    assert basis is None
+    a_d_s = sp.csr_matrix(a_d)
+    a_s = [sp.csr_matrix(x) for x in a]
+    c1, c2 = 0.5 - np.sqrt(3) / 6, 0.5 + np.sqrt(3) / 6
+
+    def gen_sparse(coeffs, t):
+        c = a_d_s.copy()
+        for cj, aj in zip(coeffs, a_s):
+            c = c + cj * aj
+        e = np.exp(d * t)
+        return sp.diags(e.conj()) @ c @ sp.diags(e)
+
+    # the CSR generator IS the oracle's generator (dense comparison at one instance / time)
+    cchk = np.array([np.real(s(1.3)) for s in sweeps[5]])
+    assert np.max(np.abs(gen_sparse(cchk, 1.3).toarray() - orc.generator_evaluate(a_d, a, cchk, d, None, 1.3))) < 1e-15
+
+    for b in (0, 63, 127):
+        y = y0.copy()
+        for st in range(20):
+            t0 = st * h
+            t1, t2 = t0 + c1 * h, t0 + c2 * h
+            g1 = gen_sparse(np.array([np.real(s(t1)) for s in sweeps[b]]), t1)
+            g2 = gen_sparse(np.array([np.real(s(t2)) for s in sweeps[b]]), t2)
+
+            def omega(v):
+                u1, u2 = g1 @ v, g2 @ v
+                return (h / 2) * (u1 + u2) + (np.sqrt(3) / 12) * h * h * (g2 @ u1 - g1 @ u2)
+
+            for _ in range(4):          # ||Omega|| ~ 0.05-0.2: four scalings, Taylor degree 14
+                term, acc = y, y.copy()
+                for j in range(1, 15):
+                    term = omega(term) / (4 * j)
+                    acc = acc + term
+                y = acc
+        assert_close(res[b].y[-1], y, SOLVE_TOL)
+
+
+def test_cfg4_sweep_sparse_mfma_route_vs_oracle(qd):
+    """BASELINE cfg 4 model (6 qubits, N = 4096 superoperators built on the device, 4 static dissipators, no
+    frame) as a 64-instance sweep: scipy_expm (Magnus 1) over 3 steps through the SPARSE MFMA work-list route
+    (asserted through the launch counters) against the oracle's matrix form of the Lindbladian
+    (oracle.lindblad_rhs, n x n products, a scaled Taylor series of expm(h L) rho) for instances 0, 31, 63;
+    trace / Hermiticity for all 64."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+
+    ctx = qd.default_context()
+    cfg = workloads.lindblad_config()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       static_dissipators=cfg["static_dissipators"], vectorized=True)
+    assert solver.model.stack.n == 4096
+    nb = 64
+    sweeps = [_gauss_signals(qd, cfg, b, 6, 2.5) for b in range(nb)]
+    h, n_steps, t0 = cfg["max_dt"], 3, 2.4
+    rng = np.random.default_rng(4)
+    psi = rng.normal(size=64) + 1j * rng.normal(size=64)
+    psi /= np.linalg.norm(psi)
+    rho0 = 0.7 * np.outer(psi, psi.conj()) + 0.3 * np.eye(64) / 64      # dense, full-rank density matrix
+    res = _profiled(ctx, lambda: solver.solve(t_span=[t0, t0 + n_steps * h], y0=rho0.flatten(order="F"),
+                                              signals=sweeps, method="scipy_expm", max_dt=h))
+    assert ctx.counters("rhs_blocks_gemm")["launches"] > 0, "the SPARSE MFMA work-list route did not run"
+    assert ctx.counters("rhs_gemm")["launches"] == 0
+    h_d, h_ops, n_static, l_ops, d, basis = orc.lindblad_model_build(cfg["h_d"], cfg["ops"],
+                                                                     cfg["static_dissipators"], None, None)
+    for b in range(nb):
+        rho_dev = res[b].y[-1].reshape(64, 64, order="F")
+        assert abs(np.trace(rho_dev) - 1.0) < 1e-12
+        assert np.linalg.norm(rho_dev - rho_dev.conj().T) < 1e-12
+    for b in (0, 31, 63):
+        rho = rho0.astype(complex)
+        for st in range(n_steps):
+            t_mid = t0 + st * h + h / 2
+            coeffs = np.array([np.real(s(t_mid)) for s in sweeps[b]])
+            scal = 64
+            for _ in range(scal):
+                term, acc = rho, rho.copy()
+                for j in range(1, 16):
+                    term = orc.lindblad_rhs(h_d, h_ops, n_static, l_ops, coeffs, None, d, t_mid, term) * (h / (scal * j))
+                    acc = acc + term
+                rho = acc
+        assert_close(res[b].y[-1].reshape(64, 64, order="F"), rho, SOLVE_TOL)
+
+
+@pytest.mark.parametrize("n,scale,kind", [(1024, 2.5, "antiherm"), (1024, 0.04, "antiherm"), (1024, 1.2, "general"),
+                                          (2048, 6.0, "antiherm"), (2048, 0.5, "general")])
+def test_expm_vs_scipy_large(qd, n, scale, kind):
+    """dev_expm (Taylor / Paterson-Stockmeyer scaling & squaring on the MFMA zgemm) against scipy.linalg.expm at
+    the sizes of cfg 2/3 propagators and beyond: ||E - E_ref||_1 / ||E_ref||_1 <= 1e-12."""
+    rng = np.random.default_rng(n + int(scale * 100))
+    a = rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n))
+    if kind == "antiherm":
+        a = a - a.conj().T
+    a *= scale / np.linalg.norm(a, 1)
+    e = qd.default_context().expm(a)
+    ref = scipy.linalg.expm(a)
+    assert np.linalg.norm(e - ref, 1) / np.linalg.norm(ref, 1) < 1e-12
+    if kind == "antiherm":
+        assert np.linalg.norm(e.conj().T @ e - np.eye(n)) < 1e-12 * n
+
+
+def test_badly_scaled_operators_rhs_is_componentwise_accurate(qd):
+    """Operators and states whose imaginary parts are 1e-8 of their real parts (entries spanning 1e-8 ... 1).
+    BLAS zgemm, which the reference calls (operator_collections.py:124-134), forms a complex product with 4 real
+    products, Im = Ar.Bi + Ai.Br: the small imaginary part of the result comes out with a relative error of a few
+    ulps (componentwise bound).  The 3M product forms Im = (Ar+Ai)(Br+Bi) - Ar.Br - Ai.Bi: an absolute error of
+    eps.|Ar.Br|, i.e. a RELATIVE error of about 1e-16 / 1e-8 in that imaginary part (normwise bound only).
+    Decision taken from this test: direct evaluations (model.evaluate_rhs / evaluate, ctx.zgemm) use 4M and are
+    componentwise accurate like the reference; 3M stays inside the solver loops and the expm pipeline, where the
+    contract is the normwise solve tolerance.  `complex_3m` = 2 forces 3M everywhere, 0 disables it."""
+    ctx = qd.default_context()
+    n, k, nb = 256, 3, 96
+    rng = np.random.default_rng(8)
+
+    def skew(*shape):
+        return rng.uniform(-1, 1, shape) + 1e-8j * rng.uniform(-1, 1, shape)
+
+    ops = skew(k, n, n)
+    static = skew(n, n)
+    stack = qd.Stack(ctx, ops, static, None)
+    y = skew(n, nb)
+    coeffs = rng.uniform(-1, 1, k)
+    g = static + np.tensordot(coeffs, ops, axes=1)
+    # reference with exact-ish imaginary part: the four real products in long double
+    gr, gi, yr, yi = (np.asarray(x, dtype=np.longdouble) for x in (g.real, g.imag, y.real, y.imag))
+    ref_im = np.asarray(gr @ yi + gi @ yr, dtype=float)
+    ref_re = np.asarray(gr @ yr - gi @ yi, dtype=float)
+    im_scale = np.max(np.abs(ref_im))
+    assert im_scale < 1e-6                                   # the imaginary part IS small
+    out = stack.eval_rhs(coeffs, 0.0, y)
+    assert np.max(np.abs(out.real - ref_re)) < 1e-12
+    rel_4m = np.max(np.abs(out.imag - ref_im)) / im_scale
+    assert rel_4m < 1e-12, f"default direct evaluation lost the small components: {rel_4m:.2e}"
+    c = ctx.zgemm(g, y)
+    assert np.max(np.abs(c.imag - ref_im)) / im_scale < 1e-12
+    ctx.set_option("complex_3m", 2)            # 2: 3M also for direct evaluations
+    try:
+        out3 = stack.eval_rhs(coeffs, 0.0, y)
+    finally:
+        ctx.set_option("complex_3m", 1)
+    ref = ref_re + 1j * ref_im
+    assert np.max(np.abs(out3 - ref)) < 1e-12 * (1 + np.max(np.abs(ref)))     # normwise: fine
+    rel_3m = np.max(np.abs(out3.imag - ref_im)) / im_scale
+    assert rel_3m > 100 * rel_4m, (rel_3m, rel_4m)                            # componentwise: visibly worse
+
+
+def test_strongly_damped_lindbladian_parallel_in_time_vs_sequential(qd, monkeypatch):
+    """Parallel-in-time propagation of a STRONGLY dissipative vectorised Lindbladian (gamma ~ the Hamiltonian
+    scale, state decays by orders of magnitude in the off-diagonals) against the sequential route and the oracle:
+    recorded evidence for the routing rule (automatic routing is limited to HamiltonianModels; `.route` says
+    which route ran)."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import solvers as S
+    from qiskit_dynamics_amd import workloads as W
+
+    cfg = W.lindblad_config(n_qubits=3, n_drives=3, n_diss=3, gamma=4.0, t_final=2.0, max_dt=0.002)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 1.0) ** 2) / 2.0), nu, 0.3 * a)
+            for a, nu in zip((0.9, 0.5, 0.7), cfg["carrier"])]
+    m = qd.LindbladModel(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], hamiltonian_signals=sigs,
+                         static_dissipators=cfg["static_dissipators"], vectorized=True)
+    rng = np.random.default_rng(1)
+    psi = rng.normal(size=8) + 1j * rng.normal(size=8)
+    psi /= np.linalg.norm(psi)
+    y0 = np.outer(psi, psi.conj()).flatten(order="F")
+    kw = dict(t_span=[0.0, 2.0], y0=y0, max_dt=0.002)
+    for method, par in (("RK4", "hip_RK4_parallel"), ("scipy_expm", "hip_expm_parallel")):
+        seq = qd.solve_lmde(m, method=method, **kw)
+        assert seq.route == "sequential"            # dissipative model: no automatic re-routing
+        par_res = qd.solve_lmde(m, method=par, **kw)
+        assert par_res.route == "parallel_in_time"
+        monkeypatch.setattr(S, "AUTO_PARALLEL_IN_TIME", "all")
+        auto = qd.solve_lmde(m, method=method, **kw)
+        monkeypatch.setattr(S, "AUTO_PARALLEL_IN_TIME", True)
+        assert auto.route == "parallel_in_time(auto)"
+        assert_close(par_res.y[-1], seq.y[-1], 1e-11)
+        assert_close(auto.y[-1], seq.y[-1], 1e-11)
+        rho = seq.y[-1].reshape(8, 8, order="F")
+        assert abs(np.trace(rho) - 1.0) < 1e-11
+        assert np.max(np.abs(rho[0, 1:])) < 0.2      # the damping is strong: coherences have decayed
+    # and the oracle
+    h_d, h_ops, n_static, l_ops, d, basis = orc.lindblad_model_build(cfg["h_d"], cfg["ops"],
+                                                                     cfg["static_dissipators"], None, None)
+    a_d, a = orc.vectorized_lindblad_stack(h_d, h_ops, n_static, l_ops)
+    _, yref = orc.solve_generator_model(a_d, a, None, None, lambda t: np.array([np.real(s(t)) for s in sigs]),
+                                        [0.0, 2.0], y0, "RK4", 0.002)
+    assert_close(qd.solve_lmde(m, method="RK4", **kw).y[-1], yref[-1], SOLVE_TOL)
+
+
+def test_shared_signal_sweep_is_folded_into_columns(qd):
+    """A sweep over y0 only (all instances share their signals): solved as ONE problem with B columns; results
+    equal the per-instance solves (solver_classes.py:568-586 would loop them)."""
+    from qiskit_dynamics_amd import workloads as W
+
+    cfg = W.schrodinger_config(n_qubits=5, n_drives=3, t_final=1.0, max_dt=0.01)
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, 0.2)
+            for a, nu in zip((0.9, 0.5, 0.7), cfg["carrier"])]
+    rng = np.random.default_rng(3)
+    y0s = [crand(rng, 32) for _ in range(20)]
+    for method, kw in (("RK4", {}), ("scipy_expm", {"magnus_order": 2})):
+        many = solver.solve(t_span=[0.0, 0.5], y0=y0s, signals=sigs, method=method, max_dt=0.01,
+                            t_eval=[0.1, 0.5], **kw)
+        assert len(many) == 20 and many[0].y.shape == (2, 32)
+        for b in (0, 7, 19):
+            one = solver.solve(t_span=[0.0, 0.5], y0=y0s[b], signals=sigs, method=method, max_dt=0.01,
+                               t_eval=[0.1, 0.5], **kw)
+            assert_close(many[b].y, one.y, 1e-11)
+    # matrix-valued states fold as well
+    y0m = [crand(rng, 32, 3) for _ in range(4)]
+    many = solver.solve(t_span=[0.0, 0.2], y0=y0m, signals=sigs, method="RK4", max_dt=0.01)
+    one = solver.solve(t_span=[0.0, 0.2], y0=y0m[2], signals=sigs, method="RK4", max_dt=0.01)
+    assert_close(many[2].y, one.y, 1e-11)
