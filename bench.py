@@ -1,25 +1,41 @@
 #!/usr/bin/env python
-"""bench.py -- RHS evals/s of the 10-qubit (dim 1024) Schrodinger sweep on N MI355X.
+"""bench.py -- RHS evals/s of the 10-qubit (dim 1024) Schrodinger sweep on N MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json metric / configs[2], SURVEY.md 8(d) cfg 3): chain Hamiltonian, n = 1024,
-k = 8 drive operators + static operator, rotating frame = H_d (dense frame-basis operators), RK4 with
-max_dt = 0.005 on t in [0, 5] (1000 steps, 4 RHS evaluations each), 4096 signal instances per GPU
-(weak scaling: every rank integrates its own 4096-instance shard; the only collective is one RCCL
-broadcast of the packed operator stack at setup).  A "step" is one RK4 step of the whole per-GPU
-batch = 4 batched RHS evaluations = 4 * 4096 instance-evaluations.
+Workload of `value` (BASELINE.json configs[1]/[2], SURVEY.md 8(d) cfg 3): chain Hamiltonian, n = 1024, k = 8 drive
+operators + static operator, rotating frame = H_d (dense frame-basis operators), RK4 with max_dt = 0.005 on
+t in [0, 5] (1000 steps, 4 RHS evaluations each), a sweep of 4096 signal instances.  A "step" is one RK4 step of
+the whole sweep = 4 batched RHS evaluations of every instance.
 
-Timed region: inputs (operator stack, coefficient table, states) are resident in HBM; K steps are
-enqueued on the library's HIP stream and bracketed by barrier + device synchronisation; the max over
-ranks is taken.  One JSON line is printed by rank 0.
+    python bench.py --gpus N --steps K --warmup W
 
-Extra objects on the same line: `roofline` (dominant kernel = the fp64-MFMA batched RHS contraction;
-average launch duration measured with HIP events on the stream the kernel runs on),
-`roofline_single_trajectory` (cfg 2: the HBM-bound streaming kernel, measured the same way) and
-`cpu_baseline` (the NumPy oracle on the host cores, rank 0, N=1 only, bounded sample).
+N = 1: all 4096 instances on one GPU.  N > 1 (default = BASELINE configs[2], "scaling": "strong"): the SAME
+4096-instance sweep sharded 4096/N per GPU; `--weak` keeps 4096 instances per GPU instead.  `--gpus N` without a
+launcher (no WORLD_SIZE in the environment) spawns the N ranks itself, one process per GPU; under torchrun /
+torch.distributed.run it is one of the ranks.  It never prints an n_gpus = 1 line for --gpus 8: a world that does
+not match --gpus, or fewer visible GPUs than ranks, is an error (non-zero exit).
+
+The only collective of the path is ONE RCCL broadcast of the packed operator stack at setup (through the C-ABI,
+`midyn_stack_broadcast`; `--torch-broadcast` uses torch.distributed's RCCL instead); its time is reported as
+`broadcast_ms`, outside the timed region.  Timed region: inputs (stack, coefficient table, states) resident in
+HBM; K steps enqueued on the library's HIP stream, bracketed by barrier + device synchronisation and by a HIP-event
+pair on that stream; MAX over ranks.  Rank 0 prints ONE JSON line.
+
+Objects on the line besides the contract fields:
+  roofline                    dominant kernel of `value` (fp64-MFMA batched RHS contraction): `achieved` = EXECUTED
+                              MFMA flops / launch time, `frac` = achieved / 78.6 TFLOP/s (a hardware fraction, <= 1);
+                              the SURVEY 8(d) "useful" figure is kept as `useful_tflops`
+  dense_complex               the same sweep without exact-zero plane skipping (general complex operators)
+  roofline_single_trajectory  cfg 2 (HBM-bound streaming kernel): `frac` = executed bytes / time / 8 TB/s
+  cfg4, cfg5                  the vectorised-Lindblad / 12-qubit Magnus-2 configurations with their own rooflines
+                              (executed work of the work lists AND the 8(d) dense-form price, labelled)
+  sharded_cfg5                second sharded leg: the 1024-instance cfg-5 sweep, 1024/N per GPU
+  cpu_baseline                the NumPy oracle on the host cores (rank 0, N = 1), bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,10 +49,64 @@ N_QUBITS = 10
 N_DRIVES = 8
 T_FINAL = 5.0
 MAX_DT = 0.005
+SWEEP = 4096                   # BASELINE.json: 4096-parameter batch
+CFG5_SWEEP = 1024              # BASELINE.json configs[4]: 1024-parameter sweep
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor FP64 matrix peak (SURVEY.md 8(d) / BASELINE.md 3)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
+# -----------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` spawns its own ranks (one process per GPU)
+# -----------------------------------------------------------------------------------------------------------------
+def visible_gpus() -> int:
+    """Number of HIP devices, probed in a child process (the launcher itself never touches the GPU)."""
+    code = "import torch; print(torch.cuda.device_count() if torch.cuda.is_available() else 0)"
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except (subprocess.SubprocessError, ValueError, IndexError):
+        return 0
+
+
+def spawn_ranks(n_ranks: int, argv) -> int:
+    """Start `n_ranks` copies of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
+    127.0.0.1), wait for all of them; non-zero if any failed (the others are then terminated by PID)."""
+    if os.environ.get("MIDYN_BENCH_STUB"):
+        have = n_ranks          # CPU plumbing test (gloo, stand-in solve): no GPUs needed
+    else:
+        have = visible_gpus()
+    if have < n_ranks:
+        print(f"bench.py: --gpus {n_ranks} but only {have} GPU(s) visible; refusing to run a smaller job",
+              file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = set(range(n_ranks))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# helpers
+# -----------------------------------------------------------------------------------------------------------------
 def measured_traffic(kernel_prefix):
     """HBM bytes per dispatch of the newest committed rocprofv3 PMC summary (profiles/*.traffic.json),
     or None.  bench.py cannot collect PMC counters itself; the profile run is tools/profile_round.sh."""
@@ -66,44 +136,381 @@ def build_frame_basis_stack(cfg):
     return ops, static, frame.frame_diag_imag
 
 
+def build_diag_frame_stack(cfg):
+    """cfg 5: diagonal rotating frame diag(H_d) (1-D frame, no eigh): operators stay in the computational basis."""
+    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
+
+    fr = RotatingFrame(np.diag(cfg["h_d"]).real.copy())
+    return -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag
+
+
+def sweep_table(workloads, times, first, count, k, carrier, t_final):
+    amps = np.empty((count, k))
+    phs = np.empty((count, k))
+    for b in range(count):
+        amps[b], phs[b] = workloads.sweep_parameters(first + b, k)
+    return workloads.gaussian_coefficient_table(times, amps, phs, carrier, t_final), amps, phs
+
+
+class Dist:
+    """torch.distributed as rendezvous / barrier / MAX plumbing (nccl = RCCL on the GPU, gloo in the CPU test)."""
+
+    def __init__(self, world, rank, local_rank, stub):
+        self.world, self.rank, self.local_rank, self.stub = world, rank, local_rank, stub
+        self.dist = None
+        self.torch = None
+        if world > 1 or os.environ.get("MIDYN_BENCH_FORCE_DIST"):
+            import torch  # BEFORE the first libmidyn call: the library then binds to torch's HIP runtime
+            import torch.distributed as dist
+
+            from qiskit_dynamics_amd.distributed import init_process_group_from_env
+
+            self.torch, self.dist = torch, dist
+            if not stub:
+                torch.cuda.set_device(local_rank)
+            init_process_group_from_env(backend="gloo" if stub else "nccl")
+
+    @property
+    def active(self):
+        return self.dist is not None
+
+    def device(self):
+        return self.torch.device("cpu") if self.stub else self.torch.device("cuda", self.local_rank)
+
+    def barrier(self):
+        if self.dist is not None:
+            if not self.stub:
+                self.torch.cuda.synchronize()
+            self.dist.barrier()
+
+    def max(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.device())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def bcast_bytes(self, payload, src=0):
+        box = [payload]
+        self.dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def shared_stack(qd, ctx, D, builder, n, k, route):
+    """The operator stack on every rank: built on rank 0, ONE RCCL broadcast (route "abi": midyn_stack_broadcast
+    on a communicator made from an ncclUniqueId shipped through the torch store; "torch": dist.broadcast of the
+    packed buffer).  Returns (stack, keepalive, info)."""
+    from qiskit_dynamics_amd import _lib
+    from qiskit_dynamics_amd.distributed import broadcast_stack
+
+    t0 = time.perf_counter()
+    arrays = builder() if D.rank == 0 else (None, None, None)
+    build_s = time.perf_counter() - t0
+    if not D.active:
+        return qd.Stack(ctx, *arrays), None, {"route": "none (one rank)", "host_build_s": round(build_s, 2)}
+    info = {"host_build_s": round(build_s, 2)}
+    if route == "abi":
+        try:
+            uid = D.bcast_bytes(_lib.Comm.unique_id() if D.rank == 0 else None)
+            comm = _lib.Comm(ctx, D.world, D.rank, uid)
+            meta = D.bcast_bytes((arrays[1] is not None, arrays[2] is not None) if D.rank == 0 else None)
+            stack = qd.Stack(ctx, *arrays) if D.rank == 0 else _lib.Stack.empty(ctx, n, k, meta[0], meta[1])
+            ctx.synchronize()
+            D.barrier()
+            t1 = time.perf_counter()
+            stack.broadcast(comm, 0)
+            ctx.synchronize()
+            info.update(route="midyn_stack_broadcast (C-ABI, RCCL ncclBroadcast)", broadcast_ms=round(D.max((time.perf_counter() - t1) * 1e3), 3),
+                        bytes=_lib.Stack.packed_bytes(n, k, meta[0]))
+            return stack, comm, info
+        except Exception as exc:  # pylint: disable=broad-except
+            info["abi_route_error"] = repr(exc)   # fall through to the torch.distributed route (still RCCL)
+    D.barrier()
+    t1 = time.perf_counter()
+    stack, keep = broadcast_stack(ctx, arrays[0], arrays[1], arrays[2], n, k, src=0)
+    info.update(route="torch.distributed broadcast (RCCL)", broadcast_ms=round(D.max((time.perf_counter() - t1) * 1e3), 3))
+    return stack, keep, info
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# CPU plumbing stub (tests/test_distributed_gloo.py): same launcher, sharding, barriers and MAX reduction, a
+# stand-in for the device solve.  Never used with a GPU; prints a line marked "stub".
+# -----------------------------------------------------------------------------------------------------------------
+def run_stub(args, D):
+    from qiskit_dynamics_amd.distributed import shard_bounds
+
+    total = args.batch or SWEEP
+    lo, hi = (D.rank * total, (D.rank + 1) * total) if args.weak else shard_bounds(total, D.rank, D.world)
+    D.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (1 + D.rank))
+    elapsed = D.max(time.perf_counter() - t0)
+    n_inst = int(D.max(float(hi)))  # highest shard end == total instances (checks the all-reduce)
+    if D.rank == 0:
+        print(json.dumps({"metric": "stub", "stub": True, "n_gpus": D.world, "instances_total": n_inst,
+                          "scaling": "weak" if args.weak else "strong", "shard_rank0": [lo, hi],
+                          "elapsed_max_s": round(elapsed, 4)}), flush=True)
+    D.close()
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# legs
+# -----------------------------------------------------------------------------------------------------------------
+def profile_pass(ctx, fn, classes):
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    try:
+        fn()
+        ctx.synchronize()
+        return {c: ctx.counters(c) for c in classes}
+    finally:
+        ctx.set_option("profile", 0)
+
+
+ALL_CLASSES = ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", "rhs_blocks", "rhs_blocks_gemm")
+
+
+def leg_cfg4(qd, ctx, workloads):
+    """cfg 4: 6-qubit vectorised Lindbladian (N = 4096 superoperators built on the device), 4 static dissipators,
+    scipy_expm magnus_order 1, max_dt 0.05, T = 5 -> 100 steps, one trajectory ("replicas only")."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+
+    cfg = workloads.lindblad_config()
+    t0 = time.perf_counter()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       static_dissipators=cfg["static_dissipators"], vectorized=True)
+    build_s = time.perf_counter() - t0
+    stack = solver.model.stack
+    n_big = stack.n
+    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(1))
+    table, _, _ = sweep_table(workloads, sched.times, 0, 1, 6, cfg["carrier"], cfg["t_final"])
+    y0 = cfg["rho0"].flatten(order="F").reshape(-1, 1)
+
+    def run():
+        return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 1,
+                                y0, 1, True)
+
+    run()                                   # warm (lazy block lists, norms, allocations)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    ys = run()
+    dev_ms = ctx.timer_stop()
+    wall = time.perf_counter() - t0
+    cs = profile_pass(ctx, run, ALL_CLASSES)
+    rho = ys[0, -1, :, 0].reshape(64, 64, order="F")
+    n_steps = len(sched.step_h)
+    blk = stack.block_info()
+    dom = max(cs, key=lambda c: cs[c]["ms"])
+    launches = cs[dom]["launches"]
+    avg_ms = cs[dom]["ms"] / max(launches, 1)
+    k_h, s_sq = 6, 0
+    out = {"workload": "cfg4: 6-qubit vectorised LindbladModel (N=4096 superoperator), 4 static dissipators, no frame, "
+                       "scipy_expm magnus_order=1, max_dt=0.05, 100 steps, 1 trajectory",
+           "steps": n_steps, "solve_s": round(wall, 4), "ms_per_step": round(wall / n_steps * 1e3, 4),
+           "stream_ms_per_step": round(dev_ms / n_steps, 4), "model_build_s": round(build_s, 2),
+           "trace_deviation": float(abs(np.trace(rho) - 1.0)),
+           "hermiticity": float(np.linalg.norm(rho - rho.conj().T)),
+           "launches_per_step": {c: round(v["launches"] / n_steps, 2) for c, v in cs.items() if v["launches"]},
+           "kernel_ms_per_step": {c: round(v["ms"] / n_steps, 4) for c, v in cs.items() if v["launches"]}}
+    if dom == "rhs_blocks" and blk["state"] == 1:
+        # one product G.v on the work lists: every listed 16x16 block (4 KiB) is read once, plus state in / out
+        bytes_launch = blk["nonzero_blocks"] * 16 * 16 * 16 + 2 * 16 * n_big
+        gbs = bytes_launch / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "kernel": "rhs_blocks_kernel<1> (expm action: one product G.v per launch over the non-zero 16x16 blocks)",
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+            "launches_timed": int(launches), "executed_bytes_per_launch": bytes_launch,
+            "nonzero_blocks": blk["nonzero_blocks"], "block_density": round(blk["block_density"], 5),
+            "products_per_step": round(launches / n_steps, 2),
+            "note": "executed bytes of the block work lists; the kernel is a latency chain of a few dozen blocks per "
+                    "row group, not a bandwidth problem (DESIGN 4.12)",
+            "dense_form_price": {
+                "labelled": "SURVEY 8(d) cfg 4 prices the reference's dense algorithm, which is NOT executed here",
+                "assembly_bytes_per_step": 16 * (k_h + 1) * n_big * n_big,
+                "expm_flops_per_step": 8.0 * n_big**3 * (7.33 + s_sq),
+                "mfma_ceiling_ms_per_step": round(8.0 * n_big**3 * 7.33 / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 1),
+                "measured_ms_per_step": round(wall / n_steps * 1e3, 4)}}
+    else:
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 5)}
+    del solver
+    return out
+
+
+def cfg5_roofline(ctx, stack, cs, n_cols, n, n_steps, wall, n_inst):
+    """Roofline object of a cfg-5 style solve whose dominant kernel is the sparse MFMA work-list contraction."""
+    dom = max(cs, key=lambda c: cs[c]["ms"])
+    launches = cs[dom]["launches"]
+    avg_ms = cs[dom]["ms"] / max(launches, 1)
+    if dom != "rhs_blocks_gemm":
+        return {"kernel": dom, "bound": "mfma", "achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 5)}
+    tile = ctx.counters("sparse_tile")
+    lst = ctx.counters("sparse_list")
+    bm, bn = int(tile["launches"]), int(tile["ms"])
+    listed, splits = lst["launches"], int(lst["ms"])
+    cols_pad = -(-n_cols // bn) * bn
+    modes = [m for m in stack.segment_modes if m != 3]
+    real_flops_per_mac = 4 if all(m in (1, 2) for m in modes) else 8
+    flops_launch = listed * bm * 16 * cols_pad * real_flops_per_mac      # every listed (BM x 16) tile times all columns
+    tf = flops_launch / (avg_ms * 1e-3) / 1e12
+    return {
+        "kernel": f"zgemm_seg_kernel<{bm},{bn},...,SPARSE> (batched contraction over the tile work lists, fp64 MFMA)",
+        "bound": "mfma", "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+        "launches_timed": int(launches), "executed_mfma_flops_per_launch": flops_launch,
+        "listed_tiles": int(listed), "tile": [bm, bn], "splits": splits, "columns": n_cols,
+        "contractions_per_step": round(launches / n_steps, 2),
+        "note": "executed flops = listed (panel, K tile, operator) tiles x BM x 16 x columns x 4 real flops per complex "
+                "MAC (single-plane operators); short panels are latency-bound (DESIGN 4.12, section 8)",
+        "dense_form_price": {
+            "labelled": "SURVEY 8(d) cfg 5 prices the reference's dense algorithm (2 commutator zgemms + expm per "
+                        "instance-step), which is NOT executed here: the expm ACTION needs no n^3 work",
+            "flops_per_instance_step": 8.0 * n**3 * (2 + 7.33),
+            "mfma_ceiling_ms_per_instance_step": round(8.0 * n**3 * 9.33 / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 1),
+            "measured_ms_per_instance_step": round(wall / n_steps / n_inst * 1e3, 5)}}
+
+
+def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
+    """cfg 5: 12-qubit (n = 4096) Schrodinger sweep in the diagonal frame, scipy_expm magnus_order 2, max_dt 0.25,
+    T = 5 -> 20 steps; instances [first, first + count)."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+
+    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(2))
+    table, _, _ = sweep_table(workloads, sched.times, first, count, 8, cfg["carrier"], cfg["t_final"])
+    y0 = cfg["y0"].reshape(-1, 1)
+
+    def run():
+        return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2,
+                                y0, count, True)
+
+    run()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    ys = run()
+    dev_ms = ctx.timer_stop()
+    wall = time.perf_counter() - t0
+    n_steps = len(sched.step_h)
+    out = {"instances": count, "steps": n_steps, "solve_s": round(wall, 4),
+           "ms_per_step": round(wall / n_steps * 1e3, 4), "stream_ms_per_step": round(dev_ms / n_steps, 4),
+           "us_per_instance_step": round(wall / n_steps / count * 1e6, 3),
+           "instance_steps_per_s": round(count * n_steps / wall, 1),
+           "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(ys[:, -1, :, 0], axis=1) - 1.0))),
+           "note": "solve_s = midyn_expm_solve wall clock: coefficient table H2D, 20 device steps, results D2H "
+                   "(%.0f MB over PCIe); stream_ms = HIP events around the same call" % (ys.nbytes / 1e6)}
+    if with_profile:
+        cs = profile_pass(ctx, run, ALL_CLASSES)
+        out["launches_per_step"] = {c: round(v["launches"] / n_steps, 2) for c, v in cs.items() if v["launches"]}
+        out["kernel_ms_per_step"] = {c: round(v["ms"] / n_steps, 4) for c, v in cs.items() if v["launches"]}
+        out["roofline"] = cfg5_roofline(ctx, stack, cs, count, stack.n, n_steps, wall, count)
+    return out
+
+
+def leg_cpu_baseline(workloads, cfg, static, ops, frame_im, amps, phs):
+    from oracle import dynamics_oracle as orc
+    from threadpoolctl import threadpool_info, threadpool_limits
+
+    a_d, a = static, ops
+    d = 1j * frame_im
+    best = None
+    for threads in sorted({8, 32, os.cpu_count() or 8}):      # short probe: which BLAS width is fastest here
+        if threads > (os.cpu_count() or 8):
+            continue
+        with threadpool_limits(limits=threads):
+            t0c = time.perf_counter()
+
+            def rhs(t, y):
+                c = workloads.gaussian_coefficient_table(np.array([t]), amps[0], phs[0], cfg["carrier"], T_FINAL)[0]
+                return orc.generator_rhs(a_d, a, c, d, None, t, y)
+
+            orc.rk4_solve(rhs, [0.0, 10 * MAX_DT], cfg["y0"], MAX_DT)
+            rate = 40 / (time.perf_counter() - t0c)
+        if best is None or rate > best[0]:
+            best = (rate, threads)
+    threads = best[1]
+    n_inst = 4
+    n_steps = int(min(200, max(20, best[0] * 15 / (4 * n_inst))))   # ~15 s of CPU work
+    with threadpool_limits(limits=threads):
+        t0c = time.perf_counter()
+        for b in range(n_inst):
+            def rhs(t, y, b=b):
+                c = workloads.gaussian_coefficient_table(np.array([t]), amps[b], phs[b], cfg["carrier"], T_FINAL)[0]
+                return orc.generator_rhs(a_d, a, c, d, None, t, y)
+
+            orc.rk4_solve(rhs, [0.0, n_steps * MAX_DT], cfg["y0"], MAX_DT)
+        cpu_s = time.perf_counter() - t0c
+    best = (n_inst * n_steps * 4 / cpu_s, threads, cpu_s)
+    return {
+        "value": round(best[0], 1), "unit": "RHS evals/s", "cores": best[1], "kind": "port",
+        "sample": f"{n_inst} instances x {n_steps} RK4 steps ({n_inst * n_steps * 4} RHS evals) of the same "
+                  f"model with the NumPy oracle (tensordot + matvec); best of BLAS thread counts 8/32/all on a "
+                  f"{os.cpu_count()}-CPU host: {best[1]} threads, {best[2]:.1f} s",
+        "host": {"cpu_count": os.cpu_count(), "numpy": np.__version__,
+                 "blas": [f"{i.get('internal_api')} {i.get('version')} ({i.get('threading_layer') or i.get('user_api')})"
+                          for i in threadpool_info()],
+                 "OPENBLAS_NUM_THREADS": os.environ.get("OPENBLAS_NUM_THREADS")}}
+
+
+# -----------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=4096, help="sweep instances per GPU")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="sweep instances: the TOTAL over all GPUs (default 4096), or per GPU with --weak")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --batch (4096) instances PER GPU")
+    ap.add_argument("--torch-broadcast", action="store_true",
+                    help="broadcast the stack with torch.distributed (RCCL) instead of the C-ABI midyn_stack_broadcast")
+    ap.add_argument("--repeats", type=int, default=3, help="timed repetitions of the K steps (spread is reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the cfg-2 single-trajectory leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the cfg-4 / cfg-5 legs")
     ap.add_argument("--dense", action="store_true",
                     help="disable exact-zero plane skipping (time the general dense-complex path)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the end-to-end Solver.solve of the whole sweep (about 12 s)")
     ap.add_argument("--full-solve", action="store_true",
                     help="also time the end-to-end solve with Python-callable envelopes (host-evaluated coefficient table)")
-    ap.add_argument("--complex-3m", action="store_true", help="dense complex products with 3 real MFMAs (A/B testing)")
+    ap.add_argument("--complex-3m", type=int, default=-1, help="A/B: ctx option complex_3m (0 | 1 | 2)")
     ap.add_argument("--plane-kernel", action="store_true", help="A/B: planar two-tiles-per-barrier kernel (opt-in)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: kernel ablation bits (results wrong)")
     ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 | 12864 (kernel A/B testing)")
     args = ap.parse_args()
+    stub = bool(os.environ.get("MIDYN_BENCH_STUB"))
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    D = Dist(world, rank, local_rank, stub)
+    if stub:
+        run_stub(args, D)
+        return
 
     import qiskit_dynamics_amd as qd
     from qiskit_dynamics_amd import workloads
-    from qiskit_dynamics_amd.distributed import broadcast_stack, init_process_group_from_env
+    from qiskit_dynamics_amd.distributed import shard_bounds
     from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
-    use_dist = world > 1 or bool(os.environ.get("MIDYN_BENCH_FORCE_DIST"))  # the latter: 1-GPU test of the RCCL path
-    if use_dist:
-        import torch  # BEFORE the first libmidyn call: the library then binds to torch's HIP runtime
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local_rank)
-        init_process_group_from_env(backend="nccl")
     ctx = qd.default_context(local_rank)
     if args.dense:
         ctx.set_option("skip_zero_planes", 0)
@@ -111,144 +518,147 @@ def main():
         ctx.set_option("force_tile", args.force_tile)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
-    if args.complex_3m:
-        ctx.set_option("complex_3m", 1)
+    if args.complex_3m >= 0:
+        ctx.set_option("complex_3m", args.complex_3m)
     if args.plane_kernel:
         ctx.set_option("plane_kernel", 1)
 
     cfg = workloads.schrodinger_config(N_QUBITS, N_DRIVES, T_FINAL, MAX_DT)
     n = 2**N_QUBITS
     k = N_DRIVES
-    t_setup = time.time()
-    if use_dist:
-        ops = static = frame_im = None
-        if rank == 0:
-            ops, static, frame_im = build_frame_basis_stack(cfg)
-        stack, _keep = broadcast_stack(ctx, ops, static, frame_im, n, k, src=0)
-    else:
-        ops, static, frame_im = build_frame_basis_stack(cfg)
-        stack = qd.Stack(ctx, ops, static, frame_im)
-    setup_s = time.time() - t_setup
+    host_arrays = {}
 
-    # schedule of the real 1000-step solve; the bench runs its first (warmup + steps) steps
+    def builder():
+        host_arrays["v"] = build_frame_basis_stack(cfg)
+        return host_arrays["v"]
+
+    t_setup = time.perf_counter()
+    stack, _keep, bcast = shared_stack(qd, ctx, D, builder, n, k, "torch" if args.torch_broadcast else "abi")
+    setup_s = time.perf_counter() - t_setup
+
+    # ---- the sweep of this rank ---------------------------------------------------------------------------------
+    total_inst = (args.batch or SWEEP) * (world if args.weak else 1)
+    lo, hi = shard_bounds(total_inst, rank, world)
+    b_loc = hi - lo
+    # schedule of the real 1000-step solve; the bench runs its first (warmup + repeats * steps) steps
     sched = FixedStepSchedule(cfg["t_span"], None, MAX_DT, _rk4_points)
-    total = args.warmup + args.steps
+    repeats = max(1, args.repeats)
+    total = args.warmup + repeats * args.steps
+    while total > len(sched.step_h) and repeats > 1:
+        repeats -= 1
+        total = args.warmup + repeats * args.steps
     if total > len(sched.step_h):
         raise SystemExit(f"warmup+steps must be <= {len(sched.step_h)}")
     rows = sched.step_rows[:total]
     n_rows = int(rows.max()) + 1
     times = sched.times[:n_rows]
-    b_loc = args.batch
-    inst0 = rank * b_loc
-    amps = np.empty((b_loc, k))
-    phs = np.empty((b_loc, k))
-    for b in range(b_loc):
-        amps[b], phs[b] = workloads.sweep_parameters(inst0 + b, k)
-    table = workloads.gaussian_coefficient_table(times, amps, phs, cfg["carrier"], T_FINAL)
+    table, amps, phs = sweep_table(workloads, times, lo, b_loc, k, cfg["carrier"], T_FINAL)
     y0 = cfg["y0"].reshape(-1, 1)
     plan = qd.Rk4Plan(stack, times, table, rows, sched.step_h[:total], y0, b_loc, True)
 
     def sync_all():
         ctx.synchronize()
-        if dist is not None:
-            import torch
-
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        D.barrier()
 
     plan.run(0, args.warmup)
     sync_all()
-    t0 = time.perf_counter()
-    plan.run(args.warmup, total)
-    ctx.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        torch.cuda.synchronize()
-        dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    samples = []          # (host seconds, HIP-event ms) of each repetition of K steps, MAX over ranks
+    for rep in range(repeats):
+        s0 = args.warmup + rep * args.steps
+        sync_all()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        plan.run(s0, s0 + args.steps)
+        ev_ms = ctx.timer_stop()          # waits for the stop event = the stream is drained
+        ctx.synchronize()
+        el = time.perf_counter() - t0
+        D.barrier()
+        samples.append((D.max(el), D.max(ev_ms)))
+    elapsed, event_ms = samples[0]        # the contract's "EXACTLY K steps": the first timed repetition
     final = plan.fetch()[:, :, 0]
     norm_dev = float(np.max(np.abs(np.linalg.norm(final, axis=1) - 1.0)))
 
-    evals = world * b_loc * 4 * args.steps
+    evals = total_inst * 4 * args.steps
     value = evals / elapsed
     ms_per_step = elapsed / args.steps * 1e3
+    rates = [total_inst * 4 * args.steps / s for s, _ in samples]
 
-    # ---- roofline of the dominant kernel: HIP-event timing of every launch on the ctx stream ----
-    ctx.reset_counters()
-    ctx.set_option("profile", 1)
+    # ---- roofline of the dominant kernel ------------------------------------------------------------------------
+    # launch duration from the SAME back-to-back region as ms_per_step: HIP events on the stream the kernel runs on
+    # around the K steps, divided by the 4K launches (+ a per-launch event pass for the launch count / class check)
     prof_steps = min(args.steps, 10)
-    plan.run(total - prof_steps, total)   # re-runs the last steps (state is re-phased automatically)
-    ctx.synchronize()
-    cnt = ctx.counters("rhs_gemm")
-    ctx.set_option("profile", 0)
+    cnt = profile_pass(ctx, lambda: plan.run(total - prof_steps, total), ("rhs_gemm", "rhs_blocks_gemm"))["rhs_gemm"]
     roofline = None
-    if cnt["launches"] > 0:
-        avg_ms = cnt["ms"] / cnt["launches"]
-        flops_per_launch = (4 * k + 10) * n * n * b_loc          # useful flops, SURVEY 8(d) cfg 3
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        n_act = stack.n_active_segments
+    n_launch_per_step = cnt["launches"] / prof_steps if cnt["launches"] else 0
+    modes = stack.segment_modes if not args.dense else [0] * stack.n_segments
+    if cnt["launches"] > 0 and abs(n_launch_per_step - 4) < 1e-9:
+        avg_ms = event_ms / (4 * args.steps)
+        useful = (4 * k + 10) * n * n * b_loc                      # SURVEY 8(d) cfg 3 "useful" flops per launch
         act_modes = [m for m in stack.segment_modes if m != 3]
         stack_um = act_modes[0] if act_modes and all(m == act_modes[0] for m in act_modes) else 3
-        modes = stack.segment_modes if not args.dense else [0] * stack.n_segments
-        executed = sum((6 if m == 0 else 4) for m in modes if m != 3) * n * n * b_loc
+        use_3m = (args.dense or stack_um == 0) and args.complex_3m != 0
+        per_seg = [(6 if use_3m else 8) if m == 0 else 4 for m in modes if m != 3]
+        executed = sum(per_seg) * n * n * b_loc                    # real MFMA flops the kernel executes per launch
+        tf = executed / (avg_ms * 1e-3) / 1e12
         roofline = {
             "kernel": "zgemm_seg_kernel (batched RHS, fp64 MFMA 16x16x4)", "bound": "mfma",
-            "achieved": round(achieved, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+            "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
             "traffic": measured_traffic("zgemm_seg_kernel<64, 64, 2, 2, 16, 4," if (args.dense or stack_um == 0)
                                         else "zgemm_seg_kernel<128, 128, 2, 4, 16, %d," % stack_um),
-            "avg_launch_ms": round(avg_ms, 4), "launches_timed": int(cnt["launches"]),
-            "algorithmic_flops_per_launch": flops_per_launch,
+            "avg_launch_ms": round(avg_ms, 4), "launches_timed": 4 * args.steps,
+            "avg_launch_ms_per_launch_events": round(cnt["ms"] / cnt["launches"], 4),
             "executed_mfma_flops_per_launch": executed,
-            "executed_tflops": round(executed / (avg_ms * 1e-3) / 1e12, 3),
-            "segment_plane_modes": modes,
-            "active_segments": n_act, "zero_plane_skipping": not args.dense,
-            "note": "achieved = useful flops (4k+10)n^2 per instance-eval (SURVEY 8(d)); the operators of this "
-                    "model are purely imaginary in the frame basis, so exact-zero plane skipping executes 4 instead "
-                    "of 8 real flops per complex MAC; see dense_complex for the general path",
+            "useful_flops_per_launch": useful, "useful_tflops": round(useful / (avg_ms * 1e-3) / 1e12, 3),
+            "segment_plane_modes": modes, "active_segments": stack.n_active_segments,
+            "zero_plane_skipping": not args.dense,
+            "note": "achieved = EXECUTED real MFMA flops / launch time (launch time = HIP events around the K timed steps "
+                    "on the library's stream / 4K launches); the operators of this model are purely imaginary in the "
+                    "frame basis, so exact-zero plane skipping executes 4 real flops per complex MAC (4(k+1)n^2 per "
+                    "instance-eval) where SURVEY 8(d) counts (4k+10)n^2 'useful' flops (useful_tflops); see "
+                    "dense_complex for general complex operators",
         }
-    # ---- the general dense-complex path on the same inputs (no exact-zero plane skipping) -------
+    # ---- the general dense-complex path on the same inputs (no exact-zero plane skipping) -----------------------
     dense = None
-    if not args.dense and roofline:
+    if not args.dense and roofline and world == 1:
         ctx.set_option("skip_zero_planes", 0)
-        ctx.reset_counters()
-        ctx.set_option("profile", 1)
-        plan.run(total - min(args.steps, 5), total)
+        d_steps = min(args.steps, 10)
+        plan.run(total - d_steps, total)
         ctx.synchronize()
-        cd = ctx.counters("rhs_gemm")
-        ctx.set_option("profile", 0)
+        ctx.timer_start()
+        plan.run(total - d_steps, total)
+        avg_d = ctx.timer_stop() / (4 * d_steps)
         ctx.set_option("skip_zero_planes", 1)
-        avg_d = cd["ms"] / max(cd["launches"], 1)
         ex_d = 6 * stack.n_segments * n * n * b_loc   # 3M: 3 real MFMA products per complex product
+        useful = (4 * k + 10) * n * n * b_loc
         dense = {"avg_launch_ms": round(avg_d, 4), "rhs_evals_per_s": round(b_loc / (avg_d * 1e-3), 1),
-                 "useful_tflops": round(flops_per_launch / (avg_d * 1e-3) / 1e12, 3),
+                 "useful_tflops": round(useful / (avg_d * 1e-3) / 1e12, 3),
                  "executed_tflops": round(ex_d / (avg_d * 1e-3) / 1e12, 3),
-                 "frac_of_peak_executed": round(ex_d / (avg_d * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
-                 "scheme": "3M complex multiplication (3 real fp64 MFMAs per complex product), 64x64 tiles"}
+                 "frac": round(ex_d / (avg_d * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                 "scheme": "3M complex multiplication (3 real fp64 MFMAs per complex product) inside the solver loop"}
     plan.close()
     measured_peaks = None
-    if rank == 0:
+    if rank == 0 and world == 1:
         measured_peaks = {"mfma_f64_tflops": round(ctx.microbench("mfma_f64"), 1),
                           "hbm_read_gbs": round(ctx.microbench("hbm_read"), 0),
                           "mall_read_gbs": round(ctx.microbench("mall_read"), 0)}
 
+    scaling = "weak" if args.weak else "strong"
     out = {
         "metric": "RHS evals/sec, 10-qubit Schrodinger (dim 1024), 4096-param batch", "value": round(value, 1),
         "unit": "RHS evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
-        "config": {"workload": "cfg3: 10-qubit chain, n=1024, k=8 drives + static, rotating frame H_d, "
-                               "RK4 max_dt=0.005, sweep of %d instances per GPU" % b_loc,
-                   "instances_per_gpu": b_loc, "global_instances": b_loc * world,
-                   "rhs_evals_per_step": 4 * b_loc * world, "parallelism": f"sweep-shard x{world}"},
+        "config": {"workload": "cfg3: 10-qubit chain, n=1024, k=8 drives + static, rotating frame H_d, RK4 max_dt=0.005, "
+                               "sweep of %d instances in total (%s scaling: %d per GPU)" % (total_inst, scaling, b_loc),
+                   "instances_per_gpu": b_loc, "global_instances": total_inst,
+                   "rhs_evals_per_step": 4 * total_inst, "parallelism": f"sweep-shard x{world}"},
+        "repeat_rhs_evals_per_s": [round(r, 1) for r in rates],
+        "repeat_spread": round((max(rates) - min(rates)) / max(rates), 4),
+        "stream_ms_per_step": round(event_ms / args.steps, 4),
         "solve_wall_clock_s": round(ms_per_step * len(sched.step_h) / 1e3, 3),
         "solve_wall_clock_note": "1000 RK4 steps = 1000 x ms_per_step (fixed step, identical work per step)",
-        "setup_s": round(setup_s, 2), "max_norm_deviation": norm_dev,
+        "setup_s": round(setup_s, 2), "stack_broadcast": bcast, "max_norm_deviation": norm_dev,
     }
     if roofline:
         out["roofline"] = roofline
@@ -257,8 +667,8 @@ def main():
     if measured_peaks:
         out["measured_peaks"] = measured_peaks
 
-    # ---- cfg 2: single trajectory, HBM-bound streaming kernel (rank 0 only) ---------------------
-    if rank == 0 and not args.no_single:
+    # ---- cfg 2: single trajectory, HBM-bound streaming kernel (rank 0, N=1) -------------------------------------
+    if rank == 0 and world == 1 and not args.no_single:
         s_total = 64
         rows1 = sched.step_rows[:s_total]
         nr1 = int(rows1.max()) + 1
@@ -267,89 +677,88 @@ def main():
         p1.run(0, 8)
         ctx.synchronize()
         t0 = time.perf_counter()
+        ctx.timer_start()
         p1.run(8, s_total)
-        ctx.synchronize()
+        ev1 = ctx.timer_stop()
         el1 = time.perf_counter() - t0
-        ctx.reset_counters()
-        ctx.set_option("profile", 1)
-        p1.run(8, s_total)
-        ctx.synchronize()
-        c1 = ctx.counters("rhs_stream")
-        ctx.set_option("profile", 0)
+        c1 = profile_pass(ctx, lambda: p1.run(8, s_total), ("rhs_stream",))["rhs_stream"]
         p1.close()
         nseg = stack.n_segments
-        bytes_per_launch = 16 * nseg * n * n + 32 * n                 # SURVEY 8(d) cfg 2: 151.03 MB
-        avg_ms1 = c1["ms"] / max(c1["launches"], 1)
-        gbs = bytes_per_launch / (avg_ms1 * 1e-3) / 1e9
+        bytes_alg = 16 * nseg * n * n + 32 * n                 # SURVEY 8(d) cfg 2: 151.03 MB
+        avg_ms1 = ev1 / (4 * (s_total - 8))                    # back-to-back launches, same region as ms_per_step
         # single-plane stack (every operator purely real or purely imaginary) and plane skipping on:
         # the kernel streams only the non-zero planes, 8 B per operator element instead of 16 B
         planar = (not args.dense) and all(m in (1, 2, 3) for m in stack.segment_modes)
         n_act = sum(1 for m in stack.segment_modes if m != 3)
-        executed_bytes = (8 * n_act * n * n + 32 * n) if planar else bytes_per_launch
+        executed_bytes = (8 * n_act * n * n + 32 * n) if planar else bytes_alg
         gbs_exec = executed_bytes / (avg_ms1 * 1e-3) / 1e9
         kname = "rhs_stream_plane_kernel<2, 3>" if planar else "rhs_stream_kernel<4, 3>"
         out["single_trajectory"] = {
             "workload": "cfg2: same model, 1 trajectory, RK4", "rhs_evals_per_s": round(4 * (s_total - 8) / el1, 1),
             "ms_per_step": round(el1 / (s_total - 8) * 1e3, 4)}
         out["roofline_single_trajectory"] = {
-            "kernel": kname.split("<")[0], "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname),
-            "avg_launch_ms": round(avg_ms1, 5), "launches_timed": int(c1["launches"]),
-            "algorithmic_bytes_per_launch": bytes_per_launch,
-            "executed_bytes_per_launch": executed_bytes, "executed_gbs": round(gbs_exec, 1),
-            "executed_frac": round(gbs_exec / HBM_PEAK_GBS, 4),
-            "note": "achieved = SURVEY 8(d) algorithmic bytes (151 MB, complex128 stack) / launch time; the "
-                    "operators of this model are purely imaginary, so the kernel streams only their non-zero "
-                    "planes (executed_bytes, exact same results); the planes fit the 256 MB Infinity Cache"}
+            "kernel": kname.split("<")[0], "bound": "hbm", "achieved": round(gbs_exec, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(gbs_exec / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname),
+            "avg_launch_ms": round(avg_ms1, 5), "launches_timed": 4 * (s_total - 8),
+            "avg_launch_ms_per_launch_events": round(c1["ms"] / max(c1["launches"], 1), 5),
+            "executed_bytes_per_launch": executed_bytes,
+            "algorithmic_bytes_per_launch": bytes_alg,
+            "algorithmic_gbs": round(bytes_alg / (avg_ms1 * 1e-3) / 1e9, 1),
+            "note": "achieved = EXECUTED bytes / launch time; the operators of this model are purely imaginary, so the "
+                    "kernel streams only their non-zero planes (75.5 MB; SURVEY 8(d) counts the full complex128 stack, "
+                    "151 MB = algorithmic_bytes, exact same results); the planes fit the 256 MB Infinity Cache, so the "
+                    "bytes come from MALL rather than HBM after the first launch"}
 
-    # ---- CPU baseline: the NumPy oracle on this host, bounded sample (rank 0, N=1 only) ---------
+    # ---- cfg 4 / cfg 5 (rank 0, N=1): the other BASELINE configurations with their rooflines --------------------
+    cfg5 = None
+    stack5 = None
+    want_cfg5 = not args.no_configs and not args.dense
+    if rank == 0 and world == 1 and want_cfg5:
+        try:
+            out["cfg4"] = leg_cfg4(qd, ctx, workloads)
+        except Exception as exc:  # pylint: disable=broad-except
+            out["cfg4"] = {"error": repr(exc)}
+    if want_cfg5:
+        # second sharded leg: cfg 5, 1024 instances in total, 1024/N per GPU; the 2.4 GB stack is broadcast
+        try:
+            cfg5 = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25) if rank == 0 else \
+                dict(t_span=[0.0, 5.0], max_dt=0.25, t_final=5.0)
+            if rank != 0:
+                nu = 5.0 + 0.05 * np.arange(12)
+                y5 = np.zeros(4096, dtype=complex)
+                y5[0] = 1.0
+                cfg5.update(carrier=nu[:8].copy(), y0=y5)
+            stack5, _keep5, bcast5 = shared_stack(qd, ctx, D, lambda: build_diag_frame_stack(cfg5), 4096, 8,
+                                                  "torch" if args.torch_broadcast else "abi")
+            if rank == 0 and world == 1:
+                shard = leg_cfg5(qd, ctx, workloads, stack5, cfg5, 0, 128)
+                shard["workload"] = ("cfg5 shard: 12-qubit (n=4096) Schrodinger, k=8, diagonal frame, scipy_expm "
+                                     "magnus_order=2, max_dt=0.25, 20 steps, 128 instances (1024-instance sweep / 8 GPUs)")
+                out["cfg5"] = shard
+            lo5, hi5 = shard_bounds(CFG5_SWEEP, rank, world)
+            D.barrier()
+            full = leg_cfg5(qd, ctx, workloads, stack5, cfg5, lo5, hi5 - lo5, with_profile=False)
+            solve5 = D.max(full["solve_s"])
+            if rank == 0:
+                out["sharded_cfg5"] = {
+                    "workload": "cfg5: 12-qubit (n=4096) Schrodinger sweep, 1024 instances in total, Magnus-2 expm, "
+                                "20 steps, sharded 1024/N per GPU (strong scaling)",
+                    "instances_total": CFG5_SWEEP, "instances_per_gpu": hi5 - lo5, "n_gpus": world,
+                    "solve_s_max_over_ranks": round(solve5, 4),
+                    "instance_steps_per_s": round(CFG5_SWEEP * full["steps"] / solve5, 1),
+                    "max_norm_deviation_rank0": full["max_norm_deviation"], "stack_broadcast": bcast5}
+        except Exception as exc:  # pylint: disable=broad-except
+            if rank == 0:
+                out["sharded_cfg5"] = {"error": repr(exc)}
+        stack5 = None
+
+    # ---- CPU baseline: the NumPy oracle on this host, bounded sample (rank 0, N=1 only) -------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import dynamics_oracle as orc
+        ops, static, frame_im = host_arrays["v"]
+        out["cpu_baseline"] = leg_cpu_baseline(workloads, cfg, static, ops, frame_im, amps, phs)
 
-        from threadpoolctl import threadpool_info, threadpool_limits
-
-        a_d, a = static, ops
-        d = 1j * frame_im
-        best = None
-        for threads in sorted({8, 32, os.cpu_count() or 8}):      # short probe: which BLAS width is fastest here
-            if threads > (os.cpu_count() or 8):
-                continue
-            with threadpool_limits(limits=threads):
-                t0c = time.perf_counter()
-
-                def rhs(t, y):
-                    c = workloads.gaussian_coefficient_table(np.array([t]), amps[0], phs[0], cfg["carrier"], T_FINAL)[0]
-                    return orc.generator_rhs(a_d, a, c, d, None, t, y)
-
-                orc.rk4_solve(rhs, [0.0, 10 * MAX_DT], cfg["y0"], MAX_DT)
-                rate = 40 / (time.perf_counter() - t0c)
-            if best is None or rate > best[0]:
-                best = (rate, threads)
-        threads = best[1]
-        n_inst = 4
-        n_steps = int(min(200, max(20, best[0] * 15 / (4 * n_inst))))   # ~15 s of CPU work
-        with threadpool_limits(limits=threads):
-            t0c = time.perf_counter()
-            for b in range(n_inst):
-                def rhs(t, y, b=b):
-                    c = workloads.gaussian_coefficient_table(np.array([t]), amps[b], phs[b], cfg["carrier"], T_FINAL)[0]
-                    return orc.generator_rhs(a_d, a, c, d, None, t, y)
-
-                orc.rk4_solve(rhs, [0.0, n_steps * MAX_DT], cfg["y0"], MAX_DT)
-            cpu_s = time.perf_counter() - t0c
-        best = (n_inst * n_steps * 4 / cpu_s, threads, cpu_s)
-        out["cpu_baseline"] = {
-            "value": round(best[0], 1), "unit": "RHS evals/s", "cores": best[1], "kind": "port",
-            "sample": f"{n_inst} instances x {n_steps} RK4 steps ({n_inst * n_steps * 4} RHS evals) of the same "
-                      f"model with the NumPy oracle (tensordot + matvec); best of BLAS thread counts 8/32/all on a "
-                      f"{os.cpu_count()}-CPU host: {best[1]} threads, {best[2]:.1f} s",
-            "host": {"cpu_count": os.cpu_count(), "numpy": np.__version__,
-                     "blas": [f"{i.get('internal_api')} {i.get('version')} ({i.get('threading_layer') or i.get('user_api')})"
-                              for i in threadpool_info()],
-                     "OPENBLAS_NUM_THREADS": os.environ.get("OPENBLAS_NUM_THREADS")}}
-    # ---- optional: the complete cfg-3 solve through the public Solver API (host work included) ----
     # ---- the complete cfg-3 solve through the public Solver API: model build, signal evaluation, PCIe
-    #      and result unpacking included (rank 0, N=1; --full-solve adds the host-table variant) --------
+    #      and result unpacking included (rank 0, N=1; --full-solve adds the host-table variant) ------------------
     if rank == 0 and world == 1 and not args.no_end_to_end:
         t0f = time.perf_counter()
         solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
@@ -382,37 +791,9 @@ def main():
                 "what": "same sweep with Python-callable Gaussian envelopes: coefficient table evaluated on the host",
                 "solve_s": round(t_solve, 2), "rhs_evals_per_s_end_to_end": round(b_loc * 4000 / t_solve, 1),
                 "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(yf, axis=1) - 1.0)))}
-    # ---- informational (NOT the BASELINE config): the same sweep set up in the diagonal frame diag(H_d) --
-    #      same physics out of the frame, but the operators stay block sparse and the contraction runs on
-    #      the work-list kernels.  Same table, same steps, timed like `value`.
-    if rank == 0 and world == 1 and not args.no_end_to_end and not args.dense:
-        try:
-            from qiskit_dynamics_amd.rotating_frame import RotatingFrame
-
-            fr = RotatingFrame(np.diag(cfg["h_d"]).real.copy())
-            stack_d = qd.Stack(ctx, -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag)
-            plan_d = qd.Rk4Plan(stack_d, times, table, rows, sched.step_h[:total], y0, b_loc, True)
-            plan_d.run(0, args.warmup)
-            ctx.synchronize()
-            t0d = time.perf_counter()
-            plan_d.run(args.warmup, total)
-            ctx.synchronize()
-            dtd = time.perf_counter() - t0d
-            fin_d = plan_d.fetch()[:, :, 0]
-            plan_d.close()
-            out["diagonal_frame_variant"] = {
-                "what": "same model, sweep and steps with rotating_frame=diag(H_d) (NOT the BASELINE config, which "
-                        "rotates into the eigenbasis of H_d): block-sparse operators, work-list kernels",
-                "rhs_evals_per_s": round(b_loc * 4 * args.steps / dtd, 1), "ms_per_step": round(dtd / args.steps * 1e3, 4),
-                "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(fin_d, axis=1) - 1.0)))}
-            del stack_d
-        except Exception as exc:  # pylint: disable=broad-except
-            out["diagonal_frame_variant"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

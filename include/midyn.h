@@ -243,13 +243,39 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * names: "rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", and for the block-sparse routes
  * "rhs_blocks" (1..8 columns) and "rhs_blocks_gemm" (MFMA tiles over work lists).
  * out[0] = launches, out[1] = total ms (events are only recorded when profiling is enabled with
- * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch). */
+ * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch).
+ * Two more names describe the LAST launch of the sparse MFMA route: "sparse_tile" -> (BM, BN) of its tile,
+ * "sparse_list" -> (listed (panel, K tile, operator) tiles of the stack for that panel height, split count). */
 int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);
 int midyn_reset_counters(midyn_ctx* ctx);
 /* Measured ceilings: "mfma_f64" -> out[0] = TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64;
  * "hbm_read" -> GB/s streaming a 4 GiB buffer; "mall_read" -> GB/s re-reading 144 MiB (the size of
  * the cfg-2 operator stack, which fits the 256 MiB Infinity Cache). */
 int midyn_microbench(midyn_ctx* ctx, const char* name, double* out);
+/* HIP-event stopwatch on the context's stream: midyn_ctx_timer(ctx, 0, NULL) records the start event,
+ * midyn_ctx_timer(ctx, 1, &ms) records the stop event, waits for it and returns the elapsed milliseconds
+ * (brackets a region of back-to-back launches without per-launch event records). */
+int midyn_ctx_timer(midyn_ctx* ctx, int stop, double* ms);
+/* Block occupancy of a stack (what the work-list kernels read and multiply): out[0] state (1 lists built, -1 not
+ * applicable), out[1] fraction of non-zero 16x16 blocks of the active operators, out[2] their number, out[3] n_pad/16,
+ * then for the MFMA tile lists of 64/128/32/16-row panels: out[4+2t] listed fraction, out[5+2t] listed tiles.
+ * `out` holds 12 doubles. */
+int midyn_stack_block_info(midyn_stack* stack, double* out);
+
+/* ---- multi-GPU: the one collective of the path --------------------------------------------------
+ * Sweep instances are independent (the reference loops them sequentially, solvers/solver_classes.py:568-586);
+ * the only exchange is ONE RCCL broadcast of the packed operator stack from the rank that built it.
+ * One process (and one midyn_ctx) per GPU.  `nccl_comm` is an RCCL `ncclComm_t` passed as void*: either the
+ * caller's own communicator or one made by midyn_comm_init_rank from a 128-byte ncclUniqueId that rank 0 obtains
+ * with midyn_comm_get_unique_id and ships to the other ranks through any channel (file, socket, MPI, torch store).
+ * librccl is resolved at first use (already loaded in the process, else MIDYN_RCCL_LIB / librccl.so.1).
+ * Receiving ranks create an empty stack of the same shape and call midyn_stack_broadcast with the same root. */
+#define MIDYN_COMM_ID_BYTES 128
+int midyn_comm_get_unique_id(void* id128);
+int midyn_comm_init_rank(midyn_ctx* ctx, int world, int rank, const void* id128, void** nccl_comm_out);
+int midyn_comm_destroy(midyn_ctx* ctx, void* nccl_comm);
+int midyn_stack_create_empty(midyn_ctx* ctx, int n, int k, int has_static, int has_frame, midyn_stack** out);
+int midyn_stack_broadcast(midyn_stack* stack, void* nccl_comm, int root);
 
 #ifdef __cplusplus
 }

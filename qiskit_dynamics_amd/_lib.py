@@ -26,7 +26,9 @@ ABI_SYMBOLS = [
     "midyn_reset_counters", "midyn_microbench", "midyn_lindblad_create", "midyn_lindblad_destroy",
     "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve", "midyn_sigtable_create", "midyn_sigtable_data",
     "midyn_sigtable_fetch", "midyn_sigtable_destroy", "midyn_parallel_solve", "midyn_expansion_create",
-    "midyn_expansion_destroy", "midyn_expansion_solve",
+    "midyn_expansion_destroy", "midyn_expansion_solve", "midyn_ctx_timer", "midyn_stack_block_info",
+    "midyn_comm_get_unique_id", "midyn_comm_init_rank", "midyn_comm_destroy", "midyn_stack_create_empty",
+    "midyn_stack_broadcast",
 ]
 
 
@@ -76,6 +78,37 @@ def _preload_hip_runtime():
         except OSError as e:  # pragma: no cover
             errors.append(f"{c}: {e}")
     raise HipLibraryError("no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errors))
+
+
+RCCL_LIBRARY = None  # path of the librccl the C side resolves its nccl* entry points from
+
+
+def preload_rccl():
+    """Make ONE librccl global in the process before the first midyn_comm_* call: the one next to the HIP runtime
+    in use (torch's bundled copy when libmidyn is bound to torch's runtime, the system ROCm one otherwise), so
+    that RCCL and libmidyn share a HIP runtime.  Override with MIDYN_RCCL_LIB=/path/to/librccl.so."""
+    global RCCL_LIBRARY
+    if RCCL_LIBRARY is not None:
+        return RCCL_LIBRARY
+    load()
+    cands = []
+    if os.environ.get("MIDYN_RCCL_LIB"):
+        cands.append(os.environ["MIDYN_RCCL_LIB"])
+    if HIP_RUNTIME and os.path.sep in HIP_RUNTIME:
+        d = os.path.dirname(HIP_RUNTIME)
+        cands += [os.path.join(d, "librccl.so"), os.path.join(d, "librccl.so.1")]
+    cands += ["/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"]
+    errors = []
+    for c in cands:
+        if os.path.sep in c and not os.path.exists(c):
+            continue
+        try:
+            ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+            RCCL_LIBRARY = c
+            return c
+        except OSError as e:  # pragma: no cover
+            errors.append(f"{c}: {e}")
+    raise HipLibraryError("librccl could not be loaded: " + "; ".join(errors))
 
 
 def load():
@@ -135,6 +168,13 @@ def load():
         lib.midyn_sigtable_data.argtypes = [_vp, P(_vp), _vp]
         lib.midyn_sigtable_fetch.argtypes = [_vp, _vp]
         lib.midyn_sigtable_destroy.argtypes = [_vp]
+        lib.midyn_ctx_timer.argtypes = [_vp, _ci, P(_cd)]
+        lib.midyn_stack_block_info.argtypes = [_vp, P(_cd)]
+        lib.midyn_comm_get_unique_id.argtypes = [_vp]
+        lib.midyn_comm_init_rank.argtypes = [_vp, _ci, _ci, _vp, P(_vp)]
+        lib.midyn_comm_destroy.argtypes = [_vp, _vp]
+        lib.midyn_stack_create_empty.argtypes = [_vp, _ci, _ci, _ci, _ci, P(_vp)]
+        lib.midyn_stack_broadcast.argtypes = [_vp, _vp, _ci]
         for name in ABI_SYMBOLS:
             if name != "midyn_last_error":
                 getattr(lib, name).restype = _ci
@@ -196,6 +236,16 @@ class Context:
 
     def reset_counters(self):
         self.check(self.lib.midyn_reset_counters(self.handle))
+
+    def timer_start(self):
+        """Record the start event of the HIP-event stopwatch on this context's stream."""
+        self.check(self.lib.midyn_ctx_timer(self.handle, 0, None))
+
+    def timer_stop(self) -> float:
+        """Record the stop event, wait for it; elapsed milliseconds on the stream since ``timer_start``."""
+        ms = _cd()
+        self.check(self.lib.midyn_ctx_timer(self.handle, 1, ctypes.byref(ms)))
+        return float(ms.value)
 
     def zgemm(self, a, b):
         a, b = c128(a), c128(b)
@@ -281,6 +331,10 @@ class Stack:
                                              _vp(dev_buffer_ptr) if dev_buffer_ptr else None,
                                              ctypes.byref(h)))
         self.handle = h
+        self._read_info()
+
+    def _read_info(self):
+        ctx, lib, h = self.ctx, self.ctx.lib, self.handle
         info = (ctypes.c_longlong * 8)()
         ctx.check(lib.midyn_stack_info(h, info))
         (self.n, self.n_pad, self.k, self.has_static, self.has_frame, self.n_segments,
@@ -288,6 +342,34 @@ class Stack:
         modes = (ctypes.c_int * max(self.n_segments, 1))()
         ctx.check(lib.midyn_stack_segment_modes(h, modes))
         self.segment_modes = [int(modes[i]) for i in range(self.n_segments)]
+
+    @classmethod
+    def empty(cls, ctx, n, k, has_static, has_frame):
+        """Receiving side of ``broadcast``: a stack of the given shape with an allocated, unfilled buffer."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        h = _vp()
+        ctx.check(ctx.lib.midyn_stack_create_empty(ctx.handle, int(n), int(k), int(bool(has_static)),
+                                                   int(bool(has_frame)), ctypes.byref(h)))
+        self.handle = h
+        self._read_info()
+        return self
+
+    def broadcast(self, comm: "Comm", root: int = 0):
+        """ONE RCCL broadcast of the packed stack from rank ``root`` (C-ABI ``midyn_stack_broadcast``)."""
+        self.ctx.check(self.ctx.lib.midyn_stack_broadcast(self.handle, comm.handle, int(root)))
+        self._read_info()
+
+    def block_info(self) -> dict:
+        """Block occupancy (work-list routes): fraction / number of non-zero 16x16 blocks and, per MFMA row-panel
+        height, the listed fraction and number of (panel, K tile, operator) tiles."""
+        out = (ctypes.c_double * 12)()
+        self.ctx.check(self.ctx.lib.midyn_stack_block_info(self.handle, out))
+        info = {"state": int(out[0]), "block_density": float(out[1]), "nonzero_blocks": int(out[2]),
+                "blocks_per_side": int(out[3]), "tile_lists": {}}
+        for t, bm in enumerate((64, 128, 32, 16)):
+            info["tile_lists"][bm] = {"listed_fraction": float(out[4 + 2 * t]), "listed_tiles": int(round(out[5 + 2 * t]))}
+        return info
 
     @classmethod
     def from_lindblad(cls, ctx, h_d, h_ops, n_static, l_ops, frame_im):
@@ -386,6 +468,43 @@ class Stack:
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:
             self.ctx.lib.midyn_stack_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+class Comm:
+    """RCCL communicator of one rank (one process per GPU), bound to the context's device; only used for the
+    single broadcast of the operator stack.  ``unique_id``: the 128 bytes of ``Comm.unique_id()`` called on ONE
+    rank and shipped to the others by the caller (any channel)."""
+
+    def __init__(self, ctx: "Context", world: int, rank: int, unique_id: bytes):
+        preload_rccl()
+        if len(unique_id) != 128:
+            raise DynamicsError("an RCCL unique id is 128 bytes")
+        self.ctx = ctx
+        h = _vp()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        ctx.check(ctx.lib.midyn_comm_init_rank(ctx.handle, int(world), int(rank), buf, ctypes.byref(h)))
+        self.handle = h
+        self.world, self.rank = int(world), int(rank)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        preload_rccl()
+        lib = load()
+        buf = ctypes.create_string_buffer(128)
+        if lib.midyn_comm_get_unique_id(buf):
+            raise DynamicsError(lib.midyn_last_error(None).decode())
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:
+            self.ctx.lib.midyn_comm_destroy(self.ctx.handle, self.handle)
             self.handle = None
 
     def __del__(self):

@@ -4,6 +4,8 @@
 // No CPU fallback exists in this library: every entry point needs a HIP device and fails with a
 // non-zero status (text via midyn_last_error) when there is none.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the entry points are resolved with dlsym (midyn_comm.inc)
 
 #include <algorithm>
 #include <cmath>
@@ -30,3 +32,4 @@ using namespace midyn;
 #include "midyn_expansion.inc"
 #include "midyn_lindblad.inc"
 #include "midyn_microbench.inc"
+#include "midyn_comm.inc"

@@ -41,6 +41,13 @@ int main(int argc, char** argv) {
     CHECK(midyn_rk4_plan_destroy); CHECK(midyn_get_counters); CHECK(midyn_reset_counters);
     CHECK(midyn_microbench); CHECK(midyn_lindblad_create); CHECK(midyn_lindblad_destroy);
     CHECK(midyn_lindblad_rhs); CHECK(midyn_lindblad_rk4_solve);
+    CHECK(midyn_stack_create_lindblad); CHECK(midyn_stack_antiherm_defect); CHECK(midyn_sigtable_create);
+    CHECK(midyn_sigtable_data); CHECK(midyn_sigtable_fetch); CHECK(midyn_sigtable_destroy);
+    CHECK(midyn_parallel_solve); CHECK(midyn_expansion_create); CHECK(midyn_expansion_destroy);
+    CHECK(midyn_expansion_solve); CHECK(midyn_ctx_timer); CHECK(midyn_stack_block_info);
+    /* multi-GPU: the RCCL broadcast of the stack (librccl itself is only resolved at first use) */
+    CHECK(midyn_comm_get_unique_id); CHECK(midyn_comm_init_rank); CHECK(midyn_comm_destroy);
+    CHECK(midyn_stack_create_empty); CHECK(midyn_stack_broadcast);
     /* a host-only entry point can be exercised without a GPU */
     int (*packed)(int, int, int, size_t*) = (int (*)(int, int, int, size_t*))dlsym(h, "midyn_stack_packed_bytes");
     size_t bytes = 0;

@@ -91,3 +91,38 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out}"
         assert f"rank {rank} ok" in out
+
+
+def test_bench_spawns_its_own_ranks_and_refuses_mismatched_worlds():
+    """`python bench.py --gpus N` without a launcher spawns N ranks itself (one process per GPU); here with the
+    CPU stand-in for the device solve (MIDYN_BENCH_STUB: gloo, no GPU) -- the launcher, the rendezvous, the
+    strong / weak shard arithmetic, the barriers and the MAX reduction are the production code.  It must never
+    print a line for fewer ranks than asked for."""
+    import json
+
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, MIDYN_BENCH_STUB="1")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    p = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                       # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["instances_total"] == 4096 and out["shard_rank0"] == [0, 2048]   # BASELINE configs[2]: 4096 in TOTAL
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--weak", "--batch", "100"], env=env, capture_output=True,
+                       text=True, timeout=240)
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "weak" and out["instances_total"] == 200 and out["shard_rank0"] == [0, 100]
+    # a launcher-provided world that disagrees with --gpus is an error, not a smaller job
+    env_bad = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, bench, "--gpus", "8"], env=env_bad, capture_output=True, text=True, timeout=60)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    # without the stub and without GPUs, --gpus 8 refuses (no n_gpus = 1 line)
+    import torch
+
+    if not torch.cuda.is_available():
+        env_real = {k_: v for k_, v in env.items() if k_ != "MIDYN_BENCH_STUB"}
+        p = subprocess.run([sys.executable, bench, "--gpus", "8"], env=env_real, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

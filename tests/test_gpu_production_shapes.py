@@ -293,3 +293,63 @@ def test_shared_signal_sweep_is_folded_into_columns(qd):
     many = solver.solve(t_span=[0.0, 0.2], y0=y0m, signals=sigs, method="RK4", max_dt=0.01)
     one = solver.solve(t_span=[0.0, 0.2], y0=y0m[2], signals=sigs, method="RK4", max_dt=0.01)
     assert_close(many[2].y, one.y, 1e-11)
+
+
+def test_stack_broadcast_over_the_c_abi_one_rank(qd):
+    """midyn_comm_get_unique_id / midyn_comm_init_rank / midyn_stack_create_empty / midyn_stack_broadcast on one
+    GPU (world size 1: the RCCL broadcast is a self-copy): librccl is resolved at first use, the communicator is
+    bound to the context's device, the stack works after the call and lazily built lists are rebuilt.  The
+    N > 1 use of the same entry points is bench.py --gpus N (driver's scaling run)."""
+    from qiskit_dynamics_amd import _lib
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(3)
+    n, k = 96, 3
+    ops, static = crand(rng, k, n, n), crand(rng, n, n)
+    fim = rng.normal(size=n)
+    stack = qd.Stack(ctx, ops, static, fim)
+    y = crand(rng, n, 5)
+    c = rng.uniform(-1, 1, k)
+    before = stack.eval_rhs(c, 0.3, y)
+    uid = _lib.Comm.unique_id()
+    assert len(uid) == 128 and _lib.RCCL_LIBRARY
+    comm = _lib.Comm(ctx, 1, 0, uid)
+    stack.broadcast(comm, 0)
+    assert stack.n == n and stack.k == k and stack.n_active_segments == k + 1
+    assert np.array_equal(stack.eval_rhs(c, 0.3, y), before)
+    # a receiving-side stack: empty until a broadcast fills it (here: filled by a device copy of the packed buffer
+    # is not possible from Python, so only the shape / zero content are checked)
+    empty = _lib.Stack.empty(ctx, n, k, True, True)
+    assert empty.n == n and empty.n_active_segments == 0
+    with pytest.raises(qd.DynamicsError):
+        stack.broadcast(comm, 3)                     # root out of range
+    comm.close()
+    empty.close()
+
+
+def test_event_timer_and_block_info(qd):
+    """midyn_ctx_timer brackets launches on the library's stream; midyn_stack_block_info reports what the
+    work-list kernels execute (checked against a host count of the non-zero 16x16 blocks)."""
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    cfg = W.schrodinger_config(n_qubits=9, n_drives=8, t_final=1.0, max_dt=0.01)
+    frame = np.diag(cfg["h_d"]).real.copy()
+    m = qd.HamiltonianModel(static_operator=cfg["h_d"], operators=cfg["ops"],
+                            signals=[qd.Signal(1.0, 5.0)] * 8, rotating_frame=frame)
+    info = m.stack.block_info()
+    assert info["state"] == 1
+    g = [-1j * (cfg["h_d"] - np.diag(np.diag(cfg["h_d"])))] + [-1j * o for o in cfg["ops"]]
+    nz = 0
+    for a in g:
+        blocks = np.abs(a).reshape(32, 16, 32, 16).max(axis=(1, 3))
+        nz += int(np.count_nonzero(blocks))
+    assert info["nonzero_blocks"] == nz and info["blocks_per_side"] == 32
+    assert abs(info["block_density"] - nz / (9 * 32 * 32)) < 1e-12
+    assert info["tile_lists"][16]["listed_tiles"] == nz          # 16-row panels list exactly the non-zero blocks
+    assert info["tile_lists"][128]["listed_tiles"] >= nz / 8
+    ctx.timer_start()
+    for _ in range(5):
+        m.evaluate_rhs(0.1, cfg["y0"])
+    ms = ctx.timer_stop()
+    assert 0.0 < ms < 1000.0

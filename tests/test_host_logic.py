@@ -207,7 +207,7 @@ def test_header_is_plain_c_and_symbols_resolve(tmp_path):
     src = os.path.join(ROOT, "tests", "abi_probe.c")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-o", str(exe), src, "-ldl"], check=True)
     p = subprocess.run([str(exe), _lib.HIP_RUNTIME, _lib.LIB_PATH], capture_output=True, text=True)
-    assert p.returncode == 0 and "ABI_OK 28 symbols" in p.stdout, p.stdout + p.stderr
+    assert p.returncode == 0 and "ABI_OK %d symbols" % len(_lib.ABI_SYMBOLS) in p.stdout, p.stdout + p.stderr
     # and the same header as C++
     cpp = tmp_path / "h.cpp"
     cpp.write_text('#include "%s"\nint main() { midyn_complex z{1.0, 2.0}; return z.re > 0 ? 0 : 1; }\n'
