@@ -356,10 +356,12 @@ def cfg5_roofline(ctx, stack, cs, n_cols, n, n_steps, wall, n_inst):
     lst = ctx.counters("sparse_list")
     bm, bn = int(tile["launches"]), int(tile["ms"])
     listed, splits = lst["launches"], int(lst["ms"])
+    per_launch = max(1, int(ctx.counters("sparse_pair")["launches"]))   # 2: two independent products share a launch
     cols_pad = -(-n_cols // bn) * bn
     modes = [m for m in stack.segment_modes if m != 3]
     real_flops_per_mac = 4 if all(m in (1, 2) for m in modes) else 8
-    flops_launch = listed * bm * 16 * cols_pad * real_flops_per_mac      # every listed (BM x 16) tile times all columns
+    # every listed (BM x 16) tile times all columns, for each contraction of the launch
+    flops_launch = per_launch * listed * bm * 16 * cols_pad * real_flops_per_mac
     tf = flops_launch / (avg_ms * 1e-3) / 1e12
     return {
         "kernel": f"zgemm_seg_kernel<{bm},{bn},...,SPARSE> (batched contraction over the tile work lists, fp64 MFMA)",
@@ -367,7 +369,7 @@ def cfg5_roofline(ctx, stack, cs, n_cols, n, n_steps, wall, n_inst):
         "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
         "launches_timed": int(launches), "executed_mfma_flops_per_launch": flops_launch,
         "listed_tiles": int(listed), "tile": [bm, bn], "splits": splits, "columns": n_cols,
-        "contractions_per_step": round(launches / n_steps, 2),
+        "contractions_per_launch": per_launch, "contractions_per_step": round(per_launch * launches / n_steps, 2),
         "note": "executed flops = listed (panel, K tile, operator) tiles x BM x 16 x columns x 4 real flops per complex "
                 "MAC (single-plane operators); short panels are latency-bound (DESIGN 4.12, section 8)",
         "dense_form_price": {
@@ -484,6 +486,7 @@ def main():
     ap.add_argument("--plane-kernel", action="store_true", help="A/B: planar two-tiles-per-barrier kernel (opt-in)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: kernel ablation bits (results wrong)")
     ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 | 12864 (kernel A/B testing)")
+    ap.add_argument("--opt", action="append", default=[], help="A/B: ctx option NAME=VALUE (repeatable)")
     args = ap.parse_args()
     stub = bool(os.environ.get("MIDYN_BENCH_STUB"))
 
@@ -522,6 +525,9 @@ def main():
         ctx.set_option("complex_3m", args.complex_3m)
     if args.plane_kernel:
         ctx.set_option("plane_kernel", 1)
+    for item in args.opt:
+        name, _, val = item.partition("=")
+        ctx.set_option(name, int(val))
 
     cfg = workloads.schrodinger_config(N_QUBITS, N_DRIVES, T_FINAL, MAX_DT)
     n = 2**N_QUBITS

@@ -61,6 +61,8 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   complex_3m [1]        dense complex products with 3 real MFMAs instead of 4 (normwise error bound): 0 never,
  *                         1 in solver loops / expm only (midyn_eval_rhs, midyn_zgemm stay 4M), 2 everywhere
  *   split_k [1], force_splits [0], force_tile [0 | 64 | 128 | 12864]   tile / split-K choice of the zgemm
+ *   splitk_inlaunch [0]   sum the split-K partials inside the contraction launch (measured slower, opt-in)
+ *   pair_launch [1]       sparse MFMA route: the two independent products of a Magnus-2 level share one launch
  *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage
  *   multi_stream [1]      2..8 state columns at n >= 256: multi-column streaming kernel
  *   tiny_rk4 [1]          small systems: whole fixed-step solve in one persistent launch
@@ -245,7 +247,8 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * out[0] = launches, out[1] = total ms (events are only recorded when profiling is enabled with
  * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch).
  * Two more names describe the LAST launch of the sparse MFMA route: "sparse_tile" -> (BM, BN) of its tile,
- * "sparse_list" -> (listed (panel, K tile, operator) tiles of the stack for that panel height, split count). */
+ * "sparse_list" -> (listed (panel, K tile, operator) tiles of the stack for that panel height, split count),
+ * "sparse_pair" -> (contractions in that launch: 2 when two independent products shared it, ctx option pair_launch). */
 int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);
 int midyn_reset_counters(midyn_ctx* ctx);
 /* Measured ceilings: "mfma_f64" -> out[0] = TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64;

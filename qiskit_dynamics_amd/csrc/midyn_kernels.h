@@ -42,6 +42,12 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 __device__ __forceinline__ double2 cmul_conj_a(double2 a, double2 b) {  // conj(a) * b
     return make_double2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
 }
+// device-coherent load of one complex number (agent-scope atomic loads: served past non-coherent cache lines)
+__device__ __forceinline__ double2 coherent_load2(const double2* p) {
+    const double* q = reinterpret_cast<const double*>(p);
+    return make_double2(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                        __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 __device__ __forceinline__ double2 cfma_r(double s, double2 a, double2 c) {  // c + s*a, s real
     return make_double2(fma(s, a.x, c.x), fma(s, a.y, c.y));
 }
@@ -708,7 +714,11 @@ struct GemmArgs {
                                           // (replaces the strides: products of scattered matrices)
     int splits;              // split-K: gridDim = tiles * splits; split z handles K tiles [z*KT/splits, ...)
     double2* partial;        // [splits][M][N] raw partial sums when splits > 1 (epilogue runs in
-                             // splitk_reduce_kernel), nullptr otherwise
+                             // splitk_reduce_kernel, or in this launch when `sync` is set), nullptr otherwise
+    int* sync;               // in-launch split-K reduction: per tile {arrived, departed} counters (all zero between
+                             // launches); every workgroup of a tile waits for its `splits` siblings, then sums and
+                             // finishes 1/splits of the tile.  Needs ALL workgroups of the launch co-resident.
+    int* sync_err;           // host-mapped error word: incremented if the wait gave up (never in normal operation)
     // block-sparse stacks (SPARSE instantiation): the tiles of row panel bm that hold a non-zero, K tile
     // outer / segment inner like the dense loop: work_idx[work_ptr[bm] .. work_ptr[bm+1]) with
     // entry = (K tile << 8) | (seg << 2 | mode); split z of `splits` takes an equal share of the LIST
@@ -763,6 +773,14 @@ __device__ __forceinline__ void mfma_kstep(const double2 (&a)[MT], const double2
     }
     const bool do_re = MODE == 3 ? (rt_mode != 2) : (MODE != 2);
     const bool do_im = MODE == 3 ? (rt_mode != 1) : (MODE != 1);
+    if (MODE == 1 || MODE == 2) {
+        // Only one plane of A feeds MFMAs here.  Without this (empty) use of the other half hipcc narrows the
+        // fragment loads to 8 bytes and pairs them as ds_read2st64_b64, whose 32-dword bank modulus makes the
+        // swizzled rows collide 2-way (rocprofv3: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 40 %, 16 LDS cycles
+        // per pair instead of 8).  Both halves live -> one conflict-free ds_read_b128 per fragment.
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(MODE == 1 ? a[mt].y : a[mt].x));
+    }
     double br[NT], bi[NT], bin[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -820,8 +838,8 @@ __device__ __forceinline__ void read_frags(const double2* __restrict__ Ab, const
 
 // second launch-bound argument = waves per SIMD the register allocation must allow: the 4-wave
 // configurations are meant to run two workgroups per CU (2 waves per SIMD -> <= 256 registers).
-template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2, bool SPARSE = false>
-__global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs g) {
+template <int BM, int BN, int WM, int WN, int BK, int MODE, bool SPARSE>
+__device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batch_idx) {
     constexpr int THREADS = 64 * WM * WN;
     constexpr int NWAVE = WM * WN;
     constexpr int TM = BM / WM;  // wave tile
@@ -908,12 +926,12 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
         const int c = wave + NWAVE * p;
         b_src[p] = (c / B_PER_ROW) * g.ldb + (c % B_PER_ROW) * 64 + lane;
     }
-    long long off_a = (long long)blockIdx.y * g.batch_a, off_b = (long long)blockIdx.y * g.batch_b;
-    long long off_c = (long long)blockIdx.y * g.batch_c;
+    long long off_a = (long long)batch_idx * g.batch_a, off_b = (long long)batch_idx * g.batch_b;
+    long long off_c = (long long)batch_idx * g.batch_c;
     if (g.batch_offs) {
-        off_a = g.batch_offs[3 * blockIdx.y];
-        off_b = g.batch_offs[3 * blockIdx.y + 1];
-        off_c = g.batch_offs[3 * blockIdx.y + 2];
+        off_a = g.batch_offs[3 * batch_idx];
+        off_b = g.batch_offs[3 * batch_idx + 1];
+        off_c = g.batch_offs[3 * batch_idx + 2];
     }
     const double2* Abase = g.A + off_a + (size_t)m0 * g.lda + (size_t)kt0 * BK;
     const double2* Bbase = g.B + off_b + n0 + (size_t)kt0 * BK * g.ldb;
@@ -1098,8 +1116,85 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
                 for (int r = 0; r < 4; ++r) {
                     const int row = m0 + wm * TM + mt * 16 + lk + 4 * r;
                     const int col = n0 + wn * TN + nt * 16 + lcol;
-                    P[(size_t)row * g.N + col] = make_double2(cre[mt][nt][r], cim[mt][nt][r]);
+                    if (g.sync) {
+                        // device-coherent (write-through) stores: the sibling workgroups run on other XCDs with
+                        // their own L2, and a full release fence (L2 write-back + invalidate by every workgroup)
+                        // was measured at +120 us per launch
+                        double* q = reinterpret_cast<double*>(P + (size_t)row * g.N + col);
+                        __hip_atomic_store(q, cre[mt][nt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(q + 1, cim[mt][nt][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        P[(size_t)row * g.N + col] = make_double2(cre[mt][nt][r], cim[mt][nt][r]);
+                    }
                 }
+        if (g.sync == nullptr) return;
+        // ---- in-launch reduction: wait for the sibling splits of this tile, then sum (in split order: the result
+        // is bit-identical to splitk_reduce_kernel's) and finish 1/splits of the tile -- no second launch ----------
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's coherent stores have completed
+        __syncthreads();
+        int* cnt = g.sync + 2 * tile_id;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.splits) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1ll << 26)) {   // seconds: a sibling never ran (the launch was not co-resident)
+                    __hip_atomic_fetch_add(g.sync_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            constexpr int E = BM * BN;
+            const int e0 = (int)((long long)E * split / g.splits), e1 = (int)((long long)E * (split + 1) / g.splits);
+            const size_t plane_mn = (size_t)g.M * g.N;
+            switch (g.epi.mode) {  // workgroup-uniform; one straight-line instantiation per mode (see store_tile)
+#define MIDYN_SLICE(EM_)                                                                         \
+    case EM_:                                                                                    \
+        for (int e = e0 + tid; e < e1; e += THREADS) {                                           \
+            const int row = m0 + e / BN, col = n0 + e % BN;                                      \
+            const size_t idx = (size_t)row * g.N + col;                                          \
+            double2 c = coherent_load2(g.partial + idx);                                         \
+            for (int z = 1; z < g.splits; ++z) {                                                 \
+                const double2 v = coherent_load2(g.partial + (size_t)z * plane_mn + idx);        \
+                c.x += v.x;                                                                      \
+                c.y += v.y;                                                                      \
+            }                                                                                    \
+            apply_epilogue_t<EM_>(g.epi, row, col, c);                                           \
+        }                                                                                        \
+        break;
+                MIDYN_SLICE(EPI_RHS)
+                MIDYN_SLICE(EPI_RK1)
+                MIDYN_SLICE(EPI_RK2)
+                MIDYN_SLICE(EPI_RK3)
+                MIDYN_SLICE(EPI_RK4)
+                MIDYN_SLICE(EPI_TAYLOR)
+                MIDYN_SLICE(EPI_CHEB)
+                default:
+                    for (int e = e0 + tid; e < e1; e += THREADS) {
+                        const int row = m0 + e / BN, col = n0 + e % BN;
+                        const size_t idx = (size_t)row * g.N + col;
+                        double2 c = coherent_load2(g.partial + idx);
+                        for (int z = 1; z < g.splits; ++z) {
+                            const double2 v = coherent_load2(g.partial + (size_t)z * plane_mn + idx);
+                            c.x += v.x;
+                            c.y += v.y;
+                        }
+                        apply_epilogue_t<EPI_PLAIN>(g.epi, row, col, c);
+                    }
+                    break;
+#undef MIDYN_SLICE
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {   // the last workgroup to leave the tile re-arms its counters for the next launch
+            const int d = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == g.splits - 1) {
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         return;
     }
     Epilogue epi = g.epi;
@@ -1117,6 +1212,23 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs 
         return;
     }
     store_tile<MT, NT>(epi, m0 + wm * TM + lk, n0 + wn * TN + lcol, cre, cim);
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2, bool SPARSE = false>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_kernel(GemmArgs g) {
+    zgemm_seg_body<BM, BN, WM, WN, BK, MODE, SPARSE>(g, blockIdx.y);
+}
+
+// TWO independent contractions of the same shape in one launch (blockIdx.y selects the argument set): the
+// independent products of a Magnus-2 term (g1.v and g2.v, then g2.u1 and g1.u2) on block-sparse stacks are short
+// latency-bound launches (~28 us each with an 11 us fixed floor); side by side they share that floor
+// and the second workgroup of a CU hides the first one's memory latency.  Results are bit-identical to two launches.
+struct GemmPair {
+    GemmArgs g[2];
+};
+template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2, bool SPARSE = true>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_pair_kernel(GemmPair gp) {
+    zgemm_seg_body<BM, BN, WM, WN, BK, MODE, SPARSE>(gp.g[blockIdx.y], 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1374,17 +1486,32 @@ __global__ __launch_bounds__(256) void extract_planes_kernel(const double2* ops,
 // inlined into this loop, hipcc (ROCm 7.2) merges the branches' final stores through one pointer
 // register and leaves it unset on the EPI_RK4 path (store to a garbage address; found as a memory
 // fault, verified in the ISA).  A compile-time mode gives every instantiation straight-line code.
-template <int EMODE>
+// SPLITS > 0: the number of partials is a compile-time constant, so all their loads are in flight together (with a
+// run-time count the loop issues load - wait - add per partial: 8 serial memory round trips per element).
+template <int EMODE, int SPLITS>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const double2* partial, int splits, int M, int N,
                                                             Epilogue epi) {
     const size_t total = (size_t)M * N;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * 256) {
-        double2 c = partial[idx];
-        for (int z = 1; z < splits; ++z) {
-            const double2 v = partial[(size_t)z * total + idx];
-            c.x += v.x;
-            c.y += v.y;
+        double2 c;
+        if (SPLITS > 0) {
+            double2 v[SPLITS > 0 ? SPLITS : 1];
+#pragma unroll
+            for (int z = 0; z < SPLITS; ++z) v[z] = partial[(size_t)z * total + idx];
+            c = v[0];
+#pragma unroll
+            for (int z = 1; z < SPLITS; ++z) {   // same order as the generic loop: bit-identical sums
+                c.x += v[z].x;
+                c.y += v[z].y;
+            }
+        } else {
+            c = partial[idx];
+            for (int z = 1; z < splits; ++z) {
+                const double2 v = partial[(size_t)z * total + idx];
+                c.x += v.x;
+                c.y += v.y;
+            }
         }
         const int row = (int)(idx / N);
         apply_epilogue_t<EMODE>(epi, row, (int)(idx - (size_t)row * N), c);

@@ -353,3 +353,34 @@ def test_event_timer_and_block_info(qd):
         m.evaluate_rhs(0.1, cfg["y0"])
     ms = ctx.timer_stop()
     assert 0.0 < ms < 1000.0
+
+
+def test_paired_sparse_launches_are_bit_identical(qd):
+    """The two independent products of a Magnus-2 level share ONE launch on the sparse MFMA route (ctx option
+    pair_launch, zgemm_seg_pair_kernel): same arithmetic per product, so the solve must be bit-identical to the
+    one-product-per-launch route -- with a diagonal frame (phased chain) and without a frame, split and unsplit."""
+    ctx = qd.default_context()
+    from qiskit_dynamics_amd import workloads as W
+
+    cfg = W.schrodinger_config(n_qubits=9, n_drives=8, t_final=1.0, max_dt=0.05)
+    rng = np.random.default_rng(6)
+    y0 = crand(rng, 512)
+    y0 /= np.linalg.norm(y0)
+    for frame in (np.diag(cfg["h_d"]).real.copy(), None):
+        solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
+        for nb in (24, 130):
+            sweeps = [_gauss_signals(qd, cfg, b, 8, 0.5) for b in range(nb)]
+            runs = {}
+            for pair in (1, 0):
+                ctx.set_option("pair_launch", pair)
+                try:
+                    r = _profiled(ctx, lambda: solver.solve(t_span=[0.0, 0.2], y0=y0, signals=sweeps,
+                                                            method="scipy_expm", max_dt=0.05, magnus_order=2))
+                finally:
+                    ctx.set_option("pair_launch", 1)
+                launches = ctx.counters("rhs_blocks_gemm")["launches"]
+                assert launches > 0
+                runs[pair] = (np.stack([x.y[-1] for x in r]), launches)
+            assert runs[1][1] * 2 == runs[0][1], (runs[1][1], runs[0][1])      # half the launches
+            assert np.array_equal(runs[1][0], runs[0][0])
+            assert np.max(np.abs(np.linalg.norm(runs[1][0], axis=1) - 1.0)) < 1e-10
