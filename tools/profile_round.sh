@@ -1,17 +1,21 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): bench + rocprofv3 kernel trace + separate PMC passes.
+# Runs on the GPU box (via gpurun): bench + rocprofv3 kernel trace + separate PMC passes (one counter set per run,
+# never combined with tracing domains other than --kernel-trace/--stats).
 # usage: tools/profile_round.sh <tag>      outputs under $GRAFT_REPO_ROOT/gpurun_out/<tag>/
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench.json 2> $O/bench.err
-python $R/tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.err
-B="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end"
+B="python $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-end-to-end"
+P="python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-end-to-end"
 rocprofv3 --kernel-trace --stats -d $O/stats -o bench -- $B > $O/prof_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/prof_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/prof_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/prof_mfma.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_lds -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end > $O/prof_lds.log 2>&1
-tail -c 3000 $O/bench.json
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench -- $P > $O/prof_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench -- $P > $O/prof_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -o bench -- $P > $O/prof_mfma.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_lds -o bench -- $P > $O/prof_lds.log 2>&1
+python $R/tools/summarize_rocprof.py $O $O/rocprof_bench.md "round $TAG: bench.py (cfg 3 headline + dense_complex + cfg 2 + cfg 4 + cfg 5 legs)" > /dev/null
+python $R/tools/bench_splitk.py 64 128 256 512 1024 2048 4096 > $O/splitk.txt 2>&1
+find $O -name "*.db" -delete; find $O -name "*.csv" -size +1M -delete; tail -5 $O/prof_stats.log; du -sh $O; ls $O
+tail -c 600 $O/bench.json
