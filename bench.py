@@ -241,7 +241,7 @@ def shared_stack(qd, ctx, D, builder, n, k, route):
 # CPU plumbing stub (tests/test_distributed_gloo.py): same launcher, sharding, barriers and MAX reduction, a
 # stand-in for the device solve.  Never used with a GPU; prints a line marked "stub".
 # -----------------------------------------------------------------------------------------------------------------
-def run_stub(args, D):
+def run_stub(args, D, json_out):
     from qiskit_dynamics_amd.distributed import shard_bounds
 
     total = args.batch or SWEEP
@@ -254,7 +254,7 @@ def run_stub(args, D):
     if D.rank == 0:
         print(json.dumps({"metric": "stub", "stub": True, "n_gpus": D.world, "instances_total": n_inst,
                           "scaling": "weak" if args.weak else "strong", "shard_rank0": [lo, hi],
-                          "elapsed_max_s": round(elapsed, 4)}), flush=True)
+                          "elapsed_max_s": round(elapsed, 4)}), file=json_out, flush=True)
     D.close()
 
 
@@ -501,12 +501,17 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr, flush=True)
         raise SystemExit(2)
+    # ONE JSON line on stdout: libraries (RCCL prints a version banner to stdout at communicator creation) get
+    # stderr as their stdout; the line itself goes to a private duplicate of the original descriptor
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     D = Dist(world, rank, local_rank, stub)
     if stub:
-        run_stub(args, D)
+        run_stub(args, D, json_out)
         return
 
     import qiskit_dynamics_amd as qd
@@ -798,7 +803,7 @@ def main():
                 "solve_s": round(t_solve, 2), "rhs_evals_per_s_end_to_end": round(b_loc * 4000 / t_solve, 1),
                 "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(yf, axis=1) - 1.0)))}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     D.close()
 
 

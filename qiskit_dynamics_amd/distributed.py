@@ -40,7 +40,10 @@ def init_process_group_from_env(backend: str = "nccl"):
         # cuda:0 (two ranks on one device = RCCL "duplicate GPU" error or a hang)
         import torch
 
-        torch.cuda.set_device(local_device())
+        dev = local_device()
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        return rank, world
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
 
