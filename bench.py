@@ -209,12 +209,24 @@ def shared_stack(qd, ctx, D, builder, n, k, route):
     from qiskit_dynamics_amd.distributed import broadcast_stack
 
     t0 = time.perf_counter()
-    arrays = builder() if D.rank == 0 else (None, None, None)
+    arrays, build_error = (None, None, None), None
+    if D.rank == 0:
+        try:
+            arrays = builder()
+        except Exception as exc:  # pylint: disable=broad-except
+            build_error = repr(exc)
     build_s = time.perf_counter() - t0
     if not D.active:
+        if build_error:
+            raise RuntimeError(build_error)
         return qd.Stack(ctx, *arrays), None, {"route": "none (one rank)", "host_build_s": round(build_s, 2)}
+    # every rank learns whether the host build on rank 0 worked BEFORE anybody enters a collective on the stack
+    build_error = D.bcast_bytes(build_error)
+    if build_error:
+        raise RuntimeError("host model build failed on rank 0: " + build_error)
     info = {"host_build_s": round(build_s, 2)}
     if route == "abi":
+        result, err = None, None
         try:
             uid = D.bcast_bytes(_lib.Comm.unique_id() if D.rank == 0 else None)
             comm = _lib.Comm(ctx, D.world, D.rank, uid)
@@ -225,11 +237,16 @@ def shared_stack(qd, ctx, D, builder, n, k, route):
             t1 = time.perf_counter()
             stack.broadcast(comm, 0)
             ctx.synchronize()
-            info.update(route="midyn_stack_broadcast (C-ABI, RCCL ncclBroadcast)", broadcast_ms=round(D.max((time.perf_counter() - t1) * 1e3), 3),
-                        bytes=_lib.Stack.packed_bytes(n, k, meta[0]))
-            return stack, comm, info
+            bc_ms = (time.perf_counter() - t1) * 1e3
+            result = (stack, comm, meta)
         except Exception as exc:  # pylint: disable=broad-except
-            info["abi_route_error"] = repr(exc)   # fall through to the torch.distributed route (still RCCL)
+            err = repr(exc)
+        # the choice of route is collective: one failing rank sends every rank to the torch.distributed route
+        if D.max(0.0 if result is not None else 1.0) == 0.0:
+            info.update(route="midyn_stack_broadcast (C-ABI, RCCL ncclBroadcast)", broadcast_ms=round(D.max(bc_ms), 3),
+                        bytes=_lib.Stack.packed_bytes(n, k, result[2][0]))
+            return result[0], result[1], info
+        info["abi_route_error"] = err or "failed on another rank"
     D.barrier()
     t1 = time.perf_counter()
     stack, keep = broadcast_stack(ctx, arrays[0], arrays[1], arrays[2], n, k, src=0)
