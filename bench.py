@@ -108,11 +108,12 @@ def spawn_ranks(n_ranks: int, argv) -> int:
 # helpers
 # -----------------------------------------------------------------------------------------------------------------
 def measured_traffic(kernel_prefix):
-    """HBM bytes per dispatch of the newest committed rocprofv3 PMC summary (profiles/*.traffic.json),
-    or None.  bench.py cannot collect PMC counters itself; the profile run is tools/profile_round.sh."""
+    """(HBM bytes per dispatch, source) of the newest committed rocprofv3 PMC summary (profiles/*.traffic.json:
+    FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate --pmc passes), or (None, None).  bench.py cannot collect
+    PMC counters itself; the profile run is tools/profile_round.sh."""
     import glob
 
-    best = None
+    best = (None, None)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*.traffic.json"))):
         try:
             data = json.load(open(path))
@@ -120,8 +121,7 @@ def measured_traffic(kernel_prefix):
             continue
         for name, t in data.get("kernels", {}).items():
             if name.startswith(kernel_prefix) and "fetch_bytes" in t:
-                best = {"bytes": round(t["fetch_bytes"] + t.get("write_bytes", 0.0)), "kernel": name,
-                        "source": os.path.basename(path)}
+                best = (round(t["fetch_bytes"] + t.get("write_bytes", 0.0)), f"{os.path.basename(path)}: {name}")
     return best
 
 
@@ -342,7 +342,8 @@ def leg_cfg4(qd, ctx, workloads):
         out["roofline"] = {
             "kernel": "rhs_blocks_kernel<1> (expm action: one product G.v per launch over the non-zero 16x16 blocks)",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic("rhs_blocks_kernel<1>")[0],
+            "traffic_source": measured_traffic("rhs_blocks_kernel<1>")[1], "avg_launch_ms": round(avg_ms, 5),
             "launches_timed": int(launches), "executed_bytes_per_launch": bytes_launch,
             "nonzero_blocks": blk["nonzero_blocks"], "block_density": round(blk["block_density"], 5),
             "products_per_step": round(launches / n_steps, 2),
@@ -628,12 +629,13 @@ def main():
         per_seg = [(6 if use_3m else 8) if m == 0 else 4 for m in modes if m != 3]
         executed = sum(per_seg) * n * n * b_loc                    # real MFMA flops the kernel executes per launch
         tf = executed / (avg_ms * 1e-3) / 1e12
+        traffic3 = measured_traffic("zgemm_seg_kernel<64, 64, 2, 2, 16, 4," if (args.dense or stack_um == 0)
+                                    else "zgemm_seg_kernel<128, 128, 2, 4, 16, %d," % stack_um)
         roofline = {
             "kernel": "zgemm_seg_kernel (batched RHS, fp64 MFMA 16x16x4)", "bound": "mfma",
             "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
-            "traffic": measured_traffic("zgemm_seg_kernel<64, 64, 2, 2, 16, 4," if (args.dense or stack_um == 0)
-                                        else "zgemm_seg_kernel<128, 128, 2, 4, 16, %d," % stack_um),
+            "traffic": traffic3[0], "traffic_source": traffic3[1],
             "avg_launch_ms": round(avg_ms, 4), "launches_timed": 4 * args.steps,
             "avg_launch_ms_per_launch_events": round(cnt["ms"] / cnt["launches"], 4),
             "executed_mfma_flops_per_launch": executed,
@@ -726,7 +728,8 @@ def main():
             "ms_per_step": round(el1 / (s_total - 8) * 1e3, 4)}
         out["roofline_single_trajectory"] = {
             "kernel": kname.split("<")[0], "bound": "hbm", "achieved": round(gbs_exec, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(gbs_exec / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname),
+            "unit": "GB/s", "frac": round(gbs_exec / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname)[0],
+            "traffic_source": measured_traffic(kname)[1],
             "avg_launch_ms": round(avg_ms1, 5), "launches_timed": 4 * (s_total - 8),
             "avg_launch_ms_per_launch_events": round(c1["ms"] / max(c1["launches"], 1), 5),
             "executed_bytes_per_launch": executed_bytes,

@@ -630,6 +630,53 @@ def gen_lab_frame():
 
 
 # ---------------------------------------------------------------------------------------------
+def gen_interface():
+    """a12: y0 into the frame basis / results out of it for Hamiltonian, Lindblad and vectorised Lindblad models
+    (test_solver_functions_interface.py:164-395: X drive, Z static, Y dissipator, frame 1.2 X - 3.132 Y,
+    y0 = (3.43, 1.31)), and the Solver sanity scenario `vectorised == non-vectorised` (test_solver_classes.py:461-697).
+    Models evaluated at t = 231.232 (the reference test's time) and solved end to end; results are stored OUT of the
+    frame basis (gauge invariant)."""
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    y = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    frame = 1.2 * x - 3.132 * y
+    y0 = np.array([3.43, 1.31], dtype=complex)
+    rho0 = np.outer(y0, y0.conj()) / np.vdot(y0, y0)
+    t = 231.232
+    out = {"frame": frame, "y0": y0, "rho0": rho0, "t": np.array(t)}
+    for ftag, fr in (("nofr", None), ("fr", frame)):
+        hm = HamiltonianModel(operators=[x], signals=[Signal(1.0, 5.0)], static_operator=z, rotating_frame=fr)
+        out[f"{ftag}_ham_eval"] = hm(t)
+        out[f"{ftag}_ham_rhs"] = hm(t, y0)
+        for method, kw in (("RK4", dict(max_dt=1e-3)), ("scipy_expm", dict(max_dt=1e-2)),
+                           ("scipy_expm", dict(max_dt=1e-2, magnus_order=2))):
+            hm2 = HamiltonianModel(operators=[x], signals=[Signal(1.0, 5.0)], static_operator=z, rotating_frame=fr)
+            r = solve_lmde(hm2, t_span=[0.0, 1.1], y0=y0, method=method, t_eval=[0.3, 1.1], **kw)
+            out[f"{ftag}_ham_{method}_{kw.get('magnus_order', 1)}_y"] = np.array(r.y)
+        for vec in (False, True):
+            lm = LindbladModel(hamiltonian_operators=[x], hamiltonian_signals=[Signal(1.0, 5.0)], static_hamiltonian=z,
+                               static_dissipators=[y], rotating_frame=fr, vectorized=vec)
+            yin = rho0.flatten(order="F") if vec else rho0
+            out[f"{ftag}_lind_{'vec' if vec else 'mat'}_rhs"] = lm(t, yin)
+            if vec:
+                out[f"{ftag}_lind_vec_eval"] = lm(t)
+            lm2 = LindbladModel(hamiltonian_operators=[x], hamiltonian_signals=[Signal(1.0, 5.0)], static_hamiltonian=z,
+                                static_dissipators=[y], rotating_frame=fr, vectorized=vec)
+            r = solve_lmde(lm2, t_span=[0.0, 0.7], y0=yin, method="RK4", max_dt=1e-3) if not vec else \
+                solve_lmde(lm2, t_span=[0.0, 0.7], y0=yin, method="scipy_expm", max_dt=1e-2)
+            out[f"{ftag}_lind_{'vec' if vec else 'mat'}_y"] = np.array(r.y)
+    # Solver: weak 0.01 X dissipator, vectorised and not, pi-pulse style drive (test_solver_classes.py:461-697)
+    for vec in (False, True):
+        s = Solver(hamiltonian_operators=[x / 2], static_hamiltonian=5 * z, rotating_frame=5 * z,
+                   static_dissipators=[0.01 * x], vectorized=vec)
+        rho = np.array([[0.0, 0.0], [0.0, 1.0]], dtype=complex)
+        r = s.solve(t_span=[0.0, 1.0], y0=rho.flatten(order="F") if vec else rho, signals=[Signal(1.0, 5.0 / np.pi)],
+                    method="RK4" if not vec else "scipy_expm", max_dt=1e-3 if not vec else 1e-2)
+        out[f"solver_{'vec' if vec else 'mat'}_y"] = np.array(r.y)
+    save("interface", **out)
+
+
+# ---------------------------------------------------------------------------------------------
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "perturbative":
@@ -637,6 +684,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lab_frame":
         gen_lab_frame()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "interface":
+        gen_interface()
         sys.exit(0)
     gen_collection()
     gen_signals()
@@ -648,3 +698,4 @@ if __name__ == "__main__":
     gen_rotating_frame()
     gen_perturbative()
     gen_lab_frame()
+    gen_interface()

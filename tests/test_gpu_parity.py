@@ -2354,3 +2354,46 @@ def test_chebyshev_action_backwards_in_time(qd, nq):
         finally:
             ctx.set_option("chebyshev", 1)
         assert_close(bw.y[-1], bw0.y[-1], 1e-12)
+
+
+@pytest.mark.parametrize("ftag", ["nofr", "fr"])
+def test_interface_scenario_golden(qd, golden, ftag):
+    """y0 into the frame basis / results out of it for Hamiltonian, Lindblad and vectorised Lindblad
+    models (test_solver_functions_interface.py:164-395: X drive, Z static, Y dissipator, frame 1.2 X - 3.132 Y,
+    y0 = (3.43, 1.31), evaluations at t = 231.232) and the Solver sanity scenario with a weak dissipator, vectorised
+    and not (test_solver_classes.py:461-697) -- the device path against values captured from the reference."""
+    g = golden("interface")
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    y = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    frame = None if ftag == "nofr" else g["frame"]
+    t = float(g["t"])
+    hm = qd.HamiltonianModel(operators=[x], signals=[qd.Signal(1.0, 5.0)], static_operator=z, rotating_frame=frame)
+    assert_close(hm(t), g[f"{ftag}_ham_eval"], 1e-10)        # |t F| ~ 800: phases to 1e-13 relative
+    assert_close(hm(t, g["y0"]), g[f"{ftag}_ham_rhs"], 1e-10)
+    for method, mo, dt in (("RK4", 1, 1e-3), ("scipy_expm", 1, 1e-2), ("scipy_expm", 2, 1e-2)):
+        kw = {"magnus_order": mo} if method == "scipy_expm" else {}
+        r = qd.solve_lmde(hm, t_span=[0.0, 1.1], y0=g["y0"], method=method, t_eval=[0.3, 1.1], max_dt=dt, **kw)
+        assert_close(r.y, g[f"{ftag}_ham_{method}_{mo}_y"], SOLVE_TOL)
+    rho0 = g["rho0"]
+    for vec in (False, True):
+        lm = qd.LindbladModel(hamiltonian_operators=[x], hamiltonian_signals=[qd.Signal(1.0, 5.0)], static_hamiltonian=z,
+                              static_dissipators=[y], rotating_frame=frame, vectorized=vec)
+        tag = "vec" if vec else "mat"
+        yin = rho0.flatten(order="F") if vec else rho0
+        assert_close(lm(t, yin), g[f"{ftag}_lind_{tag}_rhs"], 1e-10)
+        if vec:
+            assert_close(lm(t), g[f"{ftag}_lind_vec_eval"], 1e-10)
+            r = qd.solve_lmde(lm, t_span=[0.0, 0.7], y0=yin, method="scipy_expm", max_dt=1e-2)
+        else:
+            r = qd.solve_lmde(lm, t_span=[0.0, 0.7], y0=yin, method="RK4", max_dt=1e-3)
+        assert_close(r.y, g[f"{ftag}_lind_{tag}_y"], SOLVE_TOL)
+    if ftag == "fr":
+        for vec in (False, True):
+            s = qd.Solver(hamiltonian_operators=[x / 2], static_hamiltonian=5 * z, rotating_frame=5 * z,
+                          static_dissipators=[0.01 * x], vectorized=vec)
+            rho = np.array([[0.0, 0.0], [0.0, 1.0]], dtype=complex)
+            r = s.solve(t_span=[0.0, 1.0], y0=rho.flatten(order="F") if vec else rho,
+                        signals=[qd.Signal(1.0, 5.0 / np.pi)], method="scipy_expm" if vec else "RK4",
+                        max_dt=1e-2 if vec else 1e-3)
+            assert_close(r.y, g[f"solver_{'vec' if vec else 'mat'}_y"], SOLVE_TOL)
