@@ -677,6 +677,46 @@ def gen_interface():
 
 
 # ---------------------------------------------------------------------------------------------
+def gen_adaptive():
+    """Callers of the RHS either side of the hot path: solve_ode / solve_lmde with scipy's adaptive methods
+    (solvers/scipy_solve_ivp.py:31-84 via solver_functions.py:200-207, 349-364) on the random framed 7 x 7 model of
+    test_solver_functions.py:76-115 and on the Lindblad models of the interface scenario."""
+    rng = np.random.default_rng(3093)
+    n, k = 7, 3
+    hops = np.array([herm(rng, n) for _ in range(k)])
+    hstatic = herm(rng, n)
+    hframe = herm(rng, n)
+    samples = crand(rng, 5)
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    sigs = [Signal(0.5, 1.0, 0.3), DiscreteSignal(dt=0.1, samples=samples, carrier_freq=1.0),
+            Signal(lambda t: 0.3 * np.cos(t) + 0 * 1j, 0.0)]
+    out = {"r7_hops": hops, "r7_hstatic": hstatic, "r7_hframe": hframe, "r7_samples": samples, "r7_y0": y0}
+    for method in ("RK45", "RK23", "DOP853", "BDF"):   # (the real-embedded LSODA / Radau wrappers fail inside the reference)
+        hm = HamiltonianModel(static_operator=hstatic, operators=hops, signals=sigs, rotating_frame=hframe)
+        tol = 1e-10 if method in ("RK45", "DOP853") else 1e-7
+        r = solve_lmde(hm, [0.0, 0.5], y0, method=method, t_eval=[0.1, 0.3, 0.5], atol=tol, rtol=tol)
+        out[f"r7_{method}_y"] = np.asarray(r.y)
+    hm = HamiltonianModel(static_operator=hstatic, operators=hops, signals=sigs, rotating_frame=hframe)
+    r = solve_lmde(hm, [0.0, 0.3], np.eye(n, dtype=complex), method="DOP853", atol=1e-10, rtol=1e-10)
+    out["r7_DOP853_unitary"] = np.asarray(r.y)
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    yy = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    frame = 1.2 * x - 3.132 * yy
+    v = np.array([3.43, 1.31], dtype=complex)
+    rho0 = np.outer(v, v.conj()) / np.vdot(v, v)
+    out["rho0"], out["frame"] = rho0, frame
+    for vec in (False, True):
+        lm = LindbladModel(hamiltonian_operators=[x], hamiltonian_signals=[Signal(1.0, 5.0)], static_hamiltonian=z,
+                           static_dissipators=[yy], rotating_frame=frame, vectorized=vec)
+        yin = rho0.flatten(order="F") if vec else rho0
+        r = solve_lmde(lm, [0.0, 0.7], yin, method="DOP853", atol=1e-10, rtol=1e-10)
+        out[f"lind_{'vec' if vec else 'mat'}_DOP853_y"] = np.asarray(r.y)
+    save("adaptive", **out)
+
+
+# ---------------------------------------------------------------------------------------------
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "perturbative":
@@ -687,6 +727,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "interface":
         gen_interface()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "adaptive":
+        gen_adaptive()
         sys.exit(0)
     gen_collection()
     gen_signals()
@@ -699,3 +742,4 @@ if __name__ == "__main__":
     gen_perturbative()
     gen_lab_frame()
     gen_interface()
+    gen_adaptive()

@@ -35,7 +35,13 @@ EXPM_METHODS = ("scipy_expm", "hip_expm")
 # parallel-in-time LMDE methods; the reference names are accepted as aliases
 RK4_PARALLEL_METHODS = ("hip_RK4_parallel", "jax_RK4_parallel")
 EXPM_PARALLEL_METHODS = ("hip_expm_parallel", "jax_expm_parallel")
-ODE_METHODS = list(RK4_METHODS)
+# scipy's adaptive integrators with the DEVICE right-hand side as their callback (a caller either side of the hot
+# path; reference: solvers/scipy_solve_ivp.py:26-84).  COMPLEX methods integrate the complex state directly, the
+# others a real embedding (Re, Im), exactly as the reference does.
+SOLVE_IVP_COMPLEX_METHODS = ("RK45", "RK23", "BDF", "DOP853")
+SOLVE_IVP_REAL_METHODS = ("LSODA", "Radau")
+SOLVE_IVP_METHODS = SOLVE_IVP_COMPLEX_METHODS + SOLVE_IVP_REAL_METHODS
+ODE_METHODS = list(RK4_METHODS + SOLVE_IVP_METHODS)
 LMDE_METHODS = list(EXPM_METHODS + RK4_PARALLEL_METHODS + EXPM_PARALLEL_METHODS)
 
 
@@ -454,20 +460,80 @@ def _solve_batch_lindblad(model, sched, y0_list, signals_list, shared_y0):
     return results
 
 
+def _solve_ivp_device(model, t_span, y0, method, t_eval=None, signals=None, **kwargs) -> OdeResult:
+    """``scipy.integrate.solve_ivp`` with the model's RHS evaluated on the device (scipy_solve_ivp.py:31-84 through
+    solver_functions.py:200-207): y0 into the frame basis, the integrator runs on the host in the frame basis and calls
+    ``G(t) y`` (``midyn_eval_rhs`` / ``midyn_lindblad_rhs``: kernels + one small PCIe round trip per evaluation),
+    results out of the frame basis.  Keyword arguments (``atol``, ``rtol``, ``max_step``, ...) go to ``solve_ivp``."""
+    from scipy.integrate import solve_ivp
+
+    if kwargs.get("dense_output", False) is True:
+        raise DynamicsError("dense_output not supported for solve_ivp.")
+    kind = _model_kind(model)
+    if kind == "lindblad":
+        n = model.dim
+        rho0 = np.asarray(y0, dtype=complex)
+        if rho0.shape != (n, n):
+            raise DynamicsError("Shape mismatch for initial state y0 and LindbladModel.")
+        state0 = _rotate_density(model, rho0[None], True)[0]
+        shape = (n, n)
+
+        def rhs(t, rho):
+            return model._lind.rhs(_signal_table(model, signals, np.array([t]))[0], t, rho[None])[0]
+    else:
+        state0, tag = _prepare_y0_batch(model, kind, [y0], True)      # (rows, m) in the frame basis
+        shape = state0.shape
+        stack = model.stack
+
+        def rhs(t, y):
+            coeffs = _signal_table(model, signals, np.array([t]))[0] if stack.k else None
+            return stack.eval_rhs(coeffs, t, y)
+
+    def flat(t, yf):
+        return rhs(t, yf.reshape(shape)).ravel()
+
+    embed_real = method in SOLVE_IVP_REAL_METHODS
+    if embed_real:
+        half = state0.size
+
+        def fun(t, yr):
+            out = flat(t, yr[:half] + 1j * yr[half:])
+            return np.concatenate([out.real, out.imag])
+
+        start = np.concatenate([state0.ravel().real, state0.ravel().imag])
+    else:
+        fun, start = flat, state0.ravel()
+    res = solve_ivp(fun, t_span=t_span, y0=start, t_eval=t_eval, method=method, **kwargs)
+    ys = np.asarray(res.y)
+    if embed_real:
+        ys = ys[:ys.shape[0] // 2] + 1j * ys[ys.shape[0] // 2:]
+    ys = ys.T.reshape((-1,) + tuple(shape))                            # (P, *shape): leading time axis
+    if kind == "lindblad":
+        y_out = _rotate_density(model, ys, False)
+    else:
+        y_out = _restore_batch(model, kind, tag, ys[None])[0]
+    fields = dict(res)
+    fields.update(y=y_out, route="scipy_solve_ivp(device rhs)")
+    return OdeResult(**fields)
+
+
 def solve_lmde(generator, t_span, y0, method: str = "RK4", t_eval=None, **kwargs) -> OdeResult:
     """Solve ``y' = G(t) y`` for a model instance with a fixed-step HIP method."""
     if not isinstance(generator, BaseGeneratorModel):
         raise DynamicsError(
             "solve_lmde on the HIP path requires a model instance (GeneratorModel, HamiltonianModel "
             "or LindbladModel); Python callables cannot be evaluated on the device.")
+    if method in SOLVE_IVP_METHODS:   # ODE methods are accepted by solve_lmde (solver_functions.py:349-353)
+        return _solve_ivp_device(generator, t_span, y0, method, t_eval=t_eval, **kwargs)
     if method not in RK4_METHODS + EXPM_METHODS + RK4_PARALLEL_METHODS + EXPM_PARALLEL_METHODS:
         raise DynamicsError(f"Method {method} not supported by solve_lmde.")
     return _solve_batch(generator, t_span, [y0], [None], method, t_eval=t_eval, **kwargs)[0]
 
 
 def solve_ode(rhs, t_span, y0, method: str = "RK4", t_eval=None, **kwargs) -> OdeResult:
-    """ODE-method entry point; only the fixed-step RK4 of the hot path is available."""
-    if method not in RK4_METHODS:
+    """ODE-method entry point (solver_functions.py:129-217): the fixed-step RK4 of the hot path and scipy's adaptive
+    methods with the device RHS (``"RK45"``, ``"RK23"``, ``"BDF"``, ``"DOP853"``, ``"LSODA"``, ``"Radau"``)."""
+    if method not in RK4_METHODS + SOLVE_IVP_METHODS:
         raise DynamicsError(f"Method {method} not supported by solve_ode.")
     return solve_lmde(rhs, t_span, y0, method=method, t_eval=t_eval, **kwargs)
 
@@ -578,6 +644,11 @@ class Solver:
         for i in range(n):
             key = (tuple(np.asarray(t_spans[i], dtype=float).tolist()), np.asarray(y0s[i]).shape)
             groups.setdefault(key, []).append(i)
+        if method in SOLVE_IVP_METHODS:
+            # adaptive host integrators: each instance has its own step sequence (the reference loops them as well)
+            for i in range(n):
+                results[i] = _solve_ivp_device(self._model, t_spans[i], y0s[i], method, signals=sigs[i], **kwargs)
+            return results if multiple else results[0]
         for (_tkey, _shape), idxs in groups.items():
             if t_eval is not None and _nested_ndim(t_eval) > 1:
                 raise DynamicsError("t_eval must be 1 dimensional.")

@@ -2397,3 +2397,44 @@ def test_interface_scenario_golden(qd, golden, ftag):
                         signals=[qd.Signal(1.0, 5.0 / np.pi)], method="scipy_expm" if vec else "RK4",
                         max_dt=1e-2 if vec else 1e-3)
             assert_close(r.y, g[f"solver_{'vec' if vec else 'mat'}_y"], SOLVE_TOL)
+
+
+def test_adaptive_scipy_methods_golden(qd, golden):
+    """solve_lmde / solve_ode / Solver.solve with scipy's adaptive integrators calling the DEVICE right-hand side
+    (reference: solvers/scipy_solve_ivp.py:31-84): the random framed 7 x 7 model with a DiscreteSignal
+    (test_solver_functions.py:76-115) for RK45 / RK23 / DOP853 / BDF against values captured from the reference, a
+    square (propagator) state, the real-embedded LSODA / Radau against DOP853, and both Lindblad forms."""
+    g = golden("adaptive")
+    sigs = [qd.Signal(0.5, 1.0, 0.3), qd.DiscreteSignal(dt=0.1, samples=g["r7_samples"], carrier_freq=1.0),
+            qd.Signal(lambda t: 0.3 * np.cos(t) + 0 * 1j, 0.0)]
+    hm = qd.HamiltonianModel(static_operator=g["r7_hstatic"], operators=g["r7_hops"], signals=sigs,
+                             rotating_frame=g["r7_hframe"])
+    y0 = g["r7_y0"]
+    for method in ("RK45", "RK23", "DOP853", "BDF"):
+        tol = 1e-10 if method in ("RK45", "DOP853") else 1e-7
+        r = qd.solve_lmde(hm, [0.0, 0.5], y0, method=method, t_eval=[0.1, 0.3, 0.5], atol=tol, rtol=tol)
+        assert r.route == "scipy_solve_ivp(device rhs)" and r.y.shape == (3, 7)
+        assert_close(r.y, g[f"r7_{method}_y"], 5e-8 if tol < 1e-8 else 1e-5)
+    r = qd.solve_ode(hm, [0.0, 0.3], np.eye(7, dtype=complex), method="DOP853", atol=1e-10, rtol=1e-10)
+    assert_close(r.y[-1], g["r7_DOP853_unitary"][-1], 5e-8)     # (without t_eval every accepted step is returned)
+    ref = g["r7_DOP853_y"]
+    for method in ("LSODA", "Radau"):
+        r = qd.solve_lmde(hm, [0.0, 0.5], y0, method=method, t_eval=[0.1, 0.3, 0.5], atol=1e-9, rtol=1e-9)
+        assert_close(r.y, ref, 1e-6)
+    with pytest.raises(qd.DynamicsError):
+        qd.solve_lmde(hm, [0.0, 0.5], y0, method="DOP853", dense_output=True)
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    yy = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    for vec in (False, True):
+        lm = qd.LindbladModel(hamiltonian_operators=[x], hamiltonian_signals=[qd.Signal(1.0, 5.0)], static_hamiltonian=z,
+                              static_dissipators=[yy], rotating_frame=g["frame"], vectorized=vec)
+        yin = g["rho0"].flatten(order="F") if vec else g["rho0"]
+        r = qd.solve_lmde(lm, [0.0, 0.7], yin, method="DOP853", atol=1e-10, rtol=1e-10)
+        assert_close(r.y[-1], g[f"lind_{'vec' if vec else 'mat'}_DOP853_y"][-1], 5e-8)
+    # Solver.solve list mode loops the instances for adaptive methods
+    s = qd.Solver(static_hamiltonian=g["r7_hstatic"], hamiltonian_operators=g["r7_hops"], rotating_frame=g["r7_hframe"])
+    res = s.solve(t_span=[0.0, 0.5], y0=[y0, y0], signals=sigs, method="DOP853", t_eval=[0.1, 0.3, 0.5], atol=1e-10,
+                  rtol=1e-10)
+    assert len(res) == 2
+    assert_close(res[1].y, g["r7_DOP853_y"], 5e-8)
