@@ -205,7 +205,7 @@ def test_solver_error_surface(qd):
     m = qd.HamiltonianModel(operators=[x], signals=[qd.Signal(1.0)])
     y0 = np.array([1.0, 0.0], dtype=complex)
     with pytest.raises(qd.DynamicsError):
-        qd.solve_lmde(m, [0, 1], y0, method="DOP853", max_dt=0.1)
+        qd.solve_lmde(m, [0, 1], y0, method="jax_odeint", max_dt=0.1)
     with pytest.raises(qd.DynamicsError):
         qd.solve_lmde(m, [0, 1], y0, method="scipy_expm", max_dt=0.1, magnus_order=4)
     with pytest.raises(qd.DynamicsError):
