@@ -71,8 +71,8 @@ def visible_gpus() -> int:
 def spawn_ranks(n_ranks: int, argv) -> int:
     """Start `n_ranks` copies of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
     127.0.0.1), wait for all of them; non-zero if any failed (the others are then terminated by PID)."""
-    if os.environ.get("MIDYN_BENCH_STUB"):
-        have = n_ranks          # CPU plumbing test (gloo, stand-in solve): no GPUs needed
+    if os.environ.get("MIDYN_BENCH_STUB") or os.environ.get("MIDYN_BENCH_SHARE_GPU"):
+        have = n_ranks          # plumbing tests: CPU stand-in solve, or all ranks on ONE GPU (see Dist)
     else:
         have = visible_gpus()
     if have < n_ranks:
@@ -157,6 +157,10 @@ class Dist:
 
     def __init__(self, world, rank, local_rank, stub):
         self.world, self.rank, self.local_rank, self.stub = world, rank, local_rank, stub
+        # MIDYN_BENCH_SHARE_GPU (test mode for a ONE-GPU box): all ranks compute on GPU 0 and rendezvous over gloo;
+        # every rank builds its own stack (RCCL cannot put two ranks on one device).  Exercises the multi-rank flow of
+        # this file -- sharding, per-rank plans, barriers, MAX reduction, the single JSON line -- with real kernels.
+        self.share = bool(os.environ.get("MIDYN_BENCH_SHARE_GPU")) and not stub
         self.dist = None
         self.torch = None
         if world > 1 or os.environ.get("MIDYN_BENCH_FORCE_DIST"):
@@ -166,16 +170,19 @@ class Dist:
             from qiskit_dynamics_amd.distributed import init_process_group_from_env
 
             self.torch, self.dist = torch, dist
-            if not stub:
+            if self.share:
+                self.local_rank = 0
+                torch.cuda.set_device(0)
+            elif not stub:
                 torch.cuda.set_device(local_rank)
-            init_process_group_from_env(backend="gloo" if stub else "nccl")
+            init_process_group_from_env(backend="gloo" if (stub or self.share) else "nccl")
 
     @property
     def active(self):
         return self.dist is not None
 
     def device(self):
-        return self.torch.device("cpu") if self.stub else self.torch.device("cuda", self.local_rank)
+        return self.torch.device("cpu") if (self.stub or self.share) else self.torch.device("cuda", self.local_rank)
 
     def barrier(self):
         if self.dist is not None:
@@ -210,7 +217,7 @@ def shared_stack(qd, ctx, D, builder, n, k, route):
 
     t0 = time.perf_counter()
     arrays, build_error = (None, None, None), None
-    if D.rank == 0:
+    if D.rank == 0 or D.share:
         try:
             arrays = builder()
         except Exception as exc:  # pylint: disable=broad-except
@@ -225,6 +232,9 @@ def shared_stack(qd, ctx, D, builder, n, k, route):
     if build_error:
         raise RuntimeError("host model build failed on rank 0: " + build_error)
     info = {"host_build_s": round(build_s, 2)}
+    if D.share:
+        info["route"] = "test mode MIDYN_BENCH_SHARE_GPU: every rank builds its own stack on the shared GPU (no collective)"
+        return qd.Stack(ctx, *arrays), None, info
     if route == "abi":
         result, err = None, None
         try:
@@ -537,7 +547,7 @@ def main():
     from qiskit_dynamics_amd.distributed import shard_bounds
     from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
 
-    ctx = qd.default_context(local_rank)
+    ctx = qd.default_context(D.local_rank)
     if args.dense:
         ctx.set_option("skip_zero_planes", 0)
     if args.force_tile:
@@ -752,9 +762,9 @@ def main():
     if want_cfg5:
         # second sharded leg: cfg 5, 1024 instances in total, 1024/N per GPU; the 2.4 GB stack is broadcast
         try:
-            cfg5 = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25) if rank == 0 else \
-                dict(t_span=[0.0, 5.0], max_dt=0.25, t_final=5.0)
-            if rank != 0:
+            cfg5 = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25) \
+                if (rank == 0 or D.share) else dict(t_span=[0.0, 5.0], max_dt=0.25, t_final=5.0)
+            if rank != 0 and not D.share:
                 nu = 5.0 + 0.05 * np.arange(12)
                 y5 = np.zeros(4096, dtype=complex)
                 y5[0] = 1.0

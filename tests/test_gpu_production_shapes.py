@@ -384,3 +384,30 @@ def test_paired_sparse_launches_are_bit_identical(qd):
             assert runs[1][1] * 2 == runs[0][1], (runs[1][1], runs[0][1])      # half the launches
             assert np.array_equal(runs[1][0], runs[0][0])
             assert np.max(np.abs(np.linalg.norm(runs[1][0], axis=1) - 1.0)) < 1e-10
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """`python bench.py --gpus 2` spawning its own ranks, with both ranks on THIS GPU (MIDYN_BENCH_SHARE_GPU: gloo
+    rendezvous, every rank builds its stack -- RCCL cannot put two ranks on one device): the multi-rank flow of the
+    benchmark with real kernels -- strong-scaling shards of the 4096-instance sweep, per-rank plans, barriers, MAX
+    reduction, exactly one JSON line.  (The RCCL broadcast itself: test_stack_broadcast_over_the_c_abi_one_rank and
+    MIDYN_BENCH_FORCE_DIST; a real multi-GPU run is the driver's.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIDYN_BENCH_SHARE_GPU="1")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--repeats", "1", "--no-configs"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["global_instances"] == 4096 and out["config"]["instances_per_gpu"] == 2048
+    assert out["max_norm_deviation"] < 1e-10 and out["value"] > 1e5
+    assert out["roofline"]["frac"] <= 1.0
