@@ -679,9 +679,15 @@ def main():
     plan.close()
     measured_peaks = None
     if rank == 0 and world == 1:
+        co = ctx.microbench("fp64_coissue", full=True)
         measured_peaks = {"mfma_f64_tflops": round(ctx.microbench("mfma_f64"), 1),
                           "hbm_read_gbs": round(ctx.microbench("hbm_read"), 0),
-                          "mall_read_gbs": round(ctx.microbench("mall_read"), 0)}
+                          "mall_read_gbs": round(ctx.microbench("mall_read"), 0),
+                          "fp64_mfma_and_vector_fma_share_a_pipe": {
+                              "ms_interleaved": round(co[0], 3), "ms_mfma_only": round(co[1], 3),
+                              "ms_vector_fma_only": round(co[2], 3),
+                              "note": "interleaved = sum, not max: every fp64 VALU instruction in the contraction loop "
+                                      "costs matrix-pipe time"}}
 
     scaling = "weak" if args.weak else "strong"
     out = {

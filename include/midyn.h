@@ -253,7 +253,10 @@ int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);
 int midyn_reset_counters(midyn_ctx* ctx);
 /* Measured ceilings: "mfma_f64" -> out[0] = TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64;
  * "hbm_read" -> GB/s streaming a 4 GiB buffer; "mall_read" -> GB/s re-reading 144 MiB (the size of
- * the cfg-2 operator stack, which fits the 256 MiB Infinity Cache). */
+ * the cfg-2 operator stack, which fits the 256 MiB Infinity Cache);
+ * "fp64_coissue" -> out[0..2] = ms of the same rounds with MFMAs + vector fp64 FMAs interleaved, MFMAs only, FMAs only,
+ * out[3] = TFLOP/s of the combined run (do the fp64 matrix pipe and the fp64 vector ALUs run concurrently?).
+ * `out` holds 4 doubles. */
 int midyn_microbench(midyn_ctx* ctx, const char* name, double* out);
 /* HIP-event stopwatch on the context's stream: midyn_ctx_timer(ctx, 0, NULL) records the start event,
  * midyn_ctx_timer(ctx, 1, &ms) records the stop event, waits for it and returns the elapsed milliseconds

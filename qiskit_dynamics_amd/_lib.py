@@ -229,10 +229,10 @@ class Context:
         self.check(self.lib.midyn_get_counters(self.handle, name.encode(), out))
         return {"launches": out[0], "ms": out[1]}
 
-    def microbench(self, name: str) -> float:
-        out = (ctypes.c_double * 2)()
+    def microbench(self, name: str, full: bool = False):
+        out = (ctypes.c_double * 4)()
         self.check(self.lib.midyn_microbench(self.handle, name.encode(), out))
-        return float(out[0])
+        return [float(x) for x in out] if full else float(out[0])
 
     def reset_counters(self):
         self.check(self.lib.midyn_reset_counters(self.handle))

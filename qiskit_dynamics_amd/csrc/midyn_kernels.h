@@ -2465,6 +2465,38 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters)
     if (s == 123.456) sink[0] = s;
 }
 
+// Do the fp64 matrix pipe and the fp64 vector ALUs run CONCURRENTLY?  Per round and wave: NMFMA independent
+// v_mfma_f64_16x16x4 (2048 flops each) interleaved with NFMA independent v_fma_f64 (128 flops each).  MODE 0: both,
+// 1: MFMAs only, 2: FMAs only.  If the pipes were independent, the combined round would take max(...) of the two.
+template <int NMFMA, int NFMA, int MODE>
+__global__ __launch_bounds__(256) void fp64_coissue_kernel(double* sink, int iters) {
+    d4 acc[NMFMA];
+    double f[NFMA];
+#pragma unroll
+    for (int i = 0; i < NMFMA; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NFMA; ++i) f[i] = 1.0 + threadIdx.x * 1e-9 + i;
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 0.5 - threadIdx.x * 1e-9, c = 1.0 - 1e-12 * threadIdx.x;
+    constexpr int PER = NFMA / NMFMA;   // vector FMAs issued behind every MFMA
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NMFMA; ++i) {
+            if (MODE != 2) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            if (MODE != 1) {
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+                    asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(f[i * PER + j]) : "v"(c), "v"(b));
+            }
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NMFMA; ++i) s += acc[i][0] + acc[i][3];
+#pragma unroll
+    for (int i = 0; i < NFMA; ++i) s += f[i];
+    if (s == 123.456) sink[0] = s;
+}
+
 // streaming read of `n16` 16-byte elements (grid-stride, 4 independent loads per thread per round)
 __global__ __launch_bounds__(256) void stream_read_kernel(const double2* src, size_t n16, double* sink) {
     double2 acc = make_double2(0.0, 0.0);
