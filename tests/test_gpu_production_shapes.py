@@ -411,3 +411,24 @@ def test_bench_two_ranks_share_one_gpu():
     assert out["config"]["global_instances"] == 4096 and out["config"]["instances_per_gpu"] == 2048
     assert out["max_norm_deviation"] < 1e-10 and out["value"] > 1e5
     assert out["roofline"]["frac"] <= 1.0
+
+
+def test_c_program_drives_the_hot_path_through_the_c_abi(tmp_path):
+    """tests/abi_solve.c: a C99 host (gcc, dlopen of ONE HIP runtime + librccl + libmidyn.so, no Python objects, no
+    torch) creates a context and an operator stack, broadcasts it on a one-rank RCCL communicator, evaluates the RHS,
+    and solves a sweep of driven qubits with midyn_rk4_solve and midyn_expm_solve (Magnus 2) against the closed-form
+    solution -- the drop-in boundary exercised from the other side."""
+    import os
+    import subprocess
+
+    from qiskit_dynamics_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert _lib.load() is not None
+    rccl = _lib.preload_rccl()
+    exe = tmp_path / "abi_solve"
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-o", str(exe), os.path.join(root, "tests", "abi_solve.c"),
+                    "-ldl", "-lm"], check=True)
+    p = subprocess.run([str(exe), _lib.HIP_RUNTIME, _lib.LIB_PATH, rccl], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ABI_SOLVE_OK" in p.stdout, p.stdout + p.stderr
+    assert "broadcast=1" in p.stdout
