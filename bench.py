@@ -126,8 +126,9 @@ def measured_traffic(kernel_prefix):
 
 
 def build_frame_basis_stack(cfg):
-    """Host model build (a3/a4): -iH, eigh of the frame, U^dagger . U.  Uses the product classes'
-    own code path (RotatingFrame) so the stack is exactly what HamiltonianModel uploads."""
+    """Host model build (a3/a4) WITHOUT grouping symmetry sectors: -iH, eigh of the frame, U^dagger . U in the
+    reference's ascending-eigenvalue order (the exact zeros of a symmetric model are scattered: dense kernels).
+    Used by tools/ for dense-kernel measurements."""
     from qiskit_dynamics_amd.rotating_frame import RotatingFrame
 
     frame = RotatingFrame(cfg["h_d"])
@@ -136,12 +137,30 @@ def build_frame_basis_stack(cfg):
     return ops, static, frame.frame_diag_imag
 
 
+def build_model_stack(cfg):
+    """The stack exactly as HamiltonianModel uploads it (models.py): frame-basis vectors grouped by the symmetry
+    sectors of the frame operator (rotating_frame._eigh_by_sectors), so that exactly-zero operator blocks are
+    contiguous.  Returns (ops, static, frame_im, perm): internal position i holds the reference's index perm[i]."""
+    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
+
+    frame = RotatingFrame(cfg["h_d"])
+    static = frame.operator_into_frame_basis(-1j * cfg["h_d"]) - np.diag(frame.frame_diag)
+    ops = frame.operator_into_frame_basis(-1j * cfg["ops"])
+    fim = frame.frame_diag_imag
+    labels = frame.sector_labels
+    if labels is None:
+        return ops, static, fim, None
+    perm = np.argsort(labels, kind="stable")
+    take = lambda x: np.ascontiguousarray(np.take(np.take(x, perm, axis=-2), perm, axis=-1))  # noqa: E731
+    return take(ops), take(static), np.ascontiguousarray(fim[perm]), perm
+
+
 def build_diag_frame_stack(cfg):
     """cfg 5: diagonal rotating frame diag(H_d) (1-D frame, no eigh): operators stay in the computational basis."""
     from qiskit_dynamics_amd.rotating_frame import RotatingFrame
 
     fr = RotatingFrame(np.diag(cfg["h_d"]).real.copy())
-    return -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag
+    return -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag, None
 
 
 def sweep_table(workloads, times, first, count, k, carrier, t_final):
@@ -216,25 +235,33 @@ def shared_stack(qd, ctx, D, builder, n, k, route):
     from qiskit_dynamics_amd.distributed import broadcast_stack
 
     t0 = time.perf_counter()
-    arrays, build_error = (None, None, None), None
+    arrays, perm, build_error = (None, None, None), None, None
     if D.rank == 0 or D.share:
         try:
-            arrays = builder()
+            built = builder()
+            arrays, perm = tuple(built[:3]), built[3]
         except Exception as exc:  # pylint: disable=broad-except
             build_error = repr(exc)
     build_s = time.perf_counter() - t0
+
+    def finish(stack_):
+        stack_.set_permutation(perm)      # (None: no internal permutation)
+        return stack_
+
     if not D.active:
         if build_error:
             raise RuntimeError(build_error)
-        return qd.Stack(ctx, *arrays), None, {"route": "none (one rank)", "host_build_s": round(build_s, 2)}
+        return finish(qd.Stack(ctx, *arrays)), None, {"route": "none (one rank)", "host_build_s": round(build_s, 2)}
     # every rank learns whether the host build on rank 0 worked BEFORE anybody enters a collective on the stack
     build_error = D.bcast_bytes(build_error)
     if build_error:
         raise RuntimeError("host model build failed on rank 0: " + build_error)
+    if not D.share:
+        perm = D.bcast_bytes(perm)        # the internal index permutation travels with the stack (a few KB)
     info = {"host_build_s": round(build_s, 2)}
     if D.share:
         info["route"] = "test mode MIDYN_BENCH_SHARE_GPU: every rank builds its own stack on the shared GPU (no collective)"
-        return qd.Stack(ctx, *arrays), None, info
+        return finish(qd.Stack(ctx, *arrays)), None, info
     if route == "abi":
         result, err = None, None
         try:
@@ -255,13 +282,13 @@ def shared_stack(qd, ctx, D, builder, n, k, route):
         if D.max(0.0 if result is not None else 1.0) == 0.0:
             info.update(route="midyn_stack_broadcast (C-ABI, RCCL ncclBroadcast)", broadcast_ms=round(D.max(bc_ms), 3),
                         bytes=_lib.Stack.packed_bytes(n, k, result[2][0]))
-            return result[0], result[1], info
+            return finish(result[0]), result[1], info
         info["abi_route_error"] = err or "failed on another rank"
     D.barrier()
     t1 = time.perf_counter()
     stack, keep = broadcast_stack(ctx, arrays[0], arrays[1], arrays[2], n, k, src=0)
     info.update(route="torch.distributed broadcast (RCCL)", broadcast_ms=round(D.max((time.perf_counter() - t1) * 1e3), 3))
-    return stack, keep, info
+    return finish(stack), keep, info
 
 
 # -----------------------------------------------------------------------------------------------------------------
@@ -568,7 +595,7 @@ def main():
     host_arrays = {}
 
     def builder():
-        host_arrays["v"] = build_frame_basis_stack(cfg)
+        host_arrays["v"] = build_model_stack(cfg)
         return host_arrays["v"]
 
     t_setup = time.perf_counter()
@@ -626,23 +653,44 @@ def main():
     # launch duration from the SAME back-to-back region as ms_per_step: HIP events on the stream the kernel runs on
     # around the K steps, divided by the 4K launches (+ a per-launch event pass for the launch count / class check)
     prof_steps = min(args.steps, 10)
-    cnt = profile_pass(ctx, lambda: plan.run(total - prof_steps, total), ("rhs_gemm", "rhs_blocks_gemm"))["rhs_gemm"]
+    cnts = profile_pass(ctx, lambda: plan.run(total - prof_steps, total), ("rhs_gemm", "rhs_blocks_gemm"))
+    on_lists = cnts["rhs_blocks_gemm"]["launches"] > 0      # symmetry sectors: the contraction runs on tile work lists
+    cnt = cnts["rhs_blocks_gemm"] if on_lists else cnts["rhs_gemm"]
     roofline = None
     n_launch_per_step = cnt["launches"] / prof_steps if cnt["launches"] else 0
     modes = stack.segment_modes if not args.dense else [0] * stack.n_segments
+    useful = (4 * k + 10) * n * n * b_loc                          # SURVEY 8(d) cfg 3 "useful" flops per launch
     if cnt["launches"] > 0 and abs(n_launch_per_step - 4) < 1e-9:
         avg_ms = event_ms / (4 * args.steps)
-        useful = (4 * k + 10) * n * n * b_loc                      # SURVEY 8(d) cfg 3 "useful" flops per launch
         act_modes = [m for m in stack.segment_modes if m != 3]
         stack_um = act_modes[0] if act_modes and all(m == act_modes[0] for m in act_modes) else 3
-        use_3m = (args.dense or stack_um == 0) and args.complex_3m != 0
-        per_seg = [(6 if use_3m else 8) if m == 0 else 4 for m in modes if m != 3]
-        executed = sum(per_seg) * n * n * b_loc                    # real MFMA flops the kernel executes per launch
+        single_plane = (not args.dense) and all(m in (1, 2) for m in act_modes)
+        extra = {}
+        if on_lists:
+            tile = ctx.counters("sparse_tile")
+            lst = ctx.counters("sparse_list")
+            bm, bn = int(tile["launches"]), int(tile["ms"])
+            listed = lst["launches"]
+            cols = -(-b_loc // bn) * bn
+            executed = listed * bm * 16 * cols * (4 if single_plane else 8)   # listed (BM x 16) tiles x all columns
+            blk = stack.block_info()
+            kname = "zgemm_seg_kernel<%d, %d, 2, 4, 16, %d, 2, true>" % (bm, bn, stack_um)
+            extra = {"work_lists": {"tile": [bm, bn], "listed_tiles": int(listed), "splits": int(lst["ms"]),
+                                    "listed_fraction": round(blk["tile_lists"].get(bm, {}).get("listed_fraction", 0.0), 4),
+                                    "why": "the frame operator H_d conserves parity: its eigenvectors are computed sector by "
+                                           "sector (exactly zero outside their sector), so every frame-basis operator has "
+                                           "exactly-zero blocks between sectors it does not couple; skipping them is "
+                                           "bit-identical to multiplying the zeros (see dense_kernels_same_model)"}}
+        else:
+            use_3m = (args.dense or stack_um == 0) and args.complex_3m != 0
+            per_seg = [(6 if use_3m else 8) if m == 0 else 4 for m in modes if m != 3]
+            executed = sum(per_seg) * n * n * b_loc                # real MFMA flops the kernel executes per launch
+            kname = ("zgemm_seg_kernel<64, 64, 2, 2, 16, 4," if (args.dense or stack_um == 0)
+                     else "zgemm_seg_kernel<128, 128, 2, 4, 16, %d, 2, false>" % stack_um)
         tf = executed / (avg_ms * 1e-3) / 1e12
-        traffic3 = measured_traffic("zgemm_seg_kernel<64, 64, 2, 2, 16, 4," if (args.dense or stack_um == 0)
-                                    else "zgemm_seg_kernel<128, 128, 2, 4, 16, %d," % stack_um)
+        traffic3 = measured_traffic(kname)
         roofline = {
-            "kernel": "zgemm_seg_kernel (batched RHS, fp64 MFMA 16x16x4)", "bound": "mfma",
+            "kernel": kname.rstrip(",") + " (batched RHS contraction, fp64 MFMA 16x16x4)", "bound": "mfma",
             "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic3[0], "traffic_source": traffic3[1],
@@ -651,31 +699,54 @@ def main():
             "executed_mfma_flops_per_launch": executed,
             "useful_flops_per_launch": useful, "useful_tflops": round(useful / (avg_ms * 1e-3) / 1e12, 3),
             "segment_plane_modes": modes, "active_segments": stack.n_active_segments,
-            "zero_plane_skipping": not args.dense,
+            "zero_plane_skipping": not args.dense, **extra,
             "note": "achieved = EXECUTED real MFMA flops / launch time (launch time = HIP events around the K timed steps "
-                    "on the library's stream / 4K launches); the operators of this model are purely imaginary in the "
-                    "frame basis, so exact-zero plane skipping executes 4 real flops per complex MAC (4(k+1)n^2 per "
-                    "instance-eval) where SURVEY 8(d) counts (4k+10)n^2 'useful' flops (useful_tflops); see "
-                    "dense_complex for general complex operators",
+                    "on the library's stream / 4K launches).  Exact zeros are not multiplied: the operators of this model "
+                    "are purely imaginary in the frame basis (4 instead of 8 real flops per complex MAC) and vanish "
+                    "between parity sectors they do not couple (work lists); SURVEY 8(d) counts (4k+10)n^2 'useful' "
+                    "flops per instance-evaluation (useful_tflops, may exceed the peak for that reason); see "
+                    "dense_kernels_same_model and dense_complex for the same sweep without those savings",
         }
-    # ---- the general dense-complex path on the same inputs (no exact-zero plane skipping) -----------------------
+
+    def timed_variant(options, steps_=10):
+        """ms per launch of the same sweep on a fresh plan created under `options` (routes are chosen at plan creation)."""
+        for name_, val_ in options.items():
+            ctx.set_option(name_, val_)
+        try:
+            pv = qd.Rk4Plan(stack, times, table, rows, sched.step_h[:total], y0, b_loc, True)
+            d_steps = min(args.steps, steps_)
+            pv.run(0, 2)
+            ctx.synchronize()
+            ctx.timer_start()
+            pv.run(2, 2 + d_steps)
+            ms_ = ctx.timer_stop() / (4 * d_steps)
+            pv.close()
+        finally:
+            for name_ in options:
+                ctx.set_option(name_, 1)
+        return ms_
+
+    # ---- the same sweep without the symmetry-sector work lists, and as general dense-complex operators ----------
     dense = None
+    same_model_dense = None
     if not args.dense and roofline and world == 1:
-        ctx.set_option("skip_zero_planes", 0)
-        d_steps = min(args.steps, 10)
-        plan.run(total - d_steps, total)
-        ctx.synchronize()
-        ctx.timer_start()
-        plan.run(total - d_steps, total)
-        avg_d = ctx.timer_stop() / (4 * d_steps)
-        ctx.set_option("skip_zero_planes", 1)
+        plan.close()
+        if on_lists:
+            avg_k = timed_variant({"skip_zero_blocks": 0})
+            ex_k = sum(4 if m in (1, 2) else 8 for m in modes if m != 3) * n * n * b_loc
+            same_model_dense = {"avg_launch_ms": round(avg_k, 4), "rhs_evals_per_s": round(b_loc / (avg_k * 1e-3), 1),
+                                "executed_tflops": round(ex_k / (avg_k * 1e-3) / 1e12, 3),
+                                "frac": round(ex_k / (avg_k * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                                "what": "dense 128x128 kernel on the same stack (skip_zero_blocks=0): multiplies the "
+                                        "exactly-zero blocks too; bit-identical results"}
+        avg_d = timed_variant({"skip_zero_planes": 0})
         ex_d = 6 * stack.n_segments * n * n * b_loc   # 3M: 3 real MFMA products per complex product
-        useful = (4 * k + 10) * n * n * b_loc
         dense = {"avg_launch_ms": round(avg_d, 4), "rhs_evals_per_s": round(b_loc / (avg_d * 1e-3), 1),
                  "useful_tflops": round(useful / (avg_d * 1e-3) / 1e12, 3),
                  "executed_tflops": round(ex_d / (avg_d * 1e-3) / 1e12, 3),
                  "frac": round(ex_d / (avg_d * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
-                 "scheme": "3M complex multiplication (3 real fp64 MFMAs per complex product) inside the solver loop"}
+                 "scheme": "no structure exploited (general complex operators): 3M complex multiplication (3 real fp64 "
+                           "MFMAs per complex product) inside the solver loop, dense 64x64 tiles"}
     plan.close()
     measured_peaks = None
     if rank == 0 and world == 1:
@@ -708,6 +779,8 @@ def main():
     }
     if roofline:
         out["roofline"] = roofline
+    if same_model_dense:
+        out["dense_kernels_same_model"] = same_model_dense
     if dense:
         out["dense_complex"] = dense
     if measured_peaks:
@@ -801,7 +874,7 @@ def main():
 
     # ---- CPU baseline: the NumPy oracle on this host, bounded sample (rank 0, N=1 only) -------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ops, static, frame_im = host_arrays["v"]
+        ops, static, frame_im = host_arrays["v"][:3]
         out["cpu_baseline"] = leg_cpu_baseline(workloads, cfg, static, ops, frame_im, amps, phs)
 
     # ---- the complete cfg-3 solve through the public Solver API: model build, signal evaluation, PCIe

@@ -301,6 +301,9 @@ class Stack:
     ops (k,n,n) | None, static (n,n) | None, frame_im (n,) | None -- all in the frame basis.
     """
 
+    perm = None   # internal index permutation (set_permutation): internal position i holds API index perm[i]
+    inv = None
+
     def __init__(self, ctx: Context, ops, static, frame_im, dev_buffer_ptr=None, _adopt=None, _lindblad=None):
         self.ctx = ctx
         lib = ctx.lib
@@ -332,6 +335,25 @@ class Stack:
                                              ctypes.byref(h)))
         self.handle = h
         self._read_info()
+
+    def set_permutation(self, perm):
+        """The operators of this stack are stored in a permuted basis (internal position i = API index ``perm[i]``;
+        models group the frame-basis vectors by symmetry sector).  States and generators that cross this wrapper are
+        given / returned in API order: rows are permuted on the way in and back on the way out."""
+        if perm is None:
+            self.perm = self.inv = None
+            return
+        perm = np.asarray(perm, dtype=np.int64)
+        if perm.shape != (self.n,) or not np.array_equal(np.sort(perm), np.arange(self.n)):
+            raise DynamicsError("not a permutation of the stack's indices")
+        self.perm = perm
+        self.inv = np.argsort(perm)
+
+    def _rows_in(self, y, axis):
+        return y if self.perm is None else np.ascontiguousarray(np.take(y, self.perm, axis=axis))
+
+    def _rows_out(self, y, axis):
+        return y if self.perm is None else np.ascontiguousarray(np.take(y, self.inv, axis=axis))
 
     def _read_info(self):
         ctx, lib, h = self.ctx, self.ctx.lib, self.handle
@@ -398,19 +420,20 @@ class Stack:
         if c is not None and c.shape != (self.k,):
             raise DynamicsError("coefficient vector has the wrong length")
         self.ctx.check(self.ctx.lib.midyn_eval_generator(self.handle, _ptr(c), float(t), _ptr(out)))
-        return out
+        return self._rows_out(self._rows_out(out, 0), 1)
 
     def eval_rhs(self, coeffs, t, y):
         y = c128(y)
         if y.shape[0] != self.n or y.ndim > 2:
             raise DynamicsError("state has the wrong shape")
+        y = self._rows_in(y, 0)
         m = 1 if y.ndim == 1 else y.shape[1]
         out = np.empty_like(y)
         c = None if self.k == 0 else f64(coeffs)
         if c is not None and c.shape != (self.k,):
             raise DynamicsError("coefficient vector has the wrong length")
         self.ctx.check(self.ctx.lib.midyn_eval_rhs(self.handle, _ptr(c), float(t), _ptr(y), m, _ptr(out)))
-        return out
+        return self._rows_out(out, 0)
 
     # -- solves -----------------------------------------------------------------------------
     def _solve_args(self, times, table, step_rows, step_h, step_save, y0, batch):
@@ -427,7 +450,7 @@ class Stack:
         step_h = f64(step_h)
         step_save = i32(step_save)
         nsteps = step_rows.shape[0]
-        y0 = c128(y0)
+        y0 = self._rows_in(c128(y0), -2)      # (n, m) or (B, n, m): rows into the internal order
         return times, r, table, step_rows, step_h, step_save, nsteps, y0
 
     def rk4_solve(self, times, table, step_rows, step_h, step_save, n_save, y0, batch, y0_shared):
@@ -439,7 +462,7 @@ class Stack:
         self.ctx.check(self.ctx.lib.midyn_rk4_solve(
             self.handle, batch, m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows), _ptr(step_h),
             _ptr(step_save), n_save, _ptr(y0), int(bool(y0_shared)), _ptr(out)))
-        return out
+        return self._rows_out(out, 2)
 
     def expm_solve(self, times, table, step_rows, step_h, step_save, n_save, magnus_order, y0, batch,
                    y0_shared):
@@ -450,7 +473,7 @@ class Stack:
         self.ctx.check(self.ctx.lib.midyn_expm_solve(
             self.handle, batch, m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows), _ptr(step_h),
             _ptr(step_save), n_save, int(magnus_order), _ptr(y0), int(bool(y0_shared)), _ptr(out)))
-        return out
+        return self._rows_out(out, 2)
 
     def parallel_solve(self, times, table, step_rows, step_h, step_save, n_save, method, y0, batch,
                        y0_shared):
@@ -463,7 +486,7 @@ class Stack:
         self.ctx.check(self.ctx.lib.midyn_parallel_solve(
             self.handle, batch, m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows), _ptr(step_h),
             _ptr(step_save), n_save, int(method), _ptr(y0), int(bool(y0_shared)), _ptr(out)))
-        return out
+        return self._rows_out(out, 2)
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:
@@ -626,7 +649,7 @@ class Rk4Plan:
     def fetch(self):
         out = np.empty((self.batch, self.stack.n, self.m), dtype=np.complex128)
         self.stack.ctx.check(self.stack.ctx.lib.midyn_rk4_plan_fetch(self.handle, _ptr(out)))
-        return out
+        return self.stack._rows_out(out, 1)
 
     def close(self):
         # the plan points into its stack and context: only destroy it while both are alive

@@ -162,7 +162,25 @@ class GeneratorModel(BaseGeneratorModel):
         self._dim = static_fb.shape[-1] if static_fb is not None else ops_fb.shape[-1]
         if frame.dim is not None and frame.dim != self._dim:
             raise DynamicsError("rotating frame dimension does not match the operators")
-        self._stack = _lib.Stack(self._ctx, ops_fb, static_fb, self._frame_diag_imag())
+        # Frames with symmetry sectors: the device stack is stored with the frame-basis vectors grouped by sector
+        # (a permutation of the reference's ascending-eigenvalue order), so that the exactly-zero blocks of operators
+        # obeying a selection rule are contiguous and the work-list kernels skip them.  The permutation is internal to
+        # the Stack wrapper: every array that crosses the C-ABI is permuted on the way in and back on the way out.
+        perm = None
+        labels = frame.sector_labels
+        if labels is not None and type(self)._frame_diag_imag is GeneratorModel._frame_diag_imag:
+            perm = np.argsort(labels, kind="stable")
+
+        def internal(x):
+            if x is None or perm is None:
+                return x
+            return np.ascontiguousarray(np.take(np.take(x, perm, axis=-2), perm, axis=-1))
+
+        fim = self._frame_diag_imag()
+        self._stack = _lib.Stack(self._ctx, internal(ops_fb), internal(static_fb),
+                                 fim if (perm is None or fim is None) else np.ascontiguousarray(fim[perm]))
+        if perm is not None:
+            self._stack.set_permutation(perm)
         self._signals = None
         self.signals = signals
 

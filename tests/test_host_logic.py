@@ -371,3 +371,48 @@ def test_rotating_frame_maps_match_reference(golden):
     assert_close(qd.RotatingFrame(None).generator_out_of_frame(t, g["op"]), g["none_gen_out"], 0)
     # into then out of the frame is the identity
     assert_close(rf.generator_out_of_frame(t, rf.generator_into_frame(t, g["op"])), g["op"], 1e-12)
+
+
+def test_rotating_frame_symmetry_sectors():
+    """Frame operators whose non-zero pattern splits into connected components are diagonalised sector by sector
+    (rotating_frame._eigh_by_sectors): same eigenvalues and ascending order as np.linalg.eigh (the reference's call,
+    rotating_frame.py:102-107), unitary basis, but eigenvectors EXACTLY zero outside their sector -- so operators with
+    a selection rule between the sectors get exactly-zero blocks in the frame basis."""
+    from qiskit_dynamics_amd import workloads
+    from qiskit_dynamics_amd.rotating_frame import RotatingFrame, SECTOR_MIN_DIM
+
+    cfg = workloads.schrodinger_config(n_qubits=6, n_drives=6, t_final=1.0, max_dt=0.01)   # parity-conserving chain
+    h = cfg["h_d"]
+    n = h.shape[0]
+    assert n >= SECTOR_MIN_DIM
+    fr = RotatingFrame(h)
+    labels, u, d = fr.sector_labels, fr.frame_basis, fr.frame_diag
+    assert labels is not None and sorted(np.bincount(labels).tolist()) == [32, 32]
+    w_ref = np.linalg.eigvalsh(h)
+    assert np.all(np.diff(d.imag) <= 0) or np.all(np.diff((1j * d).real) >= 0)
+    assert np.max(np.abs(np.sort((1j * d).real) - w_ref)) < 1e-12
+    assert np.max(np.abs(u.conj().T @ u - np.eye(n))) < 1e-13
+    assert np.max(np.abs(u.conj().T @ h @ u - np.diag((1j * d).real))) < 1e-12
+    # exact zeros: every eigenvector lives on the computational states of its own parity only
+    parity = np.array([bin(i).count("1") & 1 for i in range(n)])
+    for a in range(n):
+        support = parity[np.flatnonzero(u[:, a])]
+        assert support.min() == support.max()
+    # a parity-flipping drive has exactly-zero same-sector entries, the static part exactly-zero cross-sector ones
+    x0 = fr.operator_into_frame_basis(-1j * cfg["ops"][0])
+    st = fr.operator_into_frame_basis(-1j * h)
+    same = labels[:, None] == labels[None, :]
+    assert np.all(x0[same] == 0) and np.any(x0[~same] != 0)
+    assert np.all(st[~same] == 0)
+    # out of the frame basis nothing depends on how the eigenvectors were obtained
+    y = np.random.default_rng(1).normal(size=n) + 0j
+    w2, u2 = np.linalg.eigh(h)
+    t = 0.7
+    ref = u2 @ (np.exp(-1j * w2 * (-t)) * (u2.conj().T @ y))
+    assert np.max(np.abs(fr.state_into_frame(t, y) - ref)) < 1e-12
+    # one connected component, a small matrix or a diagonal frame: the plain path, no labels
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(40, 40)) + 1j * rng.normal(size=(40, 40))
+    assert RotatingFrame(a + a.conj().T).sector_labels is None
+    assert RotatingFrame(np.diag([1.0, -1.0, 2.0])).sector_labels is None
+    assert RotatingFrame(np.arange(40.0)).sector_labels is None
