@@ -265,7 +265,8 @@ int midyn_ctx_timer(midyn_ctx* ctx, int stop, double* ms);
 /* Block occupancy of a stack (what the work-list kernels read and multiply): out[0] state (1 lists built, -1 not
  * applicable), out[1] fraction of non-zero 16x16 blocks of the active operators, out[2] their number, out[3] n_pad/16,
  * then for the MFMA tile lists of 64/128/32/16-row panels: out[4+2t] listed fraction, out[5+2t] listed tiles.
- * `out` holds 12 doubles. */
+ * out[12] = fraction of the active planes the one-column streaming kernel reads (column hull of the non-zero blocks
+ * per 16-row group; 1 when the hulls are not used).  `out` holds 13 doubles. */
 int midyn_stack_block_info(midyn_stack* stack, double* out);
 
 /* ---- multi-GPU: the one collective of the path --------------------------------------------------

@@ -385,10 +385,10 @@ class Stack:
     def block_info(self) -> dict:
         """Block occupancy (work-list routes): fraction / number of non-zero 16x16 blocks and, per MFMA row-panel
         height, the listed fraction and number of (panel, K tile, operator) tiles."""
-        out = (ctypes.c_double * 12)()
+        out = (ctypes.c_double * 13)()
         self.ctx.check(self.ctx.lib.midyn_stack_block_info(self.handle, out))
         info = {"state": int(out[0]), "block_density": float(out[1]), "nonzero_blocks": int(out[2]),
-                "blocks_per_side": int(out[3]), "tile_lists": {}}
+                "blocks_per_side": int(out[3]), "streamed_fraction": float(out[12]), "tile_lists": {}}
         for t, bm in enumerate((64, 128, 32, 16)):
             info["tile_lists"][bm] = {"listed_fraction": float(out[4 + 2 * t]), "listed_tiles": int(round(out[5 + 2 * t]))}
         return info

@@ -213,6 +213,9 @@ struct StreamArgs {
     const double* coeff;     // [k] coefficients of this evaluation (device) or nullptr
     const double2* yin;      // [n_pad * ld] pre-phased input, column 0 used
     const double2* e_in;     // rhs_blocks_kernel only: phase row applied to yin on load (input NOT pre-phased), or nullptr
+    const int2* hull;        // planar streaming kernel: [n_act][n_pad / 16] column ranges (lo, hi) in units of 16
+                             // columns outside of which rows 16 rb .. 16 rb + 15 of the segment are exactly zero
+                             // (symmetry sectors: contiguous ranges after the sector grouping), or nullptr
     Epilogue epi;
 };
 
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(256) void rhs_stream_plane_kernel(StreamArgs a, con
             double cr[SEGU], ci[SEGU];
             const double* p[SEGU];
             double2 v[SEGU][UNROLL];
+            int lo[SEGU], hi[SEGU];
 #pragma unroll
             for (int q = 0; q < SEGU; ++q) {
                 const int packed = a.seg_list[s + q];
@@ -613,13 +617,21 @@ __global__ __launch_bounds__(256) void rhs_stream_plane_kernel(StreamArgs a, con
                 cr[q] = (packed & 3) == 2 ? 0.0 : cf;
                 ci[q] = (packed & 3) == 2 ? cf : 0.0;
                 p[q] = planes + (size_t)(s + q) * plane + (size_t)row * n;
+                lo[q] = 0;
+                hi[q] = n;
+                if (a.hull) {   // only the column range in which this row of the segment can be non-zero is streamed
+                    const int2 h = a.hull[(size_t)(s + q) * (n >> 4) + (row >> 4)];
+                    lo[q] = h.x << 4;
+                    hi[q] = h.y << 4;
+                }
             }
 #pragma unroll
             for (int q = 0; q < SEGU; ++q)
 #pragma unroll
                 for (int u = 0; u < UNROLL; ++u) {
                     const int c = c0 + u * 512;
-                    v[q][u] = c < n ? *reinterpret_cast<const double2*>(p[q] + c) : make_double2(0.0, 0.0);
+                    v[q][u] = (c >= lo[q] && c < hi[q]) ? *reinterpret_cast<const double2*>(p[q] + c)
+                                                        : make_double2(0.0, 0.0);
                 }
 #pragma unroll
             for (int q = 0; q < SEGU; ++q)
@@ -637,10 +649,16 @@ __global__ __launch_bounds__(256) void rhs_stream_plane_kernel(StreamArgs a, con
             const double cf = (a.has_static && seg == 0) ? 1.0 : a.coeff[seg - a.has_static];
             const double cr = (packed & 3) == 2 ? 0.0 : cf, ci = (packed & 3) == 2 ? cf : 0.0;
             const double* p = planes + (size_t)s * plane + (size_t)row * n;
+            int lo = 0, hi = n;
+            if (a.hull) {
+                const int2 h = a.hull[(size_t)s * (n >> 4) + (row >> 4)];
+                lo = h.x << 4;
+                hi = h.y << 4;
+            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int c = c0 + u * 512;
-                if (c < n) {
+                if (c >= lo && c < hi) {
                     const double2 v = *reinterpret_cast<const double2*>(p + c);
                     gre[u].x = fma(cr, v.x, gre[u].x);
                     gre[u].y = fma(cr, v.y, gre[u].y);
