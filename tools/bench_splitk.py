@@ -8,14 +8,19 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import qiskit_dynamics_amd as qd  # noqa: E402
-from bench import build_frame_basis_stack  # noqa: E402
+from bench import build_frame_basis_stack, build_model_stack  # noqa: E402
 from qiskit_dynamics_amd import workloads  # noqa: E402
 from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points  # noqa: E402
 
 ctx = qd.default_context()
 cfg = workloads.schrodinger_config()
-ops, static, frame_im = build_frame_basis_stack(cfg)
-stack = qd.Stack(ctx, ops, static, frame_im)
+if os.environ.get("MIDYN_DENSE_STACK"):      # the reference's eigenvector order: scattered exact zeros, dense kernels
+    ops, static, frame_im = build_frame_basis_stack(cfg)
+    stack = qd.Stack(ctx, ops, static, frame_im)
+else:                                        # as HamiltonianModel uploads it: grouped by symmetry sector, work lists
+    ops, static, frame_im, perm = build_model_stack(cfg)
+    stack = qd.Stack(ctx, ops, static, frame_im)
+    stack.set_permutation(perm)
 sched = FixedStepSchedule(cfg["t_span"], None, 0.005, _rk4_points)
 S = 22
 rows = sched.step_rows[:S]
