@@ -57,11 +57,13 @@ def local_device() -> int:
     return local % n_dev if n_dev else 0
 
 
-def broadcast_stack(ctx, ops, static, frame_im, n, k, src: int = 0):
+def broadcast_stack(ctx, ops, static, frame_im, n, k, src: int = 0, perm=None):
     """Build the packed device stack on `src`, RCCL-broadcast it, adopt it on the other ranks.
 
     `ops`/`static`/`frame_im` are only read on rank `src` (may be None elsewhere); n, k and the
-    presence flags must be known on every rank.  Returns (Stack, torch tensor that owns the memory).
+    presence flags must be known on every rank.  `perm` (rank `src`): the internal index permutation of a
+    stack whose arrays are grouped by symmetry sector (`Stack.set_permutation`); it travels with the stack.
+    Returns (Stack, torch tensor that owns the memory).
     """
     import torch
     import torch.distributed as dist
@@ -89,6 +91,10 @@ def broadcast_stack(ctx, ops, static, frame_im, n, k, src: int = 0):
     if rank != src:
         stack = _lib.Stack(ctx, None, None, None, dev_buffer_ptr=buf.data_ptr(),
                            _adopt=(n, k, has_static, has_frame))
+    box = [None if perm is None else np.asarray(perm).tolist()]
+    dist.broadcast_object_list(box, src=src)
+    if box[0] is not None:
+        stack.set_permutation(np.asarray(box[0], dtype=np.int64))
     return stack, buf
 
 
