@@ -781,6 +781,10 @@ def main():
         out["roofline"] = roofline
     if same_model_dense:
         out["dense_kernels_same_model"] = same_model_dense
+        out["value_without_exact_zero_block_skipping"] = same_model_dense["rhs_evals_per_s"]
+        out["value_note"] = ("value = the product's default route: identical arithmetic minus products with operator "
+                             "blocks that are EXACTLY zero (parity sectors of the frame operator), bit-identical states; "
+                             "value_without_exact_zero_block_skipping = the dense kernels on the same stack")
     if dense:
         out["dense_complex"] = dense
     if measured_peaks:
