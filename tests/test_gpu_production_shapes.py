@@ -496,3 +496,62 @@ def test_symmetry_sectors_exact_zero_blocks_are_skipped(qd):
     _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt: np.array([np.real(s(tt)) for s in sweeps[5]]),
                                        [0.0, 0.2], y0, "scipy_expm", 0.02, magnus_order=2)
     assert_close(ex.y[-1], ref[-1], SOLVE_TOL)
+
+
+def test_symmetry_sectors_many_uneven_sectors_and_operators_without_selection_rules(qd):
+    """(a) A frame that conserves the excitation number (6-qubit XX+YY chain with detunings: sectors of 1, 6, 15, 20,
+    15, 6, 1 basis states) with drives X_j that connect neighbouring sectors only; (b) a block-diagonal frame with
+    random DENSE operators that respect no selection rule (the grouping must then be harmless: dense kernels).
+    Evaluations in and out of the frame basis and sweeps against the oracle (plain eigh)."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    rng = np.random.default_rng(17)
+    nq, n = 6, 64
+    x = np.array([[0, 1], [1, 0]], dtype=complex)
+    yp = np.array([[0, -1j], [1j, 0]], dtype=complex)
+    z = np.diag([1.0, -1.0]).astype(complex)
+    h_frame = np.zeros((n, n), dtype=complex)
+    for q in range(nq):
+        h_frame += 2 * np.pi * (1.0 + 0.07 * q) * W.embed(z, q, nq) / 2
+    for q in range(nq - 1):
+        h_frame += 2 * np.pi * 0.03 * (W.embed_pair(x, q, x, q + 1, nq) + W.embed_pair(yp, q, yp, q + 1, nq)) / 2
+    drives = np.array([2 * np.pi * 0.05 * W.embed(x, q, nq) / 2 for q in range(4)])
+
+    def herm(m_):
+        a_ = crand(rng, m_, m_)
+        return (a_ + a_.conj().T) / 2
+
+    block_frame = np.zeros((80, 80), dtype=complex)
+    block_frame[:30, :30] = herm(30)
+    block_frame[30:, 30:] = herm(50)
+    dense_ops = np.array([herm(80) for _ in range(3)])
+    cases = [("excitation", h_frame, h_frame, drives, [1, 1, 6, 6, 15, 15, 20]),
+             ("dense_ops", block_frame, herm(80), dense_ops, [30, 50])]
+    for tag, frame, h_static, h_ops, sizes in cases:
+        k, dim = len(h_ops), frame.shape[0]
+        sigs = [qd.Signal(lambda t, a=0.3 + 0.1 * j: a * np.cos(0.9 * t) + 0j, 0.4 * j, 0.2 * j) for j in range(k)]
+        m = qd.HamiltonianModel(static_operator=h_static, operators=h_ops, signals=sigs, rotating_frame=frame)
+        labels = m.rotating_frame.sector_labels
+        assert labels is not None and sorted(np.bincount(labels).tolist()) == sizes, tag
+        assert m.stack.perm is not None
+        a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
+        t = 0.83
+        c = np.array([np.real(s(t)) for s in sigs])
+        yv, ym = crand(rng, dim), crand(rng, dim, 9)
+        assert_close(m.evaluate(t), orc.generator_evaluate(a_d, a, c, d, basis, t, False), 1e-11)
+        assert_close(m.evaluate_rhs(t, yv), orc.generator_rhs(a_d, a, c, d, basis, t, yv, False), 1e-11)
+        assert_close(m.evaluate_rhs(t, ym), orc.generator_rhs(a_d, a, c, d, basis, t, ym, False), 1e-11)
+        u = m.rotating_frame.frame_basis
+        m.in_frame_basis = True
+        assert_close(u @ m.evaluate_rhs(t, u.conj().T @ ym), orc.generator_rhs(a_d, a, c, d, basis, t, ym, False), 1e-11)
+        m.in_frame_basis = False
+        solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=frame)
+        y0s = [crand(rng, dim) for _ in range(12)]
+        for method, kw in (("RK4", dict(max_dt=0.01)), ("scipy_expm", dict(max_dt=0.05, magnus_order=2))):
+            res = solver.solve(t_span=[0.0, 0.3], y0=y0s, signals=sigs, method=method, **kw)
+            for b in (0, 11):
+                _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt: np.array([np.real(s(tt)) for s in sigs]),
+                                                   [0.0, 0.3], y0s[b], method, kw["max_dt"],
+                                                   magnus_order=kw.get("magnus_order", 1))
+                assert_close(res[b].y[-1], ref[-1], SOLVE_TOL)
