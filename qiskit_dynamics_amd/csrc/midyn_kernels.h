@@ -420,17 +420,26 @@ __global__ __launch_bounds__(256) void rhs_stream_multi_plane_kernel(StreamArgs 
             for (int c = 0; c < C; ++c) g0[u][c] = g1[u][c] = make_double2(0.0, 0.0);
         for (int s = 0; s < a.n_act; ++s) {
             const double* p = planes + (size_t)s * plane + (size_t)row * n;
+            int lo = 0, hi = n;
+            if (a.hull) {   // column hull of this row group of the segment (symmetry sectors): exact zeros outside
+                const int2 h = a.hull[(size_t)s * (n >> 4) + (row >> 4)];
+                lo = h.x << 4;
+                hi = h.y << 4;
+            }
             double2 v[UNROLL];
+            bool in[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int col = c0 + u * 512;
-                v[u] = col < n ? *reinterpret_cast<const double2*>(p + col) : make_double2(0.0, 0.0);
+                in[u] = col >= lo && col < hi;
+                v[u] = in[u] ? *reinterpret_cast<const double2*>(p + col) : make_double2(0.0, 0.0);
             }
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const double cr = cr_s[s * C + c], ci = ci_s[s * C + c];
+            for (int u = 0; u < UNROLL; ++u) {
+                if (!in[u]) continue;      // (adding c * 0 would change nothing: skip the fp64 work as well)
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
+                for (int c = 0; c < C; ++c) {
+                    const double cr = cr_s[s * C + c], ci = ci_s[s * C + c];
                     g0[u][c].x = fma(cr, v[u].x, g0[u][c].x);
                     g0[u][c].y = fma(ci, v[u].x, g0[u][c].y);
                     g1[u][c].x = fma(cr, v[u].y, g1[u][c].x);

@@ -5,11 +5,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import qiskit_dynamics_amd as qd
 from qiskit_dynamics_amd import workloads
 from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
-from bench import build_frame_basis_stack
+from bench import build_frame_basis_stack, build_model_stack
 ctx = qd.default_context()
 cfg = workloads.schrodinger_config()
-ops, static, frame_im = build_frame_basis_stack(cfg)
-stack = qd.Stack(ctx, ops, static, frame_im)
+if os.environ.get("MIDYN_DENSE_STACK"):      # reference eigenvector order: dense kernels
+    ops, static, frame_im = build_frame_basis_stack(cfg)
+    stack = qd.Stack(ctx, ops, static, frame_im)
+else:                                        # as HamiltonianModel uploads it: grouped by symmetry sector
+    ops, static, frame_im, perm = build_model_stack(cfg)
+    stack = qd.Stack(ctx, ops, static, frame_im)
+    stack.set_permutation(perm)
 sched = FixedStepSchedule(cfg["t_span"], None, 0.005, _rk4_points)
 S = 12
 rows = sched.step_rows[:S]; nr = int(rows.max()) + 1
