@@ -144,7 +144,7 @@ def build_model_stack(cfg):
     from qiskit_dynamics_amd.rotating_frame import RotatingFrame
 
     frame = RotatingFrame(cfg["h_d"])
-    static = frame.operator_into_frame_basis(-1j * cfg["h_d"]) - np.diag(frame.frame_diag)
+    static = frame.generator_minus_frame_in_basis(-1j * cfg["h_d"])     # U^+ (G - F) U: exactly zero here (frame = H_d)
     ops = frame.operator_into_frame_basis(-1j * cfg["ops"])
     fim = frame.frame_diag_imag
     labels = frame.sector_labels

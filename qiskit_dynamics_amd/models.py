@@ -150,7 +150,8 @@ class GeneratorModel(BaseGeneratorModel):
             if static_fb.ndim != 2 or static_fb.shape[0] != static_fb.shape[1]:
                 raise DynamicsError("static_operator must be a square matrix")
             if frame.frame_diag is not None:
-                static_fb = _into_frame_basis(self._ctx, frame, static_fb) - np.diag(frame.frame_diag)
+                static_fb = frame.generator_minus_frame_in_basis(
+                    static_fb, into_basis=lambda x: _into_frame_basis(self._ctx, frame, x))
         ops_fb = None
         if operators is not None:
             ops_fb = np.asarray(operators, dtype=complex)
@@ -370,7 +371,7 @@ class LindbladModel(BaseGeneratorModel):
         if static_hamiltonian is not None:
             g = -1j * np.asarray(static_hamiltonian, dtype=complex)
             if frame.frame_diag is not None:
-                g = frame.operator_into_frame_basis(g) - np.diag(frame.frame_diag)
+                g = frame.generator_minus_frame_in_basis(g)
             h_d = 1j * g
         elif frame.frame_diag is not None:
             h_d = 1j * np.diag(-frame.frame_diag)

@@ -87,12 +87,14 @@ class RotatingFrame:
         self._frame_operator = frame_operator
         self._vec_basis = None
         self._sector_labels = None
+        self._anti_hermitian = None
         if frame_operator is None:
             self._dim = None
             self._frame_diag = None
             self._frame_basis = None
             return
         f = _to_anti_hermitian(np.asarray(frame_operator), atol=atol, rtol=rtol)
+        self._anti_hermitian = f
         if f.ndim == 1:
             self._frame_diag = f
             self._frame_basis = None
@@ -119,6 +121,24 @@ class RotatingFrame:
     @property
     def frame_basis(self):
         return self._frame_basis
+
+    def generator_minus_frame_in_basis(self, generator, into_basis=None):
+        """``U^+ G U - diag(d)`` -- the static generator of a model in this frame (generator_model.py:319-340) --
+        evaluated as ``U^+ (G - F) U``: the same matrix, but the frame is subtracted BEFORE the basis change.  The
+        reference subtracts diag(d) (entries ~ the frame's eigenvalues) from a product that carries rounding errors of
+        that size; when the static operator IS the frame operator (the usual ``rotating_frame=H_d`` set-up) it is left
+        with 1e-13 noise where the exact answer is zero, and so is every evaluation.  In this order the difference is
+        formed exactly (``G - F`` is exactly zero then, and stays zero through the basis change), otherwise the two
+        agree to rounding.  ``into_basis``: optional callable doing the basis change (the device one for large
+        operators); default ``operator_into_frame_basis``."""
+        g = np.asarray(generator, dtype=complex)
+        f = self._anti_hermitian
+        if f is None:
+            return g
+        if f.ndim == 1:
+            return g - np.diag(f)
+        fb = self.operator_into_frame_basis if into_basis is None else into_basis
+        return fb(g - f)
 
     @property
     def sector_labels(self):
