@@ -784,7 +784,9 @@ def main():
         out["value_without_exact_zero_block_skipping"] = same_model_dense["rhs_evals_per_s"]
         out["value_note"] = ("value = the product's default route: identical arithmetic minus products with operator "
                              "blocks that are EXACTLY zero (parity sectors of the frame operator), bit-identical states; "
-                             "value_without_exact_zero_block_skipping = the dense kernels on the same stack")
+                             "value_without_exact_zero_block_skipping = the dense kernels on the same stack.  On both "
+                             "routes the static operator in the frame, U^+(G_d - F)U with F = G_d, is exactly zero and "
+                             "inactive (the reference's U^+ G_d U - diag(d) leaves 1e-13 rounding noise there)")
     if dense:
         out["dense_complex"] = dense
     if measured_peaks:
