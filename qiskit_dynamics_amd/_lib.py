@@ -303,6 +303,8 @@ class Stack:
 
     perm = None   # internal index permutation (set_permutation): internal position i holds API index perm[i]
     inv = None
+    slot = None   # general embedding (set_embedding): API index a lives at internal position slot[a]
+    n_api = None  # dimension seen by the callers of this wrapper (== n unless sectors are padded)
 
     def __init__(self, ctx: Context, ops, static, frame_im, dev_buffer_ptr=None, _adopt=None, _lindblad=None):
         self.ctx = ctx
@@ -341,19 +343,46 @@ class Stack:
         models group the frame-basis vectors by symmetry sector).  States and generators that cross this wrapper are
         given / returned in API order: rows are permuted on the way in and back on the way out."""
         if perm is None:
-            self.perm = self.inv = None
+            self.perm = self.inv = self.slot = None
+            self.n_api = self.n
             return
         perm = np.asarray(perm, dtype=np.int64)
         if perm.shape != (self.n,) or not np.array_equal(np.sort(perm), np.arange(self.n)):
             raise DynamicsError("not a permutation of the stack's indices")
-        self.perm = perm
-        self.inv = np.argsort(perm)
+        self.set_embedding(np.argsort(perm))
+
+    def set_embedding(self, slot):
+        """General form of ``set_permutation``: API index a lives at internal position ``slot[a]`` of a stack that may
+        be LARGER than the API dimension (symmetry sectors padded to block boundaries; the extra rows and columns of
+        every operator are zero, so the padding rows of a state stay zero).  ``len(slot)`` is the API dimension."""
+        slot = np.asarray(slot, dtype=np.int64)
+        if slot.ndim != 1 or slot.size > self.n or np.unique(slot).size != slot.size or slot.min() < 0 \
+                or slot.max() >= self.n:
+            raise DynamicsError("not an embedding of the API indices into the stack's indices")
+        self.slot = slot
+        self.n_api = int(slot.size)
+        if self.n_api == self.n:            # a pure permutation
+            self.inv = slot                 # API index -> internal position
+            self.perm = np.argsort(slot)    # internal position -> API index
+        else:
+            self.perm = self.inv = None
 
     def _rows_in(self, y, axis):
-        return y if self.perm is None else np.ascontiguousarray(np.take(y, self.perm, axis=axis))
+        if self.slot is None:
+            return y
+        if self.perm is not None:
+            return np.ascontiguousarray(np.take(y, self.perm, axis=axis))
+        axis = axis % y.ndim
+        out = np.zeros(y.shape[:axis] + (self.n,) + y.shape[axis + 1:], dtype=y.dtype)
+        idx = [slice(None)] * y.ndim
+        idx[axis] = self.slot
+        out[tuple(idx)] = y
+        return out
 
     def _rows_out(self, y, axis):
-        return y if self.perm is None else np.ascontiguousarray(np.take(y, self.inv, axis=axis))
+        if self.slot is None:
+            return y
+        return np.ascontiguousarray(np.take(y, self.slot, axis=axis))
 
     def _read_info(self):
         ctx, lib, h = self.ctx, self.ctx.lib, self.handle
@@ -361,6 +390,8 @@ class Stack:
         ctx.check(lib.midyn_stack_info(h, info))
         (self.n, self.n_pad, self.k, self.has_static, self.has_frame, self.n_segments,
          self.n_active_segments, self.packed_mib) = [int(x) for x in info]
+        if self.slot is None:
+            self.n_api = self.n
         modes = (ctypes.c_int * max(self.n_segments, 1))()
         ctx.check(lib.midyn_stack_segment_modes(h, modes))
         self.segment_modes = [int(modes[i]) for i in range(self.n_segments)]
@@ -424,7 +455,7 @@ class Stack:
 
     def eval_rhs(self, coeffs, t, y):
         y = c128(y)
-        if y.shape[0] != self.n or y.ndim > 2:
+        if y.shape[0] != self.n_api or y.ndim > 2:
             raise DynamicsError("state has the wrong shape")
         y = self._rows_in(y, 0)
         m = 1 if y.ndim == 1 else y.shape[1]

@@ -57,12 +57,13 @@ def local_device() -> int:
     return local % n_dev if n_dev else 0
 
 
-def broadcast_stack(ctx, ops, static, frame_im, n, k, src: int = 0, perm=None):
+def broadcast_stack(ctx, ops, static, frame_im, n, k, src: int = 0, perm=None, slot=None):
     """Build the packed device stack on `src`, RCCL-broadcast it, adopt it on the other ranks.
 
     `ops`/`static`/`frame_im` are only read on rank `src` (may be None elsewhere); n, k and the
     presence flags must be known on every rank.  `perm` (rank `src`): the internal index permutation of a
-    stack whose arrays are grouped by symmetry sector (`Stack.set_permutation`); it travels with the stack.
+    stack whose arrays are grouped by symmetry sector (`Stack.set_permutation`), or `slot`, the general embedding of
+    a stack whose sectors are also padded to block boundaries (`Stack.set_embedding`); it travels with the stack.
     Returns (Stack, torch tensor that owns the memory).
     """
     import torch
@@ -91,10 +92,12 @@ def broadcast_stack(ctx, ops, static, frame_im, n, k, src: int = 0, perm=None):
     if rank != src:
         stack = _lib.Stack(ctx, None, None, None, dev_buffer_ptr=buf.data_ptr(),
                            _adopt=(n, k, has_static, has_frame))
-    box = [None if perm is None else np.asarray(perm).tolist()]
+    box = [None if perm is None else np.asarray(perm).tolist(), None if slot is None else np.asarray(slot).tolist()]
     dist.broadcast_object_list(box, src=src)
     if box[0] is not None:
         stack.set_permutation(np.asarray(box[0], dtype=np.int64))
+    elif box[1] is not None:
+        stack.set_embedding(np.asarray(box[1], dtype=np.int64))
     return stack, buf
 
 

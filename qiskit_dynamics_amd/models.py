@@ -119,6 +119,50 @@ def _into_frame_basis(ctx, frame, op):
     return out.reshape(op.shape)
 
 
+# Symmetry sectors are laid out contiguously on the device and every sector starts on a multiple of this many rows
+# (the block map works on 16 x 16 blocks; a sector that straddled a block boundary would fill it from both sides).
+# The padding rows are zero rows/columns of every operator.  Many small sectors would inflate the dimension, so the
+# alignment is dropped (sectors contiguous, unpadded) when it would add more than SECTOR_MAX_PADDING of the dimension.
+SECTOR_ALIGN = 16
+SECTOR_MAX_PADDING = 0.125
+
+
+def _sector_layout(labels):
+    """(start row of each sector, internal dimension) for the internal layout: sectors in order of first appearance
+    (the one with the most padding last), each aligned to SECTOR_ALIGN rows when that is affordable."""
+    labels = np.asarray(labels)
+    uniq, first, counts = np.unique(labels, return_index=True, return_counts=True)
+    by_first = [int(i) for i in np.argsort(first)]
+    for align in (SECTOR_ALIGN, 1):
+        waste = [(-int(counts[i])) % align for i in by_first]
+        last = by_first[int(np.argmax(waste))]           # the sector that would need the most padding goes last:
+        order = [i for i in by_first if i != last] + [last]   # nothing follows it, so it needs none
+        starts, pos = {}, 0
+        for i in order:
+            starts[int(uniq[i])] = pos
+            pos += int(counts[i]) + (0 if i == last else (-int(counts[i])) % align)
+        if pos <= labels.size * (1.0 + SECTOR_MAX_PADDING):
+            break
+    return starts, pos
+
+
+def _sector_internal_dim(labels) -> int:
+    return _sector_layout(labels)[1]
+
+
+def _sector_slots(labels):
+    """slot[a] = internal row of frame-basis vector a (API order = ascending eigenvalues): vectors of one sector are
+    contiguous, in their API order, and every sector starts on a block boundary (padding rows stay zero)."""
+    labels = np.asarray(labels)
+    starts, _ = _sector_layout(labels)
+    slot = np.empty(labels.size, dtype=np.int64)
+    fill = dict(starts)
+    for a, c in enumerate(labels):
+        slot[a] = fill[int(c)]
+        fill[int(c)] += 1
+    return slot
+
+
 class BaseGeneratorModel:
     """``model(t)`` -> generator matrix, ``model(t, y)`` -> RHS."""
 
@@ -167,21 +211,28 @@ class GeneratorModel(BaseGeneratorModel):
         # (a permutation of the reference's ascending-eigenvalue order), so that the exactly-zero blocks of operators
         # obeying a selection rule are contiguous and the work-list kernels skip them.  The permutation is internal to
         # the Stack wrapper: every array that crosses the C-ABI is permuted on the way in and back on the way out.
-        perm = None
+        slot = None
         labels = frame.sector_labels
         if labels is not None and type(self)._frame_diag_imag is GeneratorModel._frame_diag_imag:
-            perm = np.argsort(labels, kind="stable")
+            slot = _sector_slots(labels)
 
         def internal(x):
-            if x is None or perm is None:
+            """Frame-basis operator(s) in the internal layout: sectors contiguous and starting on block boundaries."""
+            if x is None or slot is None:
                 return x
-            return np.ascontiguousarray(np.take(np.take(x, perm, axis=-2), perm, axis=-1))
+            n_int = _sector_internal_dim(labels)
+            out = np.zeros(x.shape[:-2] + (n_int, n_int), dtype=complex)
+            out[..., slot[:, None], slot[None, :]] = x
+            return out
 
         fim = self._frame_diag_imag()
-        self._stack = _lib.Stack(self._ctx, internal(ops_fb), internal(static_fb),
-                                 fim if (perm is None or fim is None) else np.ascontiguousarray(fim[perm]))
-        if perm is not None:
-            self._stack.set_permutation(perm)
+        fim_int = fim
+        if slot is not None and fim is not None:
+            fim_int = np.zeros(_sector_internal_dim(labels))
+            fim_int[slot] = fim
+        self._stack = _lib.Stack(self._ctx, internal(ops_fb), internal(static_fb), fim_int)
+        if slot is not None:
+            self._stack.set_embedding(slot)
         self._signals = None
         self.signals = signals
 

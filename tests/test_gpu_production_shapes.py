@@ -449,7 +449,7 @@ def test_symmetry_sectors_exact_zero_blocks_are_skipped(qd):
     n = 256
     sigs = _gauss_signals(qd, cfg, 0, 8, 0.5)
     m = qd.HamiltonianModel(static_operator=cfg["h_d"], operators=cfg["ops"], signals=sigs, rotating_frame=cfg["h_d"])
-    assert m.rotating_frame.sector_labels is not None and m.stack.perm is not None
+    assert m.rotating_frame.sector_labels is not None and m.stack.perm is not None and m.stack.n_api == m.stack.n
     info = m.stack.block_info()
     assert info["state"] == 1 and abs(info["block_density"] - 0.5) < 0.02 and abs(info["streamed_fraction"] - 0.5) < 0.02
     a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], cfg["h_d"])
@@ -526,15 +526,34 @@ def test_symmetry_sectors_many_uneven_sectors_and_operators_without_selection_ru
     block_frame[:30, :30] = herm(30)
     block_frame[30:, 30:] = herm(50)
     dense_ops = np.array([herm(80) for _ in range(3)])
-    cases = [("excitation", h_frame, h_frame, drives, [1, 1, 6, 6, 15, 15, 20]),
-             ("dense_ops", block_frame, herm(80), dense_ops, [30, 50])]
-    for tag, frame, h_static, h_ops, sizes in cases:
+    # (c) sectors of 100, 70 and 30 states (none a multiple of the 16-row blocks): the internal layout pads each sector
+    # to a block boundary (n = 200 -> 212 rows on the device; the sector that would need the most padding goes last and gets none), operators that couple sectors 0 <-> 1 only
+    sel_frame = np.zeros((200, 200), dtype=complex)
+    bounds = [(0, 100), (100, 170), (170, 200)]
+    for lo, hi in bounds:
+        sel_frame[lo:hi, lo:hi] = herm(hi - lo)
+    sel_ops = np.zeros((3, 200, 200), dtype=complex)
+    for j, (lo, hi) in enumerate(bounds):
+        sel_ops[j, lo:hi, lo:hi] = herm(hi - lo)
+    cpl = crand(rng, 100, 70)
+    sel_ops[0, 0:100, 100:170] = cpl
+    sel_ops[0, 100:170, 0:100] = cpl.conj().T
+    cases = [("excitation", h_frame, h_frame, drives, [1, 1, 6, 6, 15, 15, 20], 64),
+             ("dense_ops", block_frame, herm(80), dense_ops, [30, 50], 82),
+             ("padded_sectors", sel_frame, sel_frame, sel_ops, [30, 70, 100], 212)]
+    for tag, frame, h_static, h_ops, sizes, n_internal in cases:
         k, dim = len(h_ops), frame.shape[0]
         sigs = [qd.Signal(lambda t, a=0.3 + 0.1 * j: a * np.cos(0.9 * t) + 0j, 0.4 * j, 0.2 * j) for j in range(k)]
         m = qd.HamiltonianModel(static_operator=h_static, operators=h_ops, signals=sigs, rotating_frame=frame)
         labels = m.rotating_frame.sector_labels
         assert labels is not None and sorted(np.bincount(labels).tolist()) == sizes, tag
-        assert m.stack.perm is not None
+        assert m.stack.slot is not None and m.stack.n_api == dim and m.stack.n == n_internal, tag
+        if tag == "padded_sectors":
+            # sectors occupy block rows 0-6, 7-11, 12-13 of the 16 x 16-block map: operator 0 fills sector 0's square
+            # and the 0 <-> 1 coupling, operators 1 and 2 their own squares; the static operator cancels the frame
+            info = m.stack.block_info()
+            assert info["state"] == 1 and info["blocks_per_side"] == 16
+            assert info["nonzero_blocks"] == (49 + 2 * 35) + 25 + 4, info
         a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
         t = 0.83
         c = np.array([np.real(s(t)) for s in sigs])

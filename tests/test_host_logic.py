@@ -416,3 +416,56 @@ def test_rotating_frame_symmetry_sectors():
     assert RotatingFrame(a + a.conj().T).sector_labels is None
     assert RotatingFrame(np.diag([1.0, -1.0, 2.0])).sector_labels is None
     assert RotatingFrame(np.arange(40.0)).sector_labels is None
+
+
+def test_sector_layout_and_stack_embedding_host_side():
+    """The internal layout of a stack with symmetry sectors (models._sector_slots): sectors contiguous in API order,
+    each starting on a 16-row block boundary when the padding is affordable (the one that needs most goes last and
+    gets none), plain grouping otherwise; and the row gather/scatter of the wrapper (Stack._rows_in/_rows_out) for a
+    pure permutation and for a padded embedding.  No device calls."""
+    from qiskit_dynamics_amd import _lib
+    from qiskit_dynamics_amd.models import SECTOR_ALIGN, _sector_internal_dim, _sector_slots
+
+    rng = np.random.default_rng(5)
+    for sizes, n_int in (([512, 512], 1024), ([30, 50], 82), ([50, 30], 82), ([100, 70, 30], 212),
+                         ([1, 1, 6, 6, 15, 15, 20], 64), ([3] * 40, 120)):
+        labels = np.repeat(np.arange(len(sizes)), sizes)
+        rng.shuffle(labels)
+        slot = _sector_slots(labels)
+        assert _sector_internal_dim(labels) == n_int and slot.max() + 1 == n_int
+        assert np.unique(slot).size == slot.size
+        padded = n_int > labels.size
+        for c in range(len(sizes)):
+            mine = slot[labels == c]
+            assert np.all(np.diff(mine) == 1)                     # contiguous, API order kept inside the sector
+            if padded:
+                assert mine[0] % SECTOR_ALIGN == 0
+    # the wrapper's row maps (no handle needed)
+    for sizes in ([4, 4], [3, 5, 2]):
+        labels = np.repeat(np.arange(len(sizes)), sizes)
+        rng.shuffle(labels)
+        n_api = labels.size
+        starts = np.cumsum([0] + [-(-s // 4) * 4 for s in sizes])  # a layout padded to multiples of 4
+        fill = list(starts[:-1])
+        slot = np.empty(n_api, dtype=np.int64)
+        for a, c in enumerate(labels):
+            slot[a] = fill[c]
+            fill[c] += 1
+        st = _lib.Stack.__new__(_lib.Stack)
+        st.handle = None
+        st.n = int(starts[-1])
+        st.set_embedding(slot)
+        assert st.n_api == n_api and (st.perm is not None) == (st.n == n_api)
+        y = rng.normal(size=(2, n_api, 3)) + 0j
+        yi = st._rows_in(y, -2)
+        assert yi.shape == (2, st.n, 3) and np.array_equal(yi[:, slot], y)
+        mask = np.ones(st.n, dtype=bool)
+        mask[slot] = False
+        assert np.all(yi[:, mask] == 0)
+        assert np.array_equal(st._rows_out(yi, 1), y)
+        g = rng.normal(size=(st.n, st.n)) + 0j
+        assert np.array_equal(st._rows_out(st._rows_out(g, 0), 1), g[np.ix_(slot, slot)])
+    with pytest.raises(_lib.DynamicsError):
+        st.set_embedding(np.array([0, 0, 1]))
+    with pytest.raises(_lib.DynamicsError):
+        st.set_embedding(np.arange(st.n + 1))
