@@ -262,6 +262,21 @@ def shared_stack(qd, ctx, D, builder, n, k, route):
     if D.share:
         info["route"] = "test mode MIDYN_BENCH_SHARE_GPU: every rank builds its own stack on the shared GPU (no collective)"
         return finish(qd.Stack(ctx, *arrays)), None, info
+    if (route == "abi" and D.world > 1) or os.environ.get("MIDYN_BENCH_PROBE"):
+        # a collective that goes wrong on a new machine hangs rather than fails: try the C-ABI communicator and
+        # broadcast on a small stack in a CHILD process per rank first (killed by PID after a time limit); if any
+        # rank's child fails, every rank takes the torch.distributed route without touching the C-ABI communicator
+        from qiskit_dynamics_amd.distributed import abi_broadcast_probe
+
+        t1 = time.perf_counter()
+        uid = D.bcast_bytes(_lib.Comm.unique_id() if D.rank == 0 else None)
+        ok, msg = abi_broadcast_probe(D.rank, D.world, ctx.device, uid,
+                                      timeout_s=float(os.environ.get("MIDYN_BENCH_PROBE_TIMEOUT", "120")))
+        all_ok = D.max(0.0 if ok else 1.0) == 0.0
+        info["abi_probe"] = {"ok": all_ok, "s": round(time.perf_counter() - t1, 2)}
+        if not all_ok:
+            info["abi_probe"]["message"] = msg if not ok else "failed on another rank"
+            route = "torch"
     if route == "abi":
         result, err = None, None
         try:

@@ -166,3 +166,86 @@ def solve_sweep(solver, t_span, y0, signals, **kwargs):
     full = gather_sweep_results(local_y, n_total, device=device)
     t_out = np.asarray(known[1], dtype=float)
     return [OdeResult(t=t_out, y=full[b]) for b in range(n_total)]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C-ABI broadcast self-test in a CHILD process.  A collective that goes wrong on a new machine usually does not
+# fail, it hangs -- and a hung RCCL kernel poisons the process that launched it.  Before a rank puts its own
+# context into `midyn_comm_init_rank` / `midyn_stack_broadcast` it can run the same calls on a small stack in a
+# child (one per rank, same devices, its own ncclUniqueId): the child either exits 0 within the time limit or is
+# killed by its PID, and the caller falls back to the torch.distributed broadcast without ever having touched
+# the C-ABI communicator.
+# ---------------------------------------------------------------------------------------------------------------
+PROBE_N, PROBE_K = 96, 2
+
+
+def _probe_arrays():
+    rng = np.random.default_rng(20240)
+    ops = rng.normal(size=(PROBE_K, PROBE_N, PROBE_N)) + 1j * rng.normal(size=(PROBE_K, PROBE_N, PROBE_N))
+    static = rng.normal(size=(PROBE_N, PROBE_N)) + 1j * rng.normal(size=(PROBE_N, PROBE_N))
+    return ops, static, rng.normal(size=PROBE_N)
+
+
+def _probe_main(argv) -> int:
+    """Child side: `python -m qiskit_dynamics_amd.distributed --probe RANK WORLD DEVICE UID_HEX`."""
+    rank, world, device = int(argv[0]), int(argv[1]), int(argv[2])
+    uid = bytes.fromhex(argv[3])
+    if os.environ.get("MIDYN_PROBE_HANG"):          # test hook: behave like a hung collective
+        import time
+
+        time.sleep(3600)
+    from . import _lib
+
+    ctx = _lib.Context(device)
+    comm = _lib.Comm(ctx, world, rank, uid)
+    ops, static, frame_im = _probe_arrays()
+    if rank == 0:
+        stack = _lib.Stack(ctx, ops, static, frame_im)
+    else:
+        stack = _lib.Stack.empty(ctx, PROBE_N, PROBE_K, True, True)
+    stack.broadcast(comm, 0)
+    ctx.synchronize()
+    c = np.array([0.3, -0.7])
+    got = stack.eval_generator(c, 0.0)
+    want = static + np.tensordot(c, ops, axes=1)
+    err = float(np.max(np.abs(got - want)))
+    comm.close()
+    if not err < 1e-12:
+        print(f"probe rank {rank}: broadcast stack differs from the source by {err:.3e}", flush=True)
+        return 3
+    return 0
+
+
+def abi_broadcast_probe(rank: int, world: int, device: int, uid: bytes, timeout_s: float = 120.0):
+    """Run the C-ABI communicator + stack broadcast self-test for this rank in a child process.  `uid`: an
+    ncclUniqueId made for the probe on rank 0 (`_lib.Comm.unique_id()`) and shipped to every rank.  Returns
+    (ok, message).  The child is killed by PID when it does not finish in `timeout_s`."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):   # the child is not a torch.distributed rank
+        env.pop(var, None)
+    cmd = [sys.executable, "-m", "qiskit_dynamics_amd.distributed", "--probe", str(rank), str(world), str(device),
+           bytes(uid).hex()]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=root)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return False, f"probe did not finish in {timeout_s:.0f} s (killed)"
+    if proc.returncode != 0:
+        tail = out.decode(errors="replace").strip().splitlines()[-3:]
+        return False, f"probe exited with {proc.returncode}: " + " | ".join(tail)
+    return True, "ok"
+
+
+if __name__ == "__main__":
+    import sys
+
+    if len(sys.argv) >= 6 and sys.argv[1] == "--probe":
+        sys.exit(_probe_main(sys.argv[2:]))
+    sys.exit("usage: python -m qiskit_dynamics_amd.distributed --probe RANK WORLD DEVICE UID_HEX")

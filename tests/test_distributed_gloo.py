@@ -126,3 +126,17 @@ def test_bench_spawns_its_own_ranks_and_refuses_mismatched_worlds():
         env_real = {k_: v for k_, v in env.items() if k_ != "MIDYN_BENCH_STUB"}
         p = subprocess.run([sys.executable, bench, "--gpus", "8"], env=env_real, capture_output=True, text=True, timeout=300)
         assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_abi_broadcast_probe_child_is_contained(monkeypatch):
+    """distributed.abi_broadcast_probe without a GPU: a child that hangs is killed by PID after the time limit, a
+    child that cannot run the C-ABI calls (no HIP device here) exits non-zero -- both reported as (False, reason),
+    which sends bench.py to the torch.distributed route."""
+    from qiskit_dynamics_amd.distributed import abi_broadcast_probe
+
+    monkeypatch.setenv("MIDYN_PROBE_HANG", "1")
+    ok, msg = abi_broadcast_probe(0, 2, 0, b"\0" * 128, timeout_s=2)
+    assert not ok and "killed" in msg
+    monkeypatch.delenv("MIDYN_PROBE_HANG")
+    ok, msg = abi_broadcast_probe(1, 2, 0, b"\0" * 128, timeout_s=120)
+    assert not ok and "exited" in msg

@@ -327,6 +327,25 @@ def test_stack_broadcast_over_the_c_abi_one_rank(qd):
     empty.close()
 
 
+def test_abi_broadcast_probe_in_a_child_process(qd, monkeypatch):
+    """distributed.abi_broadcast_probe: the C-ABI communicator + stack broadcast self-test that bench.py runs in a
+    child process per rank before it puts its own context into the collective.  One rank here: the child builds
+    the probe stack, broadcasts it, checks an evaluation and exits 0; a child that hangs is killed by PID after the
+    time limit and reported as a failure (the caller then takes the torch.distributed route)."""
+    from qiskit_dynamics_amd import _lib
+    from qiskit_dynamics_amd.distributed import abi_broadcast_probe
+
+    ctx = qd.default_context()
+    ok, msg = abi_broadcast_probe(0, 1, ctx.device, _lib.Comm.unique_id(), timeout_s=120)
+    assert ok, msg
+    monkeypatch.setenv("MIDYN_PROBE_HANG", "1")
+    ok, msg = abi_broadcast_probe(0, 1, ctx.device, _lib.Comm.unique_id(), timeout_s=3)
+    assert not ok and "killed" in msg
+    monkeypatch.delenv("MIDYN_PROBE_HANG")
+    ok, msg = abi_broadcast_probe(0, 1, ctx.device, b"\0" * 16, timeout_s=60)       # malformed id: exits non-zero
+    assert not ok and "exited" in msg
+
+
 def test_event_timer_and_block_info(qd):
     """midyn_ctx_timer brackets launches on the library's stream; midyn_stack_block_info reports what the
     work-list kernels execute (checked against a host count of the non-zero 16x16 blocks)."""
