@@ -66,6 +66,9 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage
  *   multi_stream [1]      2..8 state columns at n >= 256: multi-column streaming kernel
  *   tiny_rk4 [1]          small systems: whole fixed-step solve in one persistent launch
+ *   resident_rk4 [1]      one RK4 trajectory whose active operator planes fit the register files (32 < n, at most 64
+ *                         doubles per lane and row): whole step ranges in one launch, operators in registers, the
+ *                         stage input exchanged through a polled ring in device memory (csrc/midyn_resident.h)
  *   expm_action [1]       few columns, Magnus order <= 2: expm(Omega) y by matrix-vector products
  *   expm_degree [0]       0: Taylor degree of the dense expm chosen from the norm; else 2|4|6|9|12|16
  *   profile [0]           record HIP-event kernel times (midyn_get_counters)
@@ -243,7 +246,8 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
 /* ---- counters ----------------------------------------------------------------------------------
  * Kernel-time accounting measured with HIP events on the ctx stream.
  * names: "rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", and for the block-sparse routes
- * "rhs_blocks" (1..8 columns) and "rhs_blocks_gemm" (MFMA tiles over work lists).
+ * "rhs_blocks" (1..8 columns) and "rhs_blocks_gemm" (MFMA tiles over work lists); "rk4_resident" counts the
+ * launches of the register-resident single-trajectory kernel (one launch = a whole step range).
  * out[0] = launches, out[1] = total ms (events are only recorded when profiling is enabled with
  * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch).
  * Two more names describe the LAST launch of the sparse MFMA route: "sparse_tile" -> (BM, BN) of its tile,

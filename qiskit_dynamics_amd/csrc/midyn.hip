@@ -18,6 +18,7 @@
 
 #include "../../include/midyn.h"
 #include "midyn_kernels.h"
+#include "midyn_resident.h"
 
 using namespace midyn;
 

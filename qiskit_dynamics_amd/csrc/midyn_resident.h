@@ -1,0 +1,278 @@
+// midyn_resident.h -- rk4_resident_kernel: a single trajectory whose operators live in REGISTERS.
+//
+// One state column is launch-latency bound on the streaming route: a 10-qubit RHS evaluation reads 34 MB in 6.5 us
+// and then pays a dependent kernel boundary, 8.4 us per stage, and reads the same operators again from HBM / MALL
+// 4000 times per solve.  The active planes of such a stack fit the register files of the chip (256 CUs x 512 KB):
+// here every wave owns ONE row of the generator and keeps that row of every active operator plane in registers for
+// the whole solve (64 doubles per lane = a row of 8 single-plane operators over 512 non-zero columns).  A stage is
+//   (1) the workgroup (4 rows) polls the pre-phased stage input y' of the columns its rows couple to straight out of
+//       an exchange ring in device memory into LDS,
+//   (2) every wave forms sum_e c_e(t) A_e[row, :] . y' from its registers, reduces across its lanes,
+//   (3) lane 0 runs the fused RK4 stage of its row (frame phases, y / accumulator in registers) and publishes the
+//       next stage input of its row.
+// There is no grid barrier: the exchange is its own synchronisation.  Every 8-byte word of the ring starts as a
+// sentinel (all ones: a NaN pattern arithmetic never produces) and a reader polls a word until it is not the
+// sentinel -- one store and one load latency per stage instead of an atomic counter round trip on top.  Four ring
+// buffers rotate; in round r a row's owner publishes into buffer r+1 and then re-arms its words of buffer r-1.  That
+// is safe because the polled sets are SYMMETRIC by construction (whoever reads my rows is read by me, on 64 x 64
+// granularity): having read round r from all my neighbours proves that every reader of my round r-1 words has
+// finished with them.  The re-arming store is acknowledged before the owner publishes the NEXT round (a wait that
+// costs nothing a round later), so a reader that has seen round r+2 can never see stale round r-1 data in the buffer
+// it polls for round r+3.
+//
+// Precision: same products as the streaming kernel in a different summation order (lane-strided partial sums, then
+// a butterfly), same fused stage arithmetic (apply_epilogue_t).
+#pragma once
+
+#ifndef MIDYN_RESIDENT_ABLATE
+#define MIDYN_RESIDENT_ABLATE 0
+#endif
+
+namespace midyn {
+
+constexpr unsigned long long RESIDENT_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
+constexpr int RESIDENT_DPL = 64;          // doubles of operator data per lane
+constexpr int RESIDENT_MAX_POLL = 16;     // polled 64-column chunks per workgroup (8 words per thread)
+constexpr unsigned RESIDENT_SPIN_LIMIT = 1u << 21;
+constexpr int RESIDENT_INIT_PRESLEEP = 16, RESIDENT_MAX_PRESLEEP = 64;   // units of s_sleep(1) = 64 clocks
+
+struct ResidentArgs {
+    const double2* ops;       // [nseg][n_pad][n_pad]
+    const int* pairs;         // [NE] entry e of every chunk: (segment << 1) | plane (0 real part, 1 imaginary part), -1 = unused
+    int n, n_pad, has_static, k;
+    const double* S;          // [R][k] coefficient table of the one instance
+    const double2* E;         // [R][n_pad] frame phases or nullptr
+    const int* rows;          // [nsteps][3]
+    const double* hs;         // [nsteps]
+    const int* save;          // [nsteps] output slot or -1, or nullptr
+    int step_begin, step_end, nsteps;
+    const int* chunk_ptr;     // [n_pad/16 + 1] operand chunks of every 16-row group ...
+    const int* chunk_idx;     // ... as (slot in the poll list of the group's 64-row chunk) << 8 | chunk number
+    const int* poll_ptr;      // [n_pad/64 + 1] chunks polled by the workgroups of a 64-row chunk ...
+    const int* poll_idx;      // ... chunk numbers
+    unsigned long long* ring; // [4][2 * n_pad] exchange ring (re, im interleaved), all sentinel at launch
+    double2* y;               // [n_pad] state, updated in place
+    double2* out;             // [P][n] saved states or nullptr
+    int* err;                 // set when a wait gave up (results invalid)
+};
+
+__device__ __forceinline__ double resident_lane_value(double v, int lane) {   // v of a compile-time lane as a wave-uniform value
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double resident_dpp(double x) {   // x of the lane a DPP control selects (same row of 16)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, the same value (and summation order) in every lane: xor-butterfly inside the rows of 16
+// on the DPP crossbar (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then the four row sums
+__device__ __forceinline__ double resident_wave_sum(double x) {
+    x += resident_dpp<0xB1>(x);
+    x += resident_dpp<0x4E>(x);
+    x += resident_dpp<0x141>(x);
+    x += resident_dpp<0x140>(x);
+    return (resident_lane_value(x, 0) + resident_lane_value(x, 16)) + (resident_lane_value(x, 32) + resident_lane_value(x, 48));
+}
+
+template <int NE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const ResidentArgs a) {
+    constexpr int NQ = RESIDENT_DPL / NE;
+    constexpr int THREADS = 64 * WAVES;                          // one row per wave: WAVES rows per workgroup
+    constexpr int NPW = RESIDENT_MAX_POLL * 128 / THREADS;       // polled words per thread
+    __shared__ __attribute__((aligned(16))) double ylds[2][RESIDENT_MAX_POLL * 128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = blockIdx.x * WAVES + wave;           // this wave's row (wave-uniform: scalar loads and branches)
+    const int grp = row >> 4, rchunk = row >> 6;
+    const int n_pad = a.n_pad;
+    unsigned long long* const ring = a.ring;
+
+    // ---- operand chunks of this row group; the row of every (entry, chunk) into registers
+    const int cbase = a.chunk_ptr[grp];
+    const int nq = a.chunk_ptr[grp + 1] - cbase;
+    double v[RESIDENT_DPL];
+    int slot_of[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int packed = q < nq ? a.chunk_idx[cbase + q] : 0;
+        slot_of[q] = packed >> 8;
+        const int col = (packed & 0xff) * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int pr = a.pairs[e];     // unused entries / chunks read element (0, row, lane) and drop it: no branch
+            const double2 z = a.ops[((size_t)(pr >= 0 ? pr >> 1 : 0) * n_pad + row) * n_pad + col];
+            v[q * NE + e] = (q < nq && pr >= 0) ? ((pr & 1) ? z.y : z.x) : 0.0;
+        }
+    }
+    // entry e of the coefficient vectors lives in lane e
+    const int my_pair = lane < NE ? a.pairs[lane] : -1;
+    const int my_seg = my_pair >> 1;
+    const bool my_static = a.has_static && my_seg == 0;
+    const int my_cidx = my_seg - a.has_static;
+
+    // ---- polled words of this thread: word i*256 + tid of the workgroup's poll list (128 words per chunk)
+    const int pbase = a.poll_ptr[rchunk];
+    const int npoll = a.poll_ptr[rchunk + 1] - pbase;
+    const int npw = (npoll * 128 + THREADS - 1) / THREADS;
+    int word_of[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int slot = (i * THREADS + tid) >> 7;
+        word_of[i] = slot < npoll ? a.poll_idx[pbase + slot] * 128 + (tid & 127) : -1;
+    }
+
+    double2 yr = a.y[row];
+    double2 acc_r = make_double2(0.0, 0.0);
+    bool dead = false;
+    if (lane == 0 && a.step_begin < a.step_end) {    // round 0 input: the state phased to the first stage time
+        double2 y0 = yr;
+        if (a.E) y0 = cmul(a.E[(size_t)a.rows[3 * a.step_begin] * n_pad + row], yr);
+        __hip_atomic_store(ring + 2 * row, (unsigned long long)__double_as_longlong(y0.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ring + 2 * row + 1, (unsigned long long)__double_as_longlong(y0.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int presleep = RESIDENT_INIT_PRESLEEP, clean = 0;   // wave-uniform
+    int rr = 0;     // round = stage counter of this launch; buffers rotate rr % 4
+    int b_cur = 0;
+    for (int st = a.step_begin; st < a.step_end; ++st) {
+        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1], r2 = a.rows[3 * st + 2];
+        const int rnext = (st + 1 < a.nsteps) ? a.rows[3 * (st + 1)] : r2;
+        const double h = a.hs[st];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const int srow = sg == 0 ? r0 : (sg == 3 ? r2 : r1);
+            const int nrow = sg == 0 ? r1 : (sg == 1 ? r1 : (sg == 2 ? r2 : rnext));
+            // loads that do not depend on the exchange first: phases of this row, coefficients of this stage
+            double2 e_cur = make_double2(1.0, 0.0), e_next = make_double2(1.0, 0.0);
+            if (a.E) {
+                e_cur = a.E[(size_t)srow * n_pad + row];
+                e_next = a.E[(size_t)nrow * n_pad + row];
+            }
+            double cmine = 0.0;
+            if (my_pair >= 0) cmine = my_static ? 1.0 : a.S[(size_t)srow * a.k + my_cidx];
+            const double c_re = (my_pair >= 0 && !(my_pair & 1)) ? cmine : 0.0;
+            const double c_im = (my_pair >= 0 && (my_pair & 1)) ? cmine : 0.0;
+            // ---- (1) poll the stage input of the coupled columns into LDS
+            const int b_nxt = (b_cur + 1) & 3, b_rearm = (b_cur + 3) & 3;
+            {
+                const unsigned long long* cur = ring + (size_t)b_cur * 2 * n_pad;
+                unsigned long long w[NPW];
+#pragma unroll
+                for (int i = 0; i < NPW; ++i) w[i] = (i < npw && word_of[i] >= 0 && !dead) ? RESIDENT_SENTINEL : 0ull;
+                unsigned spins = 0;
+                // A poll that comes too early costs a whole load latency (and its traffic delays everybody's stores);
+                // one that comes a little late costs that little.  So the wave sleeps before its first poll, for a
+                // time it adapts: two units longer after a round whose first poll found a word missing, one unit
+                // shorter after eight clean rounds in a row.
+                for (int z = 0; z < presleep; ++z) __builtin_amdgcn_s_sleep(1);
+                for (;;) {
+                    // every outstanding word again, all loads in flight together (words that arrived keep their value)
+                    unsigned long long f[NPW];
+#pragma unroll
+                    for (int i = 0; i < NPW; ++i)
+                        if (i < npw) f[i] = __hip_atomic_load(cur + (word_of[i] >= 0 ? word_of[i] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool pending = false;
+#pragma unroll
+                    for (int i = 0; i < NPW; ++i)
+                        if (i < npw) {
+                            if (w[i] == RESIDENT_SENTINEL) w[i] = f[i];
+                            pending |= (w[i] == RESIDENT_SENTINEL);
+                        }
+                    if (!pending) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    if ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = RESIDENT_SPIN_LIMIT;
+                    if (spins >= RESIDENT_SPIN_LIMIT) {   // a neighbour never arrived: flag, stop waiting for good
+                        __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        dead = true;
+                        break;
+                    }
+                }
+                if (__builtin_amdgcn_readfirstlane(__any(spins > 0) ? 1 : 0)) {
+                    presleep = presleep + 2 > RESIDENT_MAX_PRESLEEP ? RESIDENT_MAX_PRESLEEP : presleep + 2;
+                    clean = 0;
+                } else if (++clean == 8) {
+                    presleep = presleep > 0 ? presleep - 1 : 0;
+                    clean = 0;
+                }
+#pragma unroll
+                for (int i = 0; i < NPW; ++i)
+                    if (i < npw) ylds[rr & 1][i * THREADS + tid] = __longlong_as_double((long long)w[i]);
+            }
+            __syncthreads();
+            // ---- (2) this row of C(t) y': per chunk g = sum_e c_e A_e[row, col] (both parts), then g * y'[col]
+            double cr[NE], ci[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                cr[e] = resident_lane_value(c_re, e);
+                ci[e] = resident_lane_value(c_im, e);
+            }
+            double2 acc = make_double2(0.0, 0.0);
+            const double* yl = ylds[rr & 1];
+#if MIDYN_RESIDENT_ABLATE == 1   // profiling only: the exchange without the arithmetic
+            acc = *reinterpret_cast<const double2*>(yl + 2 * lane);
+#else
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q < nq) {
+                    double g_re = 0.0, g_im = 0.0;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        g_re = fma(cr[e], v[q * NE + e], g_re);
+                        g_im = fma(ci[e], v[q * NE + e], g_im);
+                    }
+                    const double2 yv = *reinterpret_cast<const double2*>(yl + slot_of[q] * 128 + 2 * lane);
+                    acc.x = fma(g_re, yv.x, acc.x);
+                    acc.x = fma(-g_im, yv.y, acc.x);
+                    acc.y = fma(g_re, yv.y, acc.y);
+                    acc.y = fma(g_im, yv.x, acc.y);
+                }
+            }
+#endif
+            acc.x = resident_wave_sum(acc.x);
+            acc.y = resident_wave_sum(acc.y);
+            // ---- (3) the RK4 stage of this row (apply_epilogue_t's arithmetic), publish the next stage input
+            const double2 kk = a.E ? cmul_conj_a(e_cur, acc) : acc;
+            double2 pub;
+            if (sg == 0) {
+                acc_r = cfma_r(h * (1.0 / 6), kk, yr);
+                pub = cfma_r(0.5 * h, kk, yr);
+            } else if (sg == 1) {
+                acc_r = cfma_r(h * (1.0 / 3), kk, acc_r);
+                pub = cfma_r(0.5 * h, kk, yr);
+            } else if (sg == 2) {
+                acc_r = cfma_r(h * (1.0 / 3), kk, acc_r);
+                pub = cfma_r(h, kk, yr);
+            } else {
+                yr = cfma_r(h * (1.0 / 6), kk, acc_r);
+                pub = yr;
+            }
+            if (a.E) pub = cmul(e_next, pub);
+            if (lane == 0) {
+                // the re-arming stores of the PREVIOUS round are complete before this round's data leaves (they are a
+                // round old: no stall); this round's re-arming follows the data
+                __builtin_amdgcn_s_waitcnt(0);
+                unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row;
+                __hip_atomic_store(z, (unsigned long long)__double_as_longlong(pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(z + 1, (unsigned long long)__double_as_longlong(pub.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // re-arm this row's words of the buffer read LAST round: having read this round from all my neighbours
+                // proves that every reader of those words has moved on (see the header)
+                unsigned long long* zr = ring + (size_t)b_rearm * 2 * n_pad + 2 * row;
+                __hip_atomic_store(zr, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(zr + 1, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            b_cur = b_nxt;
+            ++rr;
+        }
+        if (a.save && a.out && lane == 0 && row < a.n) {
+            const int slot = a.save[st];
+            if (slot >= 0) a.out[(size_t)slot * a.n + row] = yr;
+        }
+    }
+    if (lane == 0) a.y[row] = yr;
+}
+
+}  // namespace midyn

@@ -1841,6 +1841,7 @@ def test_block_sparse_routes_match_dense_routes(qd, nq, nb):
         out = {}
         for flag in (1, 0):
             ctx.set_option("skip_zero_blocks", flag)
+            ctx.set_option("resident_rk4", 0)      # (one RK4 trajectory would otherwise take the resident kernel)
             ctx.reset_counters()
             ctx.set_option("profile", 1)
             try:
@@ -1848,6 +1849,7 @@ def test_block_sparse_routes_match_dense_routes(qd, nq, nb):
             finally:
                 ctx.set_option("profile", 0)
                 ctx.set_option("skip_zero_blocks", 1)
+                ctx.set_option("resident_rk4", 1)
             blocks = ctx.counters("rhs_blocks")["launches"] + ctx.counters("rhs_blocks_gemm")["launches"]
             dense = ctx.counters("rhs_stream")["launches"] + ctx.counters("rhs_gemm")["launches"]
             assert (blocks > 0 and dense == 0) if flag else (blocks == 0 and dense > 0), (method, flag, blocks, dense)

@@ -1,0 +1,223 @@
+"""rk4_resident_kernel (csrc/midyn_resident.h): one RK4 trajectory with the operators held in registers and the stage
+input exchanged through a polled ring in device memory -- against the CPU oracle, against the launch-per-stage route
+on the same inputs, across the shapes that decide its layout (entries per chunk 2..16, one to sixteen operand chunks,
+padding rows, symmetry sectors with and without padding, frames of every kind), saved states, backwards integration,
+step ranges run in pieces, and the shapes that must NOT take it.  `pytest -m gpu`.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+SOLVE_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def qd():
+    import qiskit_dynamics_amd as q
+
+    q.default_context()
+    return q
+
+
+def crand(rng, *shape):
+    return rng.uniform(-1, 1, shape) + 1j * rng.uniform(-1, 1, shape)
+
+
+def herm(rng, n, real=False):
+    a = rng.uniform(-1, 1, (n, n)).astype(complex) if real else crand(rng, n, n)
+    return (a + a.conj().T) / 2
+
+
+def _solve_both(qd, solver, **kw):
+    """(resident result, per-stage result, resident launches, per-stage launches of the resident kernel)"""
+    ctx = qd.default_context()
+    out, launches = {}, {}
+    for flag in (1, 0):
+        ctx.set_option("resident_rk4", flag)
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        try:
+            out[flag] = solver.solve(**kw)
+        finally:
+            ctx.set_option("profile", 0)
+            ctx.set_option("resident_rk4", 1)
+        launches[flag] = ctx.counters("rk4_resident")["launches"]
+    return out[1], out[0], launches[1], launches[0]
+
+
+CASES = [
+    # n, k, frame kind, real operators, expected to take the resident kernel
+    (33, 1, "none", False, True),        # smallest size above the tiny kernel; n_pad = 64: one chunk, 31 padding rows
+    (64, 3, "full", False, True),        # 8 planes: NE = 8
+    (100, 2, "full", False, True),       # n_pad = 128, 6 planes -> NE = 8, two chunks
+    (130, 1, "diag", False, True),       # n_pad = 192: three chunks, static + 1 operator complex: NE = 4
+    (200, 7, "none", True, True),        # real Hamiltonians: G = -iH purely imaginary, 8 planes with the static part
+    (256, 3, "diag", True, True),        # NE = 4, four chunks
+    (300, 0, "full", False, True),       # static operator only (k = 0)
+    (512, 1, "full", False, True),       # NE = 4, eight chunks, 8 rows per workgroup
+    (700, 1, "none", True, True),        # n_pad = 704: eleven chunks, NE = 2
+    (96, 9, "full", False, False),       # 20 planes: more than 16 entries per chunk -> per-stage route
+    (640, 3, "full", False, False),      # 8 planes x 10 chunks = 80 doubles per lane > 64 -> per-stage route
+]
+
+
+@pytest.mark.parametrize("n,k,frame_kind,real,expect", CASES)
+def test_resident_kernel_against_oracle_and_per_stage_route(qd, n, k, frame_kind, real, expect):
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(1000 + n + k)
+    hs = herm(rng, n, real) * (2.0 / np.sqrt(n))
+    ho = np.array([herm(rng, n, real) for _ in range(k)]) * (2.0 / np.sqrt(n)) if k else None
+    frame = {"none": None, "full": herm(rng, n) * (2.0 / np.sqrt(n)), "diag": rng.normal(size=n)}[frame_kind]
+    sigs = [qd.Signal(lambda t, a=0.3 + 0.1 * j: a * np.exp(-((t - 0.3) ** 2)) + 0j, 0.4 * j, 0.2 * j) for j in range(k)]
+
+    def coeff(t):
+        return np.array([np.real(s(t)) for s in sigs])
+
+    solver = qd.Solver(static_hamiltonian=hs, hamiltonian_operators=ho, rotating_frame=frame)
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    kw = dict(t_span=[0.0, 0.5], y0=y0, method="RK4", max_dt=0.01, t_eval=[0.0, 0.13, 0.5])
+    if k:
+        kw["signals"] = sigs
+    res, per_stage, l_res, l_off = _solve_both(qd, solver, **kw)
+    assert (l_res > 0) == expect and l_off == 0
+    assert_close(res.y, per_stage.y, 1e-13)
+    a_d, a, d, basis = orc.hamiltonian_model_build(hs, ho, frame)
+    t_ref, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff if k else None, [0.0, 0.5], y0, "RK4", 0.01,
+                                             t_eval=[0.0, 0.13, 0.5])
+    assert_close(res.t, t_ref, 0)
+    assert_close(res.y, y_ref, SOLVE_TOL)
+
+
+def test_resident_kernel_backwards_one_step_and_zero_length(qd):
+    """Integration backwards in time, a span shorter than max_dt (one step), a zero-length span (one step of h = 0)
+    and every step saved -- the step tables the kernel reads on the device (fixed_step_solvers.py:616-653)."""
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(7)
+    n = 80
+    hs, ho, frame = herm(rng, n) * 0.3, np.array([herm(rng, n), herm(rng, n)]) * 0.3, herm(rng, n) * 0.3
+    sigs = [qd.Signal(0.5, 1.0, 0.1), qd.Signal(lambda t: 0.2 * np.sin(t) + 0j, 0.0)]
+
+    def coeff(t):
+        return np.array([0.5 * np.cos(2 * np.pi * t + 0.1), 0.2 * np.sin(t)])
+
+    solver = qd.Solver(static_hamiltonian=hs, hamiltonian_operators=ho, rotating_frame=frame)
+    y0 = crand(rng, n)
+    a_d, a, d, basis = orc.hamiltonian_model_build(hs, ho, frame)
+    for t_span, t_eval, max_dt in (([0.5, 0.0], [0.45, 0.2, 0.0], 0.02), ([0.0, 0.004], None, 0.1),
+                                   ([0.3, 0.3], None, 0.1), ([0.0, 0.2], list(np.linspace(0.0, 0.2, 21)), 0.01)):
+        res, per_stage, l_res, _ = _solve_both(qd, solver, t_span=t_span, y0=y0, signals=sigs, method="RK4",
+                                                max_dt=max_dt, t_eval=t_eval)
+        assert l_res > 0
+        t_ref, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff, t_span, y0, "RK4", max_dt, t_eval=t_eval)
+        assert_close(res.t, t_ref, 0)
+        assert_close(res.y, y_ref, SOLVE_TOL)
+        assert_close(res.y, per_stage.y, 1e-13)
+
+
+def test_resident_kernel_symmetry_sectors(qd):
+    """Frames with conserved quantities: the parity-conserving chain (two aligned sectors, every workgroup polls only
+    the other sector's chunks) and sectors of 100 / 70 / 30 states embedded on block boundaries (padding rows inside the
+    device stack, operators that couple two of the three sectors) -- against the oracle."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    rng = np.random.default_rng(11)
+    cfg = W.schrodinger_config(n_qubits=8, n_drives=8, t_final=1.0, max_dt=0.01)
+    sel_frame = np.zeros((200, 200), dtype=complex)
+    bounds = [(0, 100), (100, 170), (170, 200)]
+    for lo, hi in bounds:
+        sel_frame[lo:hi, lo:hi] = herm(rng, hi - lo) * 0.3
+    sel_ops = np.zeros((2, 200, 200), dtype=complex)
+    cpl = crand(rng, 100, 70) * 0.05
+    sel_ops[0, 0:100, 100:170] = cpl
+    sel_ops[0, 100:170, 0:100] = cpl.conj().T
+    sel_ops[1, 170:200, 170:200] = herm(rng, 30) * 0.3
+    cases = [(cfg["h_d"], cfg["ops"], cfg["h_d"]), (sel_frame, sel_ops, sel_frame)]
+    for h_static, h_ops, frame in cases:
+        k, n = len(h_ops), frame.shape[0]
+        sigs = [qd.Signal(lambda t, a=0.3 + 0.1 * j: a * np.cos(0.9 * t) + 0j, 0.4 * j, 0.2 * j) for j in range(k)]
+        solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=frame)
+        assert solver.model.rotating_frame.sector_labels is not None
+        y0 = crand(rng, n)
+        y0 /= np.linalg.norm(y0)
+        res, per_stage, l_res, _ = _solve_both(qd, solver, t_span=[0.0, 0.3], y0=y0, signals=sigs, method="RK4",
+                                                max_dt=0.01)
+        assert l_res > 0
+        assert_close(res.y, per_stage.y, 1e-13)
+        a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
+        _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt: np.array([np.real(s(tt)) for s in sigs]),
+                                           [0.0, 0.3], y0, "RK4", 0.01)
+        assert_close(res.y[-1], ref[-1], SOLVE_TOL)
+
+
+def test_resident_kernel_step_ranges_run_in_pieces(qd):
+    """midyn_rk4_plan_run over [0, 7), [7, 8), [8, 40): every launch rebuilds the ring from the state -- equal to one
+    launch over [0, 40) to the last bits, bit-reproducible run to run, and equal to the per-stage route to rounding."""
+    from qiskit_dynamics_amd import workloads as W
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(3)
+    n, k = 192, 3
+    ops = np.array([-1j * herm(rng, n) for _ in range(k)]) * 0.2
+    static = -1j * herm(rng, n) * 0.2
+    fim = rng.normal(size=n)
+    stack = qd.Stack(ctx, ops, static, fim)
+    sched = FixedStepSchedule([0.0, 0.4], None, 0.01, _rk4_points)
+    nsteps = len(sched.step_h)
+    nr = int(sched.step_rows.max()) + 1
+    table = rng.uniform(-1, 1, (1, nr, k))
+    y0 = crand(rng, n, 1)
+    outs = {}
+    for tag, flag, pieces in (("one", 1, [(0, nsteps)]), ("pieces", 1, [(0, 7), (7, 8), (8, nsteps)]),
+                              ("again", 1, [(0, nsteps)]), ("per_stage", 0, [(0, nsteps)])):
+        ctx.set_option("resident_rk4", flag)
+        try:
+            p = qd.Rk4Plan(stack, sched.times[:nr], table, sched.step_rows, sched.step_h, y0, 1, True)
+            ctx.reset_counters()
+            ctx.set_option("profile", 1)
+            for lo, hi in pieces:
+                p.run(lo, hi)
+            ctx.synchronize()
+            ctx.set_option("profile", 0)
+            assert ctx.counters("rk4_resident")["launches"] == (len(pieces) if flag else 0)
+            outs[tag] = p.fetch()
+            p.close()
+        finally:
+            ctx.set_option("profile", 0)
+            ctx.set_option("resident_rk4", 1)
+    assert np.array_equal(outs["one"], outs["again"])          # run to run: bit-identical
+    assert_close(outs["one"], outs["pieces"], 1e-15)           # (the phase product at a launch boundary may contract differently)
+    assert_close(outs["one"], outs["per_stage"], 1e-13)
+    stack.close()
+
+
+def test_resident_kernel_cfg2_shape(qd):
+    """BASELINE configs[1]: the 10-qubit model (n = 1024, 8 drives, rotating_frame = H_d), one trajectory, 40 steps:
+    resident kernel vs the oracle and vs the per-stage route."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    cfg = W.schrodinger_config()
+    k = len(cfg["ops"])
+    amps, phases = W.sweep_parameters(3, k)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+    res, per_stage, l_res, _ = _solve_both(qd, solver, t_span=[0.0, 0.2], y0=cfg["y0"], signals=sigs, method="RK4",
+                                            max_dt=0.005)
+    assert l_res > 0
+    assert_close(res.y, per_stage.y, 1e-13)
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], cfg["h_d"])
+
+    def coeff(t):
+        return W.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], 5.0)[0]
+
+    _, ref = orc.solve_generator_model(a_d, a, d, basis, coeff, [0.0, 0.2], cfg["y0"], "RK4", 0.005)
+    assert_close(res.y[-1], ref[-1], SOLVE_TOL)
