@@ -25,7 +25,10 @@ Objects on the line besides the contract fields:
                               MFMA flops / launch time, `frac` = achieved / 78.6 TFLOP/s (a hardware fraction, <= 1);
                               the SURVEY 8(d) "useful" figure is kept as `useful_tflops`
   dense_complex               the same sweep without exact-zero plane skipping (general complex operators)
-  roofline_single_trajectory  cfg 2 (HBM-bound streaming kernel): `frac` = executed bytes / time / 8 TB/s
+  single_trajectory           cfg 2 = BASELINE configs[1], one trajectory: the register-resident RK4 kernel (whole step
+                              range in one launch) with the per-stage route beside it
+  roofline_single_trajectory  the per-stage HBM-bound streaming kernel of the same trajectory (resident_rk4=0):
+                              `frac` = executed bytes / time / 8 TB/s
   cfg4, cfg5                  the vectorised-Lindblad / 12-qubit Magnus-2 configurations with their own rooflines
                               (executed work of the work lists AND the 8(d) dense-form price, labelled)
   sharded_cfg5                second sharded leg: the 1024-instance cfg-5 sweep, 1024/N per GPU
@@ -341,7 +344,7 @@ def profile_pass(ctx, fn, classes):
         ctx.set_option("profile", 0)
 
 
-ALL_CLASSES = ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", "rhs_blocks", "rhs_blocks_gemm")
+ALL_CLASSES = ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", "rhs_blocks", "rhs_blocks_gemm", "rk4_resident")
 
 
 def leg_cfg4(qd, ctx, workloads):
@@ -809,20 +812,34 @@ def main():
 
     # ---- cfg 2: single trajectory, HBM-bound streaming kernel (rank 0, N=1) -------------------------------------
     if rank == 0 and world == 1 and not args.no_single:
-        s_total = 64
+        s_total = 264
         rows1 = sched.step_rows[:s_total]
         nr1 = int(rows1.max()) + 1
         table1 = workloads.gaussian_coefficient_table(sched.times[:nr1], amps[:1], phs[:1], cfg["carrier"], T_FINAL)
-        p1 = qd.Rk4Plan(stack, sched.times[:nr1], table1, rows1, sched.step_h[:s_total], y0, 1, True)
-        p1.run(0, 8)
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        ctx.timer_start()
-        p1.run(8, s_total)
-        ev1 = ctx.timer_stop()
-        el1 = time.perf_counter() - t0
-        c1 = profile_pass(ctx, lambda: p1.run(8, s_total), ("rhs_stream",))["rhs_stream"]
-        p1.close()
+
+        def one_trajectory(resident):
+            """(wall seconds, stream ms, counters) of steps 8..s_total of one trajectory on the chosen route"""
+            ctx.set_option("resident_rk4", 1 if resident else 0)
+            try:
+                p1 = qd.Rk4Plan(stack, sched.times[:nr1], table1, rows1, sched.step_h[:s_total], y0, 1, True)
+                p1.run(0, 8)
+                ctx.synchronize()
+                t0_ = time.perf_counter()
+                ctx.timer_start()
+                p1.run(8, s_total)
+                ev_ = ctx.timer_stop()
+                el_ = time.perf_counter() - t0_
+                cn_ = profile_pass(ctx, lambda: p1.run(8, s_total), ("rhs_stream", "rk4_resident"))
+                yfin = p1.fetch()
+                p1.close()
+            finally:
+                ctx.set_option("resident_rk4", 1)
+            return el_, ev_, cn_, yfin
+
+        el_res, ev_res, cn_res, y_res = one_trajectory(True)
+        el1, ev1, cn1, y_stage = one_trajectory(False)
+        c1 = cn1["rhs_stream"]
+        took_resident = cn_res["rk4_resident"]["launches"] > 0
         nseg = stack.n_segments
         bytes_alg = 16 * nseg * n * n + 32 * n                 # SURVEY 8(d) cfg 2: 151.03 MB
         avg_ms1 = ev1 / (4 * (s_total - 8))                    # back-to-back launches, same region as ms_per_step
@@ -834,10 +851,21 @@ def main():
         executed_bytes = (8 * n_act * n * n * streamed + 32 * n) if planar else bytes_alg
         gbs_exec = executed_bytes / (avg_ms1 * 1e-3) / 1e9
         kname = "rhs_stream_plane_kernel<2, 3>" if planar else "rhs_stream_kernel<4, 3>"
+        n_eval1 = 4 * (s_total - 8)
         out["single_trajectory"] = {
-            "workload": "cfg2: same model, 1 trajectory, RK4", "rhs_evals_per_s": round(4 * (s_total - 8) / el1, 1),
-            "ms_per_step": round(el1 / (s_total - 8) * 1e3, 4)}
+            "workload": "cfg2 (BASELINE configs[1]): same model, 1 trajectory, RK4",
+            "rhs_evals_per_s": round(n_eval1 / el_res, 1), "ms_per_step": round(el_res / (s_total - 8) * 1e3, 5),
+            "us_per_evaluation": round(el_res / n_eval1 * 1e6, 3),
+            "route": "rk4_resident_kernel (one launch for the step range; operator planes in registers, stage input "
+                     "through a polled ring in device memory)" if took_resident else "per-stage streaming kernel",
+            "bound": "exchange latency: one store -> poll hop across the XCDs per stage (no operator traffic after "
+                     "the launch has loaded its rows)" if took_resident else "hbm",
+            "per_stage_route_rhs_evals_per_s": round(n_eval1 / el1, 1),
+            "max_abs_difference_between_the_routes": float(np.max(np.abs(y_res - y_stage))),
+            "steps_timed": s_total - 8}
         out["roofline_single_trajectory"] = {
+            "route": "per-stage streaming kernel (option resident_rk4=0): the kernel of evaluate_rhs and of single "
+                     "trajectories whose operators do not fit the register files",
             "kernel": kname.split("<")[0], "bound": "hbm", "achieved": round(gbs_exec, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(gbs_exec / HBM_PEAK_GBS, 4), "traffic": measured_traffic(kname)[0],
             "traffic_source": measured_traffic(kname)[1],
