@@ -275,4 +275,320 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
     if (lane == 0) a.y[row] = yr;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// ell_resident_kernel: the same idea for VERY sparse operators (the vectorised Lindbladian of cfg 4 has at most 27
+// non-zeros per row over 7 segments, N = 4096): one LANE per row.  A lane keeps the non-zero operator elements of
+// its row -- (value of one plane, LDS index of the column, segment, plane) x at most ELL_W -- in registers; a
+// workgroup is 64 consecutive rows (one 64-row chunk, whose symmetric poll list it uses): poll the coupled chunks
+// into LDS, gather y'[col] per entry (no cross-lane reduction: a row is a lane), run the row's stage, publish 64
+// rows with one coalesced store.  MODE 0: RK4 stages.  MODE 1: the expm
+// action of Magnus order 1 (csrc/midyn_action.inc) -- per step the Chebyshev series, phi_{k+1} = 2 (h/rho) G phi_k +
+// phi_{k-1}, or the scaled Taylor series, one round per term, the accumulator and the recurrence vectors in
+// registers, every step of the solve in ONE launch.
+// ------------------------------------------------------------------------------------------------
+constexpr int ELL_W = 64;       // non-zero plane values per row at most
+constexpr int ELL_WAVES = 4;    // waves per 64-row workgroup
+
+struct EllArgs {
+    const double* val;        // [wmax][n_pad] entry e of row r: value of one plane of one operator element
+    const int* meta;          // [wmax][n_pad] LDS index of the column (bits 0-15) | segment << 16 | plane << 22 | valid << 23
+    int wmax;
+    int n, n_pad, has_static, k, nseg;
+    const double* S;          // [R][k]
+    const double2* E;         // [R][n_pad] or nullptr
+    const int* rows;          // [nsteps][3]
+    const double* hs;         // [nsteps]
+    const int* save;          // [nsteps] or nullptr
+    int step_begin, step_end, nsteps;
+    const int* poll_ptr;      // [n_pad/64 + 1]
+    const int* poll_idx;
+    unsigned long long* ring; // [4][2 * n_pad]
+    double2* y;               // [n_pad]
+    double2* out;             // [P][n] or nullptr
+    int* err;
+    // MODE 1: per step K > 0 terms of the Chebyshev series (or -K = the Taylor degree), the repetitions, h / rho (or
+    // h / scaling) and the Bessel coefficients J_0..J_K
+    const int* cheb_K;
+    const int* cheb_reps;
+    const double* cheb_hrho;
+    const double* cheb_coef;
+    int cheb_stride;
+};
+
+// rows of the ELL arrays from the block lists: one wave per row walks the listed (segment, 16-column block) entries of
+// its 16-row group four at a time; PASS 0 counts the non-zero plane values, PASS 1 writes them in that order
+template <int PASS>
+__global__ __launch_bounds__(256) void ell_build_kernel(const double2* __restrict__ ops, int n_pad, const int* __restrict__ blk_ptr,
+                                                        const int* __restrict__ blk_idx, const int* __restrict__ slot_map,
+                                                        int* __restrict__ counts, double* __restrict__ val,
+                                                        int* __restrict__ meta, int wmax) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = row >> 4, nc = n_pad >> 6;
+    const int j0 = blk_ptr[g], j1 = blk_ptr[g + 1];
+    int cnt = 0;
+    for (int j = j0; j < j1; j += 4) {
+        const int je = j + (lane >> 4);
+        double2 z = make_double2(0.0, 0.0);
+        int seg = 0, col = 0;
+        if (je < j1) {
+            const int entry = blk_idx[je];
+            seg = entry >> 16;
+            col = (entry & 0xffff) * 16 + (lane & 15);
+            z = ops[((size_t)seg * n_pad + row) * n_pad + col];
+        }
+        const unsigned long long m_re = __ballot(z.x != 0.0), m_im = __ballot(z.y != 0.0);
+        if (PASS == 1) {
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int slot = slot_map[(row >> 6) * nc + (col >> 6)];
+            const int base = (slot * 64 + (col & 63)) | (seg << 16) | (1 << 23);
+            if (z.x != 0.0) {
+                const int pos = cnt + __popcll(m_re & below);
+                if (pos < wmax) { val[(size_t)pos * n_pad + row] = z.x; meta[(size_t)pos * n_pad + row] = base; }
+            }
+            if (z.y != 0.0) {
+                const int pos = cnt + __popcll(m_re) + __popcll(m_im & below);
+                if (pos < wmax) { val[(size_t)pos * n_pad + row] = z.y; meta[(size_t)pos * n_pad + row] = base | (1 << 22); }
+            }
+        }
+        cnt += __popcll(m_re) + __popcll(m_im);
+    }
+    if (PASS == 0 && lane == 0) counts[row] = cnt;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const EllArgs a) {
+    // One workgroup = 64 consecutive rows (lane = row) x ELL_WAVES waves.  A single wave polling 26 words per lane and
+    // walking 27 entries is latency bound on its own instruction stream (measured 6.9 us per round at N = 4096);
+    // so the waves share the round: each polls a quarter of the words, each owns every ELL_WAVES-th entry of every
+    // row, the partial sums meet in LDS and wave 0 owns the rows' state, runs the stage and publishes.
+    constexpr int THREADS = 64 * ELL_WAVES;
+    constexpr int NPW = RESIDENT_MAX_POLL * 128 / THREADS;   // polled words per thread
+    constexpr int EW = ELL_W / ELL_WAVES;                    // entries per lane
+    __shared__ __attribute__((aligned(16))) double ylds[RESIDENT_MAX_POLL * 128];
+    __shared__ __attribute__((aligned(16))) double2 part[ELL_WAVES][64];
+    __shared__ double cl[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rchunk = blockIdx.x, row = rchunk * 64 + lane;
+    const int n_pad = a.n_pad;
+    unsigned long long* const ring = a.ring;
+    double val[EW];
+    int meta[EW];
+#pragma unroll
+    for (int j = 0; j < EW; ++j) {
+        const int e = j * ELL_WAVES + wave;
+        val[j] = e < a.wmax ? a.val[(size_t)e * n_pad + row] : 0.0;
+        meta[j] = e < a.wmax ? a.meta[(size_t)e * n_pad + row] : 0;
+        if (!(meta[j] & (1 << 23))) { val[j] = 0.0; meta[j] = 0; }
+    }
+    const int my_entries = (a.wmax - wave + ELL_WAVES - 1) / ELL_WAVES;   // entries e = j * ELL_WAVES + wave < wmax
+    const int pbase = a.poll_ptr[rchunk];
+    const int npoll = a.poll_ptr[rchunk + 1] - pbase;
+    const int npw = (npoll * 128 + THREADS - 1) / THREADS;
+    int word_of[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int slot = (i * THREADS + tid) >> 7;
+        word_of[i] = slot < npoll ? a.poll_idx[pbase + slot] * 128 + (tid & 127) : -1;
+    }
+    const bool cstatic = a.has_static && tid == 0;
+    const int cidx = tid - a.has_static;
+
+    double2 yr = a.y[row];     // (state only meaningful in wave 0)
+    bool dead = false;
+    int presleep = RESIDENT_INIT_PRESLEEP, clean = 0;
+    int b_cur = 0;
+
+    // one round: poll buffer b_cur into LDS, C = (sum_seg c_seg A_seg y')[row] (complete in wave 0)
+    auto product = [&]() -> double2 {
+        const unsigned long long* cur = ring + (size_t)b_cur * 2 * n_pad;
+        for (int z = 0; z < presleep; ++z) __builtin_amdgcn_s_sleep(1);
+        unsigned long long w[NPW];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) w[i] = (i < npw && word_of[i] >= 0 && !dead) ? RESIDENT_SENTINEL : 0ull;
+        unsigned spins = 0;
+        for (;;) {
+            unsigned long long f[NPW];
+#pragma unroll
+            for (int i = 0; i < NPW; ++i)
+                if (i < npw) f[i] = __hip_atomic_load(cur + (word_of[i] >= 0 ? word_of[i] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool pending = false;
+#pragma unroll
+            for (int i = 0; i < NPW; ++i)
+                if (i < npw) {
+                    if (w[i] == RESIDENT_SENTINEL) w[i] = f[i];
+                    pending |= (w[i] == RESIDENT_SENTINEL);
+                }
+            if (!pending) break;
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = RESIDENT_SPIN_LIMIT;
+            if (spins >= RESIDENT_SPIN_LIMIT) {
+                __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                dead = true;
+                break;
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane(__any(spins > 0) ? 1 : 0)) {
+            presleep = presleep + 2 > RESIDENT_MAX_PRESLEEP ? RESIDENT_MAX_PRESLEEP : presleep + 2;
+            clean = 0;
+        } else if (++clean == 8) {
+            presleep = presleep > 0 ? presleep - 1 : 0;
+            clean = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+            if (i < npw) ylds[i * THREADS + tid] = __longlong_as_double((long long)w[i]);
+        __syncthreads();
+        // this wave's entries of every row; MODE 1 holds val[] already multiplied by its segment's coefficient
+        // (constant within a step, see load_weighted)
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < EW; ++j)
+            if (j < my_entries) {
+                const int mt = meta[j];
+                const double wgt = MODE == 1 ? val[j] : cl[(mt >> 16) & 63] * val[j];
+                const double2 yv = *reinterpret_cast<const double2*>(ylds + 2 * (mt & 0xffff));
+                const bool im = (mt >> 22) & 1;
+                acc.x = fma(wgt, im ? -yv.y : yv.x, acc.x);
+                acc.y = fma(wgt, im ? yv.x : yv.y, acc.y);
+            }
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w2 = 1; w2 < ELL_WAVES; ++w2) {
+                const double2 p2 = part[w2][lane];
+                acc.x += p2.x;
+                acc.y += p2.y;
+            }
+        }
+        return acc;
+    };
+    // wave 0: publish this row's next input into buffer b_cur + 1, re-arm its words of buffer b_cur - 1; all: advance
+    auto publish = [&](double2 pub) {
+        const int b_nxt = (b_cur + 1) & 3, b_rearm = (b_cur + 3) & 3;
+        if (wave == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row;
+            __hip_atomic_store(z, (unsigned long long)__double_as_longlong(pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(z + 1, (unsigned long long)__double_as_longlong(pub.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* zr = ring + (size_t)b_rearm * 2 * n_pad + 2 * row;
+            __hip_atomic_store(zr, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(zr + 1, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        b_cur = b_nxt;
+    };
+    // coefficients of one table row into LDS; the reads of the previous round finished at its second barrier, the
+    // barrier of the next poll publishes the new values
+    auto set_coefficients = [&](int trow) {
+        if (tid < a.nseg) cl[tid] = cstatic ? 1.0 : a.S[(size_t)trow * a.k + cidx];
+    };
+    // MODE 1: the coefficients are those of ONE time for every product of a step: fold them into the values
+    auto load_weighted = [&](int trow) {
+        set_coefficients(trow);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < EW; ++j) {
+            const int e = j * ELL_WAVES + wave;
+            if (j < my_entries) val[j] = (meta[j] & (1 << 23)) ? a.val[(size_t)e * n_pad + row] * cl[(meta[j] >> 16) & 63] : 0.0;
+        }
+        __syncthreads();
+    };
+
+    if (wave == 0 && a.step_begin < a.step_end) {    // round 0 input: the state phased to the first product's time
+        double2 y0 = yr;
+        if (a.E) y0 = cmul(a.E[(size_t)a.rows[3 * a.step_begin] * n_pad + row], yr);
+        __hip_atomic_store(ring + 2 * row, (unsigned long long)__double_as_longlong(y0.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ring + 2 * row + 1, (unsigned long long)__double_as_longlong(y0.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int st = a.step_begin; st < a.step_end; ++st) {
+        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1], r2 = a.rows[3 * st + 2];
+        const int rnext = (st + 1 < a.nsteps) ? a.rows[3 * (st + 1)] : (MODE == 0 ? r2 : r0);
+        const double h = a.hs[st];
+        if (MODE == 0) {
+            double2 acc_r = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const int srow = sg == 0 ? r0 : (sg == 3 ? r2 : r1);
+                const int nrow = sg == 0 ? r1 : (sg == 1 ? r1 : (sg == 2 ? r2 : rnext));
+                double2 e_cur = make_double2(1.0, 0.0), e_next = make_double2(1.0, 0.0);
+                if (a.E && wave == 0) {
+                    e_cur = a.E[(size_t)srow * n_pad + row];
+                    e_next = a.E[(size_t)nrow * n_pad + row];
+                }
+                set_coefficients(srow);
+                const double2 c = product();
+                const double2 kk = a.E ? cmul_conj_a(e_cur, c) : c;
+                double2 pub;
+                if (sg == 0) {
+                    acc_r = cfma_r(h * (1.0 / 6), kk, yr);
+                    pub = cfma_r(0.5 * h, kk, yr);
+                } else if (sg == 1) {
+                    acc_r = cfma_r(h * (1.0 / 3), kk, acc_r);
+                    pub = cfma_r(0.5 * h, kk, yr);
+                } else if (sg == 2) {
+                    acc_r = cfma_r(h * (1.0 / 3), kk, acc_r);
+                    pub = cfma_r(h, kk, yr);
+                } else {
+                    yr = cfma_r(h * (1.0 / 6), kk, acc_r);
+                    pub = yr;
+                }
+                if (a.E) pub = cmul(e_next, pub);
+                publish(pub);
+            }
+        } else {
+            // K > 0: Chebyshev series with K terms (hr = h / rho, coef = J_0..J_K); K < 0: Taylor series of degree -K
+            // (hr = h / scaling); `reps` repetitions of the series per step
+            const int Ks = a.cheb_K[st], reps = a.cheb_reps[st];
+            const bool cheb = Ks > 0;
+            const int K = cheb ? Ks : -Ks;
+            const double hr = a.cheb_hrho[st];
+            const double* coef = a.cheb_coef + (size_t)st * a.cheb_stride;
+            double2 e_ph = make_double2(1.0, 0.0), e_nx = make_double2(1.0, 0.0);
+            if (a.E && wave == 0) {
+                e_ph = a.E[(size_t)r0 * n_pad + row];
+                e_nx = a.E[(size_t)rnext * n_pad + row];
+            }
+            load_weighted(r0);
+            for (int rep = 0; rep < reps; ++rep) {
+                const double c0 = cheb ? coef[0] : 1.0;
+                double2 accv = make_double2(c0 * yr.x, c0 * yr.y);
+                double2 phi_prev = make_double2(0.0, 0.0), phi_cur = yr;
+                for (int kt = 0; kt < K; ++kt) {
+                    const double2 c = product();
+                    const double2 kk = a.E ? cmul_conj_a(e_ph, c) : c;
+                    double2 term;
+                    if (cheb) {   // phi_{k+1} = (1 | 2) (h / rho) G phi_k + phi_{k-1};  acc += 2 J_{k+1} phi_{k+1}
+                        const double alpha = (kt == 0 ? 1.0 : 2.0) * hr;
+                        term = make_double2(alpha * kk.x + phi_prev.x, alpha * kk.y + phi_prev.y);
+                        accv = cfma_r(2.0 * coef[kt + 1], term, accv);
+                    } else {      // term_j = (h / (s j)) G term_{j-1};  acc += term_j   (EPI_TAYLOR's arithmetic)
+                        const double hj = hr / (double)(kt + 1);
+                        term = make_double2(hj * kk.x, hj * kk.y);
+                        accv = make_double2(accv.x + term.x, accv.y + term.y);
+                    }
+                    phi_prev = phi_cur;
+                    phi_cur = term;
+                    double2 pub = term;
+                    if (kt == K - 1) {
+                        yr = accv;
+                        pub = a.E ? cmul(rep + 1 < reps ? e_ph : e_nx, yr) : yr;
+                    } else if (a.E) {
+                        pub = cmul(e_ph, term);
+                    }
+                    publish(pub);
+                }
+            }
+        }
+        if (wave == 0 && a.save && a.out && row < a.n) {
+            const int slot = a.save[st];
+            if (slot >= 0) a.out[(size_t)slot * a.n + row] = yr;
+        }
+    }
+    if (wave == 0) a.y[row] = yr;
+}
+
 }  // namespace midyn

@@ -1906,6 +1906,7 @@ def test_block_sparse_vectorised_lindblad(qd):
         for kry in (2, 0):   # 2: Arnoldi on every step (the automatic rule prefers the series for cheap block products)
             ctx.set_option("skip_zero_blocks", flag)
             ctx.set_option("krylov", kry)
+            ctx.set_option("resident_rk4", 0)      # (the series would otherwise run inside ell_resident_kernel)
             ctx.reset_counters()
             ctx.set_option("profile", 1)
             try:
@@ -1914,6 +1915,7 @@ def test_block_sparse_vectorised_lindblad(qd):
                 ctx.set_option("profile", 0)
                 ctx.set_option("skip_zero_blocks", 1)
                 ctx.set_option("krylov", 1)
+                ctx.set_option("resident_rk4", 1)
             assert (ctx.counters("rhs_blocks")["launches"] > 0) == bool(flag)
             out[(flag, kry)] = r.y[-1]
     for key in ((1, 0), (0, 2), (0, 0)):

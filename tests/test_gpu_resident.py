@@ -221,3 +221,76 @@ def test_resident_kernel_cfg2_shape(qd):
 
     _, ref = orc.solve_generator_model(a_d, a, d, basis, coeff, [0.0, 0.2], cfg["y0"], "RK4", 0.005)
     assert_close(res.y[-1], ref[-1], SOLVE_TOL)
+
+
+def _chain_diag_frame(qd, nq):
+    """nq-qubit chain in the DIAGONAL frame diag(H_d): the operators stay in the computational basis, a handful of
+    non-zeros per row (block-sparse stack with work lists)."""
+    from qiskit_dynamics_amd import workloads as W
+
+    cfg = W.schrodinger_config(n_qubits=nq, n_drives=nq, t_final=1.0, max_dt=0.01)
+    amps, phases = W.sweep_parameters(1, len(cfg["ops"]))
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    frame = np.diag(cfg["h_d"]).real.copy()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
+    return cfg, sigs, frame, solver
+
+
+@pytest.mark.parametrize("nq", [8, 9])
+def test_lane_per_row_kernel_rk4_and_chebyshev_action(qd, nq):
+    """ell_resident_kernel (one lane per row, operator elements in registers) on the chain in its diagonal frame,
+    n = 256 / 512: RK4 (MODE 0) and the Magnus-1 Chebyshev action of scipy_expm (MODE 1, the whole solve in one
+    launch) against the oracle and against the launch-per-product routes, with saved states."""
+    from oracle import dynamics_oracle as orc
+
+    cfg, sigs, frame, solver = _chain_diag_frame(qd, nq)
+    info = solver.model.stack.block_info()
+    assert info["state"] == 1 and info["block_density"] < 0.25
+    rng = np.random.default_rng(nq)
+    y0 = crand(rng, 2**nq)
+    y0 /= np.linalg.norm(y0)
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
+
+    def coeff(t):
+        return np.array([np.real(s(t)) for s in sigs])
+
+    for method, kw in (("RK4", dict(max_dt=0.01)), ("scipy_expm", dict(max_dt=0.05, magnus_order=1))):
+        res, per_launch, l_res, l_off = _solve_both(qd, solver, t_span=[0.0, 0.3], y0=y0, signals=sigs, method=method,
+                                                    t_eval=[0.0, 0.1, 0.3], **kw)
+        assert l_res == 1 and l_off == 0, (method, l_res, l_off)
+        assert_close(res.y, per_launch.y, 1e-13)
+        t_ref, y_ref = orc.solve_generator_model(a_d, a, d, basis, coeff, [0.0, 0.3], y0, method, kw["max_dt"],
+                                                 t_eval=[0.0, 0.1, 0.3], magnus_order=kw.get("magnus_order", 1))
+        assert_close(res.t, t_ref, 0)
+        assert_close(res.y, y_ref, SOLVE_TOL)
+
+
+def test_lane_per_row_kernel_vectorised_lindbladian(qd):
+    """The cfg 4 shape at 4 qubits (N = 256 superoperators built on the device, static dissipators, no frame and the
+    diagonal frame of H_d): scipy_expm Magnus 1 of one density matrix in one launch against the launch-per-term route
+    (which test_gpu_parity pins to the reference goldens), trace preserved."""
+    from qiskit_dynamics_amd import workloads as W
+
+    cfg = W.lindblad_config(n_qubits=4, n_drives=4, n_diss=4, gamma=1e-2, t_final=1.0, max_dt=0.05)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, 0.1 * a)
+            for a, nu in zip((0.9, 0.5, 0.7, 0.3), cfg["carrier"])]
+    ctx = qd.default_context()
+    for frame in (None, np.diag(cfg["h_d"]).real.copy()):
+        m = qd.LindbladModel(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], hamiltonian_signals=sigs,
+                             static_dissipators=cfg["static_dissipators"], rotating_frame=frame, vectorized=True)
+        y0 = cfg["rho0"].flatten(order="F")
+        out = {}
+        for flag in (1, 0):
+            ctx.set_option("resident_rk4", flag)
+            ctx.reset_counters()
+            ctx.set_option("profile", 1)
+            try:
+                out[flag] = qd.solve_lmde(m, [0.0, 1.0], y0, method="scipy_expm", max_dt=0.05)
+            finally:
+                ctx.set_option("profile", 0)
+                ctx.set_option("resident_rk4", 1)
+            assert ctx.counters("rk4_resident")["launches"] == (1 if flag else 0)
+        assert_close(out[1].y, out[0].y, 1e-12)
+        rho = out[1].y[-1].reshape(16, 16, order="F")
+        assert abs(np.trace(rho) - 1.0) < 1e-12
