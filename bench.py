@@ -753,11 +753,12 @@ def main():
             ctx.set_option(name_, val_)
         try:
             pv = qd.Rk4Plan(stack, times, table, rows, sched.step_h[:total], y0, b_loc, True)
-            d_steps = min(args.steps, steps_)
-            pv.run(0, 2)
+            w_steps = max(1, min(2, total - 1))
+            d_steps = max(1, min(args.steps, steps_, total - w_steps))
+            pv.run(0, w_steps)
             ctx.synchronize()
             ctx.timer_start()
-            pv.run(2, 2 + d_steps)
+            pv.run(w_steps, w_steps + d_steps)
             ms_ = ctx.timer_stop() / (4 * d_steps)
             pv.close()
         finally:
