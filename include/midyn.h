@@ -69,6 +69,9 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   resident_rk4 [1]      one RK4 trajectory whose active operator planes fit the register files (32 < n, at most 64
  *                         doubles per lane and row): whole step ranges in one launch, operators in registers, the
  *                         stage input exchanged through a polled ring in device memory (csrc/midyn_resident.h)
+ *   ell_sweep [1]         sweeps (and single Magnus-2 trajectories) on very sparse stacks, n <= 4096, expm action: ONE
+ *                         launch, one workgroup per instance through all steps, state in registers, operator
+ *                         elements (ELL) from L2 (csrc/midyn_resident.h: ell_sweep_kernel)
  *   expm_action [1]       few columns, Magnus order <= 2: expm(Omega) y by matrix-vector products
  *   expm_degree [0]       0: Taylor degree of the dense expm chosen from the norm; else 2|4|6|9|12|16
  *   profile [0]           record HIP-event kernel times (midyn_get_counters)

@@ -322,7 +322,7 @@ template <int PASS>
 __global__ __launch_bounds__(256) void ell_build_kernel(const double2* __restrict__ ops, int n_pad, const int* __restrict__ blk_ptr,
                                                         const int* __restrict__ blk_idx, const int* __restrict__ slot_map,
                                                         int* __restrict__ counts, double* __restrict__ val,
-                                                        int* __restrict__ meta, int wmax) {
+                                                        int* __restrict__ meta, int* __restrict__ meta_col, int wmax) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = row >> 4, nc = n_pad >> 6;
@@ -342,14 +342,24 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const double2* __restric
         if (PASS == 1) {
             const unsigned long long below = (1ull << lane) - 1ull;
             const int slot = slot_map[(row >> 6) * nc + (col >> 6)];
-            const int base = (slot * 64 + (col & 63)) | (seg << 16) | (1 << 23);
+            const int tag = (seg << 16) | (1 << 23);
+            const int base = (slot * 64 + (col & 63)) | tag;     // column as an index into the polled chunks (resident kernel)
+            const int gcol = col | tag;                          // column itself (source of the sweep kernel's arrays)
             if (z.x != 0.0) {
                 const int pos = cnt + __popcll(m_re & below);
-                if (pos < wmax) { val[(size_t)pos * n_pad + row] = z.x; meta[(size_t)pos * n_pad + row] = base; }
+                if (pos < wmax) {
+                    val[(size_t)pos * n_pad + row] = z.x;
+                    meta[(size_t)pos * n_pad + row] = base;
+                    meta_col[(size_t)pos * n_pad + row] = gcol;
+                }
             }
             if (z.y != 0.0) {
                 const int pos = cnt + __popcll(m_re) + __popcll(m_im & below);
-                if (pos < wmax) { val[(size_t)pos * n_pad + row] = z.y; meta[(size_t)pos * n_pad + row] = base | (1 << 22); }
+                if (pos < wmax) {
+                    val[(size_t)pos * n_pad + row] = z.y;
+                    meta[(size_t)pos * n_pad + row] = base | (1 << 22);
+                    meta_col[(size_t)pos * n_pad + row] = gcol | (1 << 22);
+                }
             }
         }
         cnt += __popcll(m_re) + __popcll(m_im);
@@ -589,6 +599,225 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
         }
     }
     if (wave == 0) a.y[row] = yr;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// ell_sweep_kernel<ORDER, RPT>: a SWEEP on a very sparse stack (cfg 5: n = 4096, at most 19 non-zeros per row), expm
+// action of Magnus order 1 / 2.  Trajectories of a sweep are independent, so nothing has to cross workgroups at all:
+// one workgroup (1024 threads, RPT rows each, n_pad = 1024 RPT) integrates ONE instance through ALL steps.  The
+// vector an operator is applied to is staged, already phased, in LDS (two copies for order 2: the two Gauss points
+// have different frame phases); every thread walks the operator elements of its rows (coalesced over the threads,
+// served by L2: the arrays are shared by all instances), gathers y'[col] from LDS and keeps the series state of its
+// rows in registers.  Order 2, per term (commutator-free form, csrc/midyn_action.inc):
+//     u1 = g1 v, u2 = g2 v (one pass: same v, two coefficient sets);  q = g2 u1 - g1 u2 (second pass);
+//     w = a (u1 + u2) + b q  (+ phi_{j-2} for the Chebyshev recurrence).
+// The MFMA work-list route multiplies 16 x 16 blocks that are 94 % zeros for such operators (17 tiles x 16 columns
+// per row against 19 non-zeros).
+// ------------------------------------------------------------------------------------------------
+constexpr int SWEEP_THREADS = 1024;
+constexpr int SWEEP_MAX_RPT = 4;      // rows per thread (template parameter RPT): n_pad = 1024 * RPT <= 4096
+constexpr int SWEEP_MAX_SLOTS = 256;  // grouped slots per row at most
+
+struct SweepArgs {
+    // the operator elements grouped by (segment, plane): slot e of EVERY row belongs to the pair tags[e], so the
+    // coefficient and the plane are wave-uniform per slot
+    const double* val;        // [wsp][n_pad] (0 in unused slots)
+    const int* col;           // [wsp][n_pad] column (0 in unused slots)
+    const int* tags;          // [wsp] segment | plane << 8
+    int wsp;
+    int n, n_pad, has_static, k, nseg;
+    const double* S;          // [B][R][k]
+    long long inst_stride;    // R * k
+    const double2* E;         // [R][n_pad] or nullptr
+    const int* rows;          // [nsteps][3]
+    const double* hs;         // [nsteps]
+    const int* save;          // [nsteps] or nullptr
+    int nsteps;
+    const int* ser_K;         // per step: > 0 Chebyshev terms, < 0 -(Taylor degree)
+    const int* ser_reps;      // repetitions of the series (Taylor: the scaling s)
+    const double* ser_par;    // Chebyshev: rho; Taylor: s
+    const double* coef;       // [nsteps][stride] Bessel coefficients (Chebyshev steps)
+    int stride;
+    const double2* y0;        // [B | 1][n]
+    int y0_shared;
+    double2* out;             // [B][P][n] saved states
+    int P;
+};
+
+template <int ORDER, int SWEEP_RPT>
+__global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double2 sweep_lds[];
+    __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];   // per slot: (c1, c2) of its segment, this step
+    __shared__ int stag[SWEEP_MAX_SLOTS];                                    // per slot: segment | plane << 8
+    const int tid = threadIdx.x, b = blockIdx.x, np = a.n_pad;
+    double2* const L1 = sweep_lds;
+    double2* const L2 = sweep_lds + np;
+    const double p2 = 0.14433756729740643;   // sqrt(3) / 12
+    double2 acc[SWEEP_RPT], cur[SWEEP_RPT], prev[SWEEP_RPT];
+#pragma unroll
+    for (int i = 0; i < SWEEP_RPT; ++i) {
+        const int r = tid + SWEEP_THREADS * i;
+        acc[i] = (r < a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + r] : make_double2(0.0, 0.0);
+        cur[i] = prev[i] = make_double2(0.0, 0.0);
+    }
+    for (int e = tid; e < a.wsp; e += SWEEP_THREADS) stag[e] = a.tags[e];
+    // one pass over the operator elements of this thread's rows (n_pad = 1024 * RPT exactly: no row guards):
+    //   o1 = (sum_e ca_e A_e) . X1,  o2 = (sum_e cb_e A_e) . X2   with (ca, cb) = (c1, c2), or (c2, c1) when swapped
+    // Per slot: all column / value loads of the thread's rows first, then the LDS gathers, then the arithmetic.
+    auto pass = [&](const double2* X1, const double2* X2, bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
+#pragma unroll
+        for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = o2[i] = make_double2(0.0, 0.0);
+        const unsigned unp = (unsigned)np;
+#pragma unroll 2
+        for (int e = 0; e < a.wsp; ++e) {
+            const double2 cc = cab[e];
+            // the plane of a slot is the same for every row: a scalar branch picks the straight-line body
+            const int im = __builtin_amdgcn_readfirstlane((stag[e] >> 8) & 1);
+            const double ca = swapped ? cc.y : cc.x, cb = swapped ? cc.x : cc.y;
+            int cl[SWEEP_RPT];
+            double v[SWEEP_RPT];
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {   // 32-bit element index: scalar base + one vector offset
+                const unsigned idx = (unsigned)e * unp + (unsigned)(tid + SWEEP_THREADS * i);
+                cl[i] = a.col[idx];
+                v[i] = a.val[idx];
+            }
+            double2 x1[SWEEP_RPT], x2[SWEEP_RPT];
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                x1[i] = X1[cl[i]];
+                if (ORDER == 2) x2[i] = X2[cl[i]];
+            }
+            if (im) {   // A = i v:  A x = v (-x.y, x.x)
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const double wa = ca * v[i];
+                    o1[i].x = fma(-wa, x1[i].y, o1[i].x);
+                    o1[i].y = fma(wa, x1[i].x, o1[i].y);
+                    if (ORDER == 2) {
+                        const double wb = cb * v[i];
+                        o2[i].x = fma(-wb, x2[i].y, o2[i].x);
+                        o2[i].y = fma(wb, x2[i].x, o2[i].y);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const double wa = ca * v[i];
+                    o1[i].x = fma(wa, x1[i].x, o1[i].x);
+                    o1[i].y = fma(wa, x1[i].y, o1[i].y);
+                    if (ORDER == 2) {
+                        const double wb = cb * v[i];
+                        o2[i].x = fma(wb, x2[i].x, o2[i].x);
+                        o2[i].y = fma(wb, x2[i].y, o2[i].y);
+                    }
+                }
+            }
+        }
+    };
+    for (int st = 0; st < a.nsteps; ++st) {
+        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];
+        const double h = a.hs[st];
+        __syncthreads();   // the previous step's readers of the coefficients are done (and stag is written)
+        for (int e = tid; e < a.wsp; e += SWEEP_THREADS) {
+            const int seg = stag[e] & 63;
+            const bool stat = a.has_static && seg == 0;
+            const double* Sb = a.S + (size_t)b * a.inst_stride;
+            cab[e] = make_double2(stat ? 1.0 : Sb[(size_t)r0 * a.k + seg - a.has_static],
+                                  (ORDER == 2) ? (stat ? 1.0 : Sb[(size_t)r1 * a.k + seg - a.has_static]) : 0.0);
+        }
+        const int Ks = a.ser_K[st], reps = a.ser_reps[st];
+        const bool cheb = Ks > 0;
+        const int K = cheb ? Ks : -Ks;
+        const double par = a.ser_par[st];
+        const double* coef = a.coef + (size_t)st * a.stride;
+        for (int rep = 0; rep < reps; ++rep) {
+            const double c0 = cheb ? coef[0] : 1.0;
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                cur[i] = acc[i];
+                acc[i] = make_double2(c0 * acc[i].x, c0 * acc[i].y);
+                prev[i] = make_double2(0.0, 0.0);
+            }
+            for (int j = 1; j <= K; ++j) {
+                const double f = cheb ? (j == 1 ? 1.0 : 2.0) / par : 1.0 / (par * (double)j);
+                // stage the (phased) input
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const int r = tid + SWEEP_THREADS * i;
+                    L1[r] = a.E ? cmul(a.E[(size_t)r0 * np + r], cur[i]) : cur[i];
+                    if (ORDER == 2) L2[r] = a.E ? cmul(a.E[(size_t)r1 * np + r], cur[i]) : cur[i];
+                }
+                __syncthreads();
+                double2 o1[SWEEP_RPT], o2[SWEEP_RPT], w[SWEEP_RPT];
+                pass(L1, L2, false, o1, o2);
+                if (ORDER == 2) {
+                    // u1 = g1 v, u2 = g2 v; the half sum stays, u1 goes to g2 phased to t2, u2 to g1 phased to t1
+                    const double ca = 0.5 * h * f, cb = p2 * h * h * f;
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) {
+                        const int r = tid + SWEEP_THREADS * i;
+                        double2 u1 = o1[i], u2 = o2[i];
+                        if (a.E) {
+                            const double2 e0 = a.E[(size_t)r0 * np + r], e1 = a.E[(size_t)r1 * np + r];
+                            u1 = cmul_conj_a(e0, u1);
+                            u2 = cmul_conj_a(e1, u2);
+                            L1[r] = cmul(e1, u1);
+                            L2[r] = cmul(e0, u2);
+                        } else {
+                            L1[r] = u1;
+                            L2[r] = u2;
+                        }
+                        w[i] = make_double2(ca * (u1.x + u2.x), ca * (u1.y + u2.y));
+                    }
+                    __syncthreads();
+                    pass(L1, L2, true, o1, o2);   // o1 = C(t2) . (E2 u1), o2 = C(t1) . (E1 u2)
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) {
+                        const int r = tid + SWEEP_THREADS * i;
+                        const double2 v1 = a.E ? cmul_conj_a(a.E[(size_t)r1 * np + r], o1[i]) : o1[i];
+                        const double2 v2 = a.E ? cmul_conj_a(a.E[(size_t)r0 * np + r], o2[i]) : o2[i];
+                        w[i].x += cb * (v1.x - v2.x);
+                        w[i].y += cb * (v1.y - v2.y);
+                    }
+                } else {
+                    const double ca = h * f;
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) {
+                        const int r = tid + SWEEP_THREADS * i;
+                        const double2 u1 = a.E ? cmul_conj_a(a.E[(size_t)r0 * np + r], o1[i]) : o1[i];
+                        w[i] = make_double2(ca * u1.x, ca * u1.y);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    if (cheb) {
+                        w[i].x += prev[i].x;
+                        w[i].y += prev[i].y;
+                        acc[i] = cfma_r(2.0 * coef[j], w[i], acc[i]);
+                        prev[i] = cur[i];
+                    } else {
+                        acc[i].x += w[i].x;
+                        acc[i].y += w[i].y;
+                    }
+                    cur[i] = w[i];
+                }
+            }
+        }
+        if (a.save) {
+            const int slot = a.save[st];
+            if (slot >= 0) {
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const int r = tid + SWEEP_THREADS * i;
+                    if (r < a.n) a.out[((size_t)b * a.P + slot) * a.n + r] = acc[i];
+                }
+            }
+        }
+    }
 }
 
 }  // namespace midyn

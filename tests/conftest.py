@@ -48,3 +48,18 @@ def assert_close(a, b, tol=1e-12):
     err = float(np.max(np.abs(a - b))) if a.size else 0.0
     scale = 1.0 + (float(np.max(np.abs(b))) if b.size else 0.0)
     assert err <= tol * scale, f"max|diff|={err:.3e} > {tol:.1e}*(1+{scale - 1:.3e})"
+
+
+@pytest.fixture
+def per_launch_routes():
+    """For the tests that pin the launch-per-product routes (work-list MFMA / streaming kernels) through their launch
+    counters: the one-launch kernels that would otherwise take sweeps on very sparse stacks (ell_sweep_kernel) are
+    switched off for the duration of the test."""
+    import qiskit_dynamics_amd as q
+
+    ctx = q.default_context()
+    ctx.set_option("ell_sweep", 0)
+    try:
+        yield
+    finally:
+        ctx.set_option("ell_sweep", 1)

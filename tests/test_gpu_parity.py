@@ -1823,6 +1823,7 @@ def _chain_sweep(qd, nq, nb, t_final):
     return cfg, sweeps
 
 
+@pytest.mark.usefixtures("per_launch_routes")
 @pytest.mark.parametrize("nq,nb", [(8, 1), (8, 3), (8, 8), (8, 24), (9, 130)])
 def test_block_sparse_routes_match_dense_routes(qd, nq, nb):
     """8/9-qubit chain in the diagonal frame (n = 256 / 512, 9 operators, ~9 % of the 16 x 16 blocks non-zero):
@@ -1924,6 +1925,7 @@ def test_block_sparse_vectorised_lindblad(qd):
     assert abs(np.trace(rho) - 1.0) < 1e-12
 
 
+@pytest.mark.usefixtures("per_launch_routes")
 @pytest.mark.parametrize("nb", [24, 130])
 def test_block_sparse_mfma_route_mixed_and_complex_planes(qd, nb):
     """The SPARSE MFMA instantiations other than the single-plane ones: (a) a sweep of 5-qubit vectorised
@@ -1983,6 +1985,7 @@ def test_block_sparse_mfma_route_mixed_and_complex_planes(qd, nb):
         assert_close(out[1], out[0], 1e-12)
 
 
+@pytest.mark.usefixtures("per_launch_routes")
 @pytest.mark.parametrize("bm", [16, 32, 64, 128])
 @pytest.mark.parametrize("nb", [24, 130])
 def test_block_sparse_every_panel_height(qd, bm, nb):

@@ -51,6 +51,7 @@ def _profiled(ctx, fn):
         ctx.set_option("profile", 0)
 
 
+@pytest.mark.usefixtures("per_launch_routes")
 def test_cfg5_shard_sparse_mfma_route_vs_oracle(qd):
     """BASELINE cfg 5, the per-GPU shard of the 8-GPU run: 12 qubits (n = 4096), k = 8, diagonal rotating frame,
     scipy_expm with magnus_order = 2, max_dt = 0.25, T = 5 -> ALL 20 steps, 128 instances in ONE batched device
@@ -119,6 +120,7 @@ def test_cfg5_shard_sparse_mfma_route_vs_oracle(qd):
         assert_close(res[b].y[-1], y, SOLVE_TOL)
 
 
+@pytest.mark.usefixtures("per_launch_routes")
 def test_cfg4_sweep_sparse_mfma_route_vs_oracle(qd):
     """BASELINE cfg 4 model (6 qubits, N = 4096 superoperators built on the device, 4 static dissipators, no
     frame) as a 64-instance sweep: scipy_expm (Magnus 1) over 3 steps through the SPARSE MFMA work-list route
@@ -374,6 +376,7 @@ def test_event_timer_and_block_info(qd):
     assert 0.0 < ms < 1000.0
 
 
+@pytest.mark.usefixtures("per_launch_routes")
 def test_paired_sparse_launches_are_bit_identical(qd):
     """The two independent products of a Magnus-2 level share ONE launch on the sparse MFMA route (ctx option
     pair_launch, zgemm_seg_pair_kernel): same arithmetic per product, so the solve must be bit-identical to the

@@ -294,3 +294,48 @@ def test_lane_per_row_kernel_vectorised_lindbladian(qd):
         assert_close(out[1].y, out[0].y, 1e-12)
         rho = out[1].y[-1].reshape(16, 16, order="F")
         assert abs(np.trace(rho) - 1.0) < 1e-12
+
+
+@pytest.mark.parametrize("nq,nb,order", [(10, 5, 1), (10, 24, 2), (11, 3, 2), (11, 2, 1), (10, 1, 2)])
+def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
+    """ell_sweep_kernel: sweeps (and one Magnus-2 trajectory) of the chain in its diagonal frame (n = 1024 / 2048: one
+    and two rows per thread), scipy_expm with magnus_order 1 / 2, ONE launch for all instances and steps -- first,
+    middle and last instance against the oracle, all instances against the launch-per-product route, saved states
+    included."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    cfg = W.schrodinger_config(n_qubits=nq, n_drives=min(8, nq), t_final=1.0, max_dt=0.05)
+    k = len(cfg["ops"])
+    sweeps = []
+    for b in range(nb):
+        amps, phases = W.sweep_parameters(b, k)
+        sweeps.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, ph)
+                       for a, nu, ph in zip(amps, cfg["carrier"], phases)])
+    frame = np.diag(cfg["h_d"]).real.copy()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
+    rng = np.random.default_rng(nq + nb)
+    y0 = crand(rng, 2**nq)
+    y0 /= np.linalg.norm(y0)
+    sig = sweeps if nb > 1 else sweeps[0]
+    out, launches = {}, {}
+    for flag in (1, 0):
+        ctx.set_option("ell_sweep", flag)
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        try:
+            r = solver.solve(t_span=[0.0, 0.4], y0=y0, signals=sig, method="scipy_expm", max_dt=0.05, magnus_order=order,
+                             t_eval=[0.0, 0.15, 0.4])
+        finally:
+            ctx.set_option("profile", 0)
+            ctx.set_option("ell_sweep", 1)
+        launches[flag] = ctx.counters("rk4_resident")["launches"]
+        out[flag] = np.stack([x.y for x in r]) if nb > 1 else r.y[None]
+    assert launches[1] == 1, launches
+    assert_close(out[1], out[0], 1e-12)
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
+    for b in sorted({0, nb // 2, nb - 1}):
+        _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
+                                           [0.0, 0.4], y0, "scipy_expm", 0.05, t_eval=[0.0, 0.15, 0.4], magnus_order=order)
+        assert_close(out[1][b], ref, SOLVE_TOL)
