@@ -55,6 +55,7 @@ MAX_DT = 0.005
 SWEEP = 4096                   # BASELINE.json: 4096-parameter batch
 CFG5_SWEEP = 1024              # BASELINE.json configs[4]: 1024-parameter sweep
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor FP64 matrix peak (SURVEY.md 8(d) / BASELINE.md 3)
+LDS_PEAK_GBS = 128.0 * 256 * 2.4      # 128 B per clock and CU, 256 CUs, 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -487,13 +488,22 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
         return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2,
                                 y0, count, True)
 
-    run()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    ys = run()
-    dev_ms = ctx.timer_stop()
-    wall = time.perf_counter() - t0
+    def measure(sweep_kernel):
+        ctx.set_option("ell_sweep", 1 if sweep_kernel else 0)
+        try:
+            run()
+            ctx.synchronize()
+            t0_ = time.perf_counter()
+            ctx.timer_start()
+            ys_ = run()
+            dev_ = ctx.timer_stop()
+            wall_ = time.perf_counter() - t0_
+            cs_ = profile_pass(ctx, run, ALL_CLASSES) if with_profile else None
+        finally:
+            ctx.set_option("ell_sweep", 1)
+        return ys_, dev_, wall_, cs_
+
+    ys, dev_ms, wall, cs = measure(True)            # the product's default route
     n_steps = len(sched.step_h)
     out = {"instances": count, "steps": n_steps, "solve_s": round(wall, 4),
            "ms_per_step": round(wall / n_steps * 1e3, 4), "stream_ms_per_step": round(dev_ms / n_steps, 4),
@@ -503,10 +513,47 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
            "note": "solve_s = midyn_expm_solve wall clock: coefficient table H2D, 20 device steps, results D2H "
                    "(%.0f MB over PCIe); stream_ms = HIP events around the same call" % (ys.nbytes / 1e6)}
     if with_profile:
-        cs = profile_pass(ctx, run, ALL_CLASSES)
+        took_sweep = cs["rk4_resident"]["launches"] > 0
         out["launches_per_step"] = {c: round(v["launches"] / n_steps, 2) for c, v in cs.items() if v["launches"]}
         out["kernel_ms_per_step"] = {c: round(v["ms"] / n_steps, 4) for c, v in cs.items() if v["launches"]}
-        out["roofline"] = cfg5_roofline(ctx, stack, cs, count, stack.n, n_steps, wall, count)
+        if took_sweep:
+            ser = ctx.counters("sweep_series")
+            terms, slots = ser["launches"], int(ser["ms"])
+            k_ms = cs["rk4_resident"]["ms"]
+            n = stack.n
+            # per term and instance: 2 passes over the operator slots of every row; a pass gathers 2 complex numbers
+            # from LDS and does 2 real x complex multiply-adds per slot and reads 12 B of operator data from L2
+            flops = terms * count * 2 * slots * n * 2 * 4
+            lds_bytes = terms * count * 2 * slots * n * 2 * 16
+            l2_bytes = terms * count * 2 * slots * n * 12
+            out["route"] = ("ell_sweep_kernel<2,4>: ONE launch, one workgroup (1024 threads) per instance through all "
+                            "steps; series state in registers, staged vectors in LDS, operator elements (grouped ELL) "
+                            "from L2")
+            out["roofline"] = {
+                "kernel": "ell_sweep_kernel<2, 4>", "bound": "lds",
+                "achieved": round(lds_bytes / (k_ms * 1e-3) / 1e9, 1),
+                "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s",
+                "frac": round(lds_bytes / (k_ms * 1e-3) / 1e9 / LDS_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(k_ms / max(cs["rk4_resident"]["launches"], 1), 4),
+                "series_terms_per_instance": terms, "operator_slots_per_row": slots,
+                "executed_gflops_per_launch": round(flops / 1e9, 2),
+                "executed_tflops": round(flops / (k_ms * 1e-3) / 1e12, 3),
+                "l2_operator_bytes_per_launch": l2_bytes,
+                "l2_operator_gbs": round(l2_bytes / (k_ms * 1e-3) / 1e9, 1),
+                "note": "achieved = bytes gathered from LDS (16 B per operator slot, row and operand vector) / kernel "
+                        "time; peak = 128 B per clock and CU x 256 CUs x 2.4 GHz.  Vector fp64, no MFMA: the operators "
+                        "have at most 19 non-zeros per row"}
+        else:
+            out["roofline"] = cfg5_roofline(ctx, stack, cs, count, stack.n, n_steps, wall, count)
+        if took_sweep:     # the work-list MFMA route beside it
+            ys2, dev2, wall2, cs2 = measure(False)
+            out["max_abs_difference_between_the_routes"] = float(np.max(np.abs(ys - ys2)))
+            out["mfma_work_list_route"] = {
+                "solve_s": round(wall2, 4), "ms_per_step": round(wall2 / n_steps * 1e3, 4),
+                "stream_ms_per_step": round(dev2 / n_steps, 4),
+                "launches_per_step": {c: round(v["launches"] / n_steps, 2) for c, v in cs2.items() if v["launches"]},
+                "kernel_ms_per_step": {c: round(v["ms"] / n_steps, 4) for c, v in cs2.items() if v["launches"]},
+                "roofline": cfg5_roofline(ctx, stack, cs2, count, stack.n, n_steps, wall2, count)}
     return out
 
 

@@ -253,6 +253,8 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * launches of the register-resident single-trajectory kernel (one launch = a whole step range).
  * out[0] = launches, out[1] = total ms (events are only recorded when profiling is enabled with
  * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch).
+ * "sweep_series" describes the last ell_sweep_kernel launch: (series terms per instance summed over the steps, operator
+ * slots per row).
  * Two more names describe the LAST launch of the sparse MFMA route: "sparse_tile" -> (BM, BN) of its tile,
  * "sparse_list" -> (listed (panel, K tile, operator) tiles of the stack for that panel height, split count),
  * "sparse_pair" -> (contractions in that launch: 2 when two independent products shared it, ctx option pair_launch). */
