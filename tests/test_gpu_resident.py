@@ -339,3 +339,36 @@ def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
         _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
                                            [0.0, 0.4], y0, "scipy_expm", 0.05, t_eval=[0.0, 0.15, 0.4], magnus_order=order)
         assert_close(out[1][b], ref, SOLVE_TOL)
+
+
+def test_sweep_kernel_vectorised_lindbladian_sweep(qd):
+    """A sweep of vectorised Lindbladians (5 qubits: N = 1024 superoperators built on the device, static dissipators,
+    complex static part: slots of both planes) through ell_sweep_kernel<1>: ONE launch for all instances, against the
+    launch-per-product route (pinned to the reference goldens in test_gpu_parity) -- all instances, saved states,
+    trace preserved."""
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    cfg = W.lindblad_config(n_qubits=5, n_drives=5, n_diss=4, gamma=2e-2, t_final=1.0, max_dt=0.05)
+    nb = 6
+    sweeps = [[qd.Signal(lambda t, a=0.3 + 0.1 * j + 0.05 * b: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, 0.1 * j)
+               for j, nu in enumerate(cfg["carrier"])] for b in range(nb)]
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       static_dissipators=cfg["static_dissipators"], vectorized=True)
+    y0 = cfg["rho0"].flatten(order="F")
+    out = {}
+    for flag in (1, 0):
+        ctx.set_option("ell_sweep", flag)
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        try:
+            r = solver.solve(t_span=[0.0, 1.0], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.05,
+                             t_eval=[0.0, 0.5, 1.0])
+        finally:
+            ctx.set_option("profile", 0)
+            ctx.set_option("ell_sweep", 1)
+        assert ctx.counters("rk4_resident")["launches"] == (1 if flag else 0)
+        out[flag] = np.stack([x.y for x in r])
+    assert_close(out[1], out[0], 1e-12)
+    for b in range(nb):
+        assert abs(np.trace(out[1][b, -1].reshape(32, 32, order="F")) - 1.0) < 1e-12
