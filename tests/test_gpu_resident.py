@@ -372,3 +372,70 @@ def test_sweep_kernel_vectorised_lindbladian_sweep(qd):
     assert_close(out[1], out[0], 1e-12)
     for b in range(nb):
         assert abs(np.trace(out[1][b, -1].reshape(32, 32, order="F")) - 1.0) < 1e-12
+
+
+def _banded_model(rng, n, scale):
+    """A sparse Hermitian model that is not a qubit chain: random diagonal, three random off-diagonals at distances
+    1, 7 and 64, two drive operators on other off-diagonals -- about ten non-zeros per row, complex entries."""
+    def band(dist, amp):
+        m = np.zeros((n, n), dtype=complex)
+        v = amp * crand(rng, n - dist)
+        m[np.arange(n - dist), np.arange(dist, n)] = v
+        return m + m.conj().T
+
+    h_static = np.diag(rng.normal(size=n)).astype(complex) + band(1, scale) + band(7, 0.5 * scale) + band(64, 0.3 * scale)
+    h_ops = np.array([band(3, 0.4 * scale), band(32, 0.2 * scale)])
+    return h_static, h_ops
+
+
+@pytest.mark.parametrize("scale,max_dt", [(0.3, 0.05), (6.0, 0.5), (40.0, 2.0)])
+def test_one_launch_expm_action_routes_large_norms_backwards_and_own_initial_states(qd, scale, max_dt):
+    """The one-launch expm-action kernels where the series changes shape: small norms (short Taylor series), norms where
+    the Chebyshev series replaces it, and norms beyond the Bessel table (rho > 128: the series is repeated) -- a
+    complex banded model with n = 1024, integrated BACKWARDS, every instance with its OWN initial state, saved states.
+    ell_resident_kernel<1> (one trajectory, order 1) and ell_sweep_kernel<1 | 2> (sweeps, and one trajectory of order
+    2) against the launch-per-product routes; the smallest case also against the oracle."""
+    from oracle import dynamics_oracle as orc
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(int(scale * 10))
+    n = 1024
+    h_static, h_ops = _banded_model(rng, n, scale)
+    frame = np.diag(h_static).real.copy()
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=frame)
+    nb = 3
+    sweeps = [[qd.Signal(lambda t, a=0.5 + 0.2 * b + 0.1 * j: a * np.cos(0.7 * t) + 0j, 0.3 * j, 0.1 * b) for j in range(2)]
+              for b in range(nb)]
+    y0s = []
+    for b in range(nb):
+        y = crand(rng, n)
+        y0s.append(y / np.linalg.norm(y))
+    t_span, t_eval = [1.0, 0.0], [1.0, 0.5, 0.0]
+    for order in (1, 2):
+        for batch in (True, False):
+            sig = sweeps if batch else sweeps[1]
+            y0 = y0s if batch else y0s[1]
+            out, launches = {}, {}
+            for flag in (1, 0):
+                ctx.set_option("ell_sweep", flag)
+                ctx.set_option("resident_rk4", flag)
+                ctx.reset_counters()
+                ctx.set_option("profile", 1)
+                try:
+                    r = solver.solve(t_span=t_span, y0=y0, signals=sig, method="scipy_expm", max_dt=max_dt,
+                                     magnus_order=order, t_eval=t_eval)
+                finally:
+                    ctx.set_option("profile", 0)
+                    ctx.set_option("ell_sweep", 1)
+                    ctx.set_option("resident_rk4", 1)
+                launches[flag] = ctx.counters("rk4_resident")["launches"]
+                out[flag] = np.stack([x.y for x in r]) if batch else r.y[None]
+            assert launches[1] == 1 and launches[0] == 0, (order, batch, launches)
+            assert_close(out[1], out[0], 1e-11)
+            assert np.max(np.abs(np.linalg.norm(out[1][:, -1], axis=1) - 1.0)) < 1e-9
+            if scale < 1.0 and not batch:
+                a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
+                _, ref = orc.solve_generator_model(a_d, a, d, basis,
+                                                   lambda tt: np.array([np.real(s(tt)) for s in sweeps[1]]), t_span,
+                                                   y0s[1], "scipy_expm", max_dt, t_eval=t_eval, magnus_order=order)
+                assert_close(out[1][0], ref, SOLVE_TOL)
