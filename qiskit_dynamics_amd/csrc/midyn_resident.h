@@ -820,4 +820,259 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// ell_sweep_split_kernel<ORDER, RPT>: the sweep kernel for SMALL shards (fewer instances than half the CUs: the
+// 128-instance cfg 5 shard of an 8-GPU run leaves 128 of 256 CUs idle).  NSPLIT = 2 or 4 workgroups share one instance:
+// each owns n_pad / NSPLIT rows (RPT per thread) -- half or a quarter of the operator elements per pass and of the
+// series state per thread -- and every vector an operator is applied to is all-gathered among them through the
+// sentinel-polled ring of the resident kernels (the partners of an instance read each other: symmetric by
+// construction; four rotating buffers; the owner re-arms its words of the buffer read last round).  A workgroup
+// writes its own rows straight into its LDS copy, publishes them unphased, and phases its partners' rows as it copies
+// them in.  All NSPLIT * B workgroups must be resident at once (one per CU: LDS): cooperative launch.
+// ------------------------------------------------------------------------------------------------
+struct SweepSplitArgs {
+    SweepArgs a;
+    int nsplit;
+    unsigned long long* ring;   // [B][4][ORDER][2 * n_pad] words, all sentinel at launch
+    int* err;
+};
+
+template <int ORDER, int SWEEP_RPT>
+__global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const SweepSplitArgs sa) {
+    const SweepArgs& a = sa.a;
+    extern __shared__ __attribute__((aligned(16))) double2 sweep_lds[];
+    __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];
+    __shared__ int stag[SWEEP_MAX_SLOTS];
+    const int tid = threadIdx.x, np = a.n_pad, nsplit = sa.nsplit;
+    const int b = blockIdx.x / nsplit, part = blockIdx.x % nsplit;
+    const int part_rows = np / nsplit, row0 = part * part_rows;     // this workgroup's rows: row0 + tid + 1024 i
+    double2* const L1 = sweep_lds;
+    double2* const L2 = sweep_lds + np;
+    unsigned long long* const ring = sa.ring + (size_t)b * 4 * ORDER * 2 * np;
+    const double p2 = 0.14433756729740643;   // sqrt(3) / 12
+    double2 acc[SWEEP_RPT], cur[SWEEP_RPT], prev[SWEEP_RPT];
+#pragma unroll
+    for (int i = 0; i < SWEEP_RPT; ++i) {
+        const int r = row0 + tid + SWEEP_THREADS * i;
+        acc[i] = (r < a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + r] : make_double2(0.0, 0.0);
+        cur[i] = prev[i] = make_double2(0.0, 0.0);
+    }
+    for (int e = tid; e < a.wsp; e += SWEEP_THREADS) stag[e] = a.tags[e];
+    bool dead = false;
+    int b_cur = 0;
+    // All-gather of ORDER vectors: this thread's rows hold (va[i], vb[i]); LDS gets ea o va (and eb o vb) for ALL rows,
+    // where ea / eb are the phase rows of two table times (nullptr: no frame).
+    auto all_gather = [&](const double2 (&va)[SWEEP_RPT], const double2 (&vb)[SWEEP_RPT], const double2* ea, const double2* eb) {
+        const int b_nxt = (b_cur + 1) & 3, b_rearm = (b_cur + 3) & 3;
+        unsigned long long* nxt = ring + (size_t)b_nxt * ORDER * 2 * np;
+        __builtin_amdgcn_s_waitcnt(0);     // last round's re-arming stores are complete before this round's data leaves
+        __syncthreads();                   // every reader of the LDS copies of the previous pass is done
+#pragma unroll
+        for (int i = 0; i < SWEEP_RPT; ++i) {
+            const int r = row0 + tid + SWEEP_THREADS * i;
+            __hip_atomic_store(nxt + 2 * r, (unsigned long long)__double_as_longlong(va[i].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(nxt + 2 * r + 1, (unsigned long long)__double_as_longlong(va[i].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L1[r] = ea ? cmul(ea[r], va[i]) : va[i];
+            if (ORDER == 2) {
+                __hip_atomic_store(nxt + 2 * np + 2 * r, (unsigned long long)__double_as_longlong(vb[i].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(nxt + 2 * np + 2 * r + 1, (unsigned long long)__double_as_longlong(vb[i].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L2[r] = eb ? cmul(eb[r], vb[i]) : vb[i];
+            }
+        }
+        // re-arm this thread's words of the buffer read last round (all partners have published this ... see below)
+        {
+            unsigned long long* old = ring + (size_t)b_rearm * ORDER * 2 * np;
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                const int r = row0 + tid + SWEEP_THREADS * i;
+#pragma unroll
+                for (int v = 0; v < ORDER; ++v) {
+                    __hip_atomic_store(old + (size_t)v * 2 * np + 2 * r, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(old + (size_t)v * 2 * np + 2 * r + 1, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // the partners' rows: part (part + d) % nsplit, d = 1 .. nsplit - 1, row tid + 1024 i of that part
+        for (int d = 1; d < nsplit; ++d) {
+            const int prow0 = ((part + d) % nsplit) * part_rows;
+            unsigned long long w[SWEEP_RPT][ORDER][2];
+            unsigned spins = 0;
+            for (;;) {
+                bool pending = false;
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const int r = prow0 + tid + SWEEP_THREADS * i;
+#pragma unroll
+                    for (int v = 0; v < ORDER; ++v) {
+                        w[i][v][0] = dead ? 0ull : __hip_atomic_load(nxt + (size_t)v * 2 * np + 2 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w[i][v][1] = dead ? 0ull : __hip_atomic_load(nxt + (size_t)v * 2 * np + 2 * r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i)
+#pragma unroll
+                    for (int v = 0; v < ORDER; ++v) pending |= (w[i][v][0] == RESIDENT_SENTINEL) | (w[i][v][1] == RESIDENT_SENTINEL);
+                if (!pending) break;
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if ((spins & 1023u) == 0 && __hip_atomic_load(sa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = RESIDENT_SPIN_LIMIT;
+                if (spins >= RESIDENT_SPIN_LIMIT) {
+                    __hip_atomic_store(sa.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    dead = true;
+                    break;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                const int r = prow0 + tid + SWEEP_THREADS * i;
+                const double2 xa = make_double2(__longlong_as_double((long long)w[i][0][0]), __longlong_as_double((long long)w[i][0][1]));
+                L1[r] = ea ? cmul(ea[r], xa) : xa;
+                if (ORDER == 2) {
+                    const double2 xb = make_double2(__longlong_as_double((long long)w[i][ORDER - 1][0]), __longlong_as_double((long long)w[i][ORDER - 1][1]));
+                    L2[r] = eb ? cmul(eb[r], xb) : xb;
+                }
+            }
+        }
+        b_cur = b_nxt;
+        __syncthreads();
+    };
+    auto pass = [&](const double2* X1, const double2* X2, bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
+#pragma unroll
+        for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = o2[i] = make_double2(0.0, 0.0);
+        const unsigned unp = (unsigned)np;
+#pragma unroll 4
+        for (int e = 0; e < a.wsp; ++e) {
+            const double2 cc = cab[e];
+            const int im = __builtin_amdgcn_readfirstlane((stag[e] >> 8) & 1);
+            const double ca = swapped ? cc.y : cc.x, cb = swapped ? cc.x : cc.y;
+            int cl[SWEEP_RPT];
+            double v[SWEEP_RPT];
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                const unsigned idx = (unsigned)e * unp + (unsigned)(row0 + tid + SWEEP_THREADS * i);
+                cl[i] = a.col[idx];
+                v[i] = a.val[idx];
+            }
+            double2 x1[SWEEP_RPT], x2[SWEEP_RPT];
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                x1[i] = X1[cl[i]];
+                if (ORDER == 2) x2[i] = X2[cl[i]];
+            }
+            if (im) {
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const double wa = ca * v[i];
+                    o1[i].x = fma(-wa, x1[i].y, o1[i].x);
+                    o1[i].y = fma(wa, x1[i].x, o1[i].y);
+                    if (ORDER == 2) {
+                        const double wb = cb * v[i];
+                        o2[i].x = fma(-wb, x2[i].y, o2[i].x);
+                        o2[i].y = fma(wb, x2[i].x, o2[i].y);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const double wa = ca * v[i];
+                    o1[i].x = fma(wa, x1[i].x, o1[i].x);
+                    o1[i].y = fma(wa, x1[i].y, o1[i].y);
+                    if (ORDER == 2) {
+                        const double wb = cb * v[i];
+                        o2[i].x = fma(wb, x2[i].x, o2[i].x);
+                        o2[i].y = fma(wb, x2[i].y, o2[i].y);
+                    }
+                }
+            }
+        }
+    };
+    for (int st = 0; st < a.nsteps; ++st) {
+        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];
+        const double h = a.hs[st];
+        const double2* E0 = a.E ? a.E + (size_t)r0 * np : nullptr;
+        const double2* E1 = a.E ? a.E + (size_t)r1 * np : nullptr;
+        __syncthreads();
+        for (int e = tid; e < a.wsp; e += SWEEP_THREADS) {
+            const int seg = stag[e] & 63;
+            const bool stat = a.has_static && seg == 0;
+            const double* Sb = a.S + (size_t)b * a.inst_stride;
+            cab[e] = make_double2(stat ? 1.0 : Sb[(size_t)r0 * a.k + seg - a.has_static],
+                                  (ORDER == 2) ? (stat ? 1.0 : Sb[(size_t)r1 * a.k + seg - a.has_static]) : 0.0);
+        }
+        const int Ks = a.ser_K[st], reps = a.ser_reps[st];
+        const bool cheb = Ks > 0;
+        const int K = cheb ? Ks : -Ks;
+        const double par = a.ser_par[st];
+        const double* coef = a.coef + (size_t)st * a.stride;
+        for (int rep = 0; rep < reps; ++rep) {
+            const double c0 = cheb ? coef[0] : 1.0;
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                cur[i] = acc[i];
+                acc[i] = make_double2(c0 * acc[i].x, c0 * acc[i].y);
+                prev[i] = make_double2(0.0, 0.0);
+            }
+            for (int j = 1; j <= K; ++j) {
+                const double f = cheb ? (j == 1 ? 1.0 : 2.0) / par : 1.0 / (par * (double)j);
+                all_gather(cur, cur, E0, E1);                 // L1 = E(t1) o v, L2 = E(t2) o v
+                double2 o1[SWEEP_RPT], o2[SWEEP_RPT], w[SWEEP_RPT];
+                pass(L1, L2, false, o1, o2);
+                if (ORDER == 2) {
+                    const double ca = 0.5 * h * f, cb = p2 * h * h * f;
+                    double2 u1[SWEEP_RPT], u2[SWEEP_RPT];
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) {
+                        const int r = row0 + tid + SWEEP_THREADS * i;
+                        u1[i] = E0 ? cmul_conj_a(E0[r], o1[i]) : o1[i];
+                        u2[i] = E1 ? cmul_conj_a(E1[r], o2[i]) : o2[i];
+                        w[i] = make_double2(ca * (u1[i].x + u2[i].x), ca * (u1[i].y + u2[i].y));
+                    }
+                    all_gather(u1, u2, E1, E0);               // L1 = E(t2) o u1 (for g2), L2 = E(t1) o u2 (for g1)
+                    pass(L1, L2, true, o1, o2);
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) {
+                        const int r = row0 + tid + SWEEP_THREADS * i;
+                        const double2 v1 = E1 ? cmul_conj_a(E1[r], o1[i]) : o1[i];
+                        const double2 v2 = E0 ? cmul_conj_a(E0[r], o2[i]) : o2[i];
+                        w[i].x += cb * (v1.x - v2.x);
+                        w[i].y += cb * (v1.y - v2.y);
+                    }
+                } else {
+                    const double ca = h * f;
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) {
+                        const int r = row0 + tid + SWEEP_THREADS * i;
+                        const double2 u1 = E0 ? cmul_conj_a(E0[r], o1[i]) : o1[i];
+                        w[i] = make_double2(ca * u1.x, ca * u1.y);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    if (cheb) {
+                        w[i].x += prev[i].x;
+                        w[i].y += prev[i].y;
+                        acc[i] = cfma_r(2.0 * coef[j], w[i], acc[i]);
+                        prev[i] = cur[i];
+                    } else {
+                        acc[i].x += w[i].x;
+                        acc[i].y += w[i].y;
+                    }
+                    cur[i] = w[i];
+                }
+            }
+        }
+        if (a.save) {
+            const int slot = a.save[st];
+            if (slot >= 0) {
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const int r = row0 + tid + SWEEP_THREADS * i;
+                    if (r < a.n) a.out[((size_t)b * a.P + slot) * a.n + r] = acc[i];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace midyn
