@@ -72,6 +72,8 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   ell_sweep [1]         sweeps (and single Magnus-2 trajectories) on very sparse stacks, n <= 4096, expm action: ONE
  *                         launch, one workgroup per instance through all steps, state in registers, operator
  *                         elements (ELL) from L2 (csrc/midyn_resident.h: ell_sweep_kernel)
+ *   ell_sweep_split [1]   ... with 4 or 2 workgroups per instance while instances x workgroups <= CUs (small shards);
+ *                         the partners all-gather every operand vector through a sentinel-polled ring
  *   expm_action [1]       few columns, Magnus order <= 2: expm(Omega) y by matrix-vector products
  *   expm_degree [0]       0: Taylor degree of the dense expm chosen from the norm; else 2|4|6|9|12|16
  *   profile [0]           record HIP-event kernel times (midyn_get_counters)
@@ -254,7 +256,7 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * out[0] = launches, out[1] = total ms (events are only recorded when profiling is enabled with
  * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch).
  * "sweep_series" describes the last ell_sweep_kernel launch: (series terms per instance summed over the steps, operator
- * slots per row).
+ * slots per row); "sweep_split": (workgroups per instance of that launch, 0).
  * Two more names describe the LAST launch of the sparse MFMA route: "sparse_tile" -> (BM, BN) of its tile,
  * "sparse_list" -> (listed (panel, K tile, operator) tiles of the stack for that panel height, split count),
  * "sparse_pair" -> (contractions in that launch: 2 when two independent products shared it, ctx option pair_launch). */
