@@ -27,6 +27,12 @@
 #ifndef MIDYN_RESIDENT_ABLATE
 #define MIDYN_RESIDENT_ABLATE 0
 #endif
+#ifndef MIDYN_SWEEP_UNROLL
+#define MIDYN_SWEEP_UNROLL 2     // slots per iteration of the pass loops of ell_sweep_kernel
+#endif
+#ifndef MIDYN_SWEEP_ABLATE
+#define MIDYN_SWEEP_ABLATE 0     // 1: no operator pass; 2: element loads only (no gathers); 3: gathers only (no element loads)
+#endif
 
 namespace midyn {
 
@@ -626,6 +632,7 @@ struct SweepArgs {
     const int* col;           // [wsp][n_pad] column (0 in unused slots)
     const int* tags;          // [wsp] segment | plane << 8
     int wsp;
+    int wre;                  // slots [0, wre) hold real-plane values, [wre, wsp) imaginary-plane values
     int n, n_pad, has_static, k, nseg;
     const double* S;          // [B][R][k]
     long long inst_stride;    // R * k
@@ -662,59 +669,57 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
         cur[i] = prev[i] = make_double2(0.0, 0.0);
     }
     for (int e = tid; e < a.wsp; e += SWEEP_THREADS) stag[e] = a.tags[e];
-    // one pass over the operator elements of this thread's rows (n_pad = 1024 * RPT exactly: no row guards):
+    // one pass over the operator elements of this thread's rows:
     //   o1 = (sum_e ca_e A_e) . X1,  o2 = (sum_e cb_e A_e) . X2   with (ca, cb) = (c1, c2), or (c2, c1) when swapped
-    // Per slot: all column / value loads of the thread's rows first, then the LDS gathers, then the arithmetic.
+    // Two straight-line loops, no selects: the real-plane slots (A = v: A x = v x), then the imaginary-plane slots
+    // (A = i v: A x = v (-x.y, x.x)).
     auto pass = [&](const double2* X1, const double2* X2, bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
 #pragma unroll
         for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = o2[i] = make_double2(0.0, 0.0);
         const unsigned unp = (unsigned)np;
-#pragma unroll 2
-        for (int e = 0; e < a.wsp; ++e) {
-            const double2 cc = cab[e];
-            // the plane of a slot is the same for every row: a scalar branch picks the straight-line body
-            const int im = __builtin_amdgcn_readfirstlane((stag[e] >> 8) & 1);
-            const double ca = swapped ? cc.y : cc.x, cb = swapped ? cc.x : cc.y;
-            int cl[SWEEP_RPT];
-            double v[SWEEP_RPT];
-#pragma unroll
-            for (int i = 0; i < SWEEP_RPT; ++i) {   // 32-bit element index: scalar base + one vector offset
-                const unsigned idx = (unsigned)e * unp + (unsigned)(tid + SWEEP_THREADS * i);
-                cl[i] = a.col[idx];
-                v[i] = a.val[idx];
-            }
-            double2 x1[SWEEP_RPT], x2[SWEEP_RPT];
-#pragma unroll
-            for (int i = 0; i < SWEEP_RPT; ++i) {
-                x1[i] = X1[cl[i]];
-                if (ORDER == 2) x2[i] = X2[cl[i]];
-            }
-            if (im) {   // A = i v:  A x = v (-x.y, x.x)
-#pragma unroll
-                for (int i = 0; i < SWEEP_RPT; ++i) {
-                    const double wa = ca * v[i];
-                    o1[i].x = fma(-wa, x1[i].y, o1[i].x);
-                    o1[i].y = fma(wa, x1[i].x, o1[i].y);
-                    if (ORDER == 2) {
-                        const double wb = cb * v[i];
-                        o2[i].x = fma(-wb, x2[i].y, o2[i].x);
-                        o2[i].y = fma(wb, x2[i].x, o2[i].y);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < SWEEP_RPT; ++i) {
-                    const double wa = ca * v[i];
-                    o1[i].x = fma(wa, x1[i].x, o1[i].x);
-                    o1[i].y = fma(wa, x1[i].y, o1[i].y);
-                    if (ORDER == 2) {
-                        const double wb = cb * v[i];
-                        o2[i].x = fma(wb, x2[i].x, o2[i].x);
-                        o2[i].y = fma(wb, x2[i].y, o2[i].y);
-                    }
-                }
-            }
+#if MIDYN_SWEEP_ABLATE == 1   // profiling only: no operator pass at all
+        for (int i = 0; i < SWEEP_RPT; ++i) { o1[i] = X1[tid + SWEEP_THREADS * i]; o2[i] = X2[tid + SWEEP_THREADS * i]; }
+        return;
+#endif
+#define MIDYN_SWEEP_SLOT(IM)                                                                         \
+        {                                                                                            \
+            const double2 cc = cab[e];                                                               \
+            const double ca = swapped ? cc.y : cc.x, cb = swapped ? cc.x : cc.y;                     \
+            int cl[SWEEP_RPT];                                                                       \
+            double v[SWEEP_RPT];                                                                     \
+            _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
+                const unsigned idx = (unsigned)e * unp + (unsigned)(tid + SWEEP_THREADS * i);                        \
+                cl[i] = a.col[idx];                                                                  \
+                v[i] = a.val[idx];                                                                   \
+            }                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
+                const double2 x1 = X1[cl[i]];                                                        \
+                const double wa = ca * v[i];                                                         \
+                if (IM) {                                                                            \
+                    o1[i].x = fma(-wa, x1.y, o1[i].x);                                               \
+                    o1[i].y = fma(wa, x1.x, o1[i].y);                                                \
+                } else {                                                                             \
+                    o1[i].x = fma(wa, x1.x, o1[i].x);                                                \
+                    o1[i].y = fma(wa, x1.y, o1[i].y);                                                \
+                }                                                                                    \
+                if (ORDER == 2) {                                                                    \
+                    const double2 x2 = X2[cl[i]];                                                    \
+                    const double wb = cb * v[i];                                                     \
+                    if (IM) {                                                                        \
+                        o2[i].x = fma(-wb, x2.y, o2[i].x);                                           \
+                        o2[i].y = fma(wb, x2.x, o2[i].y);                                            \
+                    } else {                                                                         \
+                        o2[i].x = fma(wb, x2.x, o2[i].x);                                            \
+                        o2[i].y = fma(wb, x2.y, o2[i].y);                                            \
+                    }                                                                                \
+                }                                                                                    \
+            }                                                                                        \
         }
+#pragma unroll MIDYN_SWEEP_UNROLL
+        for (int e = 0; e < a.wre; ++e) MIDYN_SWEEP_SLOT(false)
+#pragma unroll MIDYN_SWEEP_UNROLL
+        for (int e = a.wre; e < a.wsp; ++e) MIDYN_SWEEP_SLOT(true)
+#undef MIDYN_SWEEP_SLOT
     };
     for (int st = 0; st < a.nsteps; ++st) {
         const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];
@@ -937,55 +942,57 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
         b_cur = b_nxt;
         __syncthreads();
     };
+    // one pass over the operator elements of this thread's rows:
+    //   o1 = (sum_e ca_e A_e) . X1,  o2 = (sum_e cb_e A_e) . X2   with (ca, cb) = (c1, c2), or (c2, c1) when swapped
+    // Two straight-line loops, no selects: the real-plane slots (A = v: A x = v x), then the imaginary-plane slots
+    // (A = i v: A x = v (-x.y, x.x)).
     auto pass = [&](const double2* X1, const double2* X2, bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
 #pragma unroll
         for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = o2[i] = make_double2(0.0, 0.0);
         const unsigned unp = (unsigned)np;
-#pragma unroll 4
-        for (int e = 0; e < a.wsp; ++e) {
-            const double2 cc = cab[e];
-            const int im = __builtin_amdgcn_readfirstlane((stag[e] >> 8) & 1);
-            const double ca = swapped ? cc.y : cc.x, cb = swapped ? cc.x : cc.y;
-            int cl[SWEEP_RPT];
-            double v[SWEEP_RPT];
-#pragma unroll
-            for (int i = 0; i < SWEEP_RPT; ++i) {
-                const unsigned idx = (unsigned)e * unp + (unsigned)(row0 + tid + SWEEP_THREADS * i);
-                cl[i] = a.col[idx];
-                v[i] = a.val[idx];
-            }
-            double2 x1[SWEEP_RPT], x2[SWEEP_RPT];
-#pragma unroll
-            for (int i = 0; i < SWEEP_RPT; ++i) {
-                x1[i] = X1[cl[i]];
-                if (ORDER == 2) x2[i] = X2[cl[i]];
-            }
-            if (im) {
-#pragma unroll
-                for (int i = 0; i < SWEEP_RPT; ++i) {
-                    const double wa = ca * v[i];
-                    o1[i].x = fma(-wa, x1[i].y, o1[i].x);
-                    o1[i].y = fma(wa, x1[i].x, o1[i].y);
-                    if (ORDER == 2) {
-                        const double wb = cb * v[i];
-                        o2[i].x = fma(-wb, x2[i].y, o2[i].x);
-                        o2[i].y = fma(wb, x2[i].x, o2[i].y);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < SWEEP_RPT; ++i) {
-                    const double wa = ca * v[i];
-                    o1[i].x = fma(wa, x1[i].x, o1[i].x);
-                    o1[i].y = fma(wa, x1[i].y, o1[i].y);
-                    if (ORDER == 2) {
-                        const double wb = cb * v[i];
-                        o2[i].x = fma(wb, x2[i].x, o2[i].x);
-                        o2[i].y = fma(wb, x2[i].y, o2[i].y);
-                    }
-                }
-            }
+#if MIDYN_SWEEP_ABLATE == 1   // profiling only: no operator pass at all
+        for (int i = 0; i < SWEEP_RPT; ++i) { o1[i] = X1[tid + SWEEP_THREADS * i]; o2[i] = X2[tid + SWEEP_THREADS * i]; }
+        return;
+#endif
+#define MIDYN_SWEEP_SLOT(IM)                                                                         \
+        {                                                                                            \
+            const double2 cc = cab[e];                                                               \
+            const double ca = swapped ? cc.y : cc.x, cb = swapped ? cc.x : cc.y;                     \
+            int cl[SWEEP_RPT];                                                                       \
+            double v[SWEEP_RPT];                                                                     \
+            _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
+                const unsigned idx = (unsigned)e * unp + (unsigned)(row0 + tid + SWEEP_THREADS * i);                        \
+                cl[i] = a.col[idx];                                                                  \
+                v[i] = a.val[idx];                                                                   \
+            }                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
+                const double2 x1 = X1[cl[i]];                                                        \
+                const double wa = ca * v[i];                                                         \
+                if (IM) {                                                                            \
+                    o1[i].x = fma(-wa, x1.y, o1[i].x);                                               \
+                    o1[i].y = fma(wa, x1.x, o1[i].y);                                                \
+                } else {                                                                             \
+                    o1[i].x = fma(wa, x1.x, o1[i].x);                                                \
+                    o1[i].y = fma(wa, x1.y, o1[i].y);                                                \
+                }                                                                                    \
+                if (ORDER == 2) {                                                                    \
+                    const double2 x2 = X2[cl[i]];                                                    \
+                    const double wb = cb * v[i];                                                     \
+                    if (IM) {                                                                        \
+                        o2[i].x = fma(-wb, x2.y, o2[i].x);                                           \
+                        o2[i].y = fma(wb, x2.x, o2[i].y);                                            \
+                    } else {                                                                         \
+                        o2[i].x = fma(wb, x2.x, o2[i].x);                                            \
+                        o2[i].y = fma(wb, x2.y, o2[i].y);                                            \
+                    }                                                                                \
+                }                                                                                    \
+            }                                                                                        \
         }
+#pragma unroll 4
+        for (int e = 0; e < a.wre; ++e) MIDYN_SWEEP_SLOT(false)
+#pragma unroll 4
+        for (int e = a.wre; e < a.wsp; ++e) MIDYN_SWEEP_SLOT(true)
+#undef MIDYN_SWEEP_SLOT
     };
     for (int st = 0; st < a.nsteps; ++st) {
         const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];

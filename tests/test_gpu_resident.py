@@ -319,9 +319,10 @@ def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
     y0 = crand(rng, 2**nq)
     y0 /= np.linalg.norm(y0)
     sig = sweeps if nb > 1 else sweeps[0]
-    out, launches = {}, {}
-    for flag in (1, 0):
-        ctx.set_option("ell_sweep", flag)
+    out, launches, split = {}, {}, {}
+    for flag in (1, 2, 0):       # 1: one workgroup per instance; 2: several (opt-in ell_sweep_split); 0: per-launch route
+        ctx.set_option("ell_sweep", 1 if flag else 0)
+        ctx.set_option("ell_sweep_split", 1 if flag == 2 else 0)
         ctx.reset_counters()
         ctx.set_option("profile", 1)
         try:
@@ -330,10 +331,14 @@ def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
         finally:
             ctx.set_option("profile", 0)
             ctx.set_option("ell_sweep", 1)
+            ctx.set_option("ell_sweep_split", 0)
         launches[flag] = ctx.counters("rk4_resident")["launches"]
+        split[flag] = ctx.counters("sweep_split")["launches"]
         out[flag] = np.stack([x.y for x in r]) if nb > 1 else r.y[None]
-    assert launches[1] == 1, launches
+    assert launches[1] == 1 and launches[2] == 1 and launches[0] == 0, launches
+    assert split[1] == 1 and split[2] == (2 if nq >= 11 else 1), split      # n = 2048: two workgroups of 1024 rows each
     assert_close(out[1], out[0], 1e-12)
+    assert_close(out[2], out[0], 1e-12)
     a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
     for b in sorted({0, nb // 2, nb - 1}):
         _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
