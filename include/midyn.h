@@ -72,9 +72,10 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   ell_sweep [1]         sweeps (and single Magnus-2 trajectories) on very sparse stacks, n <= 4096, expm action: ONE
  *                         launch, one workgroup per instance through all steps, state in registers, operator
  *                         elements (ELL) from L2 (csrc/midyn_resident.h: ell_sweep_kernel)
- *   ell_sweep_split [0]   ... with 4 or 2 workgroups per instance while instances x workgroups <= CUs (small shards);
- *                         the partners all-gather every operand vector through a sentinel-polled ring (measured
- *                         slower than one workgroup per instance: 0.41 vs 0.36 ms per cfg 5 step; opt-in)
+ *   ell_sweep_split [1]   ... small shards: 4 workgroups per instance while 4 x instances <= CUs (n_pad = 4096); the
+ *                         partners all-gather every operand vector through a sentinel-polled ring (cfg 5, 1..32
+ *                         instances: 0.18-0.24 instead of 0.29-0.33 ms per step).  2: also 2 workgroups per instance
+ *                         (measured slower: 0.41 vs 0.36 ms at 128 instances); 0: never
  *   expm_action [1]       few columns, Magnus order <= 2: expm(Omega) y by matrix-vector products
  *   expm_degree [0]       0: Taylor degree of the dense expm chosen from the norm; else 2|4|6|9|12|16
  *   profile [0]           record HIP-event kernel times (midyn_get_counters)

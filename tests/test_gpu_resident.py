@@ -320,9 +320,9 @@ def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
     y0 /= np.linalg.norm(y0)
     sig = sweeps if nb > 1 else sweeps[0]
     out, launches, split = {}, {}, {}
-    for flag in (1, 2, 0):       # 1: one workgroup per instance; 2: several (opt-in ell_sweep_split); 0: per-launch route
+    for flag in (1, 2, 0):       # 1: one workgroup per instance; 2: several (ell_sweep_split = 2); 0: per-launch route
         ctx.set_option("ell_sweep", 1 if flag else 0)
-        ctx.set_option("ell_sweep_split", 1 if flag == 2 else 0)
+        ctx.set_option("ell_sweep_split", 2 if flag == 2 else 0)
         ctx.reset_counters()
         ctx.set_option("profile", 1)
         try:
@@ -331,7 +331,7 @@ def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
         finally:
             ctx.set_option("profile", 0)
             ctx.set_option("ell_sweep", 1)
-            ctx.set_option("ell_sweep_split", 0)
+            ctx.set_option("ell_sweep_split", 1)
         launches[flag] = ctx.counters("rk4_resident")["launches"]
         split[flag] = ctx.counters("sweep_split")["launches"]
         out[flag] = np.stack([x.y for x in r]) if nb > 1 else r.y[None]
@@ -444,3 +444,42 @@ def test_one_launch_expm_action_routes_large_norms_backwards_and_own_initial_sta
                                                    lambda tt: np.array([np.real(s(tt)) for s in sweeps[1]]), t_span,
                                                    y0s[1], "scipy_expm", max_dt, t_eval=t_eval, magnus_order=order)
                 assert_close(out[1][0], ref, SOLVE_TOL)
+
+
+def test_sweep_kernel_four_workgroups_per_instance_at_full_size(qd):
+    """The cfg 5 model itself (12 qubits, n = 4096, diagonal frame, Magnus-2): 3 instances take FOUR workgroups each by
+    default (ell_sweep_split: the operand vectors are all-gathered through the sentinel ring) -- against one workgroup
+    per instance and against the launch-per-product work-list route, saved states included; norms preserved."""
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    cfg = W.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
+    k = len(cfg["ops"])
+    nb = 3
+    sweeps = []
+    for b in range(nb):
+        amps, phases = W.sweep_parameters(b, k)
+        sweeps.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+                       for a, nu, ph in zip(amps, cfg["carrier"], phases)])
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       rotating_frame=np.diag(cfg["h_d"]).real.copy(), validate=False)
+    out, split = {}, {}
+    for tag, sweep, parts in (("four", 1, 1), ("one", 1, 0), ("per_launch", 0, 1)):
+        ctx.set_option("ell_sweep", sweep)
+        ctx.set_option("ell_sweep_split", parts)
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        try:
+            r = solver.solve(t_span=[0.0, 1.0], y0=cfg["y0"], signals=sweeps, method="scipy_expm", max_dt=0.25,
+                             magnus_order=2, t_eval=[0.0, 0.5, 1.0])
+        finally:
+            ctx.set_option("profile", 0)
+            ctx.set_option("ell_sweep", 1)
+            ctx.set_option("ell_sweep_split", 1)
+        assert ctx.counters("rk4_resident")["launches"] == (1 if sweep else 0)
+        split[tag] = ctx.counters("sweep_split")["launches"]
+        out[tag] = np.stack([x.y for x in r])
+    assert split["four"] == 4 and split["one"] == 1
+    assert_close(out["four"], out["per_launch"], 1e-12)
+    assert_close(out["one"], out["per_launch"], 1e-12)
+    assert np.max(np.abs(np.linalg.norm(out["four"][:, -1], axis=1) - 1.0)) < 1e-12
