@@ -340,7 +340,7 @@ def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
     assert_close(out[1], out[0], 1e-12)
     assert_close(out[2], out[0], 1e-12)
     a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
-    for b in sorted({0, nb // 2, nb - 1}):
+    for b in (sorted({0, nb // 2, nb - 1}) if nq <= 10 else [nb - 1]):     # (a 2048 x 2048 expm per step on the host)
         _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
                                            [0.0, 0.4], y0, "scipy_expm", 0.05, t_eval=[0.0, 0.15, 0.4], magnus_order=order)
         assert_close(out[1][b], ref, SOLVE_TOL)
