@@ -257,18 +257,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                 pub = yr;
             }
             if (a.E) pub = cmul(e_next, pub);
-            if (lane == 0) {
+            if (lane < 2) {   // every lane holds the same pub: lanes 0 / 1 store re / im in ONE 16-byte transaction
                 // the re-arming stores of the PREVIOUS round are complete before this round's data leaves (they are a
                 // round old: no stall); this round's re-arming follows the data
                 __builtin_amdgcn_s_waitcnt(0);
-                unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row;
-                __hip_atomic_store(z, (unsigned long long)__double_as_longlong(pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(z + 1, (unsigned long long)__double_as_longlong(pub.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row + lane;
+                __hip_atomic_store(z, (unsigned long long)__double_as_longlong(lane ? pub.y : pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // re-arm this row's words of the buffer read LAST round: having read this round from all my neighbours
                 // proves that every reader of those words has moved on (see the header)
-                unsigned long long* zr = ring + (size_t)b_rearm * 2 * n_pad + 2 * row;
+                unsigned long long* zr = ring + (size_t)b_rearm * 2 * n_pad + 2 * row + lane;
                 __hip_atomic_store(zr, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(zr + 1, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             b_cur = b_nxt;
             ++rr;
