@@ -87,9 +87,10 @@ __device__ __forceinline__ double resident_wave_sum(double x) {
     return (resident_lane_value(x, 0) + resident_lane_value(x, 16)) + (resident_lane_value(x, 32) + resident_lane_value(x, 48));
 }
 
-template <int NE, int WAVES>
+template <int NE, int WAVES, bool HALFQ>
 __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const ResidentArgs a) {
     constexpr int NQ = RESIDENT_DPL / NE;
+    constexpr int NQ_USED = (HALFQ && NQ >= 2) ? NQ / 2 : NQ;   // chunk slots the arithmetic walks (host: nq <= NQ_USED)
     constexpr int THREADS = 64 * WAVES;                          // one row per wave: WAVES rows per workgroup
     constexpr int NPW = RESIDENT_MAX_POLL * 128 / THREADS;       // polled words per thread
     __shared__ __attribute__((aligned(16))) double ylds[2][RESIDENT_MAX_POLL * 128];
@@ -227,22 +228,34 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
 #if MIDYN_RESIDENT_ABLATE == 1   // profiling only: the exchange without the arithmetic
             acc = *reinterpret_cast<const double2*>(yl + 2 * lane);
 #else
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (q < nq) {
-                    double g_re = 0.0, g_im = 0.0;
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) {
-                        g_re = fma(cr[e], v[q * NE + e], g_re);
-                        g_im = fma(ci[e], v[q * NE + e], g_im);
-                    }
-                    const double2 yv = *reinterpret_cast<const double2*>(yl + slot_of[q] * 128 + 2 * lane);
-                    acc.x = fma(g_re, yv.x, acc.x);
-                    acc.x = fma(-g_im, yv.y, acc.x);
-                    acc.y = fma(g_re, yv.y, acc.y);
-                    acc.y = fma(g_im, yv.x, acc.y);
-                }
+            // straight-line over the chunk slots (all NQ, or the first half -- HALFQ -- when at most half are in use): the registers
+            // of unused chunks hold zeros and their LDS slot is 0 (a finite vector), so they contribute exact zeros;
+            // two accumulators halve the dependent chain
+            double2 acc_b = make_double2(0.0, 0.0);
+#define MIDYN_RESIDENT_CHUNKS(LIMIT)                                                                     \
+            _Pragma("unroll") for (int q = 0; q < (LIMIT); ++q) {                                        \
+                double g_re = 0.0, g_im = 0.0;                                                           \
+                _Pragma("unroll") for (int e = 0; e < NE; ++e) {                                         \
+                    g_re = fma(cr[e], v[q * NE + e], g_re);                                              \
+                    g_im = fma(ci[e], v[q * NE + e], g_im);                                              \
+                }                                                                                        \
+                const double2 yv = *reinterpret_cast<const double2*>(yl + slot_of[q] * 128 + 2 * lane);  \
+                if (q & 1) {                                                                             \
+                    acc_b.x = fma(g_re, yv.x, acc_b.x);                                                  \
+                    acc_b.x = fma(-g_im, yv.y, acc_b.x);                                                 \
+                    acc_b.y = fma(g_re, yv.y, acc_b.y);                                                  \
+                    acc_b.y = fma(g_im, yv.x, acc_b.y);                                                  \
+                } else {                                                                                 \
+                    acc.x = fma(g_re, yv.x, acc.x);                                                      \
+                    acc.x = fma(-g_im, yv.y, acc.x);                                                     \
+                    acc.y = fma(g_re, yv.y, acc.y);                                                      \
+                    acc.y = fma(g_im, yv.x, acc.y);                                                      \
+                }                                                                                        \
             }
+            MIDYN_RESIDENT_CHUNKS(NQ_USED)
+#undef MIDYN_RESIDENT_CHUNKS
+            acc.x += acc_b.x;
+            acc.y += acc_b.y;
 #endif
             acc.x = resident_wave_sum(acc.x);
             acc.y = resident_wave_sum(acc.y);

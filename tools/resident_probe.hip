@@ -12,6 +12,9 @@
 #include "../qiskit_dynamics_amd/csrc/midyn_kernels.h"
 #include "../qiskit_dynamics_amd/csrc/midyn_resident.h"
 using namespace midyn;
+#ifndef PROBE_HALFQ
+#define PROBE_HALFQ false
+#endif
 #ifndef PROBE_WAVES
 #define PROBE_WAVES 4
 #endif
@@ -71,7 +74,7 @@ int main(int argc, char** argv) {
         CHECK(hipMemsetAsync(ring, 0xFF, 4 * 2 * n * 8, s));
         void* params[1] = {&a};
         CHECK(hipEventRecord(e0, s));
-        CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(rk4_resident_kernel<8, PROBE_WAVES>), dim3(n / PROBE_WAVES), dim3(64 * PROBE_WAVES), params, 0, s));
+        CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(rk4_resident_kernel<8, PROBE_WAVES, PROBE_HALFQ>), dim3(n / PROBE_WAVES), dim3(64 * PROBE_WAVES), params, 0, s));
         CHECK(hipEventRecord(e1, s));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
