@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void ell_build_kernel(const double2* __restric
     if (PASS == 0 && lane == 0) counts[row] = cnt;
 }
 
-template <int MODE>
+template <int MODE, int EWU>
 __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const EllArgs a) {
     // One workgroup = 64 consecutive rows (lane = row) x ELL_WAVES waves.  A single wave polling 26 words per lane and
     // walking 27 entries is latency bound on its own instruction stream (measured 6.9 us per round at N = 4096);
@@ -412,7 +412,8 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
     // row, the partial sums meet in LDS and wave 0 owns the rows' state, runs the stage and publishes.
     constexpr int THREADS = 64 * ELL_WAVES;
     constexpr int NPW = RESIDENT_MAX_POLL * 128 / THREADS;   // polled words per thread
-    constexpr int EW = ELL_W / ELL_WAVES;                    // entries per lane
+    constexpr int EW = ELL_W / ELL_WAVES;                    // entries per lane at most (EWU of them are walked)
+    static_assert(EWU <= ELL_W / ELL_WAVES, "EWU");
     __shared__ __attribute__((aligned(16))) double ylds[RESIDENT_MAX_POLL * 128];
     __shared__ __attribute__((aligned(16))) double2 part[ELL_WAVES][64];
     __shared__ double cl[64];
@@ -491,17 +492,25 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
         __syncthreads();
         // this wave's entries of every row; MODE 1 holds val[] already multiplied by its segment's coefficient
         // (constant within a step, see load_weighted)
-        double2 acc = make_double2(0.0, 0.0);
+        // straight-line over the first EWU entry slots (the host picks EWU >= the entries any lane holds; unused slots
+        // hold zeros and gather LDS word 0), two accumulators
+        double2 acc = make_double2(0.0, 0.0), acc_b = make_double2(0.0, 0.0);
 #pragma unroll
-        for (int j = 0; j < EW; ++j)
-            if (j < my_entries) {
-                const int mt = meta[j];
-                const double wgt = MODE == 1 ? val[j] : cl[(mt >> 16) & 63] * val[j];
-                const double2 yv = *reinterpret_cast<const double2*>(ylds + 2 * (mt & 0xffff));
-                const bool im = (mt >> 22) & 1;
+        for (int j = 0; j < EWU; ++j) {
+            const int mt = meta[j];
+            const double wgt = MODE == 1 ? val[j] : cl[(mt >> 16) & 63] * val[j];
+            const double2 yv = *reinterpret_cast<const double2*>(ylds + 2 * (mt & 0xffff));
+            const bool im = (mt >> 22) & 1;
+            if (j & 1) {
+                acc_b.x = fma(wgt, im ? -yv.y : yv.x, acc_b.x);
+                acc_b.y = fma(wgt, im ? yv.x : yv.y, acc_b.y);
+            } else {
                 acc.x = fma(wgt, im ? -yv.y : yv.x, acc.x);
                 acc.y = fma(wgt, im ? yv.x : yv.y, acc.y);
             }
+        }
+        acc.x += acc_b.x;
+        acc.y += acc_b.y;
         part[wave][lane] = acc;
         __syncthreads();
         if (wave == 0) {

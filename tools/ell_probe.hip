@@ -12,6 +12,9 @@
 #include "../qiskit_dynamics_amd/csrc/midyn_kernels.h"
 #include "../qiskit_dynamics_amd/csrc/midyn_resident.h"
 using namespace midyn;
+#ifndef PROBE_EWU
+#define PROBE_EWU 8
+#endif
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 template <class T> T* upload(const std::vector<T>& h) {
     T* d = nullptr;
@@ -64,7 +67,7 @@ int main(int argc, char** argv) {
         CHECK(hipMemsetAsync(ring, 0xFF, 4 * 2 * n * 8, s));
         void* params[1] = {&a};
         CHECK(hipEventRecord(e0, s));
-        CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(ell_resident_kernel<0>), dim3(n / 64), dim3(64 * ELL_WAVES), params, 0, s));
+        CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(ell_resident_kernel<0, PROBE_EWU>), dim3(n / 64), dim3(64 * ELL_WAVES), params, 0, s));
         CHECK(hipEventRecord(e1, s));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
