@@ -43,6 +43,12 @@ constexpr unsigned long long RESIDENT_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
 constexpr int RESIDENT_DPL = 64;          // doubles of operator data per lane
 constexpr int RESIDENT_MAX_POLL = 16;     // polled 64-column chunks per workgroup (8 words per thread)
 constexpr unsigned RESIDENT_SPIN_LIMIT = 1u << 21;
+#ifndef RESIDENT_MISS_STEP
+#define RESIDENT_MISS_STEP 2       // pre-sleep units added after a round whose first poll missed ...
+#endif
+#ifndef RESIDENT_CLEAN_ROUNDS
+#define RESIDENT_CLEAN_ROUNDS 8    // ... one unit removed after this many clean rounds in a row
+#endif
 constexpr int RESIDENT_INIT_PRESLEEP = 16, RESIDENT_MAX_PRESLEEP = 64;   // units of s_sleep(1) = 64 clocks
 
 struct ResidentArgs {
@@ -205,9 +211,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                     }
                 }
                 if (__builtin_amdgcn_readfirstlane(__any(spins > 0) ? 1 : 0)) {
-                    presleep = presleep + 2 > RESIDENT_MAX_PRESLEEP ? RESIDENT_MAX_PRESLEEP : presleep + 2;
+                    presleep = presleep + RESIDENT_MISS_STEP > RESIDENT_MAX_PRESLEEP ? RESIDENT_MAX_PRESLEEP : presleep + RESIDENT_MISS_STEP;
                     clean = 0;
-                } else if (++clean == 8) {
+                } else if (++clean == RESIDENT_CLEAN_ROUNDS) {
                     presleep = presleep > 0 ? presleep - 1 : 0;
                     clean = 0;
                 }
@@ -480,9 +486,9 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
             }
         }
         if (__builtin_amdgcn_readfirstlane(__any(spins > 0) ? 1 : 0)) {
-            presleep = presleep + 2 > RESIDENT_MAX_PRESLEEP ? RESIDENT_MAX_PRESLEEP : presleep + 2;
+            presleep = presleep + RESIDENT_MISS_STEP > RESIDENT_MAX_PRESLEEP ? RESIDENT_MAX_PRESLEEP : presleep + RESIDENT_MISS_STEP;
             clean = 0;
-        } else if (++clean == 8) {
+        } else if (++clean == RESIDENT_CLEAN_ROUNDS) {
             presleep = presleep > 0 ? presleep - 1 : 0;
             clean = 0;
         }
