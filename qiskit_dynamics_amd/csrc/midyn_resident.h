@@ -144,6 +144,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
         word_of[i] = slot < npoll ? a.poll_idx[pbase + slot] * 128 + (tid & 127) : -1;
     }
 
+    // unused chunk slots gather LDS slot 0: it must hold finite numbers even when this workgroup polls nothing
+    for (int i = tid; i < 2 * RESIDENT_MAX_POLL * 128; i += THREADS) (&ylds[0][0])[i] = 0.0;
+    __syncthreads();
     double2 yr = a.y[row];
     double2 acc_r = make_double2(0.0, 0.0);
     bool dead = false;
@@ -450,6 +453,9 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
     const bool cstatic = a.has_static && tid == 0;
     const int cidx = tid - a.has_static;
 
+    // unused entry slots gather LDS word 0: it must hold finite numbers even when this workgroup polls nothing
+    for (int i = tid; i < RESIDENT_MAX_POLL * 128; i += THREADS) ylds[i] = 0.0;
+    __syncthreads();
     double2 yr = a.y[row];     // (state only meaningful in wave 0)
     bool dead = false;
     int presleep = RESIDENT_INIT_PRESLEEP, clean = 0;

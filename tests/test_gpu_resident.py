@@ -483,3 +483,31 @@ def test_sweep_kernel_four_workgroups_per_instance_at_full_size(qd):
     assert_close(out["four"], out["per_launch"], 1e-12)
     assert_close(out["one"], out["per_launch"], 1e-12)
     assert np.max(np.abs(np.linalg.norm(out["four"][:, -1], axis=1) - 1.0)) < 1e-12
+
+
+def test_resident_kernel_rows_without_any_operator(qd):
+    """Half of the rows carry no operator element at all (n = 256, operators supported on the first 128 states only;
+    the workgroups of rows 128..255 poll nothing and every chunk slot of theirs is unused): those components must
+    simply keep their frame phase -- resident kernel against the oracle and the per-stage route, RK4."""
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(21)
+    n, m = 256, 128
+    d = rng.normal(size=n)
+    h_static = np.diag(d).astype(complex)
+    h_static[:m, :m] += herm(rng, m) * 0.2
+    h_ops = np.zeros((2, n, n), dtype=complex)
+    h_ops[0, :m, :m] = herm(rng, m) * 0.2
+    h_ops[1, :m, :m] = herm(rng, m) * 0.2
+    sigs = [qd.Signal(0.7, 0.3, 0.1), qd.Signal(lambda t: 0.4 * np.cos(t) + 0j, 0.2)]
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=d)
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    res, per_stage, l_res, _ = _solve_both(qd, solver, t_span=[0.0, 0.4], y0=y0, signals=sigs, method="RK4", max_dt=0.01)
+    assert l_res > 0
+    assert np.all(np.isfinite(res.y))
+    assert_close(res.y, per_stage.y, 1e-13)
+    a_d, a, dd, basis = orc.hamiltonian_model_build(h_static, h_ops, d)
+    _, ref = orc.solve_generator_model(a_d, a, dd, basis, lambda tt: np.array([np.real(s(tt)) for s in sigs]),
+                                       [0.0, 0.4], y0, "RK4", 0.01)
+    assert_close(res.y[-1], ref[-1], SOLVE_TOL)
