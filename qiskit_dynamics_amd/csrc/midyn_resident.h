@@ -704,8 +704,9 @@ struct SweepArgs {
     int P;
 };
 
-template <int ORDER, int SWEEP_RPT>
-__global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArgs a) {
+template <int ORDER, int SWEEP_RPT, int TH>
+__global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
+    // TH threads, SWEEP_RPT rows each: n_pad = TH * SWEEP_RPT exactly (TH = 1024; 256 / 512 for n_pad = 256 / 512)
     extern __shared__ __attribute__((aligned(16))) double2 sweep_lds[];
     __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];   // per slot: (c1, c2) of its segment, this step
     __shared__ int stag[SWEEP_MAX_SLOTS];                                    // per slot: segment | plane << 8
@@ -716,11 +717,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
     double2 acc[SWEEP_RPT], cur[SWEEP_RPT], prev[SWEEP_RPT];
 #pragma unroll
     for (int i = 0; i < SWEEP_RPT; ++i) {
-        const int r = tid + SWEEP_THREADS * i;
+        const int r = tid + TH * i;
         acc[i] = (r < a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + r] : make_double2(0.0, 0.0);
         cur[i] = prev[i] = make_double2(0.0, 0.0);
     }
-    for (int e = tid; e < a.wsp; e += SWEEP_THREADS) stag[e] = a.tags[e];
+    for (int e = tid; e < a.wsp; e += TH) stag[e] = a.tags[e];
     // one pass over the operator elements of this thread's rows:
     //   o1 = (sum_e ca_e A_e) . X1,  o2 = (sum_e cb_e A_e) . X2   with (ca, cb) = (c1, c2), or (c2, c1) when swapped
     // Two straight-line loops, no selects: the real-plane slots (A = v: A x = v x), then the imaginary-plane slots
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
         for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = o2[i] = make_double2(0.0, 0.0);
         const unsigned unp = (unsigned)np;
 #if MIDYN_SWEEP_ABLATE == 1   // profiling only: no operator pass at all
-        for (int i = 0; i < SWEEP_RPT; ++i) { o1[i] = X1[tid + SWEEP_THREADS * i]; o2[i] = X2[tid + SWEEP_THREADS * i]; }
+        for (int i = 0; i < SWEEP_RPT; ++i) { o1[i] = X1[tid + TH * i]; o2[i] = X2[tid + TH * i]; }
         return;
 #endif
 #define MIDYN_SWEEP_SLOT(IM)                                                                         \
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
             int cl[SWEEP_RPT];                                                                       \
             double v[SWEEP_RPT];                                                                     \
             _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
-                const unsigned idx = (unsigned)e * unp + (unsigned)(tid + SWEEP_THREADS * i);                        \
+                const unsigned idx = (unsigned)e * unp + (unsigned)(tid + TH * i);                        \
                 cl[i] = a.col[idx];                                                                  \
                 v[i] = a.val[idx];                                                                   \
             }                                                                                        \
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
         const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];
         const double h = a.hs[st];
         __syncthreads();   // the previous step's readers of the coefficients are done (and stag is written)
-        for (int e = tid; e < a.wsp; e += SWEEP_THREADS) {
+        for (int e = tid; e < a.wsp; e += TH) {
             const int seg = stag[e] & 63;
             const bool stat = a.has_static && seg == 0;
             const double* Sb = a.S + (size_t)b * a.inst_stride;
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < SWEEP_RPT; ++i) {
-                    const int r = tid + SWEEP_THREADS * i;
+                    const int r = tid + TH * i;
                     L1[r] = a.E ? cmul(a.E[(size_t)r0 * np + r], cur[i]) : cur[i];
                     if (ORDER == 2) L2[r] = a.E ? cmul(a.E[(size_t)r1 * np + r], cur[i]) : cur[i];
                 }
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
                     __syncthreads();
 #pragma unroll
                     for (int i = 0; i < SWEEP_RPT; ++i) {
-                        const int r = tid + SWEEP_THREADS * i;
+                        const int r = tid + TH * i;
                         double2 u1 = o1[i], u2 = o2[i];
                         if (a.E) {
                             const double2 e0 = a.E[(size_t)r0 * np + r], e1 = a.E[(size_t)r1 * np + r];
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
                     pass(L1, L2, true, o1, o2);   // o1 = C(t2) . (E2 u1), o2 = C(t1) . (E1 u2)
 #pragma unroll
                     for (int i = 0; i < SWEEP_RPT; ++i) {
-                        const int r = tid + SWEEP_THREADS * i;
+                        const int r = tid + TH * i;
                         const double2 v1 = a.E ? cmul_conj_a(a.E[(size_t)r1 * np + r], o1[i]) : o1[i];
                         const double2 v2 = a.E ? cmul_conj_a(a.E[(size_t)r0 * np + r], o2[i]) : o2[i];
                         w[i].x += cb * (v1.x - v2.x);
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
                     const double ca = h * f;
 #pragma unroll
                     for (int i = 0; i < SWEEP_RPT; ++i) {
-                        const int r = tid + SWEEP_THREADS * i;
+                        const int r = tid + TH * i;
                         const double2 u1 = a.E ? cmul_conj_a(a.E[(size_t)r0 * np + r], o1[i]) : o1[i];
                         w[i] = make_double2(ca * u1.x, ca * u1.y);
                     }
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_kernel(const SweepArg
             if (slot >= 0) {
 #pragma unroll
                 for (int i = 0; i < SWEEP_RPT; ++i) {
-                    const int r = tid + SWEEP_THREADS * i;
+                    const int r = tid + TH * i;
                     if (r < a.n) a.out[((size_t)b * a.P + slot) * a.n + r] = acc[i];
                 }
             }

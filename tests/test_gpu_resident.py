@@ -296,9 +296,10 @@ def test_lane_per_row_kernel_vectorised_lindbladian(qd):
         assert abs(np.trace(rho) - 1.0) < 1e-12
 
 
-@pytest.mark.parametrize("nq,nb,order", [(10, 5, 1), (10, 24, 2), (11, 3, 2), (11, 2, 1), (10, 1, 2)])
+@pytest.mark.parametrize("nq,nb,order", [(8, 5, 2), (9, 3, 1), (10, 5, 1), (10, 24, 2), (11, 3, 2), (11, 2, 1), (10, 1, 2)])
 def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
-    """ell_sweep_kernel: sweeps (and one Magnus-2 trajectory) of the chain in its diagonal frame (n = 1024 / 2048: one
+    """ell_sweep_kernel: sweeps (and one Magnus-2 trajectory) of the chain in its diagonal frame (n = 256 / 512 on 256- and
+    512-thread workgroups; n = 1024 / 2048: one
     and two rows per thread), scipy_expm with magnus_order 1 / 2, ONE launch for all instances and steps -- first,
     middle and last instance against the oracle, all instances against the launch-per-product route, saved states
     included."""

@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
     double2* out; CHECK(hipMalloc(&out, (size_t)B * P * n * sizeof(double2))); a.out = out; a.P = P;
     hipStream_t s; CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    auto fn = ell_sweep_kernel<2, 4>;
+    auto fn = ell_sweep_kernel<2, 4, 1024>;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
     for (int rep = 0; rep < 3; ++rep) {
         CHECK(hipEventRecord(e0, s));
