@@ -1,5 +1,6 @@
-import sys, time, cProfile, pstats, io
-sys.path.insert(0, "/root/repo")
+"""cProfile of the model build of the 10-qubit (cfg 2 / 3) Solver: where the host time of a single solve goes."""
+import os, sys, time, cProfile, pstats, io
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import qiskit_dynamics_amd as qd
 from qiskit_dynamics_amd import workloads as W
