@@ -889,6 +889,106 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
 // writes its own rows straight into its LDS copy, publishes them unphased, and phases its partners' rows as it copies
 // them in.  All NSPLIT * B workgroups must be resident at once (one per CU: LDS): cooperative launch.
 // ------------------------------------------------------------------------------------------------
+// ell_sweep_rk4_kernel<RPT, TH>: the same one-workgroup-per-instance form for fixed-step RK4 sweeps (a9) on very
+// sparse stacks: a stage is ONE pass over the operator elements; y and the accumulator of the thread's rows stay in
+// registers, the stage input is staged phased in LDS, the stage arithmetic is apply_epilogue_t's.
+template <int SWEEP_RPT, int TH>
+__global__ __launch_bounds__(TH) void ell_sweep_rk4_kernel(const SweepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double2 sweep_lds[];
+    __shared__ double cst[SWEEP_MAX_SLOTS];   // per slot: coefficient of its segment at the stage time
+    __shared__ int stag[SWEEP_MAX_SLOTS];
+    const int tid = threadIdx.x, b = blockIdx.x, np = a.n_pad;
+    double2* const L1 = sweep_lds;
+    double2 y[SWEEP_RPT], acc[SWEEP_RPT], cur[SWEEP_RPT];
+#pragma unroll
+    for (int i = 0; i < SWEEP_RPT; ++i) {
+        const int r = tid + TH * i;
+        y[i] = (r < a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + r] : make_double2(0.0, 0.0);
+        acc[i] = cur[i] = y[i];
+    }
+    for (int e = tid; e < a.wsp; e += TH) stag[e] = a.tags[e];
+    const unsigned unp = (unsigned)np;
+    const double* Sb = a.S + (size_t)b * a.inst_stride;
+    for (int st = 0; st < a.nsteps; ++st) {
+        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1], r2 = a.rows[3 * st + 2];
+        const double h = a.hs[st];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const int srow = sg == 0 ? r0 : (sg == 3 ? r2 : r1);
+            const double2* Es = a.E ? a.E + (size_t)srow * np : nullptr;
+            __syncthreads();    // the previous stage's readers of L1 / cst are done (and stag is written)
+            for (int e = tid; e < a.wsp; e += TH) {
+                const int seg = stag[e] & 63;
+                cst[e] = (a.has_static && seg == 0) ? 1.0 : Sb[(size_t)srow * a.k + seg - a.has_static];
+            }
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                const int r = tid + TH * i;
+                L1[r] = Es ? cmul(Es[r], cur[i]) : cur[i];
+            }
+            __syncthreads();
+            double2 o1[SWEEP_RPT];
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = make_double2(0.0, 0.0);
+#define MIDYN_SWEEP_SLOT(IM)                                                                         \
+            {                                                                                        \
+                const double ca = cst[e];                                                            \
+                int cl[SWEEP_RPT];                                                                   \
+                double v[SWEEP_RPT];                                                                 \
+                _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                              \
+                    const unsigned idx = (unsigned)e * unp + (unsigned)(tid + TH * i);               \
+                    cl[i] = a.col[idx];                                                              \
+                    v[i] = a.val[idx];                                                               \
+                }                                                                                    \
+                _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                              \
+                    const double2 x1 = L1[cl[i]];                                                    \
+                    const double wa = ca * v[i];                                                     \
+                    if (IM) {                                                                        \
+                        o1[i].x = fma(-wa, x1.y, o1[i].x);                                           \
+                        o1[i].y = fma(wa, x1.x, o1[i].y);                                            \
+                    } else {                                                                         \
+                        o1[i].x = fma(wa, x1.x, o1[i].x);                                            \
+                        o1[i].y = fma(wa, x1.y, o1[i].y);                                            \
+                    }                                                                                \
+                }                                                                                    \
+            }
+#pragma unroll 2
+            for (int e = 0; e < a.wre; ++e) MIDYN_SWEEP_SLOT(false)
+#pragma unroll 2
+            for (int e = a.wre; e < a.wsp; ++e) MIDYN_SWEEP_SLOT(true)
+#undef MIDYN_SWEEP_SLOT
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                const int r = tid + TH * i;
+                const double2 kk = Es ? cmul_conj_a(Es[r], o1[i]) : o1[i];
+                if (sg == 0) {
+                    acc[i] = cfma_r(h * (1.0 / 6), kk, y[i]);
+                    cur[i] = cfma_r(0.5 * h, kk, y[i]);
+                } else if (sg == 1) {
+                    acc[i] = cfma_r(h * (1.0 / 3), kk, acc[i]);
+                    cur[i] = cfma_r(0.5 * h, kk, y[i]);
+                } else if (sg == 2) {
+                    acc[i] = cfma_r(h * (1.0 / 3), kk, acc[i]);
+                    cur[i] = cfma_r(h, kk, y[i]);
+                } else {
+                    y[i] = cfma_r(h * (1.0 / 6), kk, acc[i]);
+                    cur[i] = y[i];
+                }
+            }
+        }
+        if (a.save) {
+            const int slot = a.save[st];
+            if (slot >= 0) {
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const int r = tid + TH * i;
+                    if (r < a.n) a.out[((size_t)b * a.P + slot) * a.n + r] = y[i];
+                }
+            }
+        }
+    }
+}
+
 struct SweepSplitArgs {
     SweepArgs a;
     int nsplit;

@@ -512,3 +512,47 @@ def test_resident_kernel_rows_without_any_operator(qd):
     _, ref = orc.solve_generator_model(a_d, a, dd, basis, lambda tt: np.array([np.real(s(tt)) for s in sigs]),
                                        [0.0, 0.4], y0, "RK4", 0.01)
     assert_close(res.y[-1], ref[-1], SOLVE_TOL)
+
+
+@pytest.mark.parametrize("nq,nb", [(8, 6), (9, 3), (10, 17), (11, 2)])
+def test_sweep_kernel_rk4(qd, nq, nb):
+    """ell_sweep_rk4_kernel: RK4 sweeps of the chain in its diagonal frame (n = 256 .. 2048), ONE launch for all instances
+    and steps, per-instance initial states, saved states -- against the oracle (first and last instance) and against
+    the launch-per-stage work-list route (all instances)."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    cfg = W.schrodinger_config(n_qubits=nq, n_drives=min(8, nq), t_final=1.0, max_dt=0.01)
+    k = len(cfg["ops"])
+    sweeps = []
+    for b in range(nb):
+        amps, phases = W.sweep_parameters(b, k)
+        sweeps.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, ph)
+                       for a, nu, ph in zip(amps, cfg["carrier"], phases)])
+    frame = np.diag(cfg["h_d"]).real.copy()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
+    rng = np.random.default_rng(nq * 7 + nb)
+    y0s = []
+    for b in range(nb):
+        y = crand(rng, 2**nq)
+        y0s.append(y / np.linalg.norm(y))
+    out, launches = {}, {}
+    for flag in (1, 0):
+        ctx.set_option("ell_sweep", flag)
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        try:
+            r = solver.solve(t_span=[0.0, 0.3], y0=y0s, signals=sweeps, method="RK4", max_dt=0.01, t_eval=[0.0, 0.11, 0.3])
+        finally:
+            ctx.set_option("profile", 0)
+            ctx.set_option("ell_sweep", 1)
+        launches[flag] = ctx.counters("rk4_resident")["launches"]
+        out[flag] = np.stack([x.y for x in r])
+    assert launches[1] == 1 and launches[0] == 0, launches
+    assert_close(out[1], out[0], 1e-13)
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
+    for b in (0, nb - 1):
+        _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
+                                           [0.0, 0.3], y0s[b], "RK4", 0.01, t_eval=[0.0, 0.11, 0.3])
+        assert_close(out[1][b], ref, SOLVE_TOL)
