@@ -38,5 +38,17 @@ for blocks in (1, 0):
     if blocks: ref = y
     else: out["max_abs_difference_between_routes"] = float(np.max(np.abs(y - ref)))
 ctx.set_option("skip_zero_blocks", 1)
+# the same steps through midyn_rk4_solve: ONE launch of ell_sweep_rk4_kernel (kernel time by HIP events; the call itself
+# also uploads the table and copies the results back)
+n_st = warm + steps
+save = np.full(n_st, -1, dtype=np.int32); save[-1] = 1
+run = lambda: stack.rk4_solve(sched.times[:nr], table, rows, sched.step_h[:n_st], save, 2, y0, B, True)
+run(); ctx.synchronize()
+ctx.reset_counters(); ctx.set_option("profile", 1); ys = run(); ctx.set_option("profile", 0)
+c = ctx.counters("rk4_resident")
+if c["launches"]:
+    out["one_launch_sweep_kernel"] = {"kernel_ms_per_step": round(c["ms"] / n_st, 4),
+                                      "rhs_evals_per_s_in_the_kernel": round(4 * B * n_st / (c["ms"] * 1e-3)),
+                                      "max_abs_difference_to_work_lists": float(np.max(np.abs(ys[:, -1, :, 0] - ref)))}
 print(json.dumps({"what": f"cfg3 model in the diagonal frame diag(H_d), {B} instances, RK4 (block-sparse stack), "
                           f"{steps} timed steps, inputs resident", **out}))
