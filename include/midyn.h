@@ -69,9 +69,10 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   resident_rk4 [1]      one RK4 trajectory whose active operator planes fit the register files (32 < n, at most 64
  *                         doubles per lane and row): whole step ranges in one launch, operators in registers, the
  *                         stage input exchanged through a polled ring in device memory (csrc/midyn_resident.h)
- *   ell_sweep [1]         sweeps (and single Magnus-2 trajectories) on very sparse stacks, 256 <= n_pad <= 4096, expm action: ONE
- *                         launch, one workgroup per instance through all steps, state in registers, operator
- *                         elements (ELL) from L2 (csrc/midyn_resident.h: ell_sweep_kernel)
+ *   ell_sweep [1]         sweeps (and single Magnus-2 trajectories) on very sparse stacks, 256 <= n_pad <= 4096, in
+ *                         midyn_rk4_solve and the expm action of midyn_expm_solve: ONE launch, one workgroup per
+ *                         instance through all steps, state in registers, operator elements (ELL) from L2
+ *                         (csrc/midyn_resident.h: ell_sweep_kernel, ell_sweep_rk4_kernel)
  *   ell_sweep_split [1]   ... small shards: 4 workgroups per instance while 4 x instances <= CUs (n_pad = 4096); the
  *                         partners all-gather every operand vector through a sentinel-polled ring (cfg 5, 1..32
  *                         instances: 0.18-0.24 instead of 0.29-0.33 ms per step).  2: also 2 workgroups per instance
