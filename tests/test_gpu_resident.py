@@ -556,3 +556,33 @@ def test_sweep_kernel_rk4(qd, nq, nb):
         _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
                                            [0.0, 0.3], y0s[b], "RK4", 0.01, t_eval=[0.0, 0.11, 0.3])
         assert_close(out[1][b], ref, SOLVE_TOL)
+
+
+def test_small_sweep_of_a_dense_model_runs_as_single_trajectories(qd):
+    """Three instances of a dense 200-dimensional model in a full frame, RK4: midyn_rk4_solve runs them one after the
+    other on the register-resident kernel (three launches) instead of the batched stage -- against the oracle and the
+    batched route, per-instance initial states, saved states."""
+    from oracle import dynamics_oracle as orc
+
+    rng = np.random.default_rng(77)
+    n, k, nb = 200, 2, 3
+    hs = herm(rng, n) * 0.2
+    ho = np.array([herm(rng, n) for _ in range(k)]) * 0.2
+    frame = herm(rng, n) * 0.2
+    sweeps = [[qd.Signal(lambda t, a=0.3 + 0.1 * j + 0.05 * b: a * np.cos(0.8 * t) + 0j, 0.4 * j, 0.2 * b) for j in range(k)]
+              for b in range(nb)]
+    y0s = []
+    for b in range(nb):
+        y = crand(rng, n)
+        y0s.append(y / np.linalg.norm(y))
+    solver = qd.Solver(static_hamiltonian=hs, hamiltonian_operators=ho, rotating_frame=frame)
+    kw = dict(t_span=[0.0, 0.4], y0=y0s, signals=sweeps, method="RK4", max_dt=0.01, t_eval=[0.0, 0.17, 0.4])
+    res, batched, l_res, l_off = _solve_both(qd, solver, **kw)
+    assert l_res == nb and l_off == 0
+    a_d, a, d, basis = orc.hamiltonian_model_build(hs, ho, frame)
+    for b in range(nb):
+        assert_close(res[b].y, batched[b].y, 1e-13)
+        t_ref, y_ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
+                                                 [0.0, 0.4], y0s[b], "RK4", 0.01, t_eval=[0.0, 0.17, 0.4])
+        assert_close(res[b].t, t_ref, 0)
+        assert_close(res[b].y, y_ref, SOLVE_TOL)
