@@ -7,8 +7,10 @@ import qiskit_dynamics_amd as qd
 from qiskit_dynamics_amd import workloads as W
 
 ctx = qd.default_context()
-cfg = W.schrodinger_config()
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+cfg = W.schrodinger_config(n_qubits=nq, n_drives=min(8, nq))
 solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+print("n =", 2**nq)
 for nb in (2, 4, 8, 12):
     sweeps = []
     for b in range(nb):
