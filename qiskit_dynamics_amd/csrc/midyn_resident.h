@@ -994,6 +994,9 @@ struct SweepSplitArgs {
     int nsplit;
     unsigned long long* ring;   // [B][4][ORDER][2 * n_pad] words, all sentinel at launch
     int* err;
+    int part_major;             // 1: blocks [p B, (p + 1) B) hold part p of every instance -- with B a multiple of 8 the
+                                // partners of an instance sit on the same XCD under the observed b % 8 dispatch (a speed
+                                // matter only: the exchange is agent-scope either way); 0: parts of an instance adjacent
 };
 
 template <int ORDER, int SWEEP_RPT>
@@ -1003,7 +1006,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
     __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];
     __shared__ int stag[SWEEP_MAX_SLOTS];
     const int tid = threadIdx.x, np = a.n_pad, nsplit = sa.nsplit;
-    const int b = blockIdx.x / nsplit, part = blockIdx.x % nsplit;
+    const int nb = gridDim.x / nsplit;
+    const int b = sa.part_major ? blockIdx.x % nb : blockIdx.x / nsplit, part = sa.part_major ? blockIdx.x / nb : blockIdx.x % nsplit;
     const int part_rows = np / nsplit, row0 = part * part_rows;     // this workgroup's rows: row0 + tid + 1024 i
     double2* const L1 = sweep_lds;
     double2* const L2 = sweep_lds + np;
@@ -1020,9 +1024,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
     bool dead = false;
     int b_cur = 0;
     // All-gather of ORDER vectors: this thread's rows hold (va[i], vb[i]); LDS gets ea o va (and eb o vb) for ALL rows,
-    // where ea / eb are the phase rows of two table times (nullptr: no frame).
-    auto all_gather = [&](const double2 (&va)[SWEEP_RPT], const double2 (&vb)[SWEEP_RPT], const double2* ea, const double2* eb) {
+    // where ea / eb are the phase rows of two table times (nullptr: no frame).  `same`: vb IS va (the input of a term goes
+    // to both Gauss points): one vector is published and read, both phased copies are made from it.  At order 2 the rounds
+    // alternate same / two vectors, so the buffer re-armed in a round (published two rounds ago) holds what this round holds.
+    auto all_gather = [&](const double2 (&va)[SWEEP_RPT], const double2 (&vb)[SWEEP_RPT], const double2* ea, const double2* eb,
+                          const bool same) {
         const int b_nxt = (b_cur + 1) & 3, b_rearm = (b_cur + 3) & 3;
+        const int nv = (ORDER == 2 && !same) ? 2 : 1;      // vectors through the ring this round
         unsigned long long* nxt = ring + (size_t)b_nxt * ORDER * 2 * np;
         __builtin_amdgcn_s_waitcnt(0);     // last round's re-arming stores are complete before this round's data leaves
         __syncthreads();                   // every reader of the LDS copies of the previous pass is done
@@ -1033,8 +1041,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
             __hip_atomic_store(nxt + 2 * r + 1, (unsigned long long)__double_as_longlong(va[i].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             L1[r] = ea ? cmul(ea[r], va[i]) : va[i];
             if (ORDER == 2) {
-                __hip_atomic_store(nxt + 2 * np + 2 * r, (unsigned long long)__double_as_longlong(vb[i].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(nxt + 2 * np + 2 * r + 1, (unsigned long long)__double_as_longlong(vb[i].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (nv == 2) {
+                    __hip_atomic_store(nxt + 2 * np + 2 * r, (unsigned long long)__double_as_longlong(vb[i].x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(nxt + 2 * np + 2 * r + 1, (unsigned long long)__double_as_longlong(vb[i].y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 L2[r] = eb ? cmul(eb[r], vb[i]) : vb[i];
             }
         }
@@ -1046,6 +1056,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
                 const int r = row0 + tid + SWEEP_THREADS * i;
 #pragma unroll
                 for (int v = 0; v < ORDER; ++v) {
+                    if (v >= nv) continue;
                     __hip_atomic_store(old + (size_t)v * 2 * np + 2 * r, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(old + (size_t)v * 2 * np + 2 * r + 1, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1063,6 +1074,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
                     const int r = prow0 + tid + SWEEP_THREADS * i;
 #pragma unroll
                     for (int v = 0; v < ORDER; ++v) {
+                        if (v >= nv) continue;
                         w[i][v][0] = dead ? 0ull : __hip_atomic_load(nxt + (size_t)v * 2 * np + 2 * r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         w[i][v][1] = dead ? 0ull : __hip_atomic_load(nxt + (size_t)v * 2 * np + 2 * r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -1070,7 +1082,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
 #pragma unroll
                 for (int i = 0; i < SWEEP_RPT; ++i)
 #pragma unroll
-                    for (int v = 0; v < ORDER; ++v) pending |= (w[i][v][0] == RESIDENT_SENTINEL) | (w[i][v][1] == RESIDENT_SENTINEL);
+                    for (int v = 0; v < ORDER; ++v)
+                        if (v < nv) pending |= (w[i][v][0] == RESIDENT_SENTINEL) | (w[i][v][1] == RESIDENT_SENTINEL);
                 if (!pending) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
@@ -1087,7 +1100,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
                 const double2 xa = make_double2(__longlong_as_double((long long)w[i][0][0]), __longlong_as_double((long long)w[i][0][1]));
                 L1[r] = ea ? cmul(ea[r], xa) : xa;
                 if (ORDER == 2) {
-                    const double2 xb = make_double2(__longlong_as_double((long long)w[i][ORDER - 1][0]), __longlong_as_double((long long)w[i][ORDER - 1][1]));
+                    const double2 xb = nv == 2 ? make_double2(__longlong_as_double((long long)w[i][ORDER - 1][0]),
+                                                              __longlong_as_double((long long)w[i][ORDER - 1][1])) : xa;
                     L2[r] = eb ? cmul(eb[r], xb) : xb;
                 }
             }
@@ -1175,7 +1189,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
             }
             for (int j = 1; j <= K; ++j) {
                 const double f = cheb ? (j == 1 ? 1.0 : 2.0) / par : 1.0 / (par * (double)j);
-                all_gather(cur, cur, E0, E1);                 // L1 = E(t1) o v, L2 = E(t2) o v
+                all_gather(cur, cur, E0, E1, true);           // L1 = E(t1) o v, L2 = E(t2) o v
                 double2 o1[SWEEP_RPT], o2[SWEEP_RPT], w[SWEEP_RPT];
                 pass(L1, L2, false, o1, o2);
                 if (ORDER == 2) {
@@ -1188,7 +1202,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
                         u2[i] = E1 ? cmul_conj_a(E1[r], o2[i]) : o2[i];
                         w[i] = make_double2(ca * (u1[i].x + u2[i].x), ca * (u1[i].y + u2[i].y));
                     }
-                    all_gather(u1, u2, E1, E0);               // L1 = E(t2) o u1 (for g2), L2 = E(t1) o u2 (for g1)
+                    all_gather(u1, u2, E1, E0, false);        // L1 = E(t2) o u1 (for g2), L2 = E(t1) o u2 (for g1)
                     pass(L1, L2, true, o1, o2);
 #pragma unroll
                     for (int i = 0; i < SWEEP_RPT; ++i) {
