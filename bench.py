@@ -55,7 +55,7 @@ MAX_DT = 0.005
 SWEEP = 4096                   # BASELINE.json: 4096-parameter batch
 CFG5_SWEEP = 1024              # BASELINE.json configs[4]: 1024-parameter sweep
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor FP64 matrix peak (SURVEY.md 8(d) / BASELINE.md 3)
-LDS_PEAK_GBS = 128.0 * 256 * 2.4      # 128 B per clock and CU, 256 CUs, 2.4 GHz
+LDS_PEAK_GBS = 256.0 * 256 * 2.4      # ds_read_b64/b128: 256 B per clock and CU (MI355X_MICROARCH.md, LDS), 256 CUs, 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -522,27 +522,36 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
             k_ms = cs["rk4_resident"]["ms"]
             n = stack.n
             # per term and instance: 2 passes over the operator slots of every row; a pass gathers 2 complex numbers
-            # from LDS and does 2 real x complex multiply-adds per slot and reads 12 B of operator data from L2
+            # from LDS and does 2 real x complex multiply-adds per slot and reads one operator element from L2
+            form = int(ctx.counters("sweep_split")["ms"])          # 0 general (12 B elements), 1 packed, 2 direct (4 B)
+            elem_bytes = 12 if form == 0 else 4
             flops = terms * count * 2 * slots * n * 2 * 4
             lds_bytes = terms * count * 2 * slots * n * 2 * 16
-            l2_bytes = terms * count * 2 * slots * n * 12
-            out["route"] = ("ell_sweep_kernel<2,4>: ONE launch, one workgroup (1024 threads) per instance through all "
-                            "steps; series state in registers, staged vectors in LDS, operator elements (grouped ELL) "
-                            "from L2")
+            l2_bytes = terms * count * 2 * slots * n * elem_bytes
+            busy = min(count, 256)
+            form_name = {0: "general: 4 B column + 8 B value", 1: "packed: column | sign, one magnitude per slot",
+                         2: "direct: LDS address of the operand, one signed magnitude per slot"}[form]
+            out["route"] = ("ell_sweep_kernel<2,4,1024,%d>: ONE launch, one workgroup (1024 threads) per instance through "
+                            "all steps; staged vectors in LDS, operator elements (%s) from L2, series vectors the passes "
+                            "do not touch in a per-instance stash" % (form, form_name))
             out["roofline"] = {
-                "kernel": "ell_sweep_kernel<2, 4>", "bound": "lds",
+                "kernel": "ell_sweep_kernel<2, 4, 1024, %d>" % form, "bound": "lds",
                 "achieved": round(lds_bytes / (k_ms * 1e-3) / 1e9, 1),
                 "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s",
                 "frac": round(lds_bytes / (k_ms * 1e-3) / 1e9 / LDS_PEAK_GBS, 4), "traffic": None,
+                "cus_busy": busy, "frac_of_the_busy_cus": round(lds_bytes / (k_ms * 1e-3) / 1e9 / (LDS_PEAK_GBS * busy / 256), 4),
                 "avg_launch_ms": round(k_ms / max(cs["rk4_resident"]["launches"], 1), 4),
                 "series_terms_per_instance": terms, "operator_slots_per_row": slots,
+                "us_per_term": round(k_ms * 1e3 / max(terms, 1), 2),
                 "executed_gflops_per_launch": round(flops / 1e9, 2),
                 "executed_tflops": round(flops / (k_ms * 1e-3) / 1e12, 3),
+                "operator_element_bytes": elem_bytes,
                 "l2_operator_bytes_per_launch": l2_bytes,
                 "l2_operator_gbs": round(l2_bytes / (k_ms * 1e-3) / 1e9, 1),
                 "note": "achieved = bytes gathered from LDS (16 B per operator slot, row and operand vector) / kernel "
-                        "time; peak = 128 B per clock and CU x 256 CUs x 2.4 GHz.  Vector fp64, no MFMA: the operators "
-                        "have at most 19 non-zeros per row"}
+                        "time; peak = 256 B per clock and CU (ds_read_b128, MI355X_MICROARCH.md) x 256 CUs x 2.4 GHz; one "
+                        "workgroup per instance, so a 128-instance shard occupies 128 of the 256 CUs (frac_of_the_busy_cus)."
+                        "  Vector fp64, no MFMA: the operators have at most 19 non-zeros per row"}
         else:
             out["roofline"] = cfg5_roofline(ctx, stack, cs, count, stack.n, n_steps, wall, count)
         if took_sweep:     # the work-list MFMA route beside it

@@ -31,7 +31,10 @@
 #define MIDYN_RESIDENT_PACK 1     // publish a workgroup's rows with one store (0: lanes 0/1 of every wave; 2.58 vs 2.52 us)
 #endif
 #ifndef MIDYN_SWEEP_UNROLL
-#define MIDYN_SWEEP_UNROLL 2     // slots per iteration of the pass loops of ell_sweep_kernel
+#define MIDYN_SWEEP_UNROLL 2     // slots per iteration of the pass loops of the sweep kernels
+#endif
+#ifndef MIDYN_SWEEP_PREFETCH
+#define MIDYN_SWEEP_PREFETCH 2   // ell_sweep_kernel: register stages of operator elements fetched ahead of their slot (0: none)
 #endif
 #ifndef MIDYN_SWEEP_ABLATE
 #define MIDYN_SWEEP_ABLATE 0     // 1: no operator pass; 2: element loads only (no gathers); 3: gathers only (no element loads)
@@ -343,6 +346,8 @@ struct EllArgs {
     int n, n_pad, has_static, k, nseg;
     const double* S;          // [R][k]
     const double2* E;         // [R][n_pad] or nullptr
+    const double2* Dt;        // ell_sweep_kernel, order 2, framed: [nsteps][n_pad] E(t2) o conj(E(t1)) of every step
+    double2* stash;           // ell_sweep_kernel, order 2: [B][3][n_pad] series vectors kept out of the registers
     const int* rows;          // [nsteps][3]
     const double* hs;         // [nsteps]
     const int* save;          // [nsteps] or nullptr
@@ -661,17 +666,37 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
 
 
 // ------------------------------------------------------------------------------------------------
-// ell_sweep_kernel<ORDER, RPT>: a SWEEP on a very sparse stack (cfg 5: n = 4096, at most 19 non-zeros per row), expm
-// action of Magnus order 1 / 2.  Trajectories of a sweep are independent, so nothing has to cross workgroups at all:
-// one workgroup (1024 threads, RPT rows each, n_pad = 1024 RPT) integrates ONE instance through ALL steps.  The
-// vector an operator is applied to is staged, already phased, in LDS (two copies for order 2: the two Gauss points
-// have different frame phases); every thread walks the operator elements of its rows (coalesced over the threads,
-// served by L2: the arrays are shared by all instances), gathers y'[col] from LDS and keeps the series state of its
-// rows in registers.  Order 2, per term (commutator-free form, csrc/midyn_action.inc):
+// ell_sweep_kernel<ORDER, RPT, TH, PACKED>: a SWEEP on a very sparse stack (cfg 5: n = 4096, at most 19 non-zeros per
+// row), expm action of Magnus order 1 / 2.  Trajectories of a sweep are independent, so nothing has to cross workgroups
+// at all: one workgroup (TH threads, RPT rows each, n_pad = TH RPT) integrates ONE instance through ALL steps.  The
+// vector an operator is applied to is staged in LDS (two copies for order 2: the two Gauss points see different frame
+// phases); every thread walks the operator elements of its rows (coalesced over the threads, served by L2: the arrays
+// are shared by all instances) and gathers the operands from LDS.  Order 2, per term (commutator-free form,
+// csrc/midyn_action.inc):
 //     u1 = g1 v, u2 = g2 v (one pass: same v, two coefficient sets);  q = g2 u1 - g1 u2 (second pass);
 //     w = a (u1 + u2) + b q  (+ phi_{j-2} for the Chebyshev recurrence).
 // The MFMA work-list route multiplies 16 x 16 blocks that are 94 % zeros for such operators (17 tiles x 16 columns
 // per row against 19 non-zeros).
+//
+// Round 3 re-formulated the kernel around what its passes wait for (tools/sweep_probe.hip: 39.0 -> 18.1 us per term on
+// the cfg 5 shape, order 1: 14.1 -> 5.0).  A pass of the first form moved, per workgroup at n = 4096 with 19 slots,
+// 934 KB of operator elements (4 B column + 8 B value) through the CU's 64 B/clk L1 fill path, 2.5 MB of LDS gathers,
+// the frame phases of every row six times per term, and spilled 76 registers around its loops.
+//   * PACKED 1: when every slot holds ONE magnitude (operators built from Pauli strings: the XX couplings and the drives
+//     of cfg 5) an element is 4 bytes, column | sign << 31; the magnitude is folded into the slot's coefficient (one LDS
+//     broadcast per slot) and the sign is an XOR into the gathered operand's sign bits.  Unused entries point at a zero
+//     slot behind the LDS copies.  A third of the element bytes, no per-element v_mul_f64.
+//     PACKED 2: every slot also has ONE sign and no unused entry: the element is the LDS byte address of its operand,
+//     and the per-element work is the four fused multiply-adds and nothing else.  PACKED 0: any stack (12-byte elements).
+//   * The whole step runs in the frame picture of its first Gauss point: y~ = E(t1) o y once per step, then
+//     g1~ = C(t1) needs no phases at all and g2~ = conj(D) o C(t2) o D with D = E(t2) o conj(E(t1)) from a per-step table
+//     (order 2 only; sweep_dtable_kernel) -- three loads and four complex multiplications per row and term instead of six
+//     phase loads and six multiplications.
+//   * The term vector is accumulated INTO the Chebyshev predecessor (w = phi_{j-2} + ...): one vector less; at order 2 the
+//     vectors no pass touches (result, phi_{j-1}, the term between its passes) live in a per-instance stash in device
+//     memory, so that a pass holds its two output vectors and its gathers in flight and nothing else: no spills.
+//   * All global addresses are a uniform base plus a 32-bit byte offset that passes through an empty asm at every use;
+//     otherwise hipcc hoists the 64-bit address of every (array, row) pair out of the step loop and spills them.
 // ------------------------------------------------------------------------------------------------
 constexpr int SWEEP_THREADS = 1024;
 constexpr int SWEEP_MAX_RPT = 4;      // rows per thread (template parameter RPT): n_pad = 1024 * RPT <= 4096
@@ -683,12 +708,18 @@ struct SweepArgs {
     const double* val;        // [wsp][n_pad] (0 in unused slots)
     const int* col;           // [wsp][n_pad] column (0 in unused slots)
     const int* tags;          // [wsp] segment | plane << 8
+    // packed form (every slot holds ONE magnitude: Pauli-built operators): 4 bytes per element instead of 12 --
+    // pk[e][r] = column | sign << 31 (column n_pad = the zero slot of the LDS copies: unused entry), value = +-mag[e]
+    const int* pk;            // [wsp][n_pad] or nullptr  (direct form: LDS byte address of the X1 operand, mag signed)
+    const double* mag;        // [wsp]
     int wsp;
     int wre;                  // slots [0, wre) hold real-plane values, [wre, wsp) imaginary-plane values
     int n, n_pad, has_static, k, nseg;
     const double* S;          // [B][R][k]
     long long inst_stride;    // R * k
     const double2* E;         // [R][n_pad] or nullptr
+    const double2* Dt;        // ell_sweep_kernel, order 2, framed: [nsteps][n_pad] E(t2) o conj(E(t1)) of every step
+    double2* stash;           // ell_sweep_kernel, order 2: [B][3][n_pad] series vectors kept out of the registers
     const int* rows;          // [nsteps][3]
     const double* hs;         // [nsteps]
     const int* save;          // [nsteps] or nullptr
@@ -704,75 +735,198 @@ struct SweepArgs {
     int P;
 };
 
-template <int ORDER, int SWEEP_RPT, int TH>
+// D[st][r] = E[rows[3 st + 1]][r] o conj(E[rows[3 st]][r]): the frame phase between the two Gauss points of every step
+__global__ __launch_bounds__(256) void sweep_dtable_kernel(const double2* __restrict__ E, const int* __restrict__ rows, int nsteps, int np,
+                                                           double2* __restrict__ Dt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nsteps * np) return;
+    const int st = (int)(i / np), r = (int)(i % np);
+    Dt[i] = cmul_conj_a(E[(size_t)rows[3 * st] * np + r], E[(size_t)rows[3 * st + 1] * np + r]);
+}
+
+// The 32-bit byte offset of row tid + TH i in an array of 2^shift-byte elements, passed through an empty asm at every
+// use: otherwise the loop-invariant 64-bit sum base + offset of every (array, row) pair is hoisted out of the step loop
+// -- 40 registers of addresses, most of them spilled -- and the loads lose the scalar-base addressing form.
+template <int TH>
+__device__ __forceinline__ unsigned sweep_boff(const int tid, const int i_, const int shift) {
+    unsigned o = (unsigned)(tid + TH * i_) << shift;
+    asm volatile("" : "+v"(o));
+    return o;
+}
+
+// One pass over the operator elements of this thread's rows (rows tid + TH i):
+//   o1 = (sum_e ca_e A_e) . X1,  o2 = (sum_e cb_e A_e) . X2   with (ca, cb) = cab[e], or swapped
+// Two straight-line loops, no selects: the real-plane slots (A x = v x), then the imaginary-plane slots
+// (A = i v: A x = v (-x.y, x.x)).  X1 / X2: the LDS copies of the operand vectors (sweep_lds: their base; PACKED 2
+// elements are byte addresses relative to it, X2 operands 32768 bytes behind their X1 operands).
+template <int ORDER, int SWEEP_RPT, int TH, int PACKED>
+__device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* cab, const double2* sweep_lds, const double2* X1,
+                                           const double2* X2, const int tid, const bool swapped, double2 (&o1)[SWEEP_RPT],
+                                           double2 (&o2)[SWEEP_RPT]) {
+    const int np = a.n_pad;
+    const unsigned unp = (unsigned)np;
+    auto boff = [&](const int i_, const int shift) { return sweep_boff<TH>(tid, i_, shift); };
+#define ROW(i_) ((unsigned)(tid + TH * (i_)))
+
+#pragma unroll
+    for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = o2[i] = make_double2(0.0, 0.0);
+#if MIDYN_SWEEP_ABLATE == 1   // profiling only: no operator pass at all
+    for (int i = 0; i < SWEEP_RPT; ++i) { o1[i] = X1[tid + TH * i]; o2[i] = X2[tid + TH * i]; }
+    return;
+#endif
+    // The element loads depend on nothing, but a wave that asks for them when it needs them waits out an L2 round
+    // trip per slot.  A ring of PF register stages: stage s holds the elements of slot e0 + s and is refilled with
+    // those of slot e0 + s + PF as soon as it has been copied out (the slot loop is unrolled by PF).
+    // (measured, us per term, cfg 5 shape, none / 2 / 3 stages: direct form 19.9 / 18.1 / 19.3, packed 23.6 / 21.3 / 22.6; the
+    // 12-byte elements of the general form do not have the registers: 31.7 / 35.2 / 40.3)
+    constexpr bool PFON = PACKED != 0 && MIDYN_SWEEP_PREFETCH > 0;
+    constexpr int PF = PFON ? MIDYN_SWEEP_PREFETCH : 1;
+    int cn[PF][SWEEP_RPT];
+    double vn[PF][SWEEP_RPT];
+    auto fetch = [&](const int e_, int (&c_)[SWEEP_RPT], double (&v_)[SWEEP_RPT]) {
+#pragma unroll
+        for (int i = 0; i < SWEEP_RPT; ++i) {
+            if (MIDYN_SWEEP_ABLATE == 3) {
+                c_[i] = (int)((((unsigned)e_ * unp + ROW(i)) * 2654435761u) >> 8) & (np - 1);
+                v_[i] = 1e-3;
+            } else if (PACKED) {
+                c_[i] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.pk + (size_t)e_ * unp) + boff(i, 2));
+            } else {
+                c_[i] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.col + (size_t)e_ * unp) + boff(i, 2));
+                v_[i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.val + (size_t)e_ * unp) + boff(i, 3));
+            }
+        }
+    };
+#define MIDYN_SWEEP_K_SLOT(IM, S_)                                                                    \
+    {                                                                                            \
+        const double2 cc = cab[e];                                                               \
+        const double ca = swapped ? cc.y : cc.x, cb = swapped ? cc.x : cc.y;                     \
+        int cl[SWEEP_RPT];                                                                       \
+        double va[SWEEP_RPT];                                                                    \
+        if (!PFON) fetch(e, cn[S_], vn[S_]);                                                 \
+        _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
+            cl[i] = cn[S_][i];                                                                   \
+            if (PACKED == 0) va[i] = vn[S_][i];                                                    \
+        }                                                                                        \
+        if (PFON && e + PF < hi) fetch(e + PF, cn[S_], vn[S_]);                              \
+        double2 x1[SWEEP_RPT], x2[SWEEP_RPT];                                                    \
+        _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
+            if (PACKED == 2) {   /* the element IS the LDS byte address of its X1 operand */          \
+                const char* q = reinterpret_cast<const char*>(sweep_lds) +                       \
+                                (MIDYN_SWEEP_ABLATE == 2 ? (unsigned)((cl[i] & 48) + (tid << 4)) : (unsigned)cl[i]); \
+                x1[i] = *reinterpret_cast<const double2*>(q);                                    \
+                if (ORDER == 2) x2[i] = *reinterpret_cast<const double2*>(q + 32768);            \
+            } else {                                                                             \
+                int c = PACKED ? (cl[i] & 0x7fffffff) : cl[i];                                   \
+                if (MIDYN_SWEEP_ABLATE == 2) c = (c & 3) + tid;                                  \
+                x1[i] = X1[c];                                                                   \
+                if (ORDER == 2) x2[i] = X2[c];                                                   \
+            }                                                                                    \
+        }                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
+            double wa = ca, wb = cb;                                                             \
+            if (PACKED == 2) {                                                                   \
+            } else if (PACKED == 1) {   /* the sign of the element goes into the gathered operand (in place) */ \
+                const long long sgn = (long long)(((unsigned long long)(unsigned)cl[i] & 0x80000000ull) << 32); \
+                x1[i].x = __longlong_as_double(__double_as_longlong(x1[i].x) ^ sgn);             \
+                x1[i].y = __longlong_as_double(__double_as_longlong(x1[i].y) ^ sgn);             \
+                if (ORDER == 2) {                                                                \
+                    x2[i].x = __longlong_as_double(__double_as_longlong(x2[i].x) ^ sgn);         \
+                    x2[i].y = __longlong_as_double(__double_as_longlong(x2[i].y) ^ sgn);         \
+                }                                                                                \
+            } else {                                                                             \
+                wa = ca * va[i];                                                                 \
+                wb = cb * va[i];                                                                 \
+            }                                                                                    \
+            if (MIDYN_SWEEP_ABLATE == 4) {   /* profiling: one add per gathered operand */        \
+                o1[i].x += x1[i].x + x1[i].y;                                                    \
+                if (ORDER == 2) o2[i].x += x2[i].x + x2[i].y;                                    \
+                continue;                                                                        \
+            }                                                                                    \
+            if (IM) {                                                                            \
+                o1[i].x = fma(-wa, x1[i].y, o1[i].x);                                            \
+                o1[i].y = fma(wa, x1[i].x, o1[i].y);                                             \
+            } else {                                                                             \
+                o1[i].x = fma(wa, x1[i].x, o1[i].x);                                             \
+                o1[i].y = fma(wa, x1[i].y, o1[i].y);                                             \
+            }                                                                                    \
+            if (ORDER == 2) {                                                                    \
+                if (IM) {                                                                        \
+                    o2[i].x = fma(-wb, x2[i].y, o2[i].x);                                        \
+                    o2[i].y = fma(wb, x2[i].x, o2[i].y);                                         \
+                } else {                                                                         \
+                    o2[i].x = fma(wb, x2[i].x, o2[i].x);                                         \
+                    o2[i].y = fma(wb, x2[i].y, o2[i].y);                                         \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
+    }
+#define MIDYN_SWEEP_K_RANGE(IM, LO_, HI_)                                                             \
+    {                                                                                            \
+        const int lo = (LO_), hi = (HI_);                                                        \
+        if (PFON) {                                                                              \
+            _Pragma("unroll") for (int s_ = 0; s_ < PF; ++s_)                                    \
+                if (lo + s_ < hi) fetch(lo + s_, cn[s_], vn[s_]);                                \
+        }                                                                                        \
+        for (int e0 = lo; e0 < hi; e0 += PF) {                                                   \
+            _Pragma("unroll") for (int s_ = 0; s_ < PF; ++s_) {                                  \
+                const int e = e0 + s_;                                                           \
+                if (e < hi) MIDYN_SWEEP_K_SLOT(IM, s_)                                            \
+            }                                                                                    \
+        }                                                                                        \
+    }
+    MIDYN_SWEEP_K_RANGE(false, 0, a.wre)
+    MIDYN_SWEEP_K_RANGE(true, a.wre, a.wsp)
+#undef MIDYN_SWEEP_K_RANGE
+#undef MIDYN_SWEEP_K_SLOT
+#undef ROW
+}
+
+template <int ORDER, int SWEEP_RPT, int TH, int PACKED>
 __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
-    // TH threads, SWEEP_RPT rows each: n_pad = TH * SWEEP_RPT exactly (TH = 1024; 256 / 512 for n_pad = 256 / 512)
     extern __shared__ __attribute__((aligned(16))) double2 sweep_lds[];
-    __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];   // per slot: (c1, c2) of its segment, this step
+    __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];   // per slot: (c1, c2) of its segment (x magnitude), this step
     __shared__ int stag[SWEEP_MAX_SLOTS];                                    // per slot: segment | plane << 8
     const int tid = threadIdx.x, b = blockIdx.x, np = a.n_pad;
-    double2* const L1 = sweep_lds;
-    double2* const L2 = sweep_lds + np;
+    // LDS copies of the vectors the operators are applied to.  PACKED 0 / 1: X1[np + 1], X2[np + 1] ([np] = the zero
+    // slot of unused packed elements).  PACKED 2: chunks of 2048 columns, [X1 chunk | X2 chunk] of 32 KB each, so that
+    // the X2 operand of a column sits 32768 bytes behind its X1 operand -- an immediate offset of the same address.
+    const int lstride = np + 1;
+    double2* const X1 = sweep_lds;
+    double2* const X2 = PACKED == 2 ? sweep_lds + 2048 : sweep_lds + lstride;
+    auto xrow = [&](const int r_) { return PACKED == 2 ? ((r_ >> 11) << 12) | (r_ & 2047) : r_; };   // index of column r_ in X1 / X2
+    auto rowof = [&](const int i_) {   // tid + TH i_, opaque to the optimiser (see boff below: nothing derived from it is hoisted)
+        int r_ = tid + TH * i_;
+        asm volatile("" : "+v"(r_));
+        return r_;
+    };
+    // the two series vectors no pass touches live in a per-instance stash in device memory (L2): rows tid + TH i
+    // (uniform base pointers + 32-bit BYTE offsets everywhere -- the scalar-base addressing form: one offset register per
+    // row serves every array; with element indices hipcc builds a 64-bit address per row and array and spills them)
+    double2* const sacc = a.stash + (size_t)b * 3 * np;   // the accumulated result
+    double2* const scur = sacc + np;                       // phi_{j-1} (the next term's phi_{j-2})
+    double2* const spw = scur + np;                        // order 2: the term vector between its two passes
+    auto boff = [&](const int i_, const int shift) { return sweep_boff<TH>(tid, i_, shift); };   // (see sweep_boff)
+#define ROW(i_) ((unsigned)(tid + TH * (i_)))
+#define AT16(base_, i_) (*reinterpret_cast<double2*>(reinterpret_cast<char*>(const_cast<double2*>(base_)) + boff(i_, 4)))
     const double p2 = 0.14433756729740643;   // sqrt(3) / 12
-    double2 acc[SWEEP_RPT], cur[SWEEP_RPT], prev[SWEEP_RPT];
+    // order 1 has the registers for both vectors (one output vector per pass); order 2 does not
+    constexpr bool STASH = ORDER == 2;
+    double2 pw[SWEEP_RPT], racc[STASH ? 1 : SWEEP_RPT], rcur[STASH ? 1 : SWEEP_RPT];   // (pw: order 2 only outside the passes)
+#define ACC(i_) (*(STASH ? &AT16(sacc, i_) : &racc[STASH ? 0 : (i_)]))
+#define CUR(i_) (*(STASH ? &AT16(scur, i_) : &rcur[STASH ? 0 : (i_)]))
 #pragma unroll
     for (int i = 0; i < SWEEP_RPT; ++i) {
         const int r = tid + TH * i;
-        acc[i] = (r < a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + r] : make_double2(0.0, 0.0);
-        cur[i] = prev[i] = make_double2(0.0, 0.0);
+        ACC(i) = (r < a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + r] : make_double2(0.0, 0.0);
     }
     for (int e = tid; e < a.wsp; e += TH) stag[e] = a.tags[e];
-    // one pass over the operator elements of this thread's rows:
-    //   o1 = (sum_e ca_e A_e) . X1,  o2 = (sum_e cb_e A_e) . X2   with (ca, cb) = (c1, c2), or (c2, c1) when swapped
-    // Two straight-line loops, no selects: the real-plane slots (A = v: A x = v x), then the imaginary-plane slots
-    // (A = i v: A x = v (-x.y, x.x)).
-    auto pass = [&](const double2* X1, const double2* X2, bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
-#pragma unroll
-        for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = o2[i] = make_double2(0.0, 0.0);
-        const unsigned unp = (unsigned)np;
-#if MIDYN_SWEEP_ABLATE == 1   // profiling only: no operator pass at all
-        for (int i = 0; i < SWEEP_RPT; ++i) { o1[i] = X1[tid + TH * i]; o2[i] = X2[tid + TH * i]; }
-        return;
-#endif
-#define MIDYN_SWEEP_SLOT(IM)                                                                         \
-        {                                                                                            \
-            const double2 cc = cab[e];                                                               \
-            const double ca = swapped ? cc.y : cc.x, cb = swapped ? cc.x : cc.y;                     \
-            int cl[SWEEP_RPT];                                                                       \
-            double v[SWEEP_RPT];                                                                     \
-            _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
-                const unsigned idx = (unsigned)e * unp + (unsigned)(tid + TH * i);                        \
-                cl[i] = a.col[idx];                                                                  \
-                v[i] = a.val[idx];                                                                   \
-            }                                                                                        \
-            _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
-                const double2 x1 = X1[cl[i]];                                                        \
-                const double wa = ca * v[i];                                                         \
-                if (IM) {                                                                            \
-                    o1[i].x = fma(-wa, x1.y, o1[i].x);                                               \
-                    o1[i].y = fma(wa, x1.x, o1[i].y);                                                \
-                } else {                                                                             \
-                    o1[i].x = fma(wa, x1.x, o1[i].x);                                                \
-                    o1[i].y = fma(wa, x1.y, o1[i].y);                                                \
-                }                                                                                    \
-                if (ORDER == 2) {                                                                    \
-                    const double2 x2 = X2[cl[i]];                                                    \
-                    const double wb = cb * v[i];                                                     \
-                    if (IM) {                                                                        \
-                        o2[i].x = fma(-wb, x2.y, o2[i].x);                                           \
-                        o2[i].y = fma(wb, x2.x, o2[i].y);                                            \
-                    } else {                                                                         \
-                        o2[i].x = fma(wb, x2.x, o2[i].x);                                            \
-                        o2[i].y = fma(wb, x2.y, o2[i].y);                                            \
-                    }                                                                                \
-                }                                                                                    \
-            }                                                                                        \
-        }
-#pragma unroll MIDYN_SWEEP_UNROLL
-        for (int e = 0; e < a.wre; ++e) MIDYN_SWEEP_SLOT(false)
-#pragma unroll MIDYN_SWEEP_UNROLL
-        for (int e = a.wre; e < a.wsp; ++e) MIDYN_SWEEP_SLOT(true)
-#undef MIDYN_SWEEP_SLOT
+    if (tid == 0 && PACKED != 2) {
+        X1[np] = make_double2(0.0, 0.0);
+        if (ORDER == 2) X2[np] = make_double2(0.0, 0.0);
+    }
+    auto pass = [&](const bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
+        sweep_pass<ORDER, SWEEP_RPT, TH, PACKED>(a, cab, sweep_lds, X1, X2, tid, swapped, o1, o2);
     };
     for (int st = 0; st < a.nsteps; ++st) {
         const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];
@@ -782,101 +936,101 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
             const int seg = stag[e] & 63;
             const bool stat = a.has_static && seg == 0;
             const double* Sb = a.S + (size_t)b * a.inst_stride;
-            cab[e] = make_double2(stat ? 1.0 : Sb[(size_t)r0 * a.k + seg - a.has_static],
-                                  (ORDER == 2) ? (stat ? 1.0 : Sb[(size_t)r1 * a.k + seg - a.has_static]) : 0.0);
+            const double mg = PACKED ? a.mag[e] : 1.0;     // PACKED 2: signed
+            cab[e] = make_double2(mg * (stat ? 1.0 : Sb[(size_t)r0 * a.k + seg - a.has_static]),
+                                  (ORDER == 2) ? mg * (stat ? 1.0 : Sb[(size_t)r1 * a.k + seg - a.has_static]) : 0.0);
         }
+        const double2* const E0 = a.E ? a.E + (size_t)r0 * np : nullptr;
+        const double2* const D = (a.E && ORDER == 2) ? a.Dt + (size_t)st * np : nullptr;
         const int Ks = a.ser_K[st], reps = a.ser_reps[st];
         const bool cheb = Ks > 0;
         const int K = cheb ? Ks : -Ks;
         const double par = a.ser_par[st];
         const double* coef = a.coef + (size_t)st * a.stride;
+        const int slot = a.save ? a.save[st] : -1;
         for (int rep = 0; rep < reps; ++rep) {
             const double c0 = cheb ? coef[0] : 1.0;
+            // start of a series: phi_0 = the accumulated result (into the frame picture of the first Gauss point at the
+            // first repetition: y~ = E(t1) o y), staged for the first term
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < SWEEP_RPT; ++i) {
-                cur[i] = acc[i];
-                acc[i] = make_double2(c0 * acc[i].x, c0 * acc[i].y);
-                prev[i] = make_double2(0.0, 0.0);
+                const int r = rowof(i);
+                double2 v = ACC(i);
+                if (rep == 0 && a.E) v = cmul(AT16(E0, i), v);
+                X1[xrow(r)] = v;
+                if (ORDER == 2) X2[xrow(r)] = D ? cmul(AT16(D, i), v) : v;
+                CUR(i) = v;
+                ACC(i) = make_double2(c0 * v.x, c0 * v.y);
+                pw[i] = make_double2(0.0, 0.0);      // Chebyshev: phi_{j-2};  Taylor: nothing
             }
+            __syncthreads();
             for (int j = 1; j <= K; ++j) {
                 const double f = cheb ? (j == 1 ? 1.0 : 2.0) / par : 1.0 / (par * (double)j);
-                // stage the (phased) input
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < SWEEP_RPT; ++i) {
-                    const int r = tid + TH * i;
-                    L1[r] = a.E ? cmul(a.E[(size_t)r0 * np + r], cur[i]) : cur[i];
-                    if (ORDER == 2) L2[r] = a.E ? cmul(a.E[(size_t)r1 * np + r], cur[i]) : cur[i];
-                }
-                __syncthreads();
-                double2 o1[SWEEP_RPT], o2[SWEEP_RPT], w[SWEEP_RPT];
-                pass(L1, L2, false, o1, o2);
+                double hh = h;                       // (per-term scalars recomputed, not carried in registers)
+                asm volatile("" : "+v"(hh));
+                double2 o1[SWEEP_RPT], o2[SWEEP_RPT];
+                pass(false, o1, o2);                 // o1 = C(t1) v~, o2 = C(t2) (D v~)
                 if (ORDER == 2) {
-                    // u1 = g1 v, u2 = g2 v; the half sum stays, u1 goes to g2 phased to t2, u2 to g1 phased to t1
-                    const double ca = 0.5 * h * f, cb = p2 * h * h * f;
+                    const double ca = 0.5 * hh * f, cb = p2 * hh * hh * f;
                     __syncthreads();
 #pragma unroll
                     for (int i = 0; i < SWEEP_RPT; ++i) {
-                        const int r = tid + TH * i;
-                        double2 u1 = o1[i], u2 = o2[i];
-                        if (a.E) {
-                            const double2 e0 = a.E[(size_t)r0 * np + r], e1 = a.E[(size_t)r1 * np + r];
-                            u1 = cmul_conj_a(e0, u1);
-                            u2 = cmul_conj_a(e1, u2);
-                            L1[r] = cmul(e1, u1);
-                            L2[r] = cmul(e0, u2);
-                        } else {
-                            L1[r] = u1;
-                            L2[r] = u2;
+                        const int r = rowof(i);
+                        const double2 u1 = o1[i];
+                        double2 u2 = o2[i], du1 = u1;
+                        if (D) {
+                            const double2 dd = AT16(D, i);
+                            u2 = cmul_conj_a(dd, o2[i]);
+                            du1 = cmul(dd, u1);
                         }
-                        w[i] = make_double2(ca * (u1.x + u2.x), ca * (u1.y + u2.y));
+                        X1[xrow(r)] = du1;           // for g2~ = conj(D) C(t2) D
+                        X2[xrow(r)] = u2;            // for g1~ = C(t1)
+                        AT16(spw, i) = make_double2(pw[i].x + ca * (u1.x + u2.x), pw[i].y + ca * (u1.y + u2.y));
                     }
                     __syncthreads();
-                    pass(L1, L2, true, o1, o2);   // o1 = C(t2) . (E2 u1), o2 = C(t1) . (E1 u2)
+                    pass(true, o1, o2);              // o1 = C(t2) (D u1), o2 = C(t1) u2
 #pragma unroll
                     for (int i = 0; i < SWEEP_RPT; ++i) {
-                        const int r = tid + TH * i;
-                        const double2 v1 = a.E ? cmul_conj_a(a.E[(size_t)r1 * np + r], o1[i]) : o1[i];
-                        const double2 v2 = a.E ? cmul_conj_a(a.E[(size_t)r0 * np + r], o2[i]) : o2[i];
-                        w[i].x += cb * (v1.x - v2.x);
-                        w[i].y += cb * (v1.y - v2.y);
+                        const double2 v1 = D ? cmul_conj_a(AT16(D, i), o1[i]) : o1[i];
+                        const double2 t = AT16(spw, i);
+                        pw[i] = make_double2(t.x + cb * (v1.x - o2[i].x), t.y + cb * (v1.y - o2[i].y));
                     }
                 } else {
-                    const double ca = h * f;
+                    const double ca = hh * f;
 #pragma unroll
-                    for (int i = 0; i < SWEEP_RPT; ++i) {
-                        const int r = tid + TH * i;
-                        const double2 u1 = a.E ? cmul_conj_a(a.E[(size_t)r0 * np + r], o1[i]) : o1[i];
-                        w[i] = make_double2(ca * u1.x, ca * u1.y);
-                    }
+                    for (int i = 0; i < SWEEP_RPT; ++i) pw[i] = cfma_r(ca, o1[i], pw[i]);
                 }
-#pragma unroll
-                for (int i = 0; i < SWEEP_RPT; ++i) {
-                    if (cheb) {
-                        w[i].x += prev[i].x;
-                        w[i].y += prev[i].y;
-                        acc[i] = cfma_r(2.0 * coef[j], w[i], acc[i]);
-                        prev[i] = cur[i];
-                    } else {
-                        acc[i].x += w[i].x;
-                        acc[i].y += w[i].y;
-                    }
-                    cur[i] = w[i];
-                }
-            }
-        }
-        if (a.save) {
-            const int slot = a.save[st];
-            if (slot >= 0) {
+                // end of the term: w = pw joins the result; unless it was the last, it is staged for the next term and
+                // the old phi_{j-1} comes back from the stash as the next phi_{j-2}
+                const bool last = j == K;
+                const double cj = cheb ? 2.0 * coef[j] : 1.0;
+                if (!last) __syncthreads();          // every reader of X1 / X2 of this term is done
 #pragma unroll
                 for (int i = 0; i < SWEEP_RPT; ++i) {
-                    const int r = tid + TH * i;
-                    if (r < a.n) a.out[((size_t)b * a.P + slot) * a.n + r] = acc[i];
+                    const int r = rowof(i);
+                    const double2 w = pw[i];
+                    double2 acc = cfma_r(cj, w, ACC(i));
+                    if (!last) {
+                        pw[i] = cheb ? CUR(i) : make_double2(0.0, 0.0);
+                        CUR(i) = w;
+                        X1[xrow(r)] = w;
+                        if (ORDER == 2) X2[xrow(r)] = D ? cmul(AT16(D, i), w) : w;
+                    } else if (rep + 1 == reps) {    // out of the frame picture; saved states
+                        if (a.E) acc = cmul_conj_a(AT16(E0, i), acc);
+                        if (slot >= 0 && r < a.n) AT16(a.out + ((size_t)b * a.P + (slot < 0 ? 0 : slot)) * a.n, i) = acc;
+                    }
+                    ACC(i) = acc;
                 }
+                if (!last) __syncthreads();
             }
         }
     }
 }
+#undef ROW
+#undef AT16
+#undef ACC
+#undef CUR
 
 
 // ------------------------------------------------------------------------------------------------

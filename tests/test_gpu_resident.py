@@ -321,9 +321,9 @@ def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
     y0 /= np.linalg.norm(y0)
     sig = sweeps if nb > 1 else sweeps[0]
     out, launches, split = {}, {}, {}
-    for flag in (1, 2, 0):       # 1: one workgroup per instance; 2: several (ell_sweep_split = 2); 0: per-launch route
+    for flag in (1, 2, 0):       # 1: one workgroup per instance; 2: several (ell_sweep_split = 3); 0: per-launch route
         ctx.set_option("ell_sweep", 1 if flag else 0)
-        ctx.set_option("ell_sweep_split", 2 if flag == 2 else 0)
+        ctx.set_option("ell_sweep_split", 3 if flag == 2 else 0)
         ctx.reset_counters()
         ctx.set_option("profile", 1)
         try:
@@ -448,9 +448,10 @@ def test_one_launch_expm_action_routes_large_norms_backwards_and_own_initial_sta
 
 
 def test_sweep_kernel_four_workgroups_per_instance_at_full_size(qd):
-    """The cfg 5 model itself (12 qubits, n = 4096, diagonal frame, Magnus-2): 3 instances take FOUR workgroups each by
-    default (ell_sweep_split: the operand vectors are all-gathered through the sentinel ring) -- against one workgroup
-    per instance and against the launch-per-product work-list route, saved states included; norms preserved."""
+    """The cfg 5 model itself (12 qubits, n = 4096, diagonal frame, Magnus-2), 3 instances: FOUR workgroups per instance
+    (ell_sweep_split = 3: the operand vectors are all-gathered through the sentinel ring; the default for stacks without a
+    packed element form) -- against one workgroup per instance (the default here: direct element form) and against the
+    launch-per-product work-list route, saved states included; norms preserved."""
     from qiskit_dynamics_amd import workloads as W
 
     ctx = qd.default_context()
@@ -465,7 +466,7 @@ def test_sweep_kernel_four_workgroups_per_instance_at_full_size(qd):
     solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
                        rotating_frame=np.diag(cfg["h_d"]).real.copy(), validate=False)
     out, split = {}, {}
-    for tag, sweep, parts in (("four", 1, 1), ("one", 1, 0), ("per_launch", 0, 1)):
+    for tag, sweep, parts in (("four", 1, 3), ("one", 1, 1), ("per_launch", 0, 1)):
         ctx.set_option("ell_sweep", sweep)
         ctx.set_option("ell_sweep_split", parts)
         ctx.reset_counters()
@@ -478,12 +479,81 @@ def test_sweep_kernel_four_workgroups_per_instance_at_full_size(qd):
             ctx.set_option("ell_sweep", 1)
             ctx.set_option("ell_sweep_split", 1)
         assert ctx.counters("rk4_resident")["launches"] == (1 if sweep else 0)
-        split[tag] = ctx.counters("sweep_split")["launches"]
+        split[tag] = (ctx.counters("sweep_split")["launches"], ctx.counters("sweep_split")["ms"])
         out[tag] = np.stack([x.y for x in r])
-    assert split["four"] == 4 and split["one"] == 1
+    assert split["four"][0] == 4 and split["one"] == (1, 2), split     # (workgroups per instance, element form: 2 = direct)
     assert_close(out["four"], out["per_launch"], 1e-12)
     assert_close(out["one"], out["per_launch"], 1e-12)
     assert np.max(np.abs(np.linalg.norm(out["four"][:, -1], axis=1) - 1.0)) < 1e-12
+
+
+def _sweep_forms_model(kind, nq):
+    """(H_d, drive operators, carriers) of chains in their diagonal frame whose ELL stacks take the three element forms of
+    ell_sweep_kernel: "direct" -- XX couplings and X drives (one magnitude and one sign per slot, every slot full);
+    "packed" -- XX + YY couplings (flip-flop terms: rows |00>, |11> have no entry: unused slots) and Y drives (-iY is real
+    with both signs in every slot); "general" -- the XX chain with drive amplitudes that differ from row to row."""
+    from qiskit_dynamics_amd import workloads as W
+
+    h_d, ops, nu = W.chain_hamiltonian(nq, min(8, nq))
+    if kind == "direct":
+        return h_d, ops, nu[:len(ops)]
+    yy = np.array([[0.0, -1j], [1j, 0.0]])
+    if kind == "packed":
+        for q in range(nq - 1):
+            h_d = h_d + 2 * np.pi * 0.002 * W.embed_pair(yy, q, yy, q + 1, nq)
+        ops = np.stack([2 * np.pi * 0.02 * W.embed(yy, j, nq) / 2 for j in range(len(ops))])
+        return h_d, ops, nu[:len(ops)]
+    scale = 1.0 + 0.25 * np.cos(np.arange(2**nq))         # Hermitian: D X D with a real diagonal D
+    ops = np.stack([scale[:, None] * o * scale[None, :] for o in ops])
+    return h_d, ops, nu[:len(ops)]
+
+
+@pytest.mark.parametrize("kind,form,nq,order", [("direct", 2, 10, 2), ("direct", 2, 9, 1), ("packed", 1, 10, 2), ("packed", 1, 11, 1),
+                                                ("general", 0, 10, 2), ("general", 0, 9, 1)])
+def test_sweep_kernel_element_forms(qd, kind, form, nq, order):
+    """The three element forms of ell_sweep_kernel (general 12-byte elements / packed column | sign with a zero slot /
+    direct LDS addresses) are chosen from the stack's values; each against the oracle, and the packed forms against the
+    general form of the same stack (option ell_sweep_packed = 0) and against the launch-per-product route."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    h_d, ops, carrier = _sweep_forms_model(kind, nq)
+    k, nb = len(ops), 5
+    sweeps = []
+    for b in range(nb):
+        amps, phases = W.sweep_parameters(b, k)
+        sweeps.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, ph)
+                       for a, nu, ph in zip(amps, carrier, phases)])
+    frame = np.diag(h_d).real.copy()
+    solver = qd.Solver(static_hamiltonian=h_d, hamiltonian_operators=ops, rotating_frame=frame)
+    rng = np.random.default_rng(nq + order)
+    y0 = crand(rng, 2**nq)
+    y0 /= np.linalg.norm(y0)
+    out, forms = {}, {}
+    for tag, opts in (("default", {}), ("general", {"ell_sweep_packed": 0}), ("per_launch", {"ell_sweep": 0})):
+        for name, val in opts.items():
+            ctx.set_option(name, val)
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        try:
+            r = solver.solve(t_span=[0.0, 0.4], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.05, magnus_order=order,
+                             t_eval=[0.0, 0.15, 0.4])
+        finally:
+            ctx.set_option("profile", 0)
+            for name in opts:
+                ctx.set_option(name, 1)
+        assert ctx.counters("rk4_resident")["launches"] == (0 if tag == "per_launch" else 1)
+        forms[tag] = ctx.counters("sweep_split")["ms"]
+        out[tag] = np.stack([x.y for x in r])
+    assert forms["default"] == form and forms["general"] == 0, forms
+    assert_close(out["default"], out["general"], 1e-12)
+    assert_close(out["default"], out["per_launch"], 1e-12)
+    a_d, a, d, basis = orc.hamiltonian_model_build(h_d, ops, frame)
+    for b in (0, nb - 1):
+        _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
+                                           [0.0, 0.4], y0, "scipy_expm", 0.05, t_eval=[0.0, 0.15, 0.4], magnus_order=order)
+        assert_close(out["default"][b], ref, SOLVE_TOL)
 
 
 def test_resident_kernel_rows_without_any_operator(qd):

@@ -56,13 +56,19 @@ int main(int argc, char** argv) {
     hipStream_t s; CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     // reference: one workgroup per instance
-    auto fn = ell_sweep_kernel<2, 4, 1024>;
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+    auto fn = ell_sweep_kernel<2, 4, 1024, 0>;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    double2 *dt, *stash;
+    CHECK(hipMalloc(&dt, (size_t)nsteps * n * sizeof(double2)));
+    CHECK(hipMalloc(&stash, (size_t)B * 3 * n * sizeof(double2)));
+    hipLaunchKernelGGL(sweep_dtable_kernel, dim3((nsteps * n + 255) / 256), dim3(256), 0, 0, a.E, a.rows, nsteps, n, dt);
+    CHECK(hipDeviceSynchronize());
+    a.Dt = dt; a.stash = stash;
     a.out = out_ref;
     float ms_ref = 0;
     for (int rep = 0; rep < 2; ++rep) {
         CHECK(hipEventRecord(e0, s));
-        hipLaunchKernelGGL(fn, dim3(B), dim3(SWEEP_THREADS), 2 * n * sizeof(double2), s, a);
+        hipLaunchKernelGGL(fn, dim3(B), dim3(SWEEP_THREADS), 2 * (n + 1) * sizeof(double2), s, a);
         CHECK(hipEventRecord(e1, s));
         CHECK(hipEventSynchronize(e1));
         CHECK(hipEventElapsedTime(&ms_ref, e0, e1));
