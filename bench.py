@@ -310,6 +310,47 @@ def shared_stack(qd, ctx, D, builder, n, k, route):
     return finish(stack), keep, info
 
 
+def run_dry_ranks(qd, ctx, D, json_out):
+    """`bench.py --gpus N --dry-ranks`: the multi-GPU plumbing without the benchmark.  Every rank binds its own device,
+    rank 0's ncclUniqueId travels through the torch store, every rank joins the C-ABI communicator
+    (midyn_comm_init_rank), a 96-dimensional stack is broadcast from rank 0 (midyn_stack_broadcast) and evaluated on
+    every rank against the host arithmetic.  One JSON line: rccl_ranks_seen = ncclCommCount on rank 0, MIN over ranks of
+    'my evaluation of the broadcast stack is right'."""
+    from qiskit_dynamics_amd import _lib
+    from qiskit_dynamics_amd.distributed import PROBE_K, PROBE_N, _probe_arrays
+
+    info = {"mode": "dry-ranks", "n_gpus": D.world, "device_of_rank0": ctx.device}
+    ops, static, frame_im = _probe_arrays()
+    t0 = time.perf_counter()
+    if D.active and not D.share:
+        uid = D.bcast_bytes(_lib.Comm.unique_id() if D.rank == 0 else None)
+        comm = _lib.Comm(ctx, D.world, D.rank, uid)
+        seen = comm.count()
+        stack = qd.Stack(ctx, ops, static, frame_im) if D.rank == 0 else _lib.Stack.empty(ctx, PROBE_N, PROBE_K, True, True)
+        D.barrier()
+        stack.broadcast(comm, 0)
+        ctx.synchronize()
+    else:                                   # one rank (or the shared-GPU test mode): a communicator of one
+        comm = _lib.Comm(ctx, 1, 0, _lib.Comm.unique_id())
+        seen = comm.count()
+        stack = qd.Stack(ctx, ops, static, frame_im)
+        stack.broadcast(comm, 0)
+    rng = np.random.default_rng(7)
+    y = rng.normal(size=PROBE_N) + 1j * rng.normal(size=PROBE_N)
+    c = np.array([0.3, -0.7])
+    t = 0.4
+    e = np.exp(1j * frame_im * t)
+    ref = np.conj(e) * ((static + np.tensordot(c, ops, axes=1)) @ (e * y))
+    err = float(np.max(np.abs(stack.eval_rhs(c, t, y) - ref)))
+    ok = D.max(0.0 if err < 1e-12 else 1.0) == 0.0
+    info.update(rccl_ranks_seen=int(seen), every_rank_evaluates_the_broadcast_stack_correctly=bool(ok),
+                max_abs_error_rank0=err, seconds=round(time.perf_counter() - t0, 2))
+    comm.close()
+    if D.rank == 0:
+        print(json.dumps(info), file=json_out, flush=True)
+    D.close()
+
+
 # -----------------------------------------------------------------------------------------------------------------
 # CPU plumbing stub (tests/test_distributed_gloo.py): same launcher, sharding, barriers and MAX reduction, a
 # stand-in for the device solve.  Never used with a GPU; prints a line marked "stub".
@@ -602,6 +643,7 @@ def leg_cpu_baseline(workloads, cfg, static, ops, frame_im, amps, phs):
     best = (n_inst * n_steps * 4 / cpu_s, threads, cpu_s)
     return {
         "value": round(best[0], 1), "unit": "RHS evals/s", "cores": best[1], "kind": "port",
+        "cores_for_blas3": min(os.cpu_count() or 8, 64),
         "sample": f"{n_inst} instances x {n_steps} RK4 steps ({n_inst * n_steps * 4} RHS evals) of the same "
                   f"model with the NumPy oracle (tensordot + matvec); best of BLAS thread counts 8/32/all on a "
                   f"{os.cpu_count()}-CPU host: {best[1]} threads, {best[2]:.1f} s",
@@ -609,6 +651,80 @@ def leg_cpu_baseline(workloads, cfg, static, ops, frame_im, amps, phs):
                  "blas": [f"{i.get('internal_api')} {i.get('version')} ({i.get('threading_layer') or i.get('user_api')})"
                           for i in threadpool_info()],
                  "OPENBLAS_NUM_THREADS": os.environ.get("OPENBLAS_NUM_THREADS")}}
+
+
+def leg_cpu_configs(workloads, threads, want4=True, want5=True):
+    """CPU baselines of cfg 4 / cfg 5 beside the device numbers: ONE step of the reference's algorithm
+    (solvers/fixed_step_solvers.py:80-108,321-363: dense generator(s) by tensordot, Magnus term, scipy.linalg.expm, one
+    matrix-vector product) with the NumPy oracle on this host -- exactly linear in steps (and instances)."""
+    import scipy.linalg
+    import scipy.sparse as sp
+    from oracle import dynamics_oracle as orc
+    from threadpoolctl import threadpool_limits
+
+    out = {}
+    with threadpool_limits(limits=threads):
+        if want4:
+            cfg = workloads.lindblad_config()
+            n = cfg["h_d"].shape[0]
+            eye = sp.identity(n, format="csr")
+
+            def vcomm(a):        # -i (I (x) A - A^T (x) I), oracle.vec_commutator built sparse (set-up only, not timed)
+                a = sp.csr_matrix(a)
+                return (-1j * (sp.kron(eye, a) - sp.kron(a.T, eye))).toarray()
+
+            def vdiss(l):        # conj(L) (x) L - (I (x) L^+L + (L^+L)^T (x) I) / 2, oracle.vec_dissipator
+                l = sp.csr_matrix(l)
+                ldl = l.conj().T @ l
+                return (sp.kron(l.conj(), l) - 0.5 * (sp.kron(eye, ldl) + sp.kron(ldl.T, eye))).toarray()
+
+            s_d = vcomm(cfg["h_d"]) + sum(vdiss(l) for l in cfg["static_dissipators"])
+            s_ops = np.stack([vcomm(o) for o in cfg["ops"]])
+            amps, phases = workloads.sweep_parameters(0, len(cfg["ops"]))
+            h, t0 = cfg["max_dt"], cfg["t_final"] / 2
+
+            def gen(t):
+                c = workloads.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], cfg["t_final"])[0]
+                return orc.generator_evaluate(s_d, s_ops, c, None, None, t)
+
+            y = cfg["rho0"].flatten(order="F")
+            t1 = time.perf_counter()
+            omega = orc.magnus_terms(gen, t0, h, 1)
+            t2 = time.perf_counter()
+            prop = scipy.linalg.expm(omega)
+            t3 = time.perf_counter()
+            y = prop @ y
+            t4 = time.perf_counter()
+            out["cfg4"] = {"value": round(1.0 / (t4 - t1), 4), "unit": "steps/s", "s_per_step": round(t4 - t1, 2), "cores": threads,
+                           "kind": "port", "sample": "1 scipy_expm step (Magnus order 1) of the N = 4096 superoperator model "
+                           "with the NumPy oracle: generator by tensordot over the dense (7, 4096, 4096) stack %.1f s, "
+                           "scipy.linalg.expm %.1f s, matvec %.3f s; 100 steps per solve" % (t2 - t1, t3 - t2, t4 - t3),
+                           "trace_after_the_step": float(abs(np.trace(y.reshape(n, n, order="F"))))}
+            del s_d, s_ops, prop, omega
+        if want5:
+            cfg = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
+            ops, static, fim, _ = build_diag_frame_stack(cfg)
+            d = 1j * fim
+            amps, phases = workloads.sweep_parameters(0, 8)
+
+            def gen5(t):
+                c = workloads.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], cfg["t_final"])[0]
+                return orc.generator_evaluate(static, ops, c, d, None, t)
+
+            t1 = time.perf_counter()
+            omega = orc.magnus_terms(gen5, 2.5, cfg["max_dt"], 2)
+            t2 = time.perf_counter()
+            prop = scipy.linalg.expm(omega)
+            t3 = time.perf_counter()
+            y = prop @ cfg["y0"]
+            t4 = time.perf_counter()
+            out["cfg5"] = {"value": round(1.0 / (t4 - t1), 4), "unit": "instance-steps/s", "s_per_instance_step": round(t4 - t1, 2),
+                           "cores": threads, "kind": "port",
+                           "sample": "1 instance x 1 scipy_expm step (Magnus order 2) of the n = 4096 model with the NumPy "
+                                     "oracle: two dense generators + commutator %.1f s, scipy.linalg.expm %.1f s, matvec "
+                                     "%.3f s; 1024 instances x 20 steps per sweep" % (t2 - t1, t3 - t2, t4 - t3),
+                           "norm_after_the_step": float(np.linalg.norm(y))}
+    return out
 
 
 # -----------------------------------------------------------------------------------------------------------------
@@ -637,6 +753,9 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: kernel ablation bits (results wrong)")
     ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 | 12864 (kernel A/B testing)")
     ap.add_argument("--opt", action="append", default=[], help="A/B: ctx option NAME=VALUE (repeatable)")
+    ap.add_argument("--dry-ranks", action="store_true",
+                    help="multi-GPU plumbing check only: every rank binds its device, the C-ABI communicator is made from a "
+                         "shipped ncclUniqueId, a small stack is broadcast and evaluated; prints rccl_ranks_seen (no bench)")
     args = ap.parse_args()
     stub = bool(os.environ.get("MIDYN_BENCH_STUB"))
 
@@ -684,6 +803,9 @@ def main():
         name, _, val = item.partition("=")
         ctx.set_option(name, int(val))
 
+    if args.dry_ranks:
+        run_dry_ranks(qd, ctx, D, json_out)
+        return
     cfg = workloads.schrodinger_config(N_QUBITS, N_DRIVES, T_FINAL, MAX_DT)
     n = 2**N_QUBITS
     k = N_DRIVES
@@ -793,6 +915,11 @@ def main():
             "avg_launch_ms_per_launch_events": round(cnt["ms"] / cnt["launches"], 4),
             "executed_mfma_flops_per_launch": executed,
             "useful_flops_per_launch": useful, "useful_tflops": round(useful / (avg_ms * 1e-3) / 1e12, 3),
+            "frac_survey_8d": round(useful / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+            "frac_survey_8d_note": "SURVEY 8(d) prices an instance-evaluation at (4k+10)n^2 = 44.0 MFLOP; this model's kernel "
+                                   "executes 16.8 MFLOP of them (purely imaginary operators: 2 of 4 real products; parity "
+                                   "sectors: half of the blocks; the static operator in its own frame is exactly zero), so "
+                                   "the survey figure exceeds 1 -- frac counts what is executed",
             "segment_plane_modes": modes, "active_segments": stack.n_active_segments,
             "zero_plane_skipping": not args.dense, **extra,
             "note": "achieved = EXECUTED real MFMA flops / launch time (launch time = HIP events around the K timed steps "
@@ -885,6 +1012,15 @@ def main():
                              "inactive (the reference's U^+ G_d U - diag(d) leaves 1e-13 rounding noise there)")
     if dense:
         out["dense_complex"] = dense
+    if same_model_dense and dense:
+        out["cfg3_three_numbers"] = {
+            "structured_model_default_route": round(value, 1),
+            "dense_kernels_same_stack": same_model_dense["rhs_evals_per_s"],
+            "general_complex_operators": dense["rhs_evals_per_s"],
+            "unit": "RHS evals/s on one GPU, 4096 instances",
+            "read_as": "value (the first number) belongs to THIS model: real Hamiltonians in their own eigenbasis with a parity "
+                       "symmetry.  A model with dense complex frame-basis operators (e.g. a random Hermitian frame) runs at "
+                       "the third number; a model with real Hamiltonians but no conserved quantity near the second"}
     if measured_peaks:
         out["measured_peaks"] = measured_peaks
 
@@ -916,6 +1052,13 @@ def main():
 
         el_res, ev_res, cn_res, y_res = one_trajectory(True)
         el1, ev1, cn1, y_stage = one_trajectory(False)
+        # the floor of the default route: the same launch geometry with the arithmetic switched off -- every round still
+        # publishes its row and polls its neighbours' rows (results are meaningless, the time is the store -> poll hop)
+        ctx.set_option("resident_exchange_only", 1)
+        try:
+            el_floor, ev_floor, cn_floor, _ = one_trajectory(True)
+        finally:
+            ctx.set_option("resident_exchange_only", 0)
         c1 = cn1["rhs_stream"]
         took_resident = cn_res["rk4_resident"]["launches"] > 0
         nseg = stack.n_segments
@@ -941,6 +1084,20 @@ def main():
             "per_stage_route_rhs_evals_per_s": round(n_eval1 / el1, 1),
             "max_abs_difference_between_the_routes": float(np.max(np.abs(y_res - y_stage))),
             "steps_timed": s_total - 8}
+        if took_resident and cn_floor["rk4_resident"]["launches"] > 0:
+            us_round, us_floor = ev_res / n_eval1 * 1e3, ev_floor / n_eval1 * 1e3
+            out["roofline_single_trajectory_default_route"] = {
+                "kernel": "rk4_resident_kernel<8, 8, true> (one launch per step range; one exchange round per RHS evaluation)",
+                "bound": "exchange latency (store -> poll hop through device memory across the XCDs)",
+                "achieved": round(us_round, 3), "floor": round(us_floor, 3), "unit": "us per round (= per RHS evaluation)",
+                "frac": round(us_floor / us_round, 4),
+                "arithmetic_us_per_round": round(us_round - us_floor, 3),
+                "workgroups": 128, "rounds_timed": n_eval1,
+                "note": "floor = the same launch with option resident_exchange_only (every round publishes and polls, the row "
+                        "product is skipped), measured in this run; frac = floor / achieved: the share of a round that is the "
+                        "exchange.  No operator byte moves after the launch has loaded its rows, so neither the HBM nor the "
+                        "MFMA roofline applies; MI355X_MICROARCH.md prices an idle 1-to-1 hand-off at 0.8-1.1 us and "
+                        "2.3-2.9 us between loaded CUs"}
         out["roofline_single_trajectory"] = {
             "route": "per-stage streaming kernel (option resident_rk4=0): the kernel of evaluate_rhs and of single "
                      "trajectories whose operators do not fit the register files",
@@ -1004,6 +1161,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ops, static, frame_im = host_arrays["v"][:3]
         out["cpu_baseline"] = leg_cpu_baseline(workloads, cfg, static, ops, frame_im, amps, phs)
+        if not args.no_configs and not args.dense:
+            try:       # one reference-algorithm step of cfg 4 / cfg 5 on this host, beside their device numbers
+                cpu_cfg = leg_cpu_configs(workloads, out["cpu_baseline"]["cores_for_blas3"])
+                for key in ("cfg4", "cfg5"):
+                    if key in cpu_cfg and isinstance(out.get(key), dict):
+                        out[key]["cpu_baseline"] = cpu_cfg[key]
+            except Exception as exc:  # pylint: disable=broad-except
+                out["cpu_baseline_configs_error"] = repr(exc)
 
     # ---- the complete cfg-3 solve through the public Solver API: model build, signal evaluation, PCIe
     #      and result unpacking included (rank 0, N=1; --full-solve adds the host-table variant) ------------------

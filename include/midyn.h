@@ -295,6 +295,7 @@ int midyn_stack_block_info(midyn_stack* stack, double* out);
 int midyn_comm_get_unique_id(void* id128);
 int midyn_comm_init_rank(midyn_ctx* ctx, int world, int rank, const void* id128, void** nccl_comm_out);
 int midyn_comm_destroy(midyn_ctx* ctx, void* nccl_comm);
+int midyn_comm_count(midyn_ctx* ctx, void* nccl_comm, int* ranks_out);   /* ncclCommCount: ranks of the communicator */
 int midyn_stack_create_empty(midyn_ctx* ctx, int n, int k, int has_static, int has_frame, midyn_stack** out);
 int midyn_stack_broadcast(midyn_stack* stack, void* nccl_comm, int root);
 

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve", "midyn_sigtable_create", "midyn_sigtable_data",
     "midyn_sigtable_fetch", "midyn_sigtable_destroy", "midyn_parallel_solve", "midyn_expansion_create",
     "midyn_expansion_destroy", "midyn_expansion_solve", "midyn_ctx_timer", "midyn_stack_block_info",
-    "midyn_comm_get_unique_id", "midyn_comm_init_rank", "midyn_comm_destroy", "midyn_stack_create_empty",
+    "midyn_comm_get_unique_id", "midyn_comm_init_rank", "midyn_comm_destroy", "midyn_comm_count", "midyn_stack_create_empty",
     "midyn_stack_broadcast",
 ]
 
@@ -173,6 +173,7 @@ def load():
         lib.midyn_comm_get_unique_id.argtypes = [_vp]
         lib.midyn_comm_init_rank.argtypes = [_vp, _ci, _ci, _vp, P(_vp)]
         lib.midyn_comm_destroy.argtypes = [_vp, _vp]
+        lib.midyn_comm_count.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
         lib.midyn_stack_create_empty.argtypes = [_vp, _ci, _ci, _ci, _ci, P(_vp)]
         lib.midyn_stack_broadcast.argtypes = [_vp, _vp, _ci]
         for name in ABI_SYMBOLS:
@@ -555,6 +556,12 @@ class Comm:
         if lib.midyn_comm_get_unique_id(buf):
             raise DynamicsError(lib.midyn_last_error(None).decode())
         return buf.raw
+
+    def count(self) -> int:
+        """Ranks of the communicator as RCCL reports them (ncclCommCount)."""
+        n = ctypes.c_int(0)
+        self.ctx.check(self.ctx.lib.midyn_comm_count(self.ctx.handle, self.handle, ctypes.byref(n)))
+        return int(n.value)
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle and self.ctx.handle:

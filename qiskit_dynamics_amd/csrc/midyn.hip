@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>  // types only: the entry points are resolved with dlsym (midyn_comm.inc)
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

@@ -45,7 +45,7 @@ namespace midyn {
 constexpr unsigned long long RESIDENT_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
 constexpr int RESIDENT_DPL = 64;          // doubles of operator data per lane
 constexpr int RESIDENT_MAX_POLL = 16;     // polled 64-column chunks per workgroup (8 words per thread)
-constexpr unsigned RESIDENT_SPIN_LIMIT = 1u << 21;
+constexpr unsigned RESIDENT_SPIN_LIMIT = 1u << 21;   // default of the polls a wait may take (ctx option resident_spin_limit)
 #ifndef RESIDENT_MISS_STEP
 #define RESIDENT_MISS_STEP 2       // pre-sleep units added after a round whose first poll missed ...
 #endif
@@ -71,7 +71,10 @@ struct ResidentArgs {
     unsigned long long* ring; // [4][2 * n_pad] exchange ring (re, im interleaved), all sentinel at launch
     double2* y;               // [n_pad] state, updated in place
     double2* out;             // [P][n] saved states or nullptr
-    int* err;                 // set when a wait gave up (results invalid)
+    int* err;                 // set when a wait gave up (results invalid: the host re-runs the range on the per-launch route)
+    unsigned spin_limit;      // polls after which a wait gives up
+    int exchange_only;        // measurement only (ctx option resident_exchange_only): every round publishes and polls as
+                              // usual but skips the row's arithmetic -- the store -> poll floor of this launch geometry
 };
 
 __device__ __forceinline__ double resident_lane_value(double v, int lane) {   // v of a compile-time lane as a wave-uniform value
@@ -117,11 +120,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
     const int cbase = a.chunk_ptr[grp];
     const int nq = a.chunk_ptr[grp + 1] - cbase;
     double v[RESIDENT_DPL];
-    int slot_of[NQ];
+    // (LDS slot of every chunk, 4 bits each -- at most RESIDENT_MAX_POLL = 16 slots: 32 chunk slots in four words
+    // instead of 32 registers, which is what made the NE = 2 full-walk instantiation spill)
+    static_assert(RESIDENT_MAX_POLL <= 16, "chunk slots are packed in 4 bits");
+    unsigned slot_pk[(NQ + 7) / 8];
+#pragma unroll
+    for (int w_ = 0; w_ < (NQ + 7) / 8; ++w_) slot_pk[w_] = 0u;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int packed = q < nq ? a.chunk_idx[cbase + q] : 0;
-        slot_of[q] = packed >> 8;
+        slot_pk[q >> 3] |= (unsigned)(packed >> 8) << (4 * (q & 7));
         const int col = (packed & 0xff) * 64 + lane;
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -209,8 +217,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                     if (!pending) break;
                     __builtin_amdgcn_s_sleep(1);
                     ++spins;
-                    if ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = RESIDENT_SPIN_LIMIT;
-                    if (spins >= RESIDENT_SPIN_LIMIT) {   // a neighbour never arrived: flag, stop waiting for good
+                    if ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = a.spin_limit;
+                    if (spins >= a.spin_limit) {   // a neighbour never arrived: flag, stop waiting for good
                         __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         dead = true;
                         break;
@@ -236,9 +244,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                 ci[e] = resident_lane_value(c_im, e);
             }
             double2 acc = make_double2(0.0, 0.0);
-            const double* yl = ylds[rr & 1];
+            // (the lane's offset passes through an empty asm per stage: otherwise the up to 32 LDS addresses of the chunk
+            // slots are hoisted out of the step loop as loop invariants and spilled)
+            int lane_o = 2 * lane;
+            asm volatile("" : "+v"(lane_o));
+            const double* yl = ylds[rr & 1] + lane_o;
 #if MIDYN_RESIDENT_ABLATE == 1   // profiling only: the exchange without the arithmetic
-            acc = *reinterpret_cast<const double2*>(yl + 2 * lane);
+            acc = *reinterpret_cast<const double2*>(yl);
 #else
             // straight-line over the chunk slots (all NQ, or the first half -- HALFQ -- when at most half are in use): the registers
             // of unused chunks hold zeros and their LDS slot is 0 (a finite vector), so they contribute exact zeros;
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                     g_re = fma(cr[e], v[q * NE + e], g_re);                                              \
                     g_im = fma(ci[e], v[q * NE + e], g_im);                                              \
                 }                                                                                        \
-                const double2 yv = *reinterpret_cast<const double2*>(yl + slot_of[q] * 128 + 2 * lane);  \
+                const double2 yv = *reinterpret_cast<const double2*>(yl + ((slot_pk[q >> 3] >> (4 * (q & 7))) & 15u) * 128); \
                 if (q & 1) {                                                                             \
                     acc_b.x = fma(g_re, yv.x, acc_b.x);                                                  \
                     acc_b.x = fma(-g_im, yv.y, acc_b.x);                                                 \
@@ -264,7 +276,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                     acc.y = fma(g_im, yv.x, acc.y);                                                      \
                 }                                                                                        \
             }
-            MIDYN_RESIDENT_CHUNKS(NQ_USED)
+            if (a.exchange_only) {
+                acc = *reinterpret_cast<const double2*>(yl);
+            } else {
+                MIDYN_RESIDENT_CHUNKS(NQ_USED)
+            }
 #undef MIDYN_RESIDENT_CHUNKS
             acc.x += acc_b.x;
             acc.y += acc_b.y;
@@ -358,6 +374,7 @@ struct EllArgs {
     double2* y;               // [n_pad]
     double2* out;             // [P][n] or nullptr
     int* err;
+    unsigned spin_limit;      // polls after which a wait gives up
     // MODE 1: per step K > 0 terms of the Chebyshev series (or -K = the Taylor degree), the repetitions, h / rho (or
     // h / scaling) and the Bessel coefficients J_0..J_K
     const int* cheb_K;
@@ -489,8 +506,8 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
             if (!pending) break;
             __builtin_amdgcn_s_sleep(1);
             ++spins;
-            if ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = RESIDENT_SPIN_LIMIT;
-            if (spins >= RESIDENT_SPIN_LIMIT) {
+            if ((spins & 1023u) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = a.spin_limit;
+            if (spins >= a.spin_limit) {
                 __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 dead = true;
                 break;
@@ -759,7 +776,7 @@ __device__ __forceinline__ unsigned sweep_boff(const int tid, const int i_, cons
 // Two straight-line loops, no selects: the real-plane slots (A x = v x), then the imaginary-plane slots
 // (A = i v: A x = v (-x.y, x.x)).  X1 / X2: the LDS copies of the operand vectors (sweep_lds: their base; PACKED 2
 // elements are byte addresses relative to it, X2 operands 32768 bytes behind their X1 operands).
-template <int ORDER, int SWEEP_RPT, int TH, int PACKED>
+template <int ORDER, int SWEEP_RPT, int TH, int PACKED, int PFD = MIDYN_SWEEP_PREFETCH>
 __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* cab, const double2* sweep_lds, const double2* X1,
                                            const double2* X2, const int tid, const bool swapped, double2 (&o1)[SWEEP_RPT],
                                            double2 (&o2)[SWEEP_RPT]) {
@@ -779,8 +796,8 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
     // those of slot e0 + s + PF as soon as it has been copied out (the slot loop is unrolled by PF).
     // (measured, us per term, cfg 5 shape, none / 2 / 3 stages: direct form 19.9 / 18.1 / 19.3, packed 23.6 / 21.3 / 22.6; the
     // 12-byte elements of the general form do not have the registers: 31.7 / 35.2 / 40.3)
-    constexpr bool PFON = PACKED != 0 && MIDYN_SWEEP_PREFETCH > 0;
-    constexpr int PF = PFON ? MIDYN_SWEEP_PREFETCH : 1;
+    constexpr bool PFON = PACKED != 0 && PFD > 0;
+    constexpr int PF = PFON ? PFD : 1;
     int cn[PF][SWEEP_RPT];
     double vn[PF][SWEEP_RPT];
     auto fetch = [&](const int e_, int (&c_)[SWEEP_RPT], double (&v_)[SWEEP_RPT]) {
@@ -1043,16 +1060,19 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
 // writes its own rows straight into its LDS copy, publishes them unphased, and phases its partners' rows as it copies
 // them in.  All NSPLIT * B workgroups must be resident at once (one per CU: LDS): cooperative launch.
 // ------------------------------------------------------------------------------------------------
-// ell_sweep_rk4_kernel<RPT, TH>: the same one-workgroup-per-instance form for fixed-step RK4 sweeps (a9) on very
-// sparse stacks: a stage is ONE pass over the operator elements; y and the accumulator of the thread's rows stay in
-// registers, the stage input is staged phased in LDS, the stage arithmetic is apply_epilogue_t's.
-template <int SWEEP_RPT, int TH>
+// ell_sweep_rk4_kernel<RPT, TH, PACKED>: the same one-workgroup-per-instance form for fixed-step RK4 sweeps (a9) on very
+// sparse stacks: a stage is ONE pass over the operator elements (sweep_pass, order 1, the element forms of
+// ell_sweep_kernel); y and the accumulator of the thread's rows stay in registers, the stage input is staged phased in
+// LDS, the stage arithmetic is apply_epilogue_t's.
+template <int SWEEP_RPT, int TH, int PACKED>
 __global__ __launch_bounds__(TH) void ell_sweep_rk4_kernel(const SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) double2 sweep_lds[];
-    __shared__ double cst[SWEEP_MAX_SLOTS];   // per slot: coefficient of its segment at the stage time
+    __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];   // per slot: (coefficient of its segment at the stage time x magnitude, -)
     __shared__ int stag[SWEEP_MAX_SLOTS];
     const int tid = threadIdx.x, b = blockIdx.x, np = a.n_pad;
-    double2* const L1 = sweep_lds;
+    double2* const X1 = sweep_lds;            // layouts as in ell_sweep_kernel (PACKED 2: chunks of 2048 columns)
+    auto xrow = [&](const int r_) { return PACKED == 2 ? ((r_ >> 11) << 12) | (r_ & 2047) : r_; };
+    auto boff = [&](const int i_, const int shift) { return sweep_boff<TH>(tid, i_, shift); };
     double2 y[SWEEP_RPT], acc[SWEEP_RPT], cur[SWEEP_RPT];
 #pragma unroll
     for (int i = 0; i < SWEEP_RPT; ++i) {
@@ -1061,7 +1081,7 @@ __global__ __launch_bounds__(TH) void ell_sweep_rk4_kernel(const SweepArgs a) {
         acc[i] = cur[i] = y[i];
     }
     for (int e = tid; e < a.wsp; e += TH) stag[e] = a.tags[e];
-    const unsigned unp = (unsigned)np;
+    if (tid == 0 && PACKED != 2) X1[np] = make_double2(0.0, 0.0);
     const double* Sb = a.S + (size_t)b * a.inst_stride;
     for (int st = 0; st < a.nsteps; ++st) {
         const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1], r2 = a.rows[3 * st + 2];
@@ -1070,51 +1090,23 @@ __global__ __launch_bounds__(TH) void ell_sweep_rk4_kernel(const SweepArgs a) {
         for (int sg = 0; sg < 4; ++sg) {
             const int srow = sg == 0 ? r0 : (sg == 3 ? r2 : r1);
             const double2* Es = a.E ? a.E + (size_t)srow * np : nullptr;
-            __syncthreads();    // the previous stage's readers of L1 / cst are done (and stag is written)
+            __syncthreads();    // the previous stage's readers of X1 / cab are done (and stag is written)
             for (int e = tid; e < a.wsp; e += TH) {
                 const int seg = stag[e] & 63;
-                cst[e] = (a.has_static && seg == 0) ? 1.0 : Sb[(size_t)srow * a.k + seg - a.has_static];
+                const double c = (a.has_static && seg == 0) ? 1.0 : Sb[(size_t)srow * a.k + seg - a.has_static];
+                cab[e] = make_double2(PACKED ? a.mag[e] * c : c, 0.0);
             }
 #pragma unroll
             for (int i = 0; i < SWEEP_RPT; ++i) {
                 const int r = tid + TH * i;
-                L1[r] = Es ? cmul(Es[r], cur[i]) : cur[i];
+                X1[xrow(r)] = Es ? cmul(*reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Es) + boff(i, 4)), cur[i]) : cur[i];
             }
             __syncthreads();
-            double2 o1[SWEEP_RPT];
-#pragma unroll
-            for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = make_double2(0.0, 0.0);
-#define MIDYN_SWEEP_SLOT(IM)                                                                         \
-            {                                                                                        \
-                const double ca = cst[e];                                                            \
-                int cl[SWEEP_RPT];                                                                   \
-                double v[SWEEP_RPT];                                                                 \
-                _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                              \
-                    const unsigned idx = (unsigned)e * unp + (unsigned)(tid + TH * i);               \
-                    cl[i] = a.col[idx];                                                              \
-                    v[i] = a.val[idx];                                                               \
-                }                                                                                    \
-                _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                              \
-                    const double2 x1 = L1[cl[i]];                                                    \
-                    const double wa = ca * v[i];                                                     \
-                    if (IM) {                                                                        \
-                        o1[i].x = fma(-wa, x1.y, o1[i].x);                                           \
-                        o1[i].y = fma(wa, x1.x, o1[i].y);                                            \
-                    } else {                                                                         \
-                        o1[i].x = fma(wa, x1.x, o1[i].x);                                            \
-                        o1[i].y = fma(wa, x1.y, o1[i].y);                                            \
-                    }                                                                                \
-                }                                                                                    \
-            }
-#pragma unroll 2
-            for (int e = 0; e < a.wre; ++e) MIDYN_SWEEP_SLOT(false)
-#pragma unroll 2
-            for (int e = a.wre; e < a.wsp; ++e) MIDYN_SWEEP_SLOT(true)
-#undef MIDYN_SWEEP_SLOT
+            double2 o1[SWEEP_RPT], o2[SWEEP_RPT];
+            sweep_pass<1, SWEEP_RPT, TH, PACKED, (SWEEP_RPT < 4 ? MIDYN_SWEEP_PREFETCH : 0)>(a, cab, sweep_lds, X1, X1, tid, false, o1, o2);   // (four rows per thread: no registers for the element ring)
 #pragma unroll
             for (int i = 0; i < SWEEP_RPT; ++i) {
-                const int r = tid + TH * i;
-                const double2 kk = Es ? cmul_conj_a(Es[r], o1[i]) : o1[i];
+                const double2 kk = Es ? cmul_conj_a(*reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Es) + boff(i, 4)), o1[i]) : o1[i];
                 if (sg == 0) {
                     acc[i] = cfma_r(h * (1.0 / 6), kk, y[i]);
                     cur[i] = cfma_r(0.5 * h, kk, y[i]);
@@ -1148,6 +1140,7 @@ struct SweepSplitArgs {
     int nsplit;
     unsigned long long* ring;   // [B][4][ORDER][2 * n_pad] words, all sentinel at launch
     int* err;
+    unsigned spin_limit;        // polls after which a wait gives up
     int part_major;             // 1: blocks [p B, (p + 1) B) hold part p of every instance -- with B a multiple of 8 the
                                 // partners of an instance sit on the same XCD under the observed b % 8 dispatch (a speed
                                 // matter only: the exchange is agent-scope either way); 0: parts of an instance adjacent
@@ -1241,8 +1234,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
                 if (!pending) break;
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
-                if ((spins & 1023u) == 0 && __hip_atomic_load(sa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = RESIDENT_SPIN_LIMIT;
-                if (spins >= RESIDENT_SPIN_LIMIT) {
+                if ((spins & 1023u) == 0 && __hip_atomic_load(sa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = sa.spin_limit;
+                if (spins >= sa.spin_limit) {
                     __hip_atomic_store(sa.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     dead = true;
                     break;

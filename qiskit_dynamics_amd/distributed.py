@@ -127,16 +127,46 @@ def gather_sweep_results(local: np.ndarray, n_total: int, device=None):
     return full
 
 
-def solve_sweep(solver, t_span, y0, signals, **kwargs):
+def gather_sweep_to_root(local: np.ndarray, n_total: int, root: int = 0, device=None):
+    """Per-rank result blocks (b_loc, ...) concatenated on rank `root` only (None elsewhere): every rank ships its block
+    once -- SURVEY 8(e) asks for per-rank buffers concatenated, not for a copy of everything everywhere."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() == "nccl":
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+    else:
+        dev = torch.device("cpu")
+    sizes = [shard_bounds(n_total, r, world) for r in range(world)]
+    max_b = max(hi - lo for lo, hi in sizes)
+    pad = np.zeros((max_b,) + local.shape[1:], dtype=np.complex128)
+    pad[: local.shape[0]] = local
+    t = torch.view_as_real(torch.from_numpy(pad)).contiguous().to(dev)
+    outs = [torch.empty_like(t) for _ in range(world)] if rank == root else None
+    dist.gather(t, outs, dst=root)
+    if rank != root:
+        return None
+    return np.concatenate([torch.view_as_complex(o.cpu().contiguous()).numpy()[: hi - lo] for o, (lo, hi) in zip(outs, sizes)])
+
+
+def solve_sweep(solver, t_span, y0, signals, gather="all", root=0, **kwargs):
     """``solver.solve`` of a list-mode sweep, sharded over the ranks of the initialised process group
     (one process per GPU): rank r solves the contiguous shard ``shard_bounds(B, r, world)`` of the
-    ``B = len(signals)`` instances with ONE batched device solve, then the states are all-gathered so
-    that every rank returns the full list of ``OdeResult``s in sweep order.  ``y0`` is one state
-    shared by all instances or a list of B states; ``t_span`` is shared.  No per-step communication.
+    ``B = len(signals)`` instances with ONE batched device solve.  ``y0`` is one state shared by all
+    instances or a list of B states; ``t_span`` is shared.  No per-step communication.
+
+    ``gather``: what happens to the results (the reference's loop returns one list, solver_classes.py:568-586) --
+      ``"all"``   every rank returns the full list of ``OdeResult``s in sweep order (an all-gather of every shard:
+                  world x the result volume on the wire -- convenient, meant for small results and tests);
+      ``"root"``  rank ``root`` returns the full list, the other ranks ``None`` (each shard travels once);
+      ``"none"``  no communication at all: every rank returns ``(lo, results of its own shard)``.
     """
     import torch.distributed as dist
     from scipy.integrate._ivp.ivp import OdeResult
 
+    if gather not in ("all", "root", "none"):
+        raise ValueError('gather must be "all", "root" or "none"')
     if not isinstance(signals, list) or not signals or not isinstance(signals[0], (list, tuple)):
         raise ValueError("solve_sweep needs a list of per-instance signal lists")
     n_total = len(signals)
@@ -145,12 +175,14 @@ def solve_sweep(solver, t_span, y0, signals, **kwargs):
     y0_is_list = isinstance(y0, list)
     if y0_is_list and len(y0) != n_total:
         raise ValueError("y0 list and signals list must have the same length")
-    local_t, local_y = None, None
+    local_t, local_y, res = None, None, []
     if hi > lo:
         res = solver.solve(t_span=t_span, y0=y0[lo:hi] if y0_is_list else y0, signals=signals[lo:hi], **kwargs)
         res = res if isinstance(res, list) else [res]
         local_t = np.asarray(res[0].t, dtype=float)
         local_y = np.stack([np.asarray(r.y, dtype=np.complex128) for r in res])
+    if gather == "none":
+        return lo, res
     # ranks with an empty shard (B < world) learn the result shape from the others
     ctx = getattr(getattr(solver, "model", None), "_ctx", None)
     device = getattr(ctx, "device", None)
@@ -163,7 +195,12 @@ def solve_sweep(solver, t_span, y0, signals, **kwargs):
     known = next(s_ for s_ in shapes if s_ is not None)
     if local_y is None:
         local_y = np.zeros((0,) + tuple(known[0]), dtype=np.complex128)
-    full = gather_sweep_results(local_y, n_total, device=device)
+    if gather == "root":
+        full = gather_sweep_to_root(local_y, n_total, root=root, device=device)
+        if full is None:
+            return None
+    else:
+        full = gather_sweep_results(local_y, n_total, device=device)
     t_out = np.asarray(known[1], dtype=float)
     return [OdeResult(t=t_out, y=full[b]) for b in range(n_total)]
 

@@ -35,6 +35,8 @@ def _to_anti_hermitian(mat, atol=1e-10, rtol=1e-10):
 # Frame operators of this dimension or more are examined for symmetry sectors (below: plain eigh, exactly the
 # reference's call)
 SECTOR_MIN_DIM = 32
+SECTOR_MAX_COUNT = 64      # more connected components than this: not worth per-sector decompositions
+SECTOR_MAX_SHARE = 0.75    # largest component above this share of the dimension: the zeros gained are too few
 
 
 def _eigh_by_sectors(h):
@@ -59,7 +61,10 @@ def _eigh_by_sectors(h):
     from scipy.sparse.csgraph import connected_components
 
     n_comp, comp = connected_components(csr_matrix(h != 0), directed=False)
-    if n_comp <= 1:
+    # The sector path has to pay for itself: one component, dozens of tiny ones (a diagonal or nearly diagonal frame
+    # operator given as a matrix would be n one-element "sectors": n Python-level eigh calls and a device embedding that
+    # skips nothing), or one component that is almost everything -- plain eigh, as the reference does.
+    if n_comp <= 1 or n_comp > SECTOR_MAX_COUNT or np.bincount(comp).max() > SECTOR_MAX_SHARE * n:
         evals, basis = np.linalg.eigh(h)
         return evals, basis, None
     evals = np.empty(n)

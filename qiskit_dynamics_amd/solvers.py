@@ -342,6 +342,7 @@ def _batch_table(model, signals_list, times, batch, n_coeff):
 # GeneratorModel, a vectorised LindbladModel) are stepped sequentially unless AUTO_PARALLEL_IN_TIME == "all" or
 # the user names a *_parallel method.
 AUTO_PARALLEL_IN_TIME = True
+FOLD_MAX_COLUMNS = 4096      # instances that share their signals become columns of one problem up to this many columns
 AUTO_PARALLEL_MAX_ROWS = 128
 AUTO_PARALLEL_MIN_STEPS = 256
 
@@ -382,13 +383,17 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     # Instances that share their signals share the generator: they are just more COLUMNS of one problem
     # (the reference would loop them, solver_classes.py:568-586).  One coefficient table instead of B
     # copies of it on host and device, one generator evaluation per stage instead of nseg contractions.
-    folded = batch > 1 and all(s is signals_list[0] for s in signals_list)
+    same_signals = batch > 1 and all(s is signals_list[0] for s in signals_list)
     n_inst, m_cols = batch, y0_dev.shape[-1]
-    if folded:
-        if shared_y0:
-            y0_dev = np.ascontiguousarray(np.tile(y0_dev, (1, batch)))
-        else:
-            y0_dev = np.ascontiguousarray(y0_dev.transpose(1, 0, 2).reshape(y0_dev.shape[1], batch * m_cols))
+    # ... identical instances (same signals AND same y0) are ONE solve whose result is replicated; otherwise the instances
+    # are folded into columns while the folded problem stays within FOLD_MAX_COLUMNS (the output block is P x rows x
+    # columns: an unbounded fold of matrix-valued y0 could not be chunked like the per-instance path)
+    replicate = same_signals and shared_y0
+    folded = same_signals and not shared_y0 and batch * m_cols <= FOLD_MAX_COLUMNS
+    if replicate:
+        signals_list, batch = signals_list[:1], 1
+    elif folded:
+        y0_dev = np.ascontiguousarray(y0_dev.transpose(1, 0, 2).reshape(y0_dev.shape[1], batch * m_cols))
         signals_list, batch, shared_y0 = signals_list[:1], 1, True
     table = _batch_table(model, signals_list, sched.times, batch, stack.k)
     # a few instances are still cheaper one after the other in parallel-in-time form (~2 ms each) than in
@@ -416,6 +421,10 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     if folded:  # (1, P, rows, B*m) -> (B, P, rows, m)
         _, p, rows, _ = ys.shape
         ys = ys.reshape(p, rows, n_inst, m_cols).transpose(2, 0, 1, 3)
+        route += "+folded"
+    elif replicate:
+        ys = np.repeat(ys, n_inst, axis=0)
+        route += "+replicated"
     results = []
     for y_b in _restore_batch(model, kind, tag, ys):
         t_out, y_out = sched.trim(y_b)

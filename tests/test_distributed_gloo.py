@@ -60,6 +60,18 @@ WORKER = textwrap.dedent("""
         for b in range(n_inst):
             assert np.array_equal(res[b].y[0], y_list[b])
             assert np.array_equal(res[b].y[1], y_list[b] * (b + 1) + 10j * b)
+        # gather="root": rank 1 holds the full list, rank 0 gets None; gather="none": the own shard and its offset
+        res = solve_sweep(FakeSolver(), [0.0, 1.0], y_list, sigs, gather="root", root=1, method="RK4", max_dt=0.1)
+        if rank == 1:
+            assert len(res) == n_inst
+            for b in range(n_inst):
+                assert np.array_equal(res[b].y[1], y_list[b] * (b + 1) + 10j * b)
+        else:
+            assert res is None
+        lo_n, own = solve_sweep(FakeSolver(), [0.0, 1.0], y_list, sigs, gather="none", method="RK4", max_dt=0.1)
+        assert lo_n == lo_ and len(own) == hi_ - lo_
+        for i, r_ in enumerate(own):
+            assert np.array_equal(r_.y[1], y_list[lo_ + i] * (lo_ + i + 1) + 10j * (lo_ + i))
     # max-over-ranks timing reduction used by bench.py
     import torch
     t = torch.tensor([1.0 + rank], dtype=torch.float64)

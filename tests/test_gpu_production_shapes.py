@@ -295,6 +295,21 @@ def test_shared_signal_sweep_is_folded_into_columns(qd):
     many = solver.solve(t_span=[0.0, 0.2], y0=y0m, signals=sigs, method="RK4", max_dt=0.01)
     one = solver.solve(t_span=[0.0, 0.2], y0=y0m[2], signals=sigs, method="RK4", max_dt=0.01)
     assert_close(many[2].y, one.y, 1e-11)
+    assert many[0].route.endswith("+folded")
+    # identical instances (same signals AND the same y0 object): one solve, replicated
+    same = solver.solve(t_span=[[0.0, 0.2]] * 3, y0=y0m[2], signals=sigs, method="RK4", max_dt=0.01)
+    assert len(same) == 3 and same[0].route.endswith("+replicated")
+    assert_close(same[1].y, one.y, 1e-11)
+    # beyond FOLD_MAX_COLUMNS the instances stay instances
+    from qiskit_dynamics_amd import solvers as S
+    old_cap = S.FOLD_MAX_COLUMNS
+    S.FOLD_MAX_COLUMNS = 8
+    try:
+        capped = solver.solve(t_span=[0.0, 0.2], y0=y0m, signals=sigs, method="RK4", max_dt=0.01)
+    finally:
+        S.FOLD_MAX_COLUMNS = old_cap
+    assert "folded" not in capped[0].route
+    assert_close(capped[2].y, one.y, 1e-11)
 
 
 def test_stack_broadcast_over_the_c_abi_one_rank(qd):
@@ -346,6 +361,23 @@ def test_abi_broadcast_probe_in_a_child_process(qd, monkeypatch):
     monkeypatch.delenv("MIDYN_PROBE_HANG")
     ok, msg = abi_broadcast_probe(0, 1, ctx.device, b"\0" * 16, timeout_s=60)       # malformed id: exits non-zero
     assert not ok and "exited" in msg
+
+
+def test_bench_dry_ranks_mode_one_rank():
+    """bench.py --dry-ranks (the multi-GPU plumbing check) with the one GPU of this box: communicator of one rank through
+    the C-ABI, broadcast, evaluation of the broadcast stack."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-ranks"], capture_output=True, text=True,
+                       timeout=300, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["mode"] == "dry-ranks" and line["rccl_ranks_seen"] == 1
+    assert line["every_rank_evaluates_the_broadcast_stack_correctly"] is True
 
 
 def test_event_timer_and_block_info(qd):

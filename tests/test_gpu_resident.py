@@ -656,3 +656,64 @@ def test_small_sweep_of_a_dense_model_runs_as_single_trajectories(qd):
                                                  [0.0, 0.4], y0s[b], "RK4", 0.01, t_eval=[0.0, 0.17, 0.4])
         assert_close(res[b].t, t_ref, 0)
         assert_close(res[b].y, y_ref, SOLVE_TOL)
+
+
+@pytest.mark.parametrize("route", ["dense_rk4", "ell_rk4", "ell_expm", "sweep_split"])
+def test_one_launch_kernels_fall_back_when_a_wait_gives_up(qd, route):
+    """The one-launch kernels wait for each other's data inside the launch.  With the spin limit forced to zero every wait
+    whose first poll finds a word missing gives up (what a launch that is not co-resident after all, or a GPU shared with
+    another process, would cause): the solve must not fail -- the step range is re-run on the per-launch route (counter
+    resident_fallbacks) and the answer is the oracle's."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(11)
+    if route == "dense_rk4":            # rk4_resident_kernel: dense 200 x 200 operators
+        n, k = 200, 3
+        h_d, ops = herm(rng, n), np.stack([herm(rng, n) for _ in range(k)])
+        frame, method, kw = h_d, "RK4", dict(max_dt=0.01)
+        carrier = np.array([1.0, 2.0, 3.0])
+    else:                               # ELL stacks: the 9-qubit chain in its diagonal frame
+        cfg = W.schrodinger_config(n_qubits=9 if route != "sweep_split" else 12, n_drives=8, t_final=1.0, max_dt=0.05)
+        h_d, ops, carrier = cfg["h_d"], cfg["ops"], cfg["carrier"]
+        n, k = h_d.shape[0], len(ops)
+        frame = np.diag(h_d).real.copy()
+        method, kw = ("RK4", dict(max_dt=0.01)) if route == "ell_rk4" else ("scipy_expm", dict(max_dt=0.05))
+        if route == "sweep_split":
+            kw["magnus_order"] = 2
+    nb = 3 if route == "sweep_split" else 1
+    sweeps = []
+    for b in range(nb):
+        amps, phases = W.sweep_parameters(b, k)
+        sweeps.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, ph)
+                       for a, nu, ph in zip(amps, carrier, phases)])
+    solver = qd.Solver(static_hamiltonian=h_d, hamiltonian_operators=ops, rotating_frame=frame, validate=False)
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    sig = sweeps if nb > 1 else sweeps[0]
+    t_span = [0.0, 0.3]
+    runs, fallbacks = {}, {}
+    for tag, limit in (("healthy", -1), ("gives_up", 0)):
+        ctx.set_option("resident_spin_limit", limit)
+        if route == "sweep_split":
+            ctx.set_option("ell_sweep_split", 3)
+        before = ctx.counters("resident_fallbacks")["launches"]
+        ctx.reset_counters()
+        ctx.set_option("profile", 1)
+        try:
+            r = solver.solve(t_span=t_span, y0=y0, signals=sig, method=method, **kw)
+        finally:
+            ctx.set_option("profile", 0)
+            ctx.set_option("resident_spin_limit", -1)
+            ctx.set_option("ell_sweep_split", 1)
+        assert ctx.counters("rk4_resident")["launches"] >= 1, "the one-launch route was not taken"
+        fallbacks[tag] = ctx.counters("resident_fallbacks")["launches"] - before
+        runs[tag] = np.stack([x.y[-1] for x in r]) if nb > 1 else r.y[-1][None]
+    assert fallbacks["healthy"] == 0 and fallbacks["gives_up"] >= 1, fallbacks
+    assert_close(runs["gives_up"], runs["healthy"], 1e-12)
+    if route != "sweep_split":          # (n = 4096: the healthy route is pinned against the oracle elsewhere)
+        a_d, a, d, basis = orc.hamiltonian_model_build(h_d, ops, frame)
+        _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt: np.array([np.real(s(tt)) for s in sweeps[0]]),
+                                           t_span, y0, method, kw["max_dt"])
+        assert_close(runs["gives_up"][0], ref[-1], SOLVE_TOL)

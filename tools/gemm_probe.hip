@@ -3,6 +3,7 @@
 // of the basis only (parity sectors), N state columns with their own coefficient rows, fused RK4 stage-2 epilogue.
 //   variant 0: SPARSE 128x128 work-list kernel (the headline route)       variant 1: dense 128x128 kernel, same stack
 //   variant 2: dense complex operators, 3M 64x64 kernel                  variant 3: dense complex, 4M 128x128
+//   variant 4: SPARSE 64x128 tile (64-row panels)                        variant 5: SPARSE 64x64 tile
 // Checks a few output rows against a host evaluation.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o build/probes/gp tools/gemm_probe.hip && build/probes/gp [N] [variant] [splits]
 #include <hip/hip_runtime.h>
@@ -69,11 +70,12 @@ int main(int argc, char** argv) {
     for (int r = 0; r < n; ++r) { E[r] = make_double2(cos(0.3 * r), sin(0.3 * r)); En[r] = make_double2(cos(0.7 * r), sin(0.7 * r)); }
     std::vector<int> seg_list(k);
     for (int j = 0; j < k; ++j) seg_list[j] = (j << 2) | (cplx ? 0 : 2);
-    // work lists of 128-row panels: K tile outer, segment inner, only the tiles of the other half
-    std::vector<int> wptr(n / 128 + 1, 0), widx;
-    for (int bm = 0; bm < n / 128; ++bm) {
+    // work lists of PH-row panels (128; 64 for the 64-row tiles): K tile outer, segment inner, only the tiles of the other half
+    const int PH = (variant == 4 || variant == 5) ? 64 : 128;
+    std::vector<int> wptr(n / PH + 1, 0), widx;
+    for (int bm = 0; bm < n / PH; ++bm) {
         for (int kt = 0; kt < n / 16; ++kt) {
-            const bool coupled = (bm * 128 < n / 2) != (kt * 16 < n / 2);
+            const bool coupled = (bm * PH < n / 2) != (kt * 16 < n / 2);
             if (!coupled) continue;
             for (int j = 0; j < k; ++j) widx.push_back((kt << 8) | seg_list[j]);
         }
@@ -97,6 +99,8 @@ int main(int argc, char** argv) {
     if (variant == 0) { st = run<128, 128, 2, 4, 16, 2, true>(g, s, reps, &ms); flops = listed * 128 * 16 * (double)N * 4; }
     else if (variant == 1) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<128, 128, 2, 4, 16, 2, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 4; }
     else if (variant == 2) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<64, 64, 2, 2, 16, 4, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 6; }
+    else if (variant == 4) { st = run<64, 128, 2, 4, 16, 2, true>(g, s, reps, &ms); flops = listed * 64 * 16 * (double)N * 4; }
+    else if (variant == 5) { st = run<64, 64, 2, 2, 16, 2, true>(g, s, reps, &ms); flops = listed * 64 * 16 * (double)N * 4; }
     else if (variant == 3) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<128, 128, 2, 4, 16, 0, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 8; }
 #ifdef GEMM_PROBE_EXTRA
     else st = probe_extra(variant, g, s, reps, &ms, &flops, A, n, k, N);
