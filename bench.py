@@ -1026,7 +1026,7 @@ def main():
 
     # ---- cfg 2: single trajectory, HBM-bound streaming kernel (rank 0, N=1) -------------------------------------
     if rank == 0 and world == 1 and not args.no_single:
-        s_total = 264
+        s_total = min(len(sched.step_h), 1000)      # the whole configs[1] trajectory (one launch on the default route)
         rows1 = sched.step_rows[:s_total]
         nr1 = int(rows1.max()) + 1
         table1 = workloads.gaussian_coefficient_table(sched.times[:nr1], amps[:1], phs[:1], cfg["carrier"], T_FINAL)

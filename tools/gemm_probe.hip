@@ -4,6 +4,11 @@
 //   variant 0: SPARSE 128x128 work-list kernel (the headline route)       variant 1: dense 128x128 kernel, same stack
 //   variant 2: dense complex operators, 3M 64x64 kernel                  variant 3: dense complex, 4M 128x128
 //   variant 4: SPARSE 64x128 tile (64-row panels)                        variant 5: SPARSE 64x64 tile
+// Measured with this probe in round 3 and NOT adopted (kernels removed again; N = 4096, ms per launch, this probe's stack):
+//   headline SPARSE kernel 1.091-1.103; the same with PLANAR operator tiles (8-byte elements, 16 KB per tile, ds_read_b64
+//   fragments kept apart from ds_read2st64 pairing) 1.123; planar tiles + TWO list entries per barrier (128 MFMAs per
+//   wave between barriers) 1.130, with 1:1 instead of 2:1 MFMA : ds_read interleave 1.133, reads first 1.176;
+//   64 x 128 and 64 x 64 work-list tiles for the 512-column shard 168 / 172 us against 160 us (128 x 128, 8 splits).
 // Checks a few output rows against a host evaluation.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o build/probes/gp tools/gemm_probe.hip && build/probes/gp [N] [variant] [splits]
 #include <hip/hip_runtime.h>
@@ -49,7 +54,7 @@ static int run(const GemmArgs& g, hipStream_t s, int reps, float* ms_out) {
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 4096, variant = argc > 2 ? atoi(argv[2]) : 0, splits = argc > 3 ? atoi(argv[3]) : 1;
     const int n = 1024, k = 8, reps = 40;
-    const bool cplx = variant >= 2;
+    const bool cplx = variant == 2 || variant == 3;
     srand(7);
     // operators: purely imaginary, coupling rows of one half to columns of the other (variant 0/1); dense complex (2/3)
     std::vector<double2> A((size_t)k * n * n, make_double2(0.0, 0.0));

@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): bench + rocprofv3 kernel trace + separate PMC passes (one counter set per run,
 # never combined with tracing domains other than --kernel-trace/--stats).
 # usage: tools/profile_round.sh <tag>      outputs under $GRAFT_REPO_ROOT/gpurun_out/<tag>/
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
