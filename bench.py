@@ -971,6 +971,28 @@ def main():
                  "scheme": "no structure exploited (general complex operators): 3M complex multiplication (3 real fp64 "
                            "MFMAs per complex product) inside the solver loop, dense 64x64 tiles"}
     plan.close()
+    # ---- what the N-GPU strong-scaling runs should show: the per-GPU shards of 2 / 4 / 8 ranks timed on THIS GPU --------
+    projected = None
+    if rank == 0 and world == 1 and not args.dense and not args.weak and total_inst % 8 == 0:
+        projected = {"what": "strong scaling of this sweep projected from one GPU: the shard of an N-GPU run (instances / N) timed "
+                             "here with the same plan type; efficiency = N x shard rate / (N x full rate).  The stack broadcast "
+                             "is outside the timed region of bench.py and of this projection",
+                     "cfg3": {}}
+        for n_r in (2, 4, 8):
+            b_s = total_inst // n_r
+            tab_s = table[:b_s]
+            ps = qd.Rk4Plan(stack, times, tab_s, rows, sched.step_h[:total], y0, b_s, True)
+            ps.run(0, min(2, total - 1))
+            ctx.synchronize()
+            d_steps = max(1, min(args.steps, 10, total - 2))
+            t0p = time.perf_counter()
+            ps.run(2, 2 + d_steps)
+            ctx.synchronize()
+            el_p = time.perf_counter() - t0p
+            ps.close()
+            rate = b_s * 4 * d_steps / el_p
+            projected["cfg3"][str(n_r)] = {"instances_per_gpu": b_s, "us_per_batched_evaluation": round(el_p / (4 * d_steps) * 1e6, 1),
+                                          "projected_value": round(n_r * rate, 1), "efficiency": round(rate * n_r / (n_r * value), 4)}
     measured_peaks = None
     if rank == 0 and world == 1:
         co = ctx.microbench("fp64_coissue", full=True)
@@ -1010,6 +1032,8 @@ def main():
                              "value_without_exact_zero_block_skipping = the dense kernels on the same stack.  On both "
                              "routes the static operator in the frame, U^+(G_d - F)U with F = G_d, is exactly zero and "
                              "inactive (the reference's U^+ G_d U - diag(d) leaves 1e-13 rounding noise there)")
+    if projected:
+        out["projected_strong_scaling"] = projected
     if dense:
         out["dense_complex"] = dense
     if same_model_dense and dense:
@@ -1152,6 +1176,13 @@ def main():
                     "solve_s_max_over_ranks": round(solve5, 4),
                     "instance_steps_per_s": round(CFG5_SWEEP * full["steps"] / solve5, 1),
                     "max_norm_deviation_rank0": full["max_norm_deviation"], "stack_broadcast": bcast5}
+                if world == 1 and "projected_strong_scaling" in out:
+                    proj5 = {}
+                    for n_r in (2, 4, 8):
+                        sh = leg_cfg5(qd, ctx, workloads, stack5, cfg5, 0, CFG5_SWEEP // n_r, with_profile=False)
+                        proj5[str(n_r)] = {"instances_per_gpu": CFG5_SWEEP // n_r, "solve_s": sh["solve_s"],
+                                           "efficiency": round(solve5 / (n_r * sh["solve_s"]), 4)}
+                    out["projected_strong_scaling"]["cfg5"] = proj5
         except Exception as exc:  # pylint: disable=broad-except
             if rank == 0:
                 out["sharded_cfg5"] = {"error": repr(exc)}

@@ -71,12 +71,21 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         stage input exchanged through a polled ring in device memory (csrc/midyn_resident.h)
  *   ell_sweep [1]         sweeps (and single Magnus-2 trajectories) on very sparse stacks, 256 <= n_pad <= 4096, in
  *                         midyn_rk4_solve and the expm action of midyn_expm_solve: ONE launch, one workgroup per
- *                         instance through all steps, state in registers, operator elements (ELL) from L2
+ *                         instance through all steps, staged vectors in LDS, operator elements (ELL) from L2
  *                         (csrc/midyn_resident.h: ell_sweep_kernel, ell_sweep_rk4_kernel)
- *   ell_sweep_split [1]   ... small shards: 4 workgroups per instance while 4 x instances <= CUs (n_pad = 4096); the
- *                         partners all-gather every operand vector through a sentinel-polled ring (cfg 5, 1..32
- *                         instances: 0.18-0.24 instead of 0.29-0.33 ms per step).  2: also 2 workgroups per instance
- *                         (measured slower: 0.41 vs 0.36 ms at 128 instances); 0: never
+ *   ell_sweep_packed [1]  ... with the packed element form of the stack when it has one: 4-byte elements (column | sign,
+ *                         or the LDS address of the operand) when every ELL slot holds one magnitude (operators built
+ *                         from Pauli strings); 0: always the general 12-byte form.  Same results to rounding
+ *   ell_sweep_split [1]   ... small shards of stacks WITHOUT a packed form: 4 workgroups per instance while 4 x instances
+ *                         <= CUs (n_pad = 4096); the partners all-gather every operand vector through a sentinel-polled
+ *                         ring.  2: also 2 workgroups per instance; 3: packed stacks too (measured slower than the
+ *                         packed one-workgroup kernel at every shard size); 0: never
+ *   resident_spin_limit [2^21]   polls a wait inside a one-launch kernel (rk4_resident, ell_resident, ell_sweep_split)
+ *                         may take before it gives up; the solve then re-runs the step range on the launch-per-product
+ *                         route by itself (counter "resident_fallbacks").  -1 restores the default; 0 = give up at the
+ *                         first missing word (tests)
+ *   resident_exchange_only [0]   measurement only: rk4_resident_kernel publishes and polls every round but skips the
+ *                         row product (results wrong) -- the store -> poll floor bench.py reports
  *   expm_action [1]       few columns, Magnus order <= 2: expm(Omega) y by matrix-vector products
  *   expm_degree [0]       0: Taylor degree of the dense expm chosen from the norm; else 2|4|6|9|12|16
  *   profile [0]           record HIP-event kernel times (midyn_get_counters)
@@ -259,7 +268,8 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * out[0] = launches, out[1] = total ms (events are only recorded when profiling is enabled with
  * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch).
  * "sweep_series" describes the last ell_sweep_kernel launch: (series terms per instance summed over the steps, operator
- * slots per row); "sweep_split": (workgroups per instance of that launch, 0).
+ * slots per row); "sweep_split": (workgroups per instance of that launch, element form 0 general / 1 packed / 2 direct);
+ * "resident_fallbacks": (step ranges a one-launch kernel gave up on and the launch-per-product route re-ran, 0).
  * Two more names describe the LAST launch of the sparse MFMA route: "sparse_tile" -> (BM, BN) of its tile,
  * "sparse_list" -> (listed (panel, K tile, operator) tiles of the stack for that panel height, split count),
  * "sparse_pair" -> (contractions in that launch: 2 when two independent products shared it, ctx option pair_launch). */

@@ -892,6 +892,10 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
             }                                                                                    \
         }                                                                                        \
     }
+    // (Tried: the gathers of slot e + 1 issued before the multiply-adds of slot e, two operand buffers -- their times ADD
+    // in the loop below.  Order 2 has no registers for the second buffer (27 spills, 26.9 vs 19.3 us per term); order 1
+    // has them and gains nothing (5.45 vs 5.33): the waves of a CU already overlap each other's phases as far as the LDS
+    // pipeline lets them.)
     MIDYN_SWEEP_K_RANGE(false, 0, a.wre)
     MIDYN_SWEEP_K_RANGE(true, a.wre, a.wsp)
 #undef MIDYN_SWEEP_K_RANGE
