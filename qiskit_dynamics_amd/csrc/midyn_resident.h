@@ -363,7 +363,7 @@ struct EllArgs {
     const double* S;          // [R][k]
     const double2* E;         // [R][n_pad] or nullptr
     const double2* Dt;        // ell_sweep_kernel, order 2, framed: [nsteps][n_pad] E(t2) o conj(E(t1)) of every step
-    double2* stash;           // ell_sweep_kernel, order 2: [B][3][n_pad] series vectors kept out of the registers
+    double2* stash;           // ell_sweep_kernel, order 2: [B][2][n_pad] series vectors kept out of the registers
     const int* rows;          // [nsteps][3]
     const double* hs;         // [nsteps]
     const int* save;          // [nsteps] or nullptr
@@ -710,8 +710,9 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
 //     (order 2 only; sweep_dtable_kernel) -- three loads and four complex multiplications per row and term instead of six
 //     phase loads and six multiplications.
 //   * The term vector is accumulated INTO the Chebyshev predecessor (w = phi_{j-2} + ...): one vector less; at order 2 the
-//     vectors no pass touches (result, phi_{j-1}, the term between its passes) live in a per-instance stash in device
-//     memory, so that a pass holds its two output vectors and its gathers in flight and nothing else: no spills.
+//     vectors no pass touches (result, phi_{j-1}) live in a per-instance stash in device memory and the term between its
+//     two passes rides through the second pass inside its second sum, so that a pass holds its two output vectors and its
+//     gathers in flight and nothing else: no spills.
 //   * All global addresses are a uniform base plus a 32-bit byte offset that passes through an empty asm at every use;
 //     otherwise hipcc hoists the 64-bit address of every (array, row) pair out of the step loop and spills them.
 // ------------------------------------------------------------------------------------------------
@@ -736,7 +737,7 @@ struct SweepArgs {
     long long inst_stride;    // R * k
     const double2* E;         // [R][n_pad] or nullptr
     const double2* Dt;        // ell_sweep_kernel, order 2, framed: [nsteps][n_pad] E(t2) o conj(E(t1)) of every step
-    double2* stash;           // ell_sweep_kernel, order 2: [B][3][n_pad] series vectors kept out of the registers
+    double2* stash;           // ell_sweep_kernel, order 2: [B][2][n_pad] series vectors kept out of the registers
     const int* rows;          // [nsteps][3]
     const double* hs;         // [nsteps]
     const int* save;          // [nsteps] or nullptr
@@ -776,17 +777,20 @@ __device__ __forceinline__ unsigned sweep_boff(const int tid, const int i_, cons
 // Two straight-line loops, no selects: the real-plane slots (A x = v x), then the imaginary-plane slots
 // (A = i v: A x = v (-x.y, x.x)).  X1 / X2: the LDS copies of the operand vectors (sweep_lds: their base; PACKED 2
 // elements are byte addresses relative to it, X2 operands 32768 bytes behind their X1 operands).
-template <int ORDER, int SWEEP_RPT, int TH, int PACKED, int PFD = MIDYN_SWEEP_PREFETCH>
+template <int ORDER, int SWEEP_RPT, int TH, int PACKED, int PFD = MIDYN_SWEEP_PREFETCH, bool KEEP_O2 = false>
 __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* cab, const double2* sweep_lds, const double2* X1,
                                            const double2* X2, const int tid, const bool swapped, double2 (&o1)[SWEEP_RPT],
-                                           double2 (&o2)[SWEEP_RPT]) {
+                                           double2 (&o2)[SWEEP_RPT], const double scale2 = 1.0) {   // scale2: factor of the second sum
     const int np = a.n_pad;
     const unsigned unp = (unsigned)np;
     auto boff = [&](const int i_, const int shift) { return sweep_boff<TH>(tid, i_, shift); };
 #define ROW(i_) ((unsigned)(tid + TH * (i_)))
 
 #pragma unroll
-    for (int i = 0; i < SWEEP_RPT; ++i) o1[i] = o2[i] = make_double2(0.0, 0.0);
+    for (int i = 0; i < SWEEP_RPT; ++i) {
+        o1[i] = make_double2(0.0, 0.0);
+        if (!KEEP_O2) o2[i] = make_double2(0.0, 0.0);     // KEEP_O2: the caller has put a start value into the second sum
+    }
 #if MIDYN_SWEEP_ABLATE == 1   // profiling only: no operator pass at all
     for (int i = 0; i < SWEEP_RPT; ++i) { o1[i] = X1[tid + TH * i]; o2[i] = X2[tid + TH * i]; }
     return;
@@ -817,7 +821,7 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
 #define MIDYN_SWEEP_K_SLOT(IM, S_)                                                                    \
     {                                                                                            \
         const double2 cc = cab[e];                                                               \
-        const double ca = swapped ? cc.y : cc.x, cb = swapped ? cc.x : cc.y;                     \
+        const double ca = swapped ? cc.y : cc.x, cb = (swapped ? cc.x : cc.y) * (KEEP_O2 ? scale2 : 1.0); \
         int cl[SWEEP_RPT];                                                                       \
         double va[SWEEP_RPT];                                                                    \
         if (!PFON) fetch(e, cn[S_], vn[S_]);                                                 \
@@ -924,9 +928,8 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
     // the two series vectors no pass touches live in a per-instance stash in device memory (L2): rows tid + TH i
     // (uniform base pointers + 32-bit BYTE offsets everywhere -- the scalar-base addressing form: one offset register per
     // row serves every array; with element indices hipcc builds a 64-bit address per row and array and spills them)
-    double2* const sacc = a.stash + (size_t)b * 3 * np;   // the accumulated result
+    double2* const sacc = a.stash + (size_t)b * 2 * np;   // the accumulated result
     double2* const scur = sacc + np;                       // phi_{j-1} (the next term's phi_{j-2})
-    double2* const spw = scur + np;                        // order 2: the term vector between its two passes
     auto boff = [&](const int i_, const int shift) { return sweep_boff<TH>(tid, i_, shift); };   // (see sweep_boff)
 #define ROW(i_) ((unsigned)(tid + TH * (i_)))
 #define AT16(base_, i_) (*reinterpret_cast<double2*>(reinterpret_cast<char*>(const_cast<double2*>(base_)) + boff(i_, 4)))
@@ -948,6 +951,10 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
     }
     auto pass = [&](const bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
         sweep_pass<ORDER, SWEEP_RPT, TH, PACKED>(a, cab, sweep_lds, X1, X2, tid, swapped, o1, o2);
+    };
+    auto pass_keep = [&](const bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT], const double scale2) {
+        // o2 continues from its start value, its sum scaled by scale2
+        sweep_pass<ORDER, SWEEP_RPT, TH, PACKED, MIDYN_SWEEP_PREFETCH, true>(a, cab, sweep_lds, X1, X2, tid, swapped, o1, o2, scale2);
     };
     for (int st = 0; st < a.nsteps; ++st) {
         const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];
@@ -1007,15 +1014,17 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
                         }
                         X1[xrow(r)] = du1;           // for g2~ = conj(D) C(t2) D
                         X2[xrow(r)] = u2;            // for g1~ = C(t1)
-                        AT16(spw, i) = make_double2(pw[i].x + ca * (u1.x + u2.x), pw[i].y + ca * (u1.y + u2.y));
+                        // the term so far, m = phi_{j-2} + ca (u1 + u2), rides through the second pass INSIDE its second sum
+                        // (start value -m, the sum scaled by cb: cb v1 - o2 then IS m + cb (v1 - g1~ u2)) -- no vector to
+                        // keep in registers or to stash across the pass
+                        o2[i] = make_double2(-(pw[i].x + ca * (u1.x + u2.x)), -(pw[i].y + ca * (u1.y + u2.y)));
                     }
                     __syncthreads();
-                    pass(true, o1, o2);              // o1 = C(t2) (D u1), o2 = C(t1) u2
+                    pass_keep(true, o1, o2, cb);     // o1 = C(t2) (D u1), o2 = -m + cb C(t1) u2
 #pragma unroll
                     for (int i = 0; i < SWEEP_RPT; ++i) {
                         const double2 v1 = D ? cmul_conj_a(AT16(D, i), o1[i]) : o1[i];
-                        const double2 t = AT16(spw, i);
-                        pw[i] = make_double2(t.x + cb * (v1.x - o2[i].x), t.y + cb * (v1.y - o2[i].y));
+                        pw[i] = make_double2(cb * v1.x - o2[i].x, cb * v1.y - o2[i].y);
                     }
                 } else {
                     const double ca = hh * f;

@@ -32,10 +32,10 @@ template <class T> T* upload(const std::vector<T>& h) {
 }
 static double rnd() { return rand() / (double)RAND_MAX - 0.5; }
 
-template <int BM, int BN, int WM, int WN, int BK, int MODE, bool SPARSE>
+template <int BM, int BN, int WM, int WN, int BK, int MODE, bool SPARSE, int MINW = 2>
 static int run(const GemmArgs& g, hipStream_t s, int reps, float* ms_out) {
     constexpr size_t SMEM = (size_t)2 * BK * (BM + BN) * sizeof(double2);
-    auto kern = zgemm_seg_kernel<BM, BN, WM, WN, BK, MODE, 2, SPARSE>;
+    auto kern = zgemm_seg_kernel<BM, BN, WM, WN, BK, MODE, MINW, SPARSE>;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
     const int blocks = (g.M / BM) * (g.N / BN) * g.splits;
     hipEvent_t e0, e1;
@@ -106,6 +106,7 @@ int main(int argc, char** argv) {
     else if (variant == 2) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<64, 64, 2, 2, 16, 4, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 6; }
     else if (variant == 4) { st = run<64, 128, 2, 4, 16, 2, true>(g, s, reps, &ms); flops = listed * 64 * 16 * (double)N * 4; }
     else if (variant == 5) { st = run<64, 64, 2, 2, 16, 2, true>(g, s, reps, &ms); flops = listed * 64 * 16 * (double)N * 4; }
+    else if (variant == 9) { st = run<128, 128, 2, 2, 16, 2, true, 1>(g, s, reps, &ms); flops = listed * 128 * 16 * (double)N * 4; }   // 4 waves, 64 x 64 wave tiles
     else if (variant == 3) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<128, 128, 2, 4, 16, 0, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 8; }
 #ifdef GEMM_PROBE_EXTRA
     else st = probe_extra(variant, g, s, reps, &ms, &flops, A, n, k, N);

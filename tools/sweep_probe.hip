@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(sweep_dtable_kernel, dim3((nsteps * n + 255) / 256), dim3(256), 0, 0, a.E, a.rows, nsteps, n, dt);
     CHECK(hipDeviceSynchronize());
     a.Dt = dt;
-    double2* stash; CHECK(hipMalloc(&stash, (size_t)B * 3 * n * sizeof(double2)));
+    double2* stash; CHECK(hipMalloc(&stash, (size_t)B * 2 * n * sizeof(double2)));
     a.stash = stash;
     double2* outs[3];
     for (auto& o : outs) CHECK(hipMalloc(&o, (size_t)B * P * n * sizeof(double2)));

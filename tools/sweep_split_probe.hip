@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     double2 *dt, *stash;
     CHECK(hipMalloc(&dt, (size_t)nsteps * n * sizeof(double2)));
-    CHECK(hipMalloc(&stash, (size_t)B * 3 * n * sizeof(double2)));
+    CHECK(hipMalloc(&stash, (size_t)B * 2 * n * sizeof(double2)));
     hipLaunchKernelGGL(sweep_dtable_kernel, dim3((nsteps * n + 255) / 256), dim3(256), 0, 0, a.E, a.rows, nsteps, n, dt);
     CHECK(hipDeviceSynchronize());
     a.Dt = dt; a.stash = stash;
