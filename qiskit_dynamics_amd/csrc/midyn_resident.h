@@ -20,6 +20,16 @@
 // costs nothing a round later), so a reader that has seen round r+2 can never see stale round r-1 data in the buffer
 // it polls for round r+3.
 //
+// What this relies on beyond the HIP / LLVM memory model (relaxed agent-scope atomics order nothing by themselves), and
+// where it is guarded: (1) a store is complete -- visible to every later agent-scope load on any XCD -- once `s_waitcnt
+// vmcnt(0)` has let it through: agent-scope atomic stores are `sc1` write-through stores on gfx950 and the counter is
+// decremented by their acknowledgement (MI355X_MICROARCH.md, inter-workgroup visibility); the wait is followed by a
+// compiler fence so that hipcc cannot move a ring store above it.  The library is built for gfx950 only (no other code
+// object exists in libmidyn.so), so no other memory system ever runs this.  (2) 8-byte words are never torn.  (3) A
+// data word never equals the sentinel: the all-ones pattern is a NaN no arithmetic produces, but a y0 that CONTAINS it
+// (or a wait that never ends for any other reason) makes a reader give up after `spin_limit` polls -- the host then
+// re-runs the step range on the per-launch route, which propagates NaNs like NumPy does; nothing hangs, nothing fails.
+//
 // Precision: same products as the streaming kernel in a different summation order (lane-strided partial sums, then
 // a butterfly), same fused stage arithmetic (apply_epilogue_t).
 #pragma once
@@ -310,6 +320,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
             __syncthreads();
             if (wave == 0 && lane < 2 * WAVES) {
                 __builtin_amdgcn_s_waitcnt(0);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (compiler: no ring store moves above the wait)
                 const int row_wg = blockIdx.x * WAVES;
                 unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row_wg + lane;
                 __hip_atomic_store(z, (unsigned long long)__double_as_longlong(reinterpret_cast<const double*>(pubs[rr & 1])[lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                 // the re-arming stores of the PREVIOUS round are complete before this round's data leaves (they are a
                 // round old: no stall); this round's re-arming follows the data
                 __builtin_amdgcn_s_waitcnt(0);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (compiler: no ring store moves above the wait)
                 unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row + lane;
                 __hip_atomic_store(z, (unsigned long long)__double_as_longlong(lane ? pub.y : pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // re-arm this row's words of the buffer read LAST round: having read this round from all my neighbours
@@ -562,6 +574,7 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
         const int b_nxt = (b_cur + 1) & 3, b_rearm = (b_cur + 3) & 3;
         if (wave == 0) {
             __builtin_amdgcn_s_waitcnt(0);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (compiler: no ring store moves above the wait)
             unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row;
             __hip_atomic_store(z, (unsigned long long)__double_as_longlong(pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(z + 1, (unsigned long long)__double_as_longlong(pub.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1193,6 +1206,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
         const int nv = (ORDER == 2 && !same) ? 2 : 1;      // vectors through the ring this round
         unsigned long long* nxt = ring + (size_t)b_nxt * ORDER * 2 * np;
         __builtin_amdgcn_s_waitcnt(0);     // last round's re-arming stores are complete before this round's data leaves
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (compiler: no ring store moves above the wait)
         __syncthreads();                   // every reader of the LDS copies of the previous pass is done
 #pragma unroll
         for (int i = 0; i < SWEEP_RPT; ++i) {

@@ -4,11 +4,15 @@
 //   variant 0: SPARSE 128x128 work-list kernel (the headline route)       variant 1: dense 128x128 kernel, same stack
 //   variant 2: dense complex operators, 3M 64x64 kernel                  variant 3: dense complex, 4M 128x128
 //   variant 4: SPARSE 64x128 tile (64-row panels)                        variant 5: SPARSE 64x64 tile
+//   variant 9: SPARSE 128x128 on four waves with 64x64 wave tiles (see below)
 // Measured with this probe in round 3 and NOT adopted (kernels removed again; N = 4096, ms per launch, this probe's stack):
 //   headline SPARSE kernel 1.091-1.103; the same with PLANAR operator tiles (8-byte elements, 16 KB per tile, ds_read_b64
 //   fragments kept apart from ds_read2st64 pairing) 1.123; planar tiles + TWO list entries per barrier (128 MFMAs per
 //   wave between barriers) 1.130, with 1:1 instead of 2:1 MFMA : ds_read interleave 1.133, reads first 1.176;
 //   64 x 128 and 64 x 64 work-list tiles for the 512-column shard 168 / 172 us against 160 us (128 x 128, 8 splits).
+//   variant 9 (still here): the same kernel source with FOUR waves and 64 x 64 wave tiles (32 MFMAs per k-step, one
+//   workgroup of 256 threads per CU, 512 registers per lane): hipcc takes 256 VGPRs + 256 AGPRs and still spills 167
+//   registers -- 3.20 ms.  A wave tile of that size needs hand-placed AGPR accumulators.
 // Checks a few output rows against a host evaluation.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o build/probes/gp tools/gemm_probe.hip && build/probes/gp [N] [variant] [splits]
 #include <hip/hip_runtime.h>
