@@ -753,6 +753,8 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: kernel ablation bits (results wrong)")
     ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 | 12864 (kernel A/B testing)")
     ap.add_argument("--opt", action="append", default=[], help="A/B: ctx option NAME=VALUE (repeatable)")
+    ap.add_argument("--no-projection", action="store_true",
+                    help="skip projected_strong_scaling (profiling: keeps shard-sized launches out of the per-kernel averages)")
     ap.add_argument("--dry-ranks", action="store_true",
                     help="multi-GPU plumbing check only: every rank binds its device, the C-ABI communicator is made from a "
                          "shipped ncclUniqueId, a small stack is broadcast and evaluated; prints rccl_ranks_seen (no bench)")
@@ -973,7 +975,7 @@ def main():
     plan.close()
     # ---- what the N-GPU strong-scaling runs should show: the per-GPU shards of 2 / 4 / 8 ranks timed on THIS GPU --------
     projected = None
-    if rank == 0 and world == 1 and not args.dense and not args.weak and total_inst % 8 == 0:
+    if rank == 0 and world == 1 and not args.dense and not args.weak and total_inst % 8 == 0 and not args.no_projection:
         projected = {"what": "strong scaling of this sweep projected from one GPU: the shard of an N-GPU run (instances / N) timed "
                              "here with the same plan type; efficiency = N x shard rate / (N x full rate).  The stack broadcast "
                              "is outside the timed region of bench.py and of this projection",

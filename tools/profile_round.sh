@@ -8,16 +8,16 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench.json 2> $O/bench.err
-B="python $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-end-to-end"
-P="python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-end-to-end"
+B="python $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-end-to-end --no-projection"
+P="python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-end-to-end --no-projection"
 # (rocprofv3 of ROCm 7.2 sometimes dies inside a PMC pass, and segfaults at exit AFTER writing its database: a pass
-# counts when its .db exists; up to three attempts)
+# counts when its .db exists; up to six attempts)
 pass() {  # pass <dir> <log> <command...>
     local d=$1 l=$2; shift 2
-    for attempt in 1 2 3; do
+    for attempt in 1 2 3 4 5 6; do
         rm -rf $O/$d
         "$@" > $O/$l 2>&1
-        if ls $O/$d/*/*.db $O/$d/*.db > /dev/null 2>&1; then return 0; fi
+        if compgen -G "$O/$d/*.db" > /dev/null || compgen -G "$O/$d/*/*.db" > /dev/null; then return 0; fi
         echo "profile_round: $d attempt $attempt produced no database" >&2
     done
     return 1
