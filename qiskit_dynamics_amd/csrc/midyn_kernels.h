@@ -1107,7 +1107,11 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 64, 0);
+                    // then exactly the MFMAs of THIS k-step that are left: a larger count (round 2: 64) also captures the
+                    // MFMAs of the next k-step of the same scheduling region, whose fragment reads then trail them in a
+                    // block and are waited for in front of the tile barrier (ISA of round 3; 1.092 -> 1.082 ms per launch)
+                    constexpr int SGB_REST = (MODE == 0 ? 4 : 2) * MT * NT - 2 * (MT + NT);
+                    if (SGB_REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, SGB_REST, 0);
                 }
                 if (ks == 0 && !DMA_EARLY) issue_next_tile();
             }
@@ -1257,6 +1261,10 @@ template <int BM, int BN, int WM, int WN, int BK, int MODE, int MINW = 2, bool S
 __global__ __launch_bounds__(64 * WM * WN, MINW) void zgemm_seg_pair_kernel(GemmPair gp) {
     zgemm_seg_body<BM, BN, WM, WN, BK, MODE, SPARSE>(gp.g[blockIdx.y], 0);
 }
+
+#ifdef MIDYN_EXPERIMENT_LIST_KERNEL   // tools/gemm_probe.hip: the hand-scheduled work-list kernel of round 3 (not adopted)
+#include MIDYN_EXPERIMENT_LIST_KERNEL
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // zgemm_plane_kernel: the batched RHS contraction for stacks whose operators are ALL single-plane

@@ -5,6 +5,7 @@
 //   variant 2: dense complex operators, 3M 64x64 kernel                  variant 3: dense complex, 4M 128x128
 //   variant 4: SPARSE 64x128 tile (64-row panels)                        variant 5: SPARSE 64x64 tile
 //   variant 9: SPARSE 128x128 on four waves with 64x64 wave tiles (see below)
+//   variant 10 (with -DMIDYN_EXPERIMENT_LIST_KERNEL=...): hand-scheduled list kernel, tools/experiments/gemm_list_kernel.h
 // Measured with this probe in round 3 and NOT adopted (kernels removed again; N = 4096, ms per launch, this probe's stack):
 //   headline SPARSE kernel 1.091-1.103; the same with PLANAR operator tiles (8-byte elements, 16 KB per tile, ds_read_b64
 //   fragments kept apart from ds_read2st64 pairing) 1.123; planar tiles + TWO list entries per barrier (128 MFMAs per
@@ -96,6 +97,7 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&dOut, (size_t)n * N * sizeof(double2)));
     g.A = dA; g.a_seg_stride = (long long)n * n; g.lda = n; g.B = dYin; g.ldb = N; g.M = n; g.N = N; g.K = n;
     g.seg_list = upload(seg_list); g.n_act = k; g.has_static = 0; g.coeff = upload(S); g.inst_stride = k; g.m_cols = 1; g.n_inst = N;
+    g.ablate = argc > 4 ? atoi(argv[4]) : 0;
     g.batch = 1; g.splits = splits; g.work_ptr = upload(wptr); g.work_idx = upload(widx);
     if (splits > 1) { CHECK(hipMalloc(&dPart, (size_t)splits * n * N * sizeof(double2))); g.partial = dPart; }
     g.epi.mode = EPI_RK2; g.epi.ld = N; g.epi.h = 0.005; g.epi.e_cur = upload(E); g.epi.e_next = upload(En);
@@ -111,6 +113,41 @@ int main(int argc, char** argv) {
     else if (variant == 4) { st = run<64, 128, 2, 4, 16, 2, true>(g, s, reps, &ms); flops = listed * 64 * 16 * (double)N * 4; }
     else if (variant == 5) { st = run<64, 64, 2, 2, 16, 2, true>(g, s, reps, &ms); flops = listed * 64 * 16 * (double)N * 4; }
     else if (variant == 9) { st = run<128, 128, 2, 2, 16, 2, true, 1>(g, s, reps, &ms); flops = listed * 128 * 16 * (double)N * 4; }   // 4 waves, 64 x 64 wave tiles
+#ifdef MIDYN_EXPERIMENT_LIST_KERNEL
+    else if (variant == 10) {   // the hand-scheduled list kernel (tools/experiments/gemm_list_kernel.h; not adopted)
+        constexpr size_t SMEM = (size_t)2 * 16 * 256 * sizeof(double2);
+        auto kern = zgemm_list_kernel<2>;
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+        const int blocks = (g.M / 128) * (g.N / 128) * g.splits;
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), SMEM, s, g);
+        CHECK(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), SMEM, s, g);
+        CHECK(hipEventRecord(e1, s));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        flops = listed * 128 * 16 * (double)N * 4;
+#ifdef MIDYN_CLOCK_PROBE
+        {
+            long long* dclk = nullptr;
+            CHECK(hipMalloc(&dclk, blocks * 2 * sizeof(long long)));
+            GemmArgs gc = g;
+            gc.sync = reinterpret_cast<int*>(dclk);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), SMEM, s, gc);
+            CHECK(hipStreamSynchronize(s));
+            std::vector<long long> hc(blocks * 2);
+            CHECK(hipMemcpy(hc.data(), dclk, hc.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            double cs = 0, ws = 0, cmax = 0;
+            for (int b = 0; b < blocks; ++b) { cs += hc[2 * b]; ws += hc[2 * b + 1]; cmax = std::max(cmax, (double)hc[2 * b]); }
+            printf("clock probe: %.0f shader cycles, %.0f ticks of 100 MHz per workgroup -> %.3f GHz; workgroup lifetime %.1f us (max %.0f cycles)\n",
+                   cs / blocks, ws / blocks, cs / ws * 0.1, ws / blocks * 0.01, cmax);
+        }
+#endif
+    }
+#endif
     else if (variant == 3) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<128, 128, 2, 4, 16, 0, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 8; }
 #ifdef GEMM_PROBE_EXTRA
     else st = probe_extra(variant, g, s, reps, &ms, &flops, A, n, k, N);
