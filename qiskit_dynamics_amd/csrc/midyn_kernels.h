@@ -888,7 +888,9 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    // (wave-uniform by construction; told to the compiler so that the LDS-DMA destinations live in SGPRs -- every VALU
+    // instruction in the tile loop takes cycles from the matrix pipe, tools/mfma_bank_probe.hip)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN;
     const int wn = wave % WN;
 
@@ -940,18 +942,20 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
 
     // LDS-DMA source offsets (per lane, fixed): lane l of chunk c fetches A row m = 4c + l/16,
     // k = (l % 16) ^ (m & 15), and lands at LDS slot l of the chunk (= row m, slot l % 16).
-    int a_src[A_PER_W];
+    // (byte offsets below 4 GB from the tile's scalar base: the DMA instructions take the scalar-base form, no 64-bit
+    // VALU address per instruction; laundered at each use so that the zero-extension is not hoisted into a register pair)
+    unsigned a_src[A_PER_W];
 #pragma unroll
     for (int p = 0; p < A_PER_W; ++p) {
         const int m = (wave + NWAVE * p) * A_ROWS + lane / BK;
         const int k = (lane & (BK - 1)) ^ (m & (BK - 1));
-        a_src[p] = m * g.lda + k;
+        a_src[p] = (unsigned)(m * g.lda + k) * 16u;
     }
-    int b_src[B_PER_W];
+    unsigned b_src[B_PER_W];
 #pragma unroll
     for (int p = 0; p < B_PER_W; ++p) {
         const int c = wave + NWAVE * p;
-        b_src[p] = (c / B_PER_ROW) * g.ldb + (c % B_PER_ROW) * 64 + lane;
+        b_src[p] = (unsigned)((c / B_PER_ROW) * g.ldb + (c % B_PER_ROW) * 64 + lane) * 16u;
     }
     long long off_a = (long long)batch_idx * g.batch_a, off_b = (long long)batch_idx * g.batch_b;
     long long off_c = (long long)batch_idx * g.batch_c;
@@ -971,20 +975,26 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
     const int seg_vec = lane < g.n_act ? g.seg_list[lane] : 0;
     // global -> LDS direct (no VGPR staging, no ds_write).
     auto dma_a = [&](int kt_, int seg, int buf) {
-        const double2* Ab = Abase + seg * g.a_seg_stride + kt_ * BK;
+        const char* Ab = reinterpret_cast<const char*>(Abase + seg * g.a_seg_stride + kt_ * BK);
         double2* Ad = As + buf * BK * BM;
 #pragma unroll
-        for (int p = 0; p < A_PER_W; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + a_src[p]),
+        for (int p = 0; p < A_PER_W; ++p) {
+            unsigned o = a_src[p];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + (unsigned long long)o),
                                              (lds_void_t*)(Ad + (wave + NWAVE * p) * 64), 16, 0, 0);
+        }
     };
     auto dma_b = [&](int kt_, int buf) {
-        const double2* Bb = Bbase + (size_t)(kt_ * BK) * g.ldb;
+        const char* Bb = reinterpret_cast<const char*>(Bbase + (size_t)(kt_ * BK) * g.ldb);
         double2* Bd = Bs + buf * BK * BN;
 #pragma unroll
-        for (int p = 0; p < B_PER_W; ++p)
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bb + b_src[p]),
+        for (int p = 0; p < B_PER_W; ++p) {
+            unsigned o = b_src[p];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bb + (unsigned long long)o),
                                              (lds_void_t*)(Bd + (wave + NWAVE * p) * 64), 16, 0, 0);
+        }
     };
     auto load_sc = [&](int seg, double (&scv)[NT]) {
 #pragma unroll
