@@ -714,12 +714,12 @@ __global__ __launch_bounds__(256) void rhs_stream_plane_kernel(StreamArgs a, con
 // (2 when a plane of A_seg is exactly zero).  Fragment maps (one f64 per lane):
 //     A[i = lane & 15][k = lane >> 4]     B[k = lane >> 4][j = lane & 15]
 //     D[row = (lane >> 4) + 4 * reg][col = lane & 15]
-// LDS tiles are k-major ([BK][BM] / [BK][BN] complex) so that a fragment read is one conflict-free
-// ds_read_b128 per lane (the 16-lane service groups of ds_read_b128 cover 16 distinct 16-B slots).
-// The A tile is transposed on its way into LDS (register staged, lane -> (m = l & 7, k = l >> 3),
-// 128-B global row pieces, conflict-free ds_write_b128); the B tile is a straight row copy.
-// Double-buffered LDS, one barrier per K tile; one MFMA is 64 cycles on a SIMD so each 16-deep K
-// tile is >= 8192 MFMA cycles per wave against ~1.5k cycles of staging work: MFMA bound.
+// Both tiles reach LDS by LDS-DMA (global_load_lds, no VGPR staging).  The A tile is laid out per k-step,
+// [k / 4][m][k % 4] complex, so that the 64 lanes of a fragment read (16 rows x 4 k) cover 1 KB contiguously: one
+// conflict-free ds_read_b128 per lane whose k-step and row block are immediate offsets (read_frags); the B tile is a
+// straight row copy [k][BN].  Double-buffered LDS, one barrier per K tile; one MFMA is 64 cycles on a SIMD so each
+// 16-deep K tile is >= 8192 MFMA cycles per SIMD.  Every VALU instruction in the tile loop, from either wave of the
+// SIMD, takes 3-7 of those cycles (tools/mfma_bank_probe.hip): the loop keeps addresses in SGPRs and immediates.
 // ------------------------------------------------------------------------------------------------
 struct GemmArgs {
     const double2* A;        // segment 0 base
@@ -848,19 +848,18 @@ __device__ __forceinline__ void mfma_kstep(const double2 (&a)[MT], const double2
 }
 
 // Fragment read of k-step ks from the LDS tiles.
-//   A tile in LDS: [m][BK slots] complex, element (m,k) at slot k ^ (m & (BK-1))  (XOR swizzle applied
-//   on the DMA *source* address: a fragment read -- 16 rows x 4 k per wave -- touches 16 distinct
-//   16-B slots in every ds_read_b128 lane group, i.e. it is bank-conflict free without padding,
-//   which LDS-DMA could not write).   B tile in LDS: [k][BN] complex, straight.
-template <int BK, int BN, int MT, int NT>
-__device__ __forceinline__ void read_frags(const double2* __restrict__ Ab, const double2* __restrict__ Bb,
-                                           int ks, int lk, int li, double2 (&a)[MT], double2 (&b)[NT]) {
-    const int k = ks * 4 + lk;
-    const int slot = k ^ (li & (BK - 1));
+//   A tile in LDS: [k-step][m][4 k] complex -- element (m, k) at ((k / 4) * BM + m) * 4 + (k % 4).  The 64 lanes of a
+//   fragment read (16 rows x 4 k of one k-step) cover 1 KB contiguously: conflict-free without a swizzle, and the k-step
+//   and the 16-row block are IMMEDIATE offsets of the ds_read (one address register per tile instead of one per k-step:
+//   every VALU instruction in the tile loop takes matrix-pipe cycles, tools/mfma_bank_probe.hip).
+//   B tile in LDS: [k][BN] complex, straight; `Bb` already points at this lane's row (k % 4) and column.
+template <int BM, int BN, int MT, int NT>
+__device__ __forceinline__ void read_frags(const double2* __restrict__ Ab, const double2* __restrict__ Bb, int ks,
+                                           double2 (&a)[MT], double2 (&b)[NT]) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = Ab[mt * 16 * BK + slot];
+    for (int mt = 0; mt < MT; ++mt) a[mt] = Ab[ks * (BM * 4) + mt * 64];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = Bb[k * BN + nt * 16];
+    for (int nt = 0; nt < NT; ++nt) b[nt] = Bb[ks * (4 * BN) + nt * 16];
 }
 
 // second launch-bound argument = waves per SIMD the register allocation must allow: the 4-wave
@@ -873,14 +872,14 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
     constexpr int TN = BN / WN;
     constexpr int MT = TM / 16;
     constexpr int NT = TN / 16;
-    constexpr int A_ROWS = 64 / BK;              // A rows per 1-KiB DMA piece (row = BK complex)
-    constexpr int A_CHUNKS = BM / A_ROWS;
+    constexpr int A_CHUNKS = BM * BK / 64;       // 1-KiB DMA pieces per A tile
     constexpr int B_PER_ROW = BN / 64;           // 1-KiB DMA pieces per B tile row
     constexpr int B_CHUNKS = BK * B_PER_ROW;
     constexpr int A_PER_W = A_CHUNKS / NWAVE;
     constexpr int B_PER_W = B_CHUNKS / NWAVE;
     static_assert(A_PER_W * NWAVE == A_CHUNKS && B_PER_W * NWAVE == B_CHUNKS, "DMA split");
-    static_assert(BK == 16 || BK == 8, "swizzle assumes 8 or 16 slots per A row");
+    static_assert(BK == 16 || BK == 8, "k-steps of 4");
+    static_assert(BM % 16 == 0, "16-row fragment blocks");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double2* As = reinterpret_cast<double2*>(smem_raw);             // [2][BM][16]
@@ -940,15 +939,17 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
             c2[i][j] = d4{0.0, 0.0, 0.0, 0.0};
         }
 
-    // LDS-DMA source offsets (per lane, fixed): lane l of chunk c fetches A row m = 4c + l/16,
-    // k = (l % 16) ^ (m & 15), and lands at LDS slot l of the chunk (= row m, slot l % 16).
+    // LDS-DMA source offsets (per lane, fixed)
     // (byte offsets below 4 GB from the tile's scalar base: the DMA instructions take the scalar-base form, no 64-bit
     // VALU address per instruction; laundered at each use so that the zero-extension is not hoisted into a register pair)
+    // A: the 1-KiB piece c of the LDS tile is k-step c / (BM/16), rows 16 (c % (BM/16)) .. +15: lane l fetches
+    // row + l / 4, k = 4 (k-step) + l % 4 (64 contiguous bytes of an operator row per four lanes)
     unsigned a_src[A_PER_W];
 #pragma unroll
     for (int p = 0; p < A_PER_W; ++p) {
-        const int m = (wave + NWAVE * p) * A_ROWS + lane / BK;
-        const int k = (lane & (BK - 1)) ^ (m & (BK - 1));
+        const int c = wave + NWAVE * p;
+        const int m = (c % (BM / 16)) * 16 + (lane >> 2);
+        const int k = (c / (BM / 16)) * 4 + (lane & 3);
         a_src[p] = (unsigned)(m * g.lda + k) * 16u;
     }
     unsigned b_src[B_PER_W];
@@ -979,9 +980,8 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
         double2* Ad = As + buf * BK * BM;
 #pragma unroll
         for (int p = 0; p < A_PER_W; ++p) {
-            unsigned o = a_src[p];
-            asm volatile("" : "+v"(o));
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + (unsigned long long)o),
+            asm volatile("" : "+v"(a_src[p]));   // (in place: no copy)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Ab + (unsigned long long)a_src[p]),
                                              (lds_void_t*)(Ad + (wave + NWAVE * p) * 64), 16, 0, 0);
         }
     };
@@ -990,9 +990,8 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
         double2* Bd = Bs + buf * BK * BN;
 #pragma unroll
         for (int p = 0; p < B_PER_W; ++p) {
-            unsigned o = b_src[p];
-            asm volatile("" : "+v"(o));
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bb + (unsigned long long)o),
+            asm volatile("" : "+v"(b_src[p]));
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(Bb + (unsigned long long)b_src[p]),
                                              (lds_void_t*)(Bd + (wave + NWAVE * p) * 64), 16, 0, 0);
         }
     };
@@ -1035,9 +1034,9 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
     // first k-step so that it has three k-steps (not two) to land ahead of the barrier
     constexpr bool DMA_EARLY = false;  // measured: issuing before the first k-step is 1.5 % slower
     double2 fa[MODE == 4 ? 1 : 2][MT], fb[MODE == 4 ? 1 : 2][NT];
-    const int a_lane_off = (wm * TM + lcol) * BK;
-    const int b_lane_off = wn * TN + lcol;
-    if (total > 0) read_frags<BK, BN, MT, NT>(As + a_lane_off, Bs + b_lane_off, 0, lk, lcol, fa[0], fb[0]);
+    const int a_lane_off = (wm * TM + lcol) * 4 + lk;
+    const int b_lane_off = lk * BN + wn * TN + lcol;
+    if (total > 0) read_frags<BM, BN, MT, NT>(As + a_lane_off, Bs + b_lane_off, 0, fa[0], fb[0]);
 
     int kt = SPARSE ? kt_first : 0, s = 0;
     int bb = 0;  // SPARSE: LDS buffer of the current B tile (toggles whenever the K tile changes)
@@ -1053,8 +1052,10 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
                 wvec_next = e < total ? g.work_idx[w0 + e] : 0;
             }
             kt_n = ent_n >> 8;
-            s_n = kt_n != kt ? 0 : 1;  // 0 = a new B tile is needed
-            bb_n = bb ^ (kt_n != kt ? 1 : 0);
+            // (integer arithmetic: a bool here is materialised in a VGPR and read back with v_readfirstlane)
+            const int newk = (int)((unsigned)((kt_n - kt) | (kt - kt_n)) >> 31);
+            s_n = newk ^ 1;  // 0 = a new B tile is needed
+            bb_n = bb ^ newk;
         } else if (s_n == g.n_act) {
             s_n = 0;
             kt_n = kt + 1;
@@ -1064,10 +1065,11 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
         const double2* Ab_n = As + ((it + 1) & 1) * BK * BM + a_lane_off;
         const double2* Bb_n = Bs + (SPARSE ? bb_n : (kt_n & 1)) * BK * BN + b_lane_off;
         const int mode = packed & 3;
+        const int more = (int)((unsigned)(it + 1 - total) >> 31);   // it + 1 < total, as an integer (stays in an SGPR)
         auto issue_next_tile = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             packed_n = SPARSE ? (ent_n & 255) : __builtin_amdgcn_readlane(seg_vec, s_n);
-            if (it + 1 < total && !MIDYN_ABL(g, 2)) {
+            if (more && !MIDYN_ABL(g, 2)) {
                 dma_a(kt_n, packed_n >> 2, (it + 1) & 1);
                 if (s_n == 0) dma_b(kt_n, SPARSE ? bb_n : (kt_n & 1));
             }
@@ -1082,12 +1084,12 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
                 mfma_kstep<MODE, MT, NT>(fa[0], fb[0], mode, sc, cre, cim, c2);
                 if (ks == 0) issue_next_tile();
                 if (ks + 1 < KS) {
-                    read_frags<BK, BN, MT, NT>(Ab, Bb, ks + 1, lk, lcol, fa[0], fb[0]);
+                    read_frags<BM, BN, MT, NT>(Ab, Bb, ks + 1, fa[0], fb[0]);
                 } else {
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (it + 1 < total) read_frags<BK, BN, MT, NT>(Ab_n, Bb_n, 0, lk, lcol, fa[0], fb[0]);
+                    if (more) read_frags<BM, BN, MT, NT>(Ab_n, Bb_n, 0, fa[0], fb[0]);
                 }
             }
         } else {
@@ -1095,15 +1097,15 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
             for (int ks = 0; ks < KS; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
                 if (ks + 1 < KS) {
-                    if (!MIDYN_ABL(g, 8)) read_frags<BK, BN, MT, NT>(Ab, Bb, ks + 1, lk, lcol, fa[nxt], fb[nxt]);
+                    if (!MIDYN_ABL(g, 8)) read_frags<BM, BN, MT, NT>(Ab, Bb, ks + 1, fa[nxt], fb[nxt]);
                 } else {
                     __builtin_amdgcn_sched_barrier(0);
                     if (!MIDYN_ABL(g, 1)) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __syncthreads();
                     }
-                    if (it + 1 < total && !MIDYN_ABL(g, 8))
-                        read_frags<BK, BN, MT, NT>(Ab_n, Bb_n, 0, lk, lcol, fa[nxt], fb[nxt]);
+                    if (more && !MIDYN_ABL(g, 8))
+                        read_frags<BM, BN, MT, NT>(Ab_n, Bb_n, 0, fa[nxt], fb[nxt]);
                 }
                 if (ks == 0 && DMA_EARLY) issue_next_tile();
                 mfma_kstep<MODE, MT, NT>(fa[cur], fb[cur], mode, sc, cre, cim, c2);
