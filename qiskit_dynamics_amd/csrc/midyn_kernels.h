@@ -91,66 +91,84 @@ struct Epilogue {
 // inlined into a store loop, hipcc 7.2 was seen to merge the branches' final stores through one
 // pointer register and leave it unset on one path -- see splitk_reduce_kernel -- so all kernels
 // dispatch on the mode ONCE, outside their store loops.)
+// Split in two so that a tile can LOAD a batch of elements before it stores any (store_tile_t): the arithmetic lives in
+// epilogue_finish, the loads in the callers.  v1 = y (RK1-3) or z (PLAIN / CHEB with an addend), v2 = acc.
 template <int EMODE>
-__device__ __forceinline__ void apply_epilogue_t(const Epilogue& e, int row, int col, double2 c) {
-    const size_t idx = (size_t)row * e.ld + col;
+struct EpiLoads {
+    static constexpr bool Y = EMODE == EPI_RK1 || EMODE == EPI_RK2 || EMODE == EPI_RK3;
+    static constexpr bool Z = EMODE == EPI_PLAIN || EMODE == EPI_CHEB;
+    static constexpr bool ACC = EMODE == EPI_RK2 || EMODE == EPI_RK3 || EMODE == EPI_RK4 || EMODE == EPI_TAYLOR || EMODE == EPI_CHEB;
+};
+
+template <int EMODE>
+__device__ __forceinline__ void epilogue_finish(const Epilogue& e, size_t idx, double2 c, double2 ecur, double2 enext,
+                                                double2 v1, double2 v2) {
     if (EMODE == EPI_PLAIN) {
         double2 r = make_double2(e.alpha * c.x, e.alpha * c.y);
         if (e.z) {
-            const double2 z = e.z[idx];
-            r.x = fma(e.beta, z.x, r.x);
-            r.y = fma(e.beta, z.y, r.y);
+            r.x = fma(e.beta, v1.x, r.x);
+            r.y = fma(e.beta, v1.y, r.y);
         }
         e.out[idx] = r;
         return;
     }
     double2 k = c;
-    if (e.e_cur) k = cmul_conj_a(e.e_cur[row], c);
+    if (e.e_cur) k = cmul_conj_a(ecur, c);
     if (EMODE == EPI_RHS) {
         e.out[idx] = k;
         // optional second output: the same result already phased for the product that consumes it next
         // (saves a separate re-phasing pass over the state block)
-        if (e.yin_next) e.yin_next[idx] = e.e_next ? cmul(e.e_next[row], k) : k;
+        if (e.yin_next) e.yin_next[idx] = e.e_next ? cmul(enext, k) : k;
         return;
     }
-    const double2 en = e.e_next ? e.e_next[row] : make_double2(1.0, 0.0);
+    const double2 en = e.e_next ? enext : make_double2(1.0, 0.0);
     const double h = e.h;
     if (EMODE == EPI_TAYLOR) {
         const double2 term = make_double2(h * k.x, h * k.y);
-        const double2 a = e.acc[idx];
-        e.acc[idx] = make_double2(a.x + term.x, a.y + term.y);
+        e.acc[idx] = make_double2(v2.x + term.x, v2.y + term.y);
         e.yin_next[idx] = cmul(en, term);
         return;
     }
     if (EMODE == EPI_CHEB) {
         double2 term = make_double2(e.alpha * k.x, e.alpha * k.y);
         if (e.z) {
-            const double2 z = e.z[idx];
-            term.x += z.x;
-            term.y += z.y;
+            term.x += v1.x;
+            term.y += v1.y;
         }
         e.out[idx] = term;
-        e.acc[idx] = cfma_r(e.beta, term, e.acc[idx]);
+        e.acc[idx] = cfma_r(e.beta, term, v2);
         e.yin_next[idx] = cmul(en, term);
         return;
     }
+    double2 next;
     if (EMODE == EPI_RK1) {
-        const double2 y = e.y[idx];
-        e.acc[idx] = cfma_r(h * (1.0 / 6), k, y);
-        e.yin_next[idx] = cmul(en, cfma_r(0.5 * h, k, y));
+        e.acc[idx] = cfma_r(h * (1.0 / 6), k, v1);
+        next = cmul(en, cfma_r(0.5 * h, k, v1));
     } else if (EMODE == EPI_RK2) {
-        const double2 y = e.y[idx];
-        e.acc[idx] = cfma_r(h * (1.0 / 3), k, e.acc[idx]);
-        e.yin_next[idx] = cmul(en, cfma_r(0.5 * h, k, y));
+        e.acc[idx] = cfma_r(h * (1.0 / 3), k, v2);
+        next = cmul(en, cfma_r(0.5 * h, k, v1));
     } else if (EMODE == EPI_RK3) {
-        const double2 y = e.y[idx];
-        e.acc[idx] = cfma_r(h * (1.0 / 3), k, e.acc[idx]);
-        e.yin_next[idx] = cmul(en, cfma_r(h, k, y));
+        e.acc[idx] = cfma_r(h * (1.0 / 3), k, v2);
+        next = cmul(en, cfma_r(h, k, v1));
     } else {  // EPI_RK4
-        const double2 yn = cfma_r(h * (1.0 / 6), k, e.acc[idx]);
+        const double2 yn = cfma_r(h * (1.0 / 6), k, v2);
         e.y[idx] = yn;
-        e.yin_next[idx] = cmul(en, yn);
+        next = cmul(en, yn);
     }
+    e.yin_next[idx] = next;
+}
+
+template <int EMODE>
+__device__ __forceinline__ void apply_epilogue_t(const Epilogue& e, int row, int col, double2 c) {
+    const size_t idx = (size_t)row * e.ld + col;
+    const double2 zero = make_double2(0.0, 0.0);
+    const double2 ecur = (EMODE != EPI_PLAIN && e.e_cur) ? e.e_cur[row] : zero;
+    const double2 enext = (EMODE != EPI_PLAIN && e.e_next) ? e.e_next[row] : zero;
+    double2 v1 = zero, v2 = zero;
+    if (EpiLoads<EMODE>::Y) v1 = e.y[idx];
+    if (EpiLoads<EMODE>::Z && e.z) v1 = e.z[idx];
+    if (EpiLoads<EMODE>::ACC) v2 = e.acc[idx];
+    epilogue_finish<EMODE>(e, idx, c, ecur, enext, v1, v2);
 }
 
 // run-time dispatch for a single element (stream kernel: one output per workgroup)
@@ -168,17 +186,44 @@ __device__ __forceinline__ void apply_epilogue(const Epilogue& e, int row, int c
 }
 
 // store a wave's accumulator tile through the epilogue: D[row = (lane>>4) + 4*reg][col = lane & 15]
+// One 16-row block of the wave tile at a time: ALL loads of the block first (4 NT elements: phases, y / z, acc), then the
+// arithmetic and the stores.  Element by element -- load, wait, store, and the next load behind the store because the
+// arrays may alias -- a tile of 64 elements per lane took 64 dependent trips to memory: 43 of the 57 us a launch of the
+// cfg 3 contraction spent outside its tile loop (round 3; tools/experiments/fixed_cost.py, ISA).
 template <int EMODE, int MT, int NT>
 __device__ __forceinline__ void store_tile_t(const Epilogue& e, int row0, int col0, const d4 (&cre)[MT][NT],
                                              const d4 (&cim)[MT][NT]) {
+    const double2 zero = make_double2(0.0, 0.0);
+    constexpr int RB = MT * NT >= 8 ? 2 : 4;   // rows of a 16-row block per batch (registers: the accumulators are still live)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mb = 0; mb < MT * (4 / RB); ++mb) {
+        const int mt = mb / (4 / RB), rb = (mb % (4 / RB)) * RB;
+        double2 ecur[RB], enext[RB], v1[RB][NT], v2[RB][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int r = 0; r < RB; ++r) {
+            const int row = row0 + mt * 16 + 4 * (rb + r);
+            ecur[r] = (EMODE != EPI_PLAIN && e.e_cur) ? e.e_cur[row] : zero;
+            enext[r] = (EMODE != EPI_PLAIN && e.e_next) ? e.e_next[row] : zero;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                apply_epilogue_t<EMODE>(e, row0 + mt * 16 + 4 * r, col0 + nt * 16,
-                                        make_double2(cre[mt][nt][r], cim[mt][nt][r]));
+            for (int nt = 0; nt < NT; ++nt) {
+                const size_t idx = (size_t)row * e.ld + col0 + nt * 16;
+                v1[r][nt] = zero;
+                v2[r][nt] = zero;
+                if (EpiLoads<EMODE>::Y) v1[r][nt] = e.y[idx];
+                if (EpiLoads<EMODE>::Z && e.z) v1[r][nt] = e.z[idx];
+                if (EpiLoads<EMODE>::ACC) v2[r][nt] = e.acc[idx];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int row = row0 + mt * 16 + 4 * (rb + r);
+                const size_t idx = (size_t)row * e.ld + col0 + nt * 16;
+                epilogue_finish<EMODE>(e, idx, make_double2(cre[mt][nt][rb + r], cim[mt][nt][rb + r]), ecur[r],
+                                            enext[r], v1[r][nt], v2[r][nt]);
+            }
+    }
 }
 
 template <int MT, int NT>
