@@ -73,3 +73,52 @@ def test_register_budgets_of_the_one_workgroup_per_cu_kernels(kernels):
             assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 128, (name, k[".vgpr_count"])
         if "rk4_resident_kernelILi" in name and "ELi8EL" in name:
             assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256, (name, k[".vgpr_count"])
+
+
+# ---- the tile loop of the MFMA contraction: every VALU instruction in it takes matrix-pipe cycles -------------------------
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _tile_loop(symbol_fragment, tmp_path):
+    """Instructions between the first and the last MFMA of the kernel whose mangled name contains the fragment."""
+    import subprocess
+
+    co = tmp_path / "midyn.co"
+    co.write_bytes(codeobj.extract_code_object(LIB))
+    text = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, check=True).stdout
+    lines = text.split("\n")
+    start = next(i for i, l in enumerate(lines) if symbol_fragment in l and l.rstrip().endswith(">:"))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].rstrip().endswith(">:"))
+    ops = [l.split("//")[0].split() for l in lines[start + 1:end]]
+    ops = [o for o in ops if o]
+    mf = [i for i, o in enumerate(ops) if o[0].startswith("v_mfma")]
+    return ops[mf[0]:mf[-1] + 1]
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm image not found")
+@pytest.mark.parametrize("fragment, mfmas", [
+    ("zgemm_seg_kernelILi128ELi128ELi2ELi4ELi16ELi2ELi2ELb1EE", 64),   # headline: work lists, single plane
+    ("zgemm_seg_kernelILi128ELi128ELi2ELi4ELi16ELi2ELi2ELb0EE", 64),   # dense, single plane
+    ("zgemm_seg_kernelILi128ELi128ELi2ELi4ELi16ELi0ELi2ELb0EE", 128),  # dense complex, 4M
+])
+def test_tile_loop_of_the_contraction_stays_lean(fragment, mfmas, tmp_path):
+    """Round 3 (tools/mfma_bank_probe.hip): a VALU instruction in the tile loop costs 3-7 cycles of the matrix
+    pipe whichever wave issues it; the loop went from 46 to 30 of them per tile (16 are the coefficient scalings).  Guards
+    what the compiler can silently undo: LDS-DMA in scalar-base form with SGPR destinations (no v_readfirstlane, no 64-bit
+    VALU address per DMA), fragment reads with immediate k-step offsets, no spills."""
+    if not os.path.exists(LIB):
+        pytest.skip("libmidyn.so has not been built")
+    loop = _tile_loop(fragment, tmp_path)
+    names = [o[0] for o in loop]
+    assert sum(n.startswith("v_mfma_f64_16x16x4") for n in names) == mfmas
+    valu = [n for n in names if n.startswith("v_") and not n.startswith("v_mfma")]
+    scalings = sum(n == "v_mul_f64" for n in valu)
+    assert 12 <= scalings <= 16            # (the loop is rotated: the first k-step's four precede the first MFMA)
+    assert len(valu) - scalings <= 30, valu          # static count incl. the once-per-64-entries list refill
+    dma = [o for o in loop if o[0].startswith("global_load_lds")]
+    assert dma and all(any(t.startswith("s[") for t in o) for o in dma), dma      # scalar base + 32-bit lane offset
+    reads = [o for o in loop if o[0] == "ds_read_b128"]
+    # (the six reads of the next tile's first k-step sit behind the barrier, outside this window; within a tile all but
+    # the first fragment of each operand carry their k-step / row block as an immediate)
+    assert len(reads) >= 18 and sum("offset:" in " ".join(o) for o in reads) >= len(reads) - 2
+    assert not any(n.startswith("scratch_") or n.startswith("buffer_") for n in names)
