@@ -1005,7 +1005,8 @@ def main():
                               "ms_interleaved": round(co[0], 3), "ms_mfma_only": round(co[1], 3),
                               "ms_vector_fma_only": round(co[2], 3),
                               "note": "interleaved = sum, not max: every fp64 VALU instruction in the contraction loop "
-                                      "costs matrix-pipe time"}}
+                                      "costs matrix-pipe time (tools/mfma_bank_probe.hip: so does every other VALU "
+                                      "instruction, 3-7 cycles each: 96 v_mov_b32 per 64 MFMAs run at 0.93 of the peak)"}}
 
     scaling = "weak" if args.weak else "strong"
     out = {
