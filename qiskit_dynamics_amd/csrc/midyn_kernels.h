@@ -845,14 +845,6 @@ __device__ __forceinline__ void mfma_kstep(const double2 (&a)[MT], const double2
     }
     const bool do_re = MODE == 3 ? (rt_mode != 2) : (MODE != 2);
     const bool do_im = MODE == 3 ? (rt_mode != 1) : (MODE != 1);
-    if (MODE == 1 || MODE == 2) {
-        // Only one plane of A feeds MFMAs here.  Without this (empty) use of the other half hipcc narrows the
-        // fragment loads to 8 bytes and pairs them as ds_read2st64_b64, whose 32-dword bank modulus makes the
-        // swizzled rows collide 2-way (rocprofv3: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 40 %, 16 LDS cycles
-        // per pair instead of 8).  Both halves live -> one conflict-free ds_read_b128 per fragment.
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(MODE == 1 ? a[mt].y : a[mt].x));
-    }
     double br[NT], bi[NT], bin[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -901,11 +893,25 @@ __device__ __forceinline__ void mfma_kstep(const double2 (&a)[MT], const double2
 //   16-byte slots modulo 256 B; unswizzled, rows m and m + 4 (k) / m + 8 (k + 1) share their banks (rocprofv3: bank
 //   conflicts 40 % of the LDS cycles).
 //   B tile in LDS: [k][BN] complex, straight; `Bb` already points at this lane's row (k % 4) and column.
-template <int BM, int BN, int MT, int NT>
+template <int BM, int BN, int MT, int NT, int HALF = 0>
 __device__ __forceinline__ void read_frags(const double2* __restrict__ Ab, const double2* __restrict__ Bb, int ks,
                                            double2 (&a)[MT], double2 (&b)[NT]) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = Ab[ks * (BM * 4) + mt * 64];
+    for (int mt = 0; mt < MT; ++mt) {
+        if (HALF == 0) {
+            a[mt] = Ab[ks * (BM * 4) + mt * 64];
+        } else {
+            // Only one plane (HALF 1: real, 2: imaginary) of A feeds MFMAs: an 8-byte read of that half.  volatile, in
+            // the LDS address space: left to itself hipcc pairs such reads as ds_read2st64_b64, whose 32-dword bank
+            // modulus makes the rows of a tile collide (round 1: 40 % of the LDS cycles; round 2 kept both halves live
+            // to stay on ds_read_b128 instead, at twice the register-file traffic).
+            typedef const volatile __attribute__((address_space(3))) double lds_vdouble_t;
+            const unsigned o = (unsigned)(unsigned long long)Ab + (unsigned)(ks * (BM * 4) + mt * 64) * 16u + 8u * (HALF - 1);
+            const double v = *(lds_vdouble_t*)(unsigned long long)o;
+            if (HALF == 1) a[mt].x = v;
+            else a[mt].y = v;
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b[nt] = Bb[ks * (4 * BN) + nt * 16];
 }
@@ -927,6 +933,9 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
     constexpr int B_PER_W = B_CHUNKS / NWAVE;
     static_assert(A_PER_W * NWAVE == A_CHUNKS && B_PER_W * NWAVE == B_CHUNKS, "DMA split");
     static_assert(BK == 16 || BK == 8, "k-steps of 4");
+    // single-plane stacks read only the plane of the operator fragments that feeds MFMAs (8-byte reads: half the VGPR
+    // write traffic of the operator fragments; dense single-plane kernel +2.9 %, work lists +0.3 %, round 3)
+    constexpr int A_HALF = MODE == 1 ? 1 : (MODE == 2 ? 2 : 0);
     static_assert(BM % 16 == 0, "16-row fragment blocks");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1086,7 +1095,7 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
     double2 fa[MODE == 4 ? 1 : 2][MT], fb[MODE == 4 ? 1 : 2][NT];
     const int a_lane_off = (wm * TM + lcol) * 4 + (lk ^ ((lcol >> 2) & 2));
     const int b_lane_off = lk * BN + wn * TN + lcol;
-    if (total > 0) read_frags<BM, BN, MT, NT>(As + a_lane_off, Bs + b_lane_off, 0, fa[0], fb[0]);
+    if (total > 0) read_frags<BM, BN, MT, NT, A_HALF>(As + a_lane_off, Bs + b_lane_off, 0, fa[0], fb[0]);
 
     int kt = SPARSE ? kt_first : 0, s = 0;
     int bb = 0;  // SPARSE: LDS buffer of the current B tile (toggles whenever the K tile changes)
@@ -1134,12 +1143,12 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
                 mfma_kstep<MODE, MT, NT>(fa[0], fb[0], mode, sc, cre, cim, c2);
                 if (ks == 0) issue_next_tile();
                 if (ks + 1 < KS) {
-                    read_frags<BM, BN, MT, NT>(Ab, Bb, ks + 1, fa[0], fb[0]);
+                    read_frags<BM, BN, MT, NT, A_HALF>(Ab, Bb, ks + 1, fa[0], fb[0]);
                 } else {
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (more) read_frags<BM, BN, MT, NT>(Ab_n, Bb_n, 0, fa[0], fb[0]);
+                    if (more) read_frags<BM, BN, MT, NT, A_HALF>(Ab_n, Bb_n, 0, fa[0], fb[0]);
                 }
             }
         } else {
@@ -1147,7 +1156,7 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
             for (int ks = 0; ks < KS; ++ks) {
                 const int cur = ks & 1, nxt = cur ^ 1;
                 if (ks + 1 < KS) {
-                    if (!MIDYN_ABL(g, 8)) read_frags<BM, BN, MT, NT>(Ab, Bb, ks + 1, fa[nxt], fb[nxt]);
+                    if (!MIDYN_ABL(g, 8)) read_frags<BM, BN, MT, NT, A_HALF>(Ab, Bb, ks + 1, fa[nxt], fb[nxt]);
                 } else {
                     __builtin_amdgcn_sched_barrier(0);
                     if (!MIDYN_ABL(g, 1)) {
@@ -1155,7 +1164,7 @@ __device__ __forceinline__ void zgemm_seg_body(const GemmArgs& g, const int batc
                         __syncthreads();
                     }
                     if (more && !MIDYN_ABL(g, 8))
-                        read_frags<BM, BN, MT, NT>(Ab_n, Bb_n, 0, fa[nxt], fb[nxt]);
+                        read_frags<BM, BN, MT, NT, A_HALF>(Ab_n, Bb_n, 0, fa[nxt], fb[nxt]);
                 }
                 if (ks == 0 && DMA_EARLY) issue_next_tile();
                 mfma_kstep<MODE, MT, NT>(fa[cur], fb[cur], mode, sc, cre, cim, c2);

@@ -117,7 +117,10 @@ def test_tile_loop_of_the_contraction_stays_lean(fragment, mfmas, tmp_path):
     assert len(valu) - scalings <= 30, valu          # static count incl. the once-per-64-entries list refill
     dma = [o for o in loop if o[0].startswith("global_load_lds")]
     assert dma and all(any(t.startswith("s[") for t in o) for o in dma), dma      # scalar base + 32-bit lane offset
-    reads = [o for o in loop if o[0] == "ds_read_b128"]
+    reads = [o for o in loop if o[0] in ("ds_read_b128", "ds_read_b64")]
+    assert not any(n.startswith("ds_read2") for n in names)      # (paired 8-byte reads collide in the banks)
+    if mfmas == 64:      # single plane: the operator fragments are 8-byte reads of the plane that feeds MFMAs
+        assert sum(o[0] == "ds_read_b64" for o in reads) >= 12
     # (the six reads of the next tile's first k-step sit behind the barrier, outside this window; within a tile all but
     # the first fragment of each operand carry their k-step / row block as an immediate)
     assert len(reads) >= 18 and sum("offset:" in " ".join(o) for o in reads) >= len(reads) - 2
