@@ -915,6 +915,11 @@ def main():
             "traffic": traffic3[0], "traffic_source": traffic3[1],
             "avg_launch_ms": round(avg_ms, 4), "launches_timed": 4 * args.steps,
             "avg_launch_ms_per_launch_events": round(cnt["ms"] / cnt["launches"], 4),
+            # dispatch order of THIS kernel in this process (what tools/summarize_rocprof.py slices a rocprofv3
+            # --kernel-trace of the same command by): warm-up, the timed repetitions (back to back), then the pass that
+            # brackets every launch with its own HIP events
+            "launch_sequence": [["warmup", 4 * args.warmup]] + [["timed_rep%d" % r, 4 * args.steps] for r in range(repeats)]
+                               + [["per_launch_events", 4 * prof_steps]],
             "executed_mfma_flops_per_launch": executed,
             "useful_flops_per_launch": useful, "useful_tflops": round(useful / (avg_ms * 1e-3) / 1e12, 3),
             "frac_survey_8d": round(useful / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
@@ -1081,11 +1086,13 @@ def main():
         el1, ev1, cn1, y_stage = one_trajectory(False)
         # the floor of the default route: the same launch geometry with the arithmetic switched off -- every round still
         # publishes its row and polls its neighbours' rows (results are meaningless, the time is the store -> poll hop)
+        os.environ["MIDYN_DEBUG_OPTIONS"] = "1"     # the library refuses this measurement switch otherwise
         ctx.set_option("resident_exchange_only", 1)
         try:
             el_floor, ev_floor, cn_floor, _ = one_trajectory(True)
         finally:
             ctx.set_option("resident_exchange_only", 0)
+            os.environ.pop("MIDYN_DEBUG_OPTIONS", None)
         c1 = cn1["rhs_stream"]
         took_resident = cn_res["rk4_resident"]["launches"] > 0
         nseg = stack.n_segments

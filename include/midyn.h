@@ -85,7 +85,8 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         route by itself (counter "resident_fallbacks").  -1 restores the default; 0 = give up at the
  *                         first missing word (tests)
  *   resident_exchange_only [0]   measurement only: rk4_resident_kernel publishes and polls every round but skips the
- *                         row product (results wrong) -- the store -> poll floor bench.py reports
+ *                         row product (results wrong) -- the store -> poll floor bench.py reports; refused (error)
+ *                         unless the process environment holds MIDYN_DEBUG_OPTIONS=1
  *   expm_action [1]       few columns, Magnus order <= 2: expm(Omega) y by matrix-vector products
  *   expm_degree [0]       0: Taylor degree of the dense expm chosen from the norm; else 2|4|6|9|12|16
  *   profile [0]           record HIP-event kernel times (midyn_get_counters)
@@ -308,6 +309,12 @@ int midyn_comm_destroy(midyn_ctx* ctx, void* nccl_comm);
 int midyn_comm_count(midyn_ctx* ctx, void* nccl_comm, int* ranks_out);   /* ncclCommCount: ranks of the communicator */
 int midyn_stack_create_empty(midyn_ctx* ctx, int n, int k, int has_static, int has_frame, midyn_stack** out);
 int midyn_stack_broadcast(midyn_stack* stack, void* nccl_comm, int root);
+/* The same broadcast OUT OF PLACE: the root sends `src`'s packed buffer (read on the root only; NULL elsewhere), every
+ * rank -- the root too -- receives into `dst` (same shape, normally from midyn_stack_create_empty) and derives its
+ * host-side lists from the received content, exactly as a non-root rank of midyn_stack_broadcast does.  With a
+ * one-rank communicator it is a copy through RCCL plus the receiving side, i.e. a single GPU can run what ranks
+ * 1..N-1 run.  midyn_stack_broadcast(s, comm, root) == midyn_stack_broadcast_from(s, s, comm, root). */
+int midyn_stack_broadcast_from(midyn_stack* dst, midyn_stack* src, void* nccl_comm, int root);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "midyn_sigtable_fetch", "midyn_sigtable_destroy", "midyn_parallel_solve", "midyn_expansion_create",
     "midyn_expansion_destroy", "midyn_expansion_solve", "midyn_ctx_timer", "midyn_stack_block_info",
     "midyn_comm_get_unique_id", "midyn_comm_init_rank", "midyn_comm_destroy", "midyn_comm_count", "midyn_stack_create_empty",
-    "midyn_stack_broadcast",
+    "midyn_stack_broadcast", "midyn_stack_broadcast_from",
 ]
 
 
@@ -176,6 +176,7 @@ def load():
         lib.midyn_comm_count.argtypes = [_vp, _vp, ctypes.POINTER(ctypes.c_int)]
         lib.midyn_stack_create_empty.argtypes = [_vp, _ci, _ci, _ci, _ci, P(_vp)]
         lib.midyn_stack_broadcast.argtypes = [_vp, _vp, _ci]
+        lib.midyn_stack_broadcast_from.argtypes = [_vp, _vp, _vp, _ci]
         for name in ABI_SYMBOLS:
             if name != "midyn_last_error":
                 getattr(lib, name).restype = _ci
@@ -412,6 +413,15 @@ class Stack:
     def broadcast(self, comm: "Comm", root: int = 0):
         """ONE RCCL broadcast of the packed stack from rank ``root`` (C-ABI ``midyn_stack_broadcast``)."""
         self.ctx.check(self.ctx.lib.midyn_stack_broadcast(self.handle, comm.handle, int(root)))
+        self._read_info()
+
+    def broadcast_from(self, src: "Stack | None", comm: "Comm", root: int = 0):
+        """The same broadcast out of place (C-ABI ``midyn_stack_broadcast_from``): ``self`` (normally ``Stack.empty``)
+        receives the packed buffer that rank ``root`` sends from ``src`` (``None`` off the root) and runs the receiving
+        side.  The host-side index maps of ``src`` (``set_permutation`` / ``set_embedding``) are not part of the packed
+        buffer: they travel separately (``distributed.broadcast_stack`` ships them with ``broadcast_object_list``)."""
+        self.ctx.check(self.ctx.lib.midyn_stack_broadcast_from(self.handle, None if src is None else src.handle,
+                                                               comm.handle, int(root)))
         self._read_info()
 
     def block_info(self) -> dict:

@@ -21,6 +21,7 @@ the model's signals (the reference's ``_set_new_signals`` is not reentrant).
 """
 from __future__ import annotations
 
+import time
 from typing import List, Optional, Tuple, Union
 
 import numpy as np
@@ -403,6 +404,7 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
                      and len(sched.step_h) >= AUTO_PARALLEL_MIN_STEPS and y0_dev.shape[-1] <= 64
                      and method in RK4_METHODS + EXPM_METHODS)
     route = "sequential"
+    t_wall = time.perf_counter()
     if auto_parallel:
         route = "parallel_in_time(auto)"
         ys = stack.parallel_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save,
@@ -418,18 +420,40 @@ def _solve_batch(model, t_span, y0_list, signals_list, method, t_eval=None, max_
     else:
         ys = stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
                               sched.n_save, magnus_order, y0_dev, batch, shared_y0)
+    wall_s = time.perf_counter() - t_wall
     if folded:  # (1, P, rows, B*m) -> (B, P, rows, m)
         _, p, rows, _ = ys.shape
         ys = ys.reshape(p, rows, n_inst, m_cols).transpose(2, 0, 1, 3)
         route += "+folded"
     elif replicate:
-        ys = np.repeat(ys, n_inst, axis=0)
         route += "+replicated"
+    extras = _result_extras(model, method, magnus_order, len(sched.step_h), wall_s)
     results = []
-    for y_b in _restore_batch(model, kind, tag, ys):
+    for y_b in _restore_batch(model, kind, tag, ys):     # (replicate: the ONE solved instance is restored ...)
         t_out, y_out = sched.trim(y_b)
-        results.append(OdeResult(t=t_out, y=y_out, route=route))
+        results.append(OdeResult(t=t_out, y=y_out, route=route, **extras))
+    if replicate:                                        # (... and the restored arrays are copied per instance)
+        one = results[0]
+        results = [one] + [OdeResult(t=one.t.copy(), y=one.y.copy(), route=route, **extras) for _ in range(n_inst - 1)]
     return results
+
+
+def _result_extras(model, method, magnus_order, n_steps, wall_s):
+    """The bookkeeping fields of an ``OdeResult`` besides ``t`` / ``y`` / ``route``:
+
+    ``nfev``    evaluations of the model per instance, as scipy counts them for its own methods (the reference passes
+                scipy's fields through, solvers/scipy_solve_ivp.py:84; its fixed-step results carry none,
+                solvers/fixed_step_solvers.py:445-459): 4 RHS evaluations per RK4 step; for the Magnus / expm methods
+                the generator evaluations per step (1, 2, 3 quadrature points for magnus_order 1, 2, 3);
+    ``wall_s``  wall-clock seconds of the ONE device call that solved the batch this instance belongs to (coefficient
+                table H2D, device loop, results D2H) -- shared by the instances of a batch, not a per-instance share;
+    ``device``  where it ran: ``"hip:<ordinal>"``."""
+    if method in RK4_METHODS + RK4_PARALLEL_METHODS:
+        per_step = 4
+    else:
+        per_step = int(magnus_order)
+    ctx = getattr(model, "_ctx", None)
+    return dict(nfev=int(per_step * n_steps), wall_s=float(wall_s), device=f"hip:{getattr(ctx, 'device', 0)}")
 
 
 def _rotate_density(model, mats, into_frame_basis):
@@ -459,13 +483,15 @@ def _solve_batch_lindblad(model, sched, y0_list, signals_list, shared_y0):
     rho0 = _rotate_density(model, np.stack(mats), True)
     rho0 = rho0[0] if shared_y0 else rho0
     table = _batch_table(model, signals_list, sched.times, batch, model._lind.k)
+    t_wall = time.perf_counter()
     ys = model._lind.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save,
                                rho0, batch, shared_y0)
+    extras = _result_extras(model, "RK4", 1, len(sched.step_h), time.perf_counter() - t_wall)
     ys = _rotate_density(model, ys, False)
     results = []
     for b in range(batch):
         t_out, y_out = sched.trim(ys[b])
-        results.append(OdeResult(t=t_out, y=y_out, route="sequential"))
+        results.append(OdeResult(t=t_out, y=y_out, route="sequential", **extras))
     return results
 
 
@@ -512,6 +538,7 @@ def _solve_ivp_device(model, t_span, y0, method, t_eval=None, signals=None, **kw
         start = np.concatenate([state0.ravel().real, state0.ravel().imag])
     else:
         fun, start = flat, state0.ravel()
+    t_wall = time.perf_counter()
     res = solve_ivp(fun, t_span=t_span, y0=start, t_eval=t_eval, method=method, **kwargs)
     ys = np.asarray(res.y)
     if embed_real:
@@ -521,8 +548,9 @@ def _solve_ivp_device(model, t_span, y0, method, t_eval=None, signals=None, **kw
         y_out = _rotate_density(model, ys, False)
     else:
         y_out = _restore_batch(model, kind, tag, ys[None])[0]
-    fields = dict(res)
-    fields.update(y=y_out, route="scipy_solve_ivp(device rhs)")
+    fields = dict(res)        # scipy's own fields (nfev, njev, nlu, status, message, success, ...) pass through
+    fields.update(y=y_out, route="scipy_solve_ivp(device rhs)", wall_s=float(time.perf_counter() - t_wall),
+                  device=f"hip:{getattr(getattr(model, '_ctx', None), 'device', 0)}")
     return OdeResult(**fields)
 
 

@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
     CHECK(midyn_expansion_solve); CHECK(midyn_ctx_timer); CHECK(midyn_stack_block_info);
     /* multi-GPU: the RCCL broadcast of the stack (librccl itself is only resolved at first use) */
     CHECK(midyn_comm_get_unique_id); CHECK(midyn_comm_init_rank); CHECK(midyn_comm_destroy); CHECK(midyn_comm_count);
-    CHECK(midyn_stack_create_empty); CHECK(midyn_stack_broadcast);
+    CHECK(midyn_stack_create_empty); CHECK(midyn_stack_broadcast); CHECK(midyn_stack_broadcast_from);
     /* a host-only entry point can be exercised without a GPU */
     int (*packed)(int, int, int, size_t*) = (int (*)(int, int, int, size_t*))dlsym(h, "midyn_stack_packed_bytes");
     size_t bytes = 0;

@@ -3,7 +3,9 @@
  * whose exact solution is y(T) = cos(theta) e0 - i sin(theta) e1 with theta = (w/2) int_0^T s = (w/2) sin(2 pi nu T) / (2 pi nu),
  * as a sweep of B instances with different drive strengths w_b -- fixed-step RK4 (midyn_rk4_solve) and the Magnus-2
  * propagator (midyn_expm_solve), a direct RHS evaluation (midyn_eval_rhs), and the one-rank RCCL broadcast of the
- * stack (midyn_comm_* / midyn_stack_broadcast).  Built and run by tests/test_gpu_production_shapes.py with gcc;
+ * stack (midyn_comm_* / midyn_stack_broadcast in place, then midyn_stack_broadcast_from into a stack made by
+ * midyn_stack_create_empty: the source is destroyed and EVERYTHING below runs on the received stack, i.e. on what a
+ * non-root rank holds).  Built and run by tests/test_gpu_production_shapes.py with gcc;
  * libmidyn.so and the HIP runtime are dlopen'ed exactly as a non-Python host would do it.
  * Exit code 0 and a line "ABI_SOLVE_OK ..." on success. */
 #include <dlfcn.h>
@@ -36,6 +38,8 @@ static int (*p_midyn_comm_get_unique_id)(void*);
 static int (*p_midyn_comm_init_rank)(midyn_ctx*, int, int, const void*, void**);
 static int (*p_midyn_comm_destroy)(midyn_ctx*, void*);
 static int (*p_midyn_stack_broadcast)(midyn_stack*, void*, int);
+static int (*p_midyn_stack_broadcast_from)(midyn_stack*, midyn_stack*, void*, int);
+static int (*p_midyn_stack_create_empty)(midyn_ctx*, int, int, int, int, midyn_stack**);
 
 #define CHECK(ctx, call)                                                              \
     do {                                                                              \
@@ -63,6 +67,7 @@ int main(int argc, char** argv) {
     LOAD(midyn_ctx_create) LOAD(midyn_ctx_destroy) LOAD(midyn_last_error) LOAD(midyn_stack_create)
     LOAD(midyn_stack_destroy) LOAD(midyn_eval_rhs) LOAD(midyn_rk4_solve) LOAD(midyn_expm_solve)
     LOAD(midyn_comm_get_unique_id) LOAD(midyn_comm_init_rank) LOAD(midyn_comm_destroy) LOAD(midyn_stack_broadcast)
+    LOAD(midyn_stack_broadcast_from) LOAD(midyn_stack_create_empty)
 
     midyn_ctx* ctx = NULL;
     CHECK(NULL, p_midyn_ctx_create(0, &ctx));
@@ -81,6 +86,12 @@ int main(int argc, char** argv) {
         CHECK(ctx, p_midyn_comm_get_unique_id(id));
         CHECK(ctx, p_midyn_comm_init_rank(ctx, 1, 0, id, &comm));
         CHECK(ctx, p_midyn_stack_broadcast(stack, comm, 0));
+        /* the receiving side with data: an empty stack of the same shape is filled through ncclBroadcast */
+        midyn_stack* received = NULL;
+        CHECK(ctx, p_midyn_stack_create_empty(ctx, N, K, 0, 0, &received));
+        CHECK(ctx, p_midyn_stack_broadcast_from(received, stack, comm, 0));
+        CHECK(ctx, p_midyn_stack_destroy(stack));
+        stack = received;
     }
 
     /* direct evaluation: G(t) y = c G_1 y */

@@ -209,3 +209,19 @@ def test_largest_affordable_operator_single_evaluation(qd):
         ref = (e.conj() * (g @ ey).T).T                   # conj(e) o (C (e o y))
         out = m.evaluate_rhs(t, y)
         assert_close(out, ref, 1e-11)
+
+
+def test_measurement_only_option_is_refused_without_the_debug_environment(qd, monkeypatch):
+    """`resident_exchange_only` makes rk4_resident_kernel skip its arithmetic (bench.py's store -> poll floor): an
+    ordinary caller of a shared context cannot switch it on -- the library refuses it unless MIDYN_DEBUG_OPTIONS=1 is
+    in the process environment; switching it OFF is always allowed."""
+    ctx = qd.default_context()
+    monkeypatch.delenv("MIDYN_DEBUG_OPTIONS", raising=False)
+    with pytest.raises(qd.DynamicsError, match="MIDYN_DEBUG_OPTIONS"):
+        ctx.set_option("resident_exchange_only", 1)
+    ctx.set_option("resident_exchange_only", 0)
+    monkeypatch.setenv("MIDYN_DEBUG_OPTIONS", "1")
+    try:
+        ctx.set_option("resident_exchange_only", 1)
+    finally:
+        ctx.set_option("resident_exchange_only", 0)

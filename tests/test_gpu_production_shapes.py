@@ -51,12 +51,17 @@ def _profiled(ctx, fn):
         ctx.set_option("profile", 0)
 
 
-@pytest.mark.usefixtures("per_launch_routes")
-def test_cfg5_shard_sparse_mfma_route_vs_oracle(qd):
+@pytest.mark.parametrize("route", ["default", "mfma_work_lists"])
+def test_cfg5_shard_vs_oracle(qd, route):
     """BASELINE cfg 5, the per-GPU shard of the 8-GPU run: 12 qubits (n = 4096), k = 8, diagonal rotating frame,
     scipy_expm with magnus_order = 2, max_dt = 0.25, T = 5 -> ALL 20 steps, 128 instances in ONE batched device
-    solve, dense random y0.  The launch counters must show the SPARSE MFMA work-list contraction.  Instances
-    0, 63 and 127 are compared with a CPU evaluation of the same 20 steps that uses the ORACLE's generators
+    solve, dense random y0.  Two routes, each asserted through the launch counters:
+
+      * "default": what the product (and bench.py's cfg5 leg) runs -- ONE launch of ell_sweep_kernel<2,4,1024,2>
+        (counter "rk4_resident" == 1 launch, "sweep_split" == (1 workgroup per instance, element form 2 = direct));
+      * "mfma_work_lists": option ell_sweep = 0, the SPARSE MFMA work-list contraction ("rhs_blocks_gemm").
+
+    Instances 0, 63 and 127 are compared with a CPU evaluation of the same 20 steps that uses the ORACLE's generators
     (oracle.generator_evaluate: G(t) = Delta(t) o (A_d + sum c_j A_j), dense, checked entry by entry against the
     CSR copy used for the matrix-vector products) and a commutator-free Taylor series of expm(Omega_2)
     (fixed_step_solvers.py:345-363 applied to a vector); all 128 instances are checked for norm conservation."""
@@ -74,11 +79,25 @@ def test_cfg5_shard_sparse_mfma_route_vs_oracle(qd):
     y0 = rng.normal(size=n) + 1j * rng.normal(size=n)
     y0 /= np.linalg.norm(y0)
     h, t_final = 0.25, 5.0
-    res = _profiled(ctx, lambda: solver.solve(t_span=[0.0, t_final], y0=y0, signals=sweeps, method="scipy_expm",
-                                              max_dt=h, magnus_order=2))
-    assert ctx.counters("rhs_blocks_gemm")["launches"] > 0, "the SPARSE MFMA work-list route did not run"
+    gave_up_before = ctx.counters("resident_fallbacks")["launches"]
+    ctx.set_option("ell_sweep", 1 if route == "default" else 0)
+    try:
+        res = _profiled(ctx, lambda: solver.solve(t_span=[0.0, t_final], y0=y0, signals=sweeps, method="scipy_expm",
+                                                  max_dt=h, magnus_order=2))
+    finally:
+        ctx.set_option("ell_sweep", 1)
+    if route == "default":
+        assert ctx.counters("rk4_resident")["launches"] == 1, "the one-launch sweep kernel did not take the solve"
+        split = ctx.counters("sweep_split")
+        assert (int(split["launches"]), int(split["ms"])) == (1, 2), f"not ell_sweep_kernel<2,4,1024,2>: {split}"
+        assert ctx.counters("rhs_blocks_gemm")["launches"] == 0
+        assert ctx.counters("resident_fallbacks")["launches"] == gave_up_before, "the sweep kernel gave up"
+    else:
+        assert ctx.counters("rhs_blocks_gemm")["launches"] > 0, "the SPARSE MFMA work-list route did not run"
+        assert ctx.counters("rk4_resident")["launches"] == 0
     assert ctx.counters("rhs_gemm")["launches"] == 0, "a dense contraction ran"
     assert all(r.route == "sequential" for r in res)
+    assert all(r.nfev == 2 * 20 and r.device == f"hip:{ctx.device}" and r.wall_s > 0 for r in res)   # Magnus 2: 2 / step
     finals = np.stack([r.y[-1] for r in res])
     assert np.max(np.abs(np.linalg.norm(finals, axis=1) - 1.0)) < 1e-11
 
@@ -118,6 +137,65 @@ def test_cfg5_shard_sparse_mfma_route_vs_oracle(qd):
                     acc = acc + term
                 y = acc
         assert_close(res[b].y[-1], y, SOLVE_TOL)
+
+
+@pytest.mark.parametrize("frame", ["no_frame", "diag_frame"])
+def test_cfg4_default_route_all_steps_vs_oracle(qd, frame):
+    """BASELINE cfg 4 exactly as bench.py's cfg4 leg times it: 6 qubits, N = 4096 superoperators built
+    on the device, 4 static dissipators, scipy_expm with magnus_order = 1, max_dt = 0.05, t_span = [0, 5] -> ALL 100
+    steps, one trajectory from the projector on e_0 -- once without a frame and once in the diagonal frame diag(H_d)
+    (the "second run" of 8(d)).  The launch counters must show the product's default route: the whole solve in ONE
+    launch of ell_resident_kernel<1, E> (counter "rk4_resident" == 1 launch, no per-product launches, no fallback).
+    Compared with the ORACLE's matrix form of the Lindbladian (oracle.lindblad_rhs: n x n products, frame phases of
+    models/lindblad_model.py:510-531) through the Magnus-1 step of fixed_step_solvers.py:345-349 applied to rho as a
+    scaled Taylor series of expm(h L(t + h/2)) -- 100 steps x 16 scalings x 24 terms, about half a minute of CPU."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+
+    ctx = qd.default_context()
+    cfg = workloads.lindblad_config()
+    frame_op = None if frame == "no_frame" else np.diag(cfg["h_d"]).real.copy()
+    sigs = _gauss_signals(qd, cfg, 0, 6, 2.5)
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       static_dissipators=cfg["static_dissipators"], rotating_frame=frame_op, vectorized=True)
+    assert solver.model.stack.n == 4096
+    h = cfg["max_dt"]
+    assert (h, cfg["t_span"]) == (0.05, [0.0, 5.0])
+    gave_up_before = ctx.counters("resident_fallbacks")["launches"]
+    res = _profiled(ctx, lambda: solver.solve(t_span=cfg["t_span"], y0=cfg["rho0"].flatten(order="F"), signals=sigs,
+                                              method="scipy_expm", max_dt=h))
+    assert ctx.counters("rk4_resident")["launches"] == 1, "not the one-launch ell_resident route"
+    assert ctx.counters("rhs_blocks")["launches"] == 0 and ctx.counters("rhs_stream")["launches"] == 0
+    assert ctx.counters("rhs_blocks_gemm")["launches"] == 0 and ctx.counters("zgemm")["launches"] == 0
+    assert ctx.counters("resident_fallbacks")["launches"] == gave_up_before, "the one-launch kernel gave up"
+    assert res.nfev == 100 and res.device == f"hip:{ctx.device}" and res.wall_s > 0   # Magnus 1: one G(t) per step
+    rho_dev = res.y[-1].reshape(64, 64, order="F")
+
+    h_d, h_ops, n_static, l_ops, d, basis = orc.lindblad_model_build(cfg["h_d"], cfg["ops"],
+                                                                     cfg["static_dissipators"], None, frame_op)
+    assert basis is None and (d is None) == (frame == "no_frame")
+    from threadpoolctl import threadpool_limits
+
+    n_steps = 100
+    rho = cfg["rho0"].astype(complex)
+    scal, degree = 16, 24                    # ||h L|| ~ 10 without a frame -> ||h L / 16|| < 0.7, 0.7^24 / 24! ~ 1e-28
+    with threadpool_limits(limits=1):        # 64 x 64 products: BLAS threads only add overhead
+        for st in range(n_steps):
+            t_mid = st * h + h / 2           # Magnus order 1: Omega = h L(t + h/2)
+            coeffs = np.array([np.real(s(t_mid)) for s in sigs])
+            for _ in range(scal):
+                term = rho
+                acc = rho.copy()
+                for j in range(1, degree + 1):
+                    term = orc.lindblad_rhs(h_d, h_ops, n_static, l_ops, coeffs, None, d, t_mid, term) * (h / (scal * j))
+                    acc = acc + term
+                rho = acc
+    assert_close(rho_dev, rho, SOLVE_TOL)
+    assert abs(np.trace(rho_dev) - 1.0) < 1e-11
+    assert np.linalg.norm(rho_dev - rho_dev.conj().T) < 1e-11
+    assert np.min(np.linalg.eigvalsh((rho_dev + rho_dev.conj().T) / 2)) > -1e-11
+    # the pulse has acted: the state is far from where it started (a test on a quiet window would pass a wrong operator)
+    assert np.linalg.norm(rho_dev - cfg["rho0"]) > 0.05
 
 
 @pytest.mark.usefixtures("per_launch_routes")
@@ -299,6 +377,7 @@ def test_shared_signal_sweep_is_folded_into_columns(qd):
     # identical instances (same signals AND the same y0 object): one solve, replicated
     same = solver.solve(t_span=[[0.0, 0.2]] * 3, y0=y0m[2], signals=sigs, method="RK4", max_dt=0.01)
     assert len(same) == 3 and same[0].route.endswith("+replicated")
+    assert same[1].y is not same[0].y and np.array_equal(same[1].y, same[0].y) and same[2].nfev == 4 * 20
     assert_close(same[1].y, one.y, 1e-11)
     # beyond FOLD_MAX_COLUMNS the instances stay instances
     from qiskit_dynamics_amd import solvers as S
@@ -313,10 +392,11 @@ def test_shared_signal_sweep_is_folded_into_columns(qd):
 
 
 def test_stack_broadcast_over_the_c_abi_one_rank(qd):
-    """midyn_comm_get_unique_id / midyn_comm_init_rank / midyn_stack_create_empty / midyn_stack_broadcast on one
-    GPU (world size 1: the RCCL broadcast is a self-copy): librccl is resolved at first use, the communicator is
-    bound to the context's device, the stack works after the call and lazily built lists are rebuilt.  The
-    N > 1 use of the same entry points is bench.py --gpus N (driver's scaling run)."""
+    """midyn_comm_get_unique_id / midyn_comm_init_rank / midyn_stack_create_empty / midyn_stack_broadcast /
+    midyn_stack_broadcast_from on one GPU (world size 1): librccl is resolved at first use, the communicator is bound
+    to the context's device, the stack works after the in-place call and lazily built lists are rebuilt; the
+    out-of-place call fills an empty stack, which then evaluates bit-identically.  The N > 1 use of the same entry
+    points is bench.py --gpus N (driver's scaling run)."""
     from qiskit_dynamics_amd import _lib
 
     ctx = qd.default_context()
@@ -334,14 +414,85 @@ def test_stack_broadcast_over_the_c_abi_one_rank(qd):
     stack.broadcast(comm, 0)
     assert stack.n == n and stack.k == k and stack.n_active_segments == k + 1
     assert np.array_equal(stack.eval_rhs(c, 0.3, y), before)
-    # a receiving-side stack: empty until a broadcast fills it (here: filled by a device copy of the packed buffer
-    # is not possible from Python, so only the shape / zero content are checked)
+    # a receiving-side stack: empty until a broadcast fills it -- the out-of-place broadcast of a one-rank
+    # communicator is a copy through RCCL followed by the receiving side (stack_after_receive)
     empty = _lib.Stack.empty(ctx, n, k, True, True)
     assert empty.n == n and empty.n_active_segments == 0
+    empty.broadcast_from(stack, comm, 0)
+    assert empty.n_active_segments == k + 1 and empty.segment_modes == stack.segment_modes
+    assert np.array_equal(empty.eval_rhs(c, 0.3, y), before)
+    assert np.array_equal(empty.eval_generator(c, 0.3), stack.eval_generator(c, 0.3))
     with pytest.raises(qd.DynamicsError):
         stack.broadcast(comm, 3)                     # root out of range
+    other = _lib.Stack.empty(ctx, n, k + 1, True, True)
+    with pytest.raises(qd.DynamicsError):
+        other.broadcast_from(stack, comm, 0)         # shapes differ
     comm.close()
     empty.close()
+    other.close()
+
+
+def test_receiving_rank_of_the_stack_broadcast_runs_the_headline_solve(qd):
+    """What ranks 1..N-1 of `bench.py --gpus N` do, on ONE GPU and with data: the sector-grouped stack of the 10-qubit
+    model (BASELINE configs[2]: n = 1024, k = 8, rotating_frame = H_d) is sent through ncclBroadcast into a stack
+    from midyn_stack_create_empty (midyn_stack_broadcast_from, one-rank communicator); the receiving side re-derives
+    plane flags, active-segment lists and -- lazily -- the tile work lists from the RECEIVED buffer.  The product
+    Solver then runs the headline sweep (512 instances x 20 RK4 steps, active pulse window) once on the stack it built
+    and once on the received one: same route (128 x 128 SPARSE work-list tile, same listed tiles and split count,
+    no dense launch) and `np.array_equal` final states; instance 100 against the oracle.  Reference seam:
+    solvers/solver_classes.py:568-586 (the sequential instance loop the shards replace)."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import _lib, workloads
+    from threadpoolctl import threadpool_limits
+
+    ctx = qd.default_context()
+    cfg = workloads.schrodinger_config()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+    src = solver.model.stack
+    assert src.n >= 1024 and src.slot is not None, "the sector-grouped stack was expected"
+    nb, t_span = 512, [2.4, 2.5]
+    sweeps = [_gauss_signals(qd, cfg, b, 8, 2.5) for b in range(nb)]
+    rng = np.random.default_rng(77)
+    y0 = crand(rng, 1024)
+    y0 /= np.linalg.norm(y0)
+
+    def run():
+        res = _profiled(ctx, lambda: solver.solve(t_span=t_span, y0=y0, signals=sweeps, method="RK4",
+                                                  max_dt=cfg["max_dt"]))
+        counts = {c: ctx.counters(c) for c in ("rhs_blocks_gemm", "rhs_gemm", "sparse_tile", "sparse_list")}
+        return np.stack([r.y[-1] for r in res]), counts
+
+    built, c_built = run()
+    assert c_built["rhs_blocks_gemm"]["launches"] == 80 and c_built["rhs_gemm"]["launches"] == 0, c_built
+
+    comm = _lib.Comm(ctx, 1, 0, _lib.Comm.unique_id())
+    dst = _lib.Stack.empty(ctx, src.n, src.k, src.has_static, src.has_frame)
+    assert dst.n_active_segments == 0
+    dst.broadcast_from(src, comm, 0)
+    comm.close()
+    dst.set_embedding(src.slot)        # host-side index map: travels beside the buffer (distributed.broadcast_stack)
+    assert dst.n_active_segments == src.n_active_segments and dst.segment_modes == src.segment_modes
+    assert dst.block_info() == src.block_info()
+    solver.model._stack = dst          # the solver of a receiving rank holds the received stack
+    try:
+        received, c_recv = run()
+    finally:
+        solver.model._stack = src
+    assert c_recv == c_built or all(c_recv[c]["launches"] == c_built[c]["launches"] for c in c_built), (c_recv, c_built)
+    assert (int(c_recv["sparse_tile"]["launches"]), int(c_recv["sparse_tile"]["ms"])) == (128, 128)
+    assert c_recv["sparse_list"] == c_built["sparse_list"]
+    assert np.array_equal(received, built), f"received stack: max|d| = {np.max(np.abs(received - built)):.3e}"
+    dst.close()
+
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], cfg["h_d"])
+    amps, phases = workloads.sweep_parameters(100, 8)
+
+    def coeffs(t):
+        return workloads.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], cfg["t_final"])[0]
+
+    with threadpool_limits(limits=8):
+        _, yref = orc.solve_generator_model(a_d, a, d, basis, coeffs, t_span, y0, "RK4", cfg["max_dt"])
+    assert_close(received[100], yref[-1], SOLVE_TOL)
 
 
 def test_abi_broadcast_probe_in_a_child_process(qd, monkeypatch):

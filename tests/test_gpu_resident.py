@@ -223,6 +223,78 @@ def test_resident_kernel_cfg2_shape(qd):
     assert_close(res.y[-1], ref[-1], SOLVE_TOL)
 
 
+def _cfg2_solver_and_oracle(qd, b=3):
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    cfg = W.schrodinger_config()
+    k = len(cfg["ops"])
+    amps, phases = W.sweep_parameters(b, k)
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
+            for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+    model = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], cfg["h_d"])   # plain eigh, no symmetry sectors
+
+    def coeff(t):
+        return W.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], 5.0)[0]
+
+    return cfg, sigs, solver, model, coeff
+
+
+def test_resident_kernel_cfg2_active_pulse_window(qd):
+    """BASELINE configs[1], 40 RK4 steps in t = [2.4, 2.6] -- the top of the Gaussian envelopes, where the drive
+    operators carry their full weight (on [0, 0.2] the envelopes are at 4 % of their peak and a relative operator
+    error of 1e-5 would pass the 1e-9 gate): the resident kernel (one launch, counter asserted) against the oracle
+    from a dense random state."""
+    from oracle import dynamics_oracle as orc
+
+    cfg, sigs, solver, (a_d, a, d, basis), coeff = _cfg2_solver_and_oracle(qd)
+    rng = np.random.default_rng(24)
+    y0 = crand(rng, 1024)
+    y0 /= np.linalg.norm(y0)
+    res, per_stage, l_res, l_off = _solve_both(qd, solver, t_span=[2.4, 2.6], y0=y0, signals=sigs, method="RK4",
+                                               max_dt=0.005)
+    assert (l_res, l_off) == (1, 0)
+    assert_close(res.y, per_stage.y, 1e-13)
+    _, ref = orc.solve_generator_model(a_d, a, d, basis, coeff, [2.4, 2.6], y0, "RK4", 0.005)
+    assert_close(res.y[-1], ref[-1], SOLVE_TOL)
+    assert np.linalg.norm(ref[-1] - ref[0]) > 2e-3      # the drives have acted inside the window (10x the quiet one)
+
+
+def test_resident_kernel_cfg2_all_1000_steps_one_launch_vs_oracle(qd):
+    """BASELINE configs[1] exactly as bench.py times it: the product `Solver` of the 10-qubit model (n = 1024, 8
+    drives, rotating_frame = H_d), ONE trajectory from e_0, RK4 with max_dt = 0.005 over t_span = [0, 5] -> all 1000
+    steps (4000 RHS evaluations) in ONE launch of rk4_resident_kernel (counter asserted, no fallback), against
+    oracle.solve_generator_model (fixed_step_solvers.py:43-77,406-459; plain eigh) over the same 1000 steps --
+    about half a minute of CPU."""
+    from threadpoolctl import threadpool_limits
+
+    from oracle import dynamics_oracle as orc
+
+    ctx = qd.default_context()
+    cfg, sigs, solver, (a_d, a, d, basis), coeff = _cfg2_solver_and_oracle(qd, b=0)
+    assert (cfg["t_span"], cfg["max_dt"]) == ([0.0, 5.0], 0.005)
+    gave_up_before = ctx.counters("resident_fallbacks")["launches"]
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    try:
+        res = solver.solve(t_span=cfg["t_span"], y0=cfg["y0"], signals=sigs, method="RK4", max_dt=cfg["max_dt"])
+    finally:
+        ctx.set_option("profile", 0)
+    assert ctx.counters("rk4_resident")["launches"] == 1, "the 1000 steps did not run as one resident launch"
+    for cls in ("rhs_stream", "rhs_gemm", "rhs_blocks", "rhs_blocks_gemm"):
+        assert ctx.counters(cls)["launches"] == 0, f"a per-stage kernel ({cls}) ran"
+    assert ctx.counters("resident_fallbacks")["launches"] == gave_up_before
+    # bookkeeping fields of the result (scipy's names; the reference passes them through for its scipy methods)
+    assert res.nfev == 4000 and res.device == f"hip:{ctx.device}" and 0.0 < res.wall_s < 60.0
+    assert res.route == "sequential"
+    with threadpool_limits(limits=8):   # the oracle's matvecs run best on a few BLAS threads (see bench.py)
+        _, ref = orc.solve_generator_model(a_d, a, d, basis, coeff, cfg["t_span"], cfg["y0"], "RK4", cfg["max_dt"])
+    assert_close(res.y[-1], ref[-1], SOLVE_TOL)
+    assert abs(np.linalg.norm(res.y[-1]) - 1.0) < 1e-8
+    assert np.linalg.norm(res.y[-1] - res.y[0]) > 0.03  # the pulses have moved the state
+
+
 def _chain_diag_frame(qd, nq):
     """nq-qubit chain in the DIAGONAL frame diag(H_d): the operators stay in the computational basis, a handful of
     non-zeros per row (block-sparse stack with work lists)."""

@@ -469,3 +469,22 @@ def test_sector_layout_and_stack_embedding_host_side():
         st.set_embedding(np.array([0, 0, 1]))
     with pytest.raises(_lib.DynamicsError):
         st.set_embedding(np.arange(st.n + 1))
+
+
+def test_result_bookkeeping_fields():
+    """`OdeResult.nfev / wall_s / device` of the fixed-step HIP methods: nfev as scipy counts its own
+    methods -- 4 RHS evaluations per RK4 step, the generator evaluations per step for the Magnus / expm methods
+    (the reference passes scipy's fields through, solvers/scipy_solve_ivp.py:84)."""
+    from qiskit_dynamics_amd import solvers as S
+
+    class Ctx:
+        device = 3
+
+    class Model:
+        _ctx = Ctx()
+
+    assert S._result_extras(Model(), "RK4", 1, 1000, 0.25) == dict(nfev=4000, wall_s=0.25, device="hip:3")
+    assert S._result_extras(Model(), "hip_RK4_parallel", 1, 10, 0.0)["nfev"] == 40
+    for order in (1, 2, 3):
+        assert S._result_extras(Model(), "scipy_expm", order, 20, 0.0)["nfev"] == order * 20
+        assert S._result_extras(Model(), "hip_expm_parallel", order, 20, 0.0)["nfev"] == order * 20
