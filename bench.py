@@ -389,6 +389,48 @@ def profile_pass(ctx, fn, classes):
 ALL_CLASSES = ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", "rhs_blocks", "rhs_blocks_gemm", "rk4_resident")
 
 
+def leg_cfg4_diag_frame(qd, ctx, workloads):
+    """cfg 4's "second run" of SURVEY 8(d): the same Lindbladian in the diagonal rotating frame diag(H_d), the same 100
+    steps through the product's default route (pinned to the oracle at this shape by
+    tests/test_gpu_production_shapes.py::test_cfg4_default_route_all_steps_vs_oracle[diag_frame])."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+
+    cfg = workloads.lindblad_config()
+    frame = np.diag(cfg["h_d"]).real.copy()
+    t0 = time.perf_counter()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
+                       static_dissipators=cfg["static_dissipators"], rotating_frame=frame, vectorized=True)
+    build_s = time.perf_counter() - t0
+    stack = solver.model.stack
+    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(1))
+    table, _, _ = sweep_table(workloads, sched.times, 0, 1, 6, cfg["carrier"], cfg["t_final"])
+    y0 = cfg["rho0"].flatten(order="F").reshape(-1, 1)
+
+    def run():
+        return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 1,
+                                y0, 1, True)
+
+    run()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    ys = run()
+    dev_ms = ctx.timer_stop()
+    wall = time.perf_counter() - t0
+    cs = profile_pass(ctx, run, ALL_CLASSES)
+    n_steps = len(sched.step_h)
+    rho = ys[0, -1, :, 0].reshape(64, 64, order="F")
+    out = {"workload": "cfg4, second run of SURVEY 8(d): the same model in the diagonal rotating frame diag(H_d)",
+           "steps": n_steps, "solve_s": round(wall, 4), "ms_per_step": round(wall / n_steps * 1e3, 4),
+           "stream_ms_per_step": round(dev_ms / n_steps, 4), "model_build_s": round(build_s, 2),
+           "route": "ell_resident_kernel<1>: the whole solve in ONE launch" if cs["rk4_resident"]["launches"] == 1
+                    else "one launch per product",
+           "launches": {c: int(v["launches"]) for c, v in cs.items() if v["launches"]},
+           "trace_deviation": float(abs(np.trace(rho) - 1.0)), "hermiticity": float(np.linalg.norm(rho - rho.conj().T))}
+    del solver
+    return out
+
+
 def leg_cfg4(qd, ctx, workloads):
     """cfg 4: 6-qubit vectorised Lindbladian (N = 4096 superoperators built on the device), 4 static dissipators,
     scipy_expm magnus_order 1, max_dt 0.05, T = 5 -> 100 steps, one trajectory ("replicas only")."""
@@ -872,9 +914,10 @@ def main():
     # launch duration from the SAME back-to-back region as ms_per_step: HIP events on the stream the kernel runs on
     # around the K steps, divided by the 4K launches (+ a per-launch event pass for the launch count / class check)
     prof_steps = min(args.steps, 10)
-    cnts = profile_pass(ctx, lambda: plan.run(total - prof_steps, total), ("rhs_gemm", "rhs_blocks_gemm"))
+    cnts = profile_pass(ctx, lambda: plan.run(total - prof_steps, total), ("rhs_gemm", "rhs_blocks_gemm", "rhs_combine"))
+    on_combine = cnts["rhs_combine"]["launches"] > 0        # sweeps: combine (MFMA over the operator planes) + apply (VALU)
     on_lists = cnts["rhs_blocks_gemm"]["launches"] > 0      # symmetry sectors: the contraction runs on tile work lists
-    cnt = cnts["rhs_blocks_gemm"] if on_lists else cnts["rhs_gemm"]
+    cnt = cnts["rhs_combine"] if on_combine else (cnts["rhs_blocks_gemm"] if on_lists else cnts["rhs_gemm"])
     roofline = None
     n_launch_per_step = cnt["launches"] / prof_steps if cnt["launches"] else 0
     modes = stack.segment_modes if not args.dense else [0] * stack.n_segments
@@ -885,7 +928,31 @@ def main():
         stack_um = act_modes[0] if act_modes and all(m == act_modes[0] for m in act_modes) else 3
         single_plane = (not args.dense) and all(m in (1, 2) for m in act_modes)
         extra = {}
-        if on_lists:
+        if on_combine:
+            info = ctx.counters("combine_info")
+            shape = ctx.counters("combine_shape")
+            entries, code = info["launches"], int(info["ms"])
+            nre4, nim4, stat = code // 100, (code // 10) % 10, code % 10
+            kinds = int(nre4 > 0 or (stat & 1)) + int(nim4 > 0 or (stat & 2))
+            pairs = entries * 16 * 32 * float(p_ld := (-(-b_loc // 128) * 128))   # listed (row, kk) positions x state columns
+            mfma_flops = 2.0 * 4 * (nre4 + nim4) * pairs          # one MFMA-FMA per plane slot (padding slots included)
+            valu_flops = 2.0 * (2 if kinds == 1 else 4) * pairs   # apply: 2 (one plane kind) or 4 vector FMAs
+            executed = mfma_flops + valu_flops
+            gemm_equiv = sum(4 if m in (1, 2) else 8 for m in modes if m != 3) * n * n * b_loc
+            kname = "rhs_combine_kernel<%d, %d, %d>" % (nre4, nim4, stat)
+            extra = {"combine_apply": {
+                "listed_entries": int(entries), "listed_fraction": round(entries / ((n // 32) * (n // 16)), 4),
+                "plane_groups_re_im": [nre4, nim4], "static_planes": stat,
+                "row_group_x_column_block_pairs_per_workgroup": int(shape["launches"]), "list_splits": int(shape["ms"]),
+                "mfma_flops_per_launch": mfma_flops, "vector_fma_flops_per_launch": valu_flops,
+                "fmas_per_row_kk_instance": 4 * (nre4 + nim4) + (2 if kinds == 1 else 4),
+                "dense_gemm_formulation_flops_per_launch": gemm_equiv,
+                "why": "sum_j c_j[b] G_j is combined per instance first (one v_mfma_f64_16x16x4 per 4 operator planes: 16 rows x "
+                       "16 instances x 4 planes, every FMA useful) and then applied to the state (2 vector FMAs per element for "
+                       "purely imaginary generators) -- the reference's own order of operations (operator_collections.py:"
+                       "101-134) -- instead of k + 1 GEMMs (2 MFMA-FMAs per plane and element); exactly-zero 16-column "
+                       "blocks of a 32-row group (parity sectors) are not listed"}}
+        elif on_lists:
             tile = ctx.counters("sparse_tile")
             lst = ctx.counters("sparse_list")
             bm, bn = int(tile["launches"]), int(tile["ms"])
@@ -909,7 +976,10 @@ def main():
         tf = executed / (avg_ms * 1e-3) / 1e12
         traffic3 = measured_traffic(kname)
         roofline = {
-            "kernel": kname.rstrip(",") + " (batched RHS contraction, fp64 MFMA 16x16x4)", "bound": "mfma",
+            "kernel": kname.rstrip(",") + (" (sweep contraction: fp64 MFMA 16x16x4 over the operator planes + fp64 vector FMAs; "
+                                           "both on the SIMD's one fp64 pipe, whose matrix peak and vector peak are the same "
+                                           "78.6 TFLOP/s)" if on_combine else " (batched RHS contraction, fp64 MFMA 16x16x4)"),
+            "bound": "mfma",
             "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
             "traffic": traffic3[0], "traffic_source": traffic3[1],
@@ -959,24 +1029,56 @@ def main():
     # ---- the same sweep without the symmetry-sector work lists, and as general dense-complex operators ----------
     dense = None
     same_model_dense = None
+    gemm_route = None
+    if not args.dense and roofline and world == 1 and on_combine:
+        # the MFMA GEMM formulation of the same sweep (the default route until round 3): work-list tiles, k + 1 GEMMs
+        avg_g = timed_variant({"combine": 0})
+        ex_g = None
+        lst_g = ctx.counters("sparse_list")
+        tile_g = ctx.counters("sparse_tile")
+        if lst_g["launches"] > 0:
+            ex_g = lst_g["launches"] * tile_g["launches"] * 16 * (-(-b_loc // int(tile_g["ms"])) * int(tile_g["ms"])) * 4
+        gemm_route = {"option": "combine=0", "avg_launch_ms": round(avg_g, 4), "rhs_evals_per_s": round(b_loc / (avg_g * 1e-3), 1),
+                      "executed_tflops": round(ex_g / (avg_g * 1e-3) / 1e12, 3) if ex_g else None,
+                      "frac": round(ex_g / (avg_g * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if ex_g else None,
+                      "what": "zgemm_seg_kernel<128,128,...,SPARSE> on the sector work lists: k GEMMs whose results are scaled "
+                              "and summed (16 MFMA-FMAs per element against 10 FMAs of combine + apply); same results to rounding"}
     if not args.dense and roofline and world == 1:
         plan.close()
-        if on_lists:
-            avg_k = timed_variant({"skip_zero_blocks": 0})
+        if on_lists or on_combine:
+            avg_k = timed_variant({"skip_zero_blocks": 0, "combine": 0} if on_combine else {"skip_zero_blocks": 0})
             ex_k = sum(4 if m in (1, 2) else 8 for m in modes if m != 3) * n * n * b_loc
             same_model_dense = {"avg_launch_ms": round(avg_k, 4), "rhs_evals_per_s": round(b_loc / (avg_k * 1e-3), 1),
                                 "executed_tflops": round(ex_k / (avg_k * 1e-3) / 1e12, 3),
                                 "frac": round(ex_k / (avg_k * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
-                                "what": "dense 128x128 kernel on the same stack (skip_zero_blocks=0): multiplies the "
-                                        "exactly-zero blocks too; bit-identical results"}
+                                "what": "dense 128x128 MFMA GEMM kernel on the same stack (skip_zero_blocks=0, combine=0): "
+                                        "multiplies the exactly-zero blocks too"}
         avg_d = timed_variant({"skip_zero_planes": 0})
-        ex_d = 6 * stack.n_segments * n * n * b_loc   # 3M: 3 real MFMA products per complex product
+        info_d = ctx.counters("combine_info")
+        took_combine_d = on_combine and info_d["launches"] > 0 and int(info_d["ms"]) // 100 > 0
+        if took_combine_d:
+            code_d = int(info_d["ms"])
+            nq_d = code_d // 100 + (code_d // 10) % 10
+            ex_d = (2.0 * 4 * nq_d + 8.0) * info_d["launches"] * 16 * 32 * (-(-b_loc // 128) * 128)
+        else:
+            ex_d = 6 * stack.n_segments * n * n * b_loc   # 3M: 3 real MFMA products per complex product
         dense = {"avg_launch_ms": round(avg_d, 4), "rhs_evals_per_s": round(b_loc / (avg_d * 1e-3), 1),
                  "useful_tflops": round(useful / (avg_d * 1e-3) / 1e12, 3),
+                 "frac_survey_8d_useful": round(useful / (avg_d * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
                  "executed_tflops": round(ex_d / (avg_d * 1e-3) / 1e12, 3),
                  "frac": round(ex_d / (avg_d * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
-                 "scheme": "no structure exploited (general complex operators): 3M complex multiplication (3 real fp64 "
-                           "MFMAs per complex product) inside the solver loop, dense 64x64 tiles"}
+                 "scheme": ("no structure exploited (every operator treated as complex, no zero planes / blocks skipped): "
+                            "combine + apply, 8 real + 8 imaginary planes through the MFMAs, the static operator as their C "
+                            "input, 4 vector FMAs per element (rhs_combine_kernel<2, 2, 3>)") if took_combine_d else
+                           ("no structure exploited (general complex operators): 3M complex multiplication (3 real fp64 "
+                            "MFMAs per complex product) inside the solver loop, dense 64x64 tiles")}
+        if took_combine_d:
+            avg_3m = timed_variant({"skip_zero_planes": 0, "combine": 0})
+            ex_3m = 6 * stack.n_segments * n * n * b_loc
+            dense["mfma_gemm_3m_route"] = {"option": "combine=0", "avg_launch_ms": round(avg_3m, 4),
+                                           "rhs_evals_per_s": round(b_loc / (avg_3m * 1e-3), 1),
+                                           "executed_tflops": round(ex_3m / (avg_3m * 1e-3) / 1e12, 3),
+                                           "frac": round(ex_3m / (avg_3m * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
     plan.close()
     # ---- what the N-GPU strong-scaling runs should show: the per-GPU shards of 2 / 4 / 8 ranks timed on THIS GPU --------
     projected = None
@@ -1003,7 +1105,18 @@ def main():
     measured_peaks = None
     if rank == 0 and world == 1:
         co = ctx.microbench("fp64_coissue", full=True)
+        sus = ctx.microbench("mfma_f64_sustained", full=True)
+        sus0 = ctx.microbench("mfma_f64_sustained_zero", full=True)
         measured_peaks = {"mfma_f64_tflops": round(ctx.microbench("mfma_f64"), 1),
+                          "mfma_f64_sustained_random_operands": {
+                              "tflops": round(sus[0], 2), "frac_of_78.6": round(sus[0] / FP64_MFMA_PEAK_TFLOPS, 4),
+                              "shader_clock_ghz": round(sus[1], 3), "ms": round(sus[2], 2),
+                              "all_zero_operands": {"tflops": round(sus0[0], 2), "shader_clock_ghz": round(sus0[1], 3)},
+                              "note": "bare v_mfma_f64_16x16x4 stream at the contraction kernels' cadence (2 waves per SIMD, "
+                                      "16 accumulator quads) for ~40 ms: with random-mantissa operands the chip clocks to its "
+                                      "power budget below the 2.4 GHz that 78.6 TFLOP/s is quoted at -- this, not 1.0, is what "
+                                      "a kernel that did nothing but MFMAs on real data would reach; roofline.frac stays "
+                                      "against 78.6"},
                           "hbm_read_gbs": round(ctx.microbench("hbm_read"), 0),
                           "mall_read_gbs": round(ctx.microbench("mall_read"), 0),
                           "fp64_mfma_and_vector_fma_share_a_pipe": {
@@ -1040,6 +1153,8 @@ def main():
                              "value_without_exact_zero_block_skipping = the dense kernels on the same stack.  On both "
                              "routes the static operator in the frame, U^+(G_d - F)U with F = G_d, is exactly zero and "
                              "inactive (the reference's U^+ G_d U - diag(d) leaves 1e-13 rounding noise there)")
+    if gemm_route:
+        out["mfma_gemm_route_same_model"] = gemm_route
     if projected:
         out["projected_strong_scaling"] = projected
     if dense:
@@ -1155,6 +1270,7 @@ def main():
     if rank == 0 and world == 1 and want_cfg5:
         try:
             out["cfg4"] = leg_cfg4(qd, ctx, workloads)
+            out["cfg4"]["diag_frame_run"] = leg_cfg4_diag_frame(qd, ctx, workloads)
         except Exception as exc:  # pylint: disable=broad-except
             out["cfg4"] = {"error": repr(exc)}
     if want_cfg5:

@@ -20,12 +20,14 @@
 #include "../../include/midyn.h"
 #include "midyn_kernels.h"
 #include "midyn_resident.h"
+#include "midyn_combine.h"
 
 using namespace midyn;
 
 // The implementation is one translation unit, split by concern (included in this order):
 #include "midyn_core.inc"
 #include "midyn_launch.inc"
+#include "midyn_combine.inc"
 #include "midyn_eval.inc"
 #include "midyn_rk4.inc"
 #include "midyn_expm.inc"

@@ -1,0 +1,266 @@
+// midyn_combine.h -- the sweep contraction as COMBINE + APPLY (round 4): for many instances with their own coefficients
+//
+//     out[r][b] = sum_kk ( G_d[r][kk] + sum_j c_j[b] G_j[r][kk] ) y[kk][b]
+//
+// is evaluated the way the reference evaluates it per instance (models/operator_collections.py:101-134: first the
+// signal-weighted operator sum, then the product), instead of as k + 1 GEMMs whose results are scaled and added:
+//
+//   COMBINE  g[r][b] = sum_j a_j[r][kk] c_j[b]     v_mfma_f64_16x16x4: M = 16 rows, N = 16 instances, K = 4 operator PLANES
+//                                                  per instruction (real and imaginary planes are separate "operators";
+//                                                  planes that are exactly zero do not exist here); the static operator
+//                                                  enters as the C input of the first MFMA (coefficient 1, no plane slot)
+//   APPLY    out[r][b] += g[r][b] * y[kk][b]       2 (one plane kind) or 4 (both) v_fma_f64 in the lane that holds D[r][b]
+//
+// Per (row, kk, instance): P MFMA-FMAs for P time-dependent planes + 2..4 vector FMAs, against 2 P (single-plane
+// operators) / 3..4 P (complex operators, 3M / 4M) MFMA-FMAs of the GEMM formulation -- both run on the same fp64 pipe
+// of the SIMD.  BASELINE configs[2] (8 purely imaginary operators): 10 instead of 16 FMAs per element.
+//
+// No LDS and no barrier: the operator planes are re-packed once per stack in MFMA A-operand order (rows of a 16-row tile x
+// 4 planes per 512-byte wave load, contiguous per wave through its list of kk blocks), the stage input row y[kk][.] and the
+// static operator element are read straight from memory (16 lanes per address), two kk ahead of their use.
+// Exactly-zero 16-column blocks of a 32-row group are skipped through per-group lists (symmetry sectors).
+#pragma once
+
+namespace midyn {
+
+constexpr int CMB_MAXQ = 2;     // plane groups (of 4) per kind that have kernels: k <= 8 operators with a plane of that kind
+constexpr int CMB_ROWS = 32;    // rows per row group (two 16-row MFMA tiles per wave)
+
+struct CombineArgs {
+    const double* frags;     // [list entry][kk % 16][tile < 2][group q < NRE4 + NIM4][lane] doubles (entries of a row group contiguous)
+    const int* list_ptr;     // [n_row_groups + 1]
+    const int* list_idx;     // kk block (16 columns of the operators) of every entry
+    const double2* stat;     // static operator [lda][lda] (complex) or nullptr
+    int lda;
+    const double2* B;        // stage input [K][ldb], pre-phased
+    int ldb;
+    const double* coeff;     // [instance][inst_stride]: coefficient row of this evaluation
+    long long inst_stride;
+    int m_cols, n_inst;
+    int plane_col[8 * CMB_MAXQ];   // coefficient column of plane 4 q + i (first the real-plane groups, then the imaginary ones); -1: padding
+    int n_row_groups;
+    int wr;                  // waves of a workgroup along the rows (the others along the instances)
+    int splits;              // > 1: that many waves share one (row group, instance block) and split its list (small sweeps: more
+                             // waves than (row group, instance block) pairs are needed to fill the chip); summed through LDS
+    Epilogue epi;
+};
+
+// Re-pack: one workgroup per list entry.  plane_seg[p] = segment of plane p (or -1), plane_im[p] = 1 for an imaginary plane.
+struct CombinePackArgs {
+    const double2* ops;
+    long long seg_stride;
+    int lda;
+    const int* ent_rg;       // row group of every entry
+    const int* list_idx;
+    int nq;                  // NRE4 + NIM4
+    int plane_seg[8 * CMB_MAXQ];
+    int plane_im[8 * CMB_MAXQ];
+    double* frags;
+};
+
+__global__ __launch_bounds__(256) void combine_pack_kernel(CombinePackArgs a) {
+    const int e = blockIdx.x;
+    const int rg = a.ent_rg[e], kb = a.list_idx[e];
+    const int per_entry = 16 * 2 * a.nq * 64;
+    double* out = a.frags + (size_t)e * per_entry;
+    for (int i = threadIdx.x; i < per_entry; i += 256) {
+        const int lane = i & 63;
+        const int q = (i >> 6) % a.nq;
+        const int t = ((i >> 6) / a.nq) & 1;
+        const int k16 = (i >> 6) / (a.nq * 2);
+        const int p = 4 * q + (lane >> 4);
+        const int seg = a.plane_seg[p];
+        double v = 0.0;
+        if (seg >= 0) {
+            const double2 z = a.ops[(size_t)seg * a.seg_stride + (size_t)(rg * CMB_ROWS + t * 16 + (lane & 15)) * a.lda + kb * 16 + k16];
+            v = a.plane_im[p] ? z.y : z.x;
+        }
+        out[i] = v;
+    }
+}
+
+// 16-instance groups per wave: 4 (64 instances) when the combined operator has one kind of plane only -- purely real or
+// purely imaginary generators, e.g. real Hamiltonians in their eigenbasis -- in two groups (5..8 operators), else 2 (the
+// second kind doubles the combined elements and the static rows a wave holds; 256 registers per lane at two waves per SIMD).
+constexpr int combine_ng(int nre4, int nim4, int stat) {
+    return (((nre4 > 0 || (stat & 1)) != (nim4 > 0 || (stat & 2))) && nre4 + nim4 == 2) ? 4 : 2;
+}
+
+// STAT: bit 0 = the static operator has a real plane, bit 1 = an imaginary plane.
+template <int NRE4, int NIM4, int STAT>
+__global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a) {
+    constexpr int NQ = NRE4 + NIM4, RT = 2, NG = combine_ng(NRE4, NIM4, STAT);
+    constexpr bool RE = NRE4 > 0 || (STAT & 1), IM = NIM4 > 0 || (STAT & 2);
+    static_assert(NQ > 0 && NRE4 <= CMB_MAXQ && NIM4 <= CMB_MAXQ, "plane groups");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sp = wave % a.splits, wv = wave / a.splits;
+    const int waves = (blockDim.x >> 6) / a.splits;
+    const int wr = wv % a.wr, wi = wv / a.wr, nwi = waves / a.wr;
+    const int rgb = (a.n_row_groups + a.wr - 1) / a.wr;
+    const int rg = (blockIdx.x % rgb) * a.wr + wr;
+    if (rg >= a.n_row_groups) return;                      // (splits == 1: no barrier anywhere; splits > 1: wr == 1, the whole
+                                                           //  workgroup shares rg and leaves together)
+    const int col0 = ((blockIdx.x / rgb) * nwi + wi) * (NG * 16);
+    const int lb = lane & 15, lq = lane >> 4;
+
+    // B operands of the MFMAs: the coefficients c[plane 4 q + lq][column 16 g + lb] (constant over the launch)
+    double cb[NG][NQ];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        int in = (col0 + 16 * g + lb) / a.m_cols;
+        in = in < a.n_inst ? in : a.n_inst - 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int pc = a.plane_col[4 * q + lq];
+            cb[g][q] = pc >= 0 ? a.coeff[(long long)in * a.inst_stride + pc] : 0.0;
+        }
+    }
+    d4 ore[RT][NG], oim[RT][NG];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            ore[t][g] = d4{0.0, 0.0, 0.0, 0.0};
+            oim[t][g] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+    int e0 = a.list_ptr[rg], e1 = a.list_ptr[rg + 1];
+    if (a.splits > 1) {      // this wave's share of the list
+        const int len = e1 - e0;
+        e1 = e0 + (int)((long long)len * (sp + 1) / a.splits);
+        e0 = e0 + (int)((long long)len * sp / a.splits);
+    }
+    // (wave-uniform bases + one 32-bit lane offset each: the loads take the scalar-base form, no 64-bit address registers)
+    const double* __restrict__ fr = a.frags + (size_t)e0 * (16 * RT * NQ * 64);
+    const double2* __restrict__ yb = a.B + col0;
+    // static rows lq + 4 r (+ 16 t) of this lane, as doubles (only the planes the static operator has are read)
+    const double* __restrict__ sb = reinterpret_cast<const double*>(a.stat + (size_t)(rg * CMB_ROWS) * a.lda);
+    const unsigned s_lane = (unsigned)(lq * a.lda) * 2u;
+
+    double afr[2][RT][NQ];
+    double2 yv[2][NG];
+    double svr[2][RT][4], svi[2][RT][4];
+    // loads of flat step `sf` (entry sf / 16 of this row group, kk = 16 kb + sf % 16) into buffer b
+    auto load = [&](int sf, int kb, int b) {
+        const int kk = kb * 16 + (sf & 15);
+        const double* __restrict__ fn = fr + (size_t)sf * (RT * NQ * 64);
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) afr[b][t][q] = fn[(unsigned)((t * NQ + q) * 64 + lane)];
+        const double2* __restrict__ yrow = yb + (size_t)kk * a.ldb;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) yv[b][g] = yrow[(unsigned)(16 * g + lb)];
+        if (STAT) {
+            const double* __restrict__ srow = sb + 2 * (size_t)kk;
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double* q = srow + 2 * ((size_t)(t * 16 + 4 * r) * a.lda) + s_lane;
+                    if (STAT & 1) svr[b][t][r] = q[0];
+                    if (STAT & 2) svi[b][t][r] = q[1];
+                }
+        }
+        // (the loads stay HERE, one step ahead of their use: left alone, the scheduler sinks them to their first use to
+        // shorten live ranges, and every step then waits for its own loads)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute = [&](int b) {
+        // one plane kind at a time (the combined elements of the other kind are not live meanwhile): first the MFMAs of
+        // all instance groups, then their vector FMAs -- the first results are ready when the last MFMA has issued
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            if (RE) {
+                d4 gre[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    gre[g] = (STAT & 1) ? d4{svr[b][t][0], svr[b][t][1], svr[b][t][2], svr[b][t][3]} : d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < NRE4; ++q)
+                        gre[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[b][t][q], cb[g][q], gre[g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {           // (g_re)(y_re + i y_im)
+                        ore[t][g][r] = fma(gre[g][r], yv[b][g].x, ore[t][g][r]);
+                        oim[t][g][r] = fma(gre[g][r], yv[b][g].y, oim[t][g][r]);
+                    }
+            }
+            if (IM) {
+                d4 gim[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    gim[g] = (STAT & 2) ? d4{svi[b][t][0], svi[b][t][1], svi[b][t][2], svi[b][t][3]} : d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < NIM4; ++q)
+                        gim[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[b][t][NRE4 + q], cb[g][NRE4 + q], gim[g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {           // (i g_im)(y_re + i y_im) = -g_im y_im + i g_im y_re
+                        ore[t][g][r] = fma(-gim[g][r], yv[b][g].y, ore[t][g][r]);
+                        oim[t][g][r] = fma(gim[g][r], yv[b][g].x, oim[t][g][r]);
+                    }
+            }
+        }
+    };
+    const int steps = (e1 - e0) * 16;
+    if (steps > 0) {
+        // kk blocks of the entry that holds step s and of the next one (scalar loads, an entry ahead of their first use)
+        int kb_cur = a.list_idx[e0], kb_nxt = a.list_idx[e1 - e0 > 1 ? e0 + 1 : e0];
+        load(0, kb_cur, 0);
+        for (int s = 0; s < steps; s += 2) {      // (steps is a multiple of 16; the look-ahead past the end reads the padding entry)
+            // the step after next may open a new entry (selects, no branch: the loop stays one block; the scalar load is
+            // issued a whole step ahead of the select that consumes it)
+            const int wrap = ((s + 2) & 15) == 0;
+            const int en = e0 + ((s + 2) >> 4) + 1;
+            const int kb_far = a.list_idx[en < e1 ? en : e1 - 1];
+            load(s + 1, kb_cur, 1);
+            compute(0);
+            __builtin_amdgcn_sched_barrier(0);
+            kb_cur = wrap ? kb_nxt : kb_cur;
+            kb_nxt = wrap ? kb_far : kb_nxt;
+            load(s + 2, kb_cur, 0);
+            compute(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (a.splits > 1) {
+        // partial sums of waves 1 .. splits-1 through LDS, added by wave 0 in wave order (bit-reproducible)
+        double* red = reinterpret_cast<double*>(smem_raw);
+        constexpr int NV = RT * NG * 8;     // doubles per lane
+        if (sp > 0) {
+            double* mine = red + (size_t)(sp - 1) * NV * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        mine[((t * NG + g) * 8 + r) * 64] = ore[t][g][r];
+                        mine[((t * NG + g) * 8 + 4 + r) * 64] = oim[t][g][r];
+                    }
+        }
+        __syncthreads();
+        if (sp > 0) return;
+        for (int z = 1; z < a.splits; ++z) {
+            const double* theirs = red + (size_t)(z - 1) * NV * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ore[t][g][r] += theirs[((t * NG + g) * 8 + r) * 64];
+                        oim[t][g][r] += theirs[((t * NG + g) * 8 + 4 + r) * 64];
+                    }
+        }
+    }
+    store_tile<RT, NG>(a.epi, rg * CMB_ROWS + lq, col0 + lb, ore, oim);
+}
+
+}  // namespace midyn

@@ -825,7 +825,13 @@ __device__ __forceinline__ void mfma_kstep(const double2 (&a)[MT], const double2
             bs[nt] = br[nt] + bi[nt];
         }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) as[mt] = a[mt].x + a[mt].y;
+        for (int mt = 0; mt < MT; ++mt) {
+#ifdef MIDYN_3M_NOAS   // profiling only: what would a precomputed Ar + Ai plane save? (results wrong)
+            as[mt] = a[mt].x;
+#else
+            as[mt] = a[mt].x + a[mt].y;
+#endif
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -2569,6 +2575,40 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters)
 #pragma unroll
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 123.456) sink[0] = s;
+}
+
+// The same pipe under the POWER of real data: the contraction kernels' cadence (512 threads = 2 waves per SIMD, 16
+// accumulator quads per wave, one workgroup per CU), operands with random mantissas in [0.5, 1) and both signs.  The
+// chip clocks to its power budget: a dense fp64 MFMA stream on such operands sustains a lower shader clock than the
+// 2.4 GHz the 78.6 TFLOP/s peak is quoted at (operands that are all zero, or nearly constant as in mfma_peak_kernel,
+// toggle few bits and keep the full clock).  sink[1], sink[2] = shader cycles and 100 MHz ticks of one workgroup.
+__global__ __launch_bounds__(512, 2) void mfma_sustained_kernel(double* sink, int iters, int random_operands) {
+    const long long c0 = clock64(), w0 = wall_clock64();
+    d4 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double a[4], b[4];
+    unsigned h = (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo0 = (h = h * 1664525u + 1013904223u), hi0 = (h = h * 1664525u + 1013904223u);
+        const unsigned lo1 = (h = h * 1664525u + 1013904223u), hi1 = (h = h * 1664525u + 1013904223u);
+        a[i] = random_operands ? __hiloint2double((int)(0x3FE00000u | (hi0 >> 12) | ((hi0 & 1u) << 31)), (int)lo0) : 0.0;
+        b[i] = random_operands ? __hiloint2double((int)(0x3FE00000u | (hi1 >> 12) | ((hi1 & 1u) << 31)), (int)lo1) : 0.0;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i & 3]), "v"(b[i >> 2]));
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456) sink[0] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        sink[1] = (double)(clock64() - c0);
+        sink[2] = (double)(wall_clock64() - w0);
+    }
 }
 
 // Do the fp64 matrix pipe and the fp64 vector ALUs run CONCURRENTLY?  Per round and wave: NMFMA independent

@@ -19,6 +19,13 @@ MAY_SPILL = (
     "ell_sweep_split_kernelILi2ELi2EE",      # two workgroups per instance at n = 4096 (ell_sweep_split >= 2)
 )
 
+# rhs_combine_kernel<NRE4, NIM4, STAT> sits at the 256-register limit of two waves per SIMD in its larger variants: hipcc
+# parks a few loop-invariant values (pointers of the epilogue, strides) in scratch BEFORE the kk loop and fetches them back
+# AFTER it.  Bounded here, and test_combine_kernels_keep_scratch_out_of_their_loop checks that none of it is inside the
+# loop; the BASELINE model's variant (8 imaginary planes, no static operator) must be clean altogether.
+COMBINE_SMALL_SPILL = ("rhs_combine_kernelILi",)
+COMBINE_SPILL_LIMIT = 12
+
 # kernels of the default routes of the BASELINE configurations, by mangled-name fragment: they must exist (a rename must
 # not silently empty this test) and must not spill
 DEFAULT_ROUTE = (
@@ -36,6 +43,8 @@ DEFAULT_ROUTE = (
     "ell_sweep_kernelILi1ELi4ELi1024ELi2EE",
     "ell_sweep_rk4_kernelILi4ELi1024ELi2EE",
     "ell_sweep_rk4_kernelILi4ELi1024ELi0EE",
+    "rhs_combine_kernelILi0ELi2ELi0EE",                          # cfg 3 headline (round 4): combine + apply, 8 imaginary planes
+    "rhs_combine_kernelILi2ELi0ELi0EE",
     "rhs_stream_plane_kernel",
     "rhs_blocks_kernel",
     "splitk_reduce_kernel",
@@ -58,7 +67,8 @@ def test_code_object_is_gfx950_and_lists_the_kernels(kernels):
 def test_no_kernel_of_a_default_route_spills_registers(kernels):
     spilled = {name: (k[".vgpr_spill_count"], k.get(".private_segment_fixed_size", 0)) for name, k in kernels.items()
                if k.get(".vgpr_spill_count", 0) or k.get(".private_segment_fixed_size", 0)}
-    unexpected = {n: v for n, v in spilled.items() if not any(f in n for f in MAY_SPILL)}
+    unexpected = {n: v for n, v in spilled.items() if not any(f in n for f in MAY_SPILL)
+                  and not (any(f in n for f in COMBINE_SMALL_SPILL) and v[0] <= COMBINE_SPILL_LIMIT)}
     assert not unexpected, f"kernels with spilled registers / scratch (count, bytes per lane): {unexpected}"
     for frag in DEFAULT_ROUTE:
         for name, k in kernels.items():
@@ -125,3 +135,30 @@ def test_tile_loop_of_the_contraction_stays_lean(fragment, mfmas, tmp_path):
     # the first fragment of each operand carry their k-step / row block as an immediate)
     assert len(reads) >= 18 and sum("offset:" in " ".join(o) for o in reads) >= len(reads) - 2
     assert not any(n.startswith("scratch_") or n.startswith("buffer_") for n in names)
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm image not found")
+def test_combine_kernels_keep_scratch_out_of_their_loop(tmp_path):
+    """rhs_combine_kernel (midyn_combine.h): whatever hipcc spills in the larger variants stays outside the kk loop -- no
+    scratch instruction between the first and the last MFMA of any variant -- and the loads of a step are issued a step
+    ahead of their use (the loop waits with vmcnt > 0: it never drains the loads it has just issued)."""
+    import subprocess
+
+    if not os.path.exists(LIB):
+        pytest.skip("libmidyn.so has not been built")
+    co = tmp_path / "midyn.co"
+    co.write_bytes(codeobj.extract_code_object(LIB))
+    text = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, check=True).stdout
+    lines = text.split("\n")
+    starts = [i for i, l in enumerate(lines) if "rhs_combine_kernel" in l and l.rstrip().endswith(">:")]
+    assert len(starts) == 32
+    for st in starts:
+        end = next(i for i in range(st + 1, len(lines)) if lines[i].rstrip().endswith(">:") or i == len(lines) - 1)
+        ops = [l.split("//")[0].split() for l in lines[st + 1:end]]
+        ops = [o for o in ops if o]
+        mf = [i for i, o in enumerate(ops) if o[0].startswith("v_mfma_f64_16x16x4")]
+        assert mf, lines[st]
+        loop = ops[mf[0]:mf[-1] + 1]
+        assert not any(o[0].startswith("scratch_") for o in loop), lines[st]
+        waits = [o for o in loop if o[0] == "s_waitcnt" and any(t.startswith("vmcnt") for t in o[1:])]
+        assert waits and not any("vmcnt(0)" in " ".join(o) for o in waits), lines[st]

@@ -1,0 +1,201 @@
+"""The COMBINE + APPLY sweep contraction (csrc/midyn_combine.h, rhs_combine_kernel<NRE4, NIM4, STAT>) against the oracle and
+against the MFMA GEMM routes (ctx option combine = 0), one test per kernel variant:
+
+  * operators with real planes only / imaginary planes only / both / a mix of the three, 2 .. 8 of them, so that every
+    (NRE4, NIM4) in {0, 1, 2}^2 \\ (0, 0) occurs;
+  * no static operator, a real one, an imaginary one, a complex one (STAT 0 .. 3: the C input of the combining MFMAs);
+  * a frame diagonal (phases in the stage input and in the epilogue), ragged dimension (n = 96 -> 128 padded rows),
+    300 instances (384 padded columns: four waves split every list and sum through LDS);
+  * RK4 (epilogues RK1..4) and the expm action of scipy_expm with magnus_order 1 and 2 (Taylor / Chebyshev epilogues).
+
+Plus: operators with exactly-zero blocks (lists shorter than the dense ones), matrix-valued states (several columns per
+instance share a coefficient row), a stack with more operators than the kernels cover (falls back to the GEMM route).
+The reference computes the same thing per instance as  (G_d + sum_j c_j G_j) y  (models/operator_collections.py:101-134).
+
+All of them need a real MI355X (`pytest -m gpu`).
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+SOLVE_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def qd():
+    import qiskit_dynamics_amd as q
+
+    q.default_context()
+    return q
+
+
+def crand(rng, *shape):
+    return rng.uniform(-1, 1, shape) + 1j * rng.uniform(-1, 1, shape)
+
+
+def _operators(rng, n, kinds):
+    """One n x n generator per entry of `kinds`: 'r' real plane only, 'i' imaginary plane only, 'c' both."""
+    ops = []
+    for kind in kinds:
+        a = crand(rng, n, n) * 0.3
+        ops.append(a.real + 0j if kind == "r" else (1j * a.imag if kind == "i" else a))
+    return np.array(ops)
+
+
+def _solve(qd, stack, method, sched, table, y0, batch, shared, combine, magnus_order=1):
+    ctx = qd.default_context()
+    ctx.set_option("combine", combine)
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    try:
+        if method == "RK4":
+            ys = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, y0, batch, shared)
+        else:
+            ys = stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, magnus_order,
+                                  y0, batch, shared)
+    finally:
+        ctx.set_option("profile", 0)
+        ctx.set_option("combine", 1)
+    return ys, {c: ctx.counters(c) for c in ("rhs_combine", "rhs_gemm", "rhs_blocks_gemm", "combine_info", "combine_shape")}
+
+
+CASES = [
+    # operator kinds, static kind -> (NRE4, NIM4, STAT)
+    ("rr", None, (1, 0, 0)), ("rr", "r", (1, 0, 1)), ("rr", "i", (1, 0, 2)), ("rr", "c", (1, 0, 3)),
+    ("rrrrr", None, (2, 0, 0)), ("rrrrr", "r", (2, 0, 1)), ("rrrrr", "i", (2, 0, 2)), ("rrrrrrrr", "c", (2, 0, 3)),
+    ("iii", None, (0, 1, 0)), ("iii", "r", (0, 1, 1)), ("iiii", "i", (0, 1, 2)), ("i", "c", (0, 1, 3)),
+    ("iiiiiiii", None, (0, 2, 0)), ("iiiii", "r", (0, 2, 1)), ("iiiiiiii", "i", (0, 2, 2)), ("iiiiii", "c", (0, 2, 3)),
+    ("cc", None, (1, 1, 0)), ("ri", "r", (1, 1, 1)), ("cci", "i", (1, 1, 2)), ("cccc", "c", (1, 1, 3)),
+    ("rrrrri", None, (2, 1, 0)), ("ccrrr", "r", (2, 1, 1)), ("rrrrrc", "i", (2, 1, 2)), ("ccccr", "c", (2, 1, 3)),
+    ("iiiiir", None, (1, 2, 0)), ("cciii", "r", (1, 2, 1)), ("iiiiic", "i", (1, 2, 2)), ("cccci", "c", (1, 2, 3)),
+    ("ccccc", None, (2, 2, 0)), ("cccccc", "r", (2, 2, 1)), ("cccccccc", "i", (2, 2, 2)), ("cccccccc", "c", (2, 2, 3)),
+]
+
+
+@pytest.mark.parametrize("kinds,static_kind,variant", CASES, ids=["%d%d%d" % v for _, _, v in CASES])
+def test_combine_kernel_variant_vs_oracle_and_gemm_route(qd, kinds, static_kind, variant):
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(sum(variant) * 100 + len(kinds))
+    n, batch = 96, 300
+    ops = _operators(rng, n, kinds)
+    static = None if static_kind is None else _operators(rng, n, static_kind)[0]
+    fim = rng.normal(size=n)
+    stack = qd.Stack(ctx, ops, static, fim)
+    sched = FixedStepSchedule([0.0, 0.03], None, 0.01, _rk4_points)
+    table = rng.uniform(-1, 1, (batch, len(sched.times), len(kinds)))
+    y0 = crand(rng, batch, n, 1)
+    comb, cc = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 1)
+    assert cc["rhs_combine"]["launches"] == 12 and cc["rhs_gemm"]["launches"] == 0 and cc["rhs_blocks_gemm"]["launches"] == 0, cc
+    assert int(cc["combine_info"]["ms"]) == 100 * variant[0] + 10 * variant[1] + variant[2], cc["combine_info"]
+    assert int(cc["combine_shape"]["ms"]) == 4, cc["combine_shape"]          # four waves split every list
+    gemm, cg = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 0)
+    assert cg["rhs_combine"]["launches"] == 0 and cg["rhs_gemm"]["launches"] + cg["rhs_blocks_gemm"]["launches"] == 12, cg
+    assert_close(comb, gemm, 1e-13)
+    d = 1j * fim
+    for b in (0, 157, 299):
+        def rhs(t, y, b=b):
+            row = int(np.argmin(np.abs(np.asarray(sched.times) - t)))
+            return orc.generator_rhs(static, ops, table[b, row], d, None, t, y)
+
+        _, yref = orc.rk4_solve(rhs, [0.0, 0.03], y0[b, :, 0], 0.01)
+        assert_close(comb[b, -1, :, 0], yref[-1], 1e-11)
+    stack.close()
+
+
+@pytest.mark.parametrize("magnus_order", [1, 2])
+def test_combine_route_inside_the_expm_action(qd, magnus_order):
+    """scipy_expm through the expm ACTION (Taylor / Chebyshev series of products, fixed_step_solvers.py:80-108,345-363): every
+    product of the series runs on the combine kernel; against the GEMM route and, for two instances, the oracle's
+    scipy.linalg.expm solve."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(40 + magnus_order)
+    n, k, batch = 96, 6, 280
+
+    def antiherm():
+        a = crand(rng, n, n) * 0.2
+        return -1j * (a + a.conj().T) / 2
+
+    ops = np.array([antiherm() for _ in range(k)])
+    static = antiherm()
+    fim = rng.normal(size=n)
+    stack = qd.Stack(ctx, ops, static, fim)
+    sched = FixedStepSchedule([0.0, 0.2], None, 0.05, _magnus_points(magnus_order))
+    table = rng.uniform(-1, 1, (batch, len(sched.times), k))
+    y0 = crand(rng, n, 1)
+    y0 /= np.linalg.norm(y0)
+    comb, cc = _solve(qd, stack, "scipy_expm", sched, table, y0, batch, True, 1, magnus_order)
+    assert cc["rhs_combine"]["launches"] > 0 and cc["rhs_gemm"]["launches"] == 0 and cc["rhs_blocks_gemm"]["launches"] == 0, cc
+    assert int(cc["combine_info"]["ms"]) == 223, cc["combine_info"]          # complex operators + complex static operator
+    gemm, cg = _solve(qd, stack, "scipy_expm", sched, table, y0, batch, True, 0, magnus_order)
+    assert cg["rhs_combine"]["launches"] == 0
+    assert_close(comb, gemm, 1e-12)
+    assert np.max(np.abs(np.linalg.norm(comb[:, -1, :, 0], axis=1) - 1.0)) < 1e-10
+    d = 1j * fim
+    times = np.asarray(sched.times)
+    for b in (3, 279):
+        def gen(t, b=b):
+            return orc.generator_evaluate(static, ops, table[b, int(np.argmin(np.abs(times - t)))], d, None, t)
+
+        _, yref = orc.expm_solve(gen, [0.0, 0.2], y0[:, 0], 0.05, None, magnus_order)
+        assert_close(comb[b, -1, :, 0], yref[-1], SOLVE_TOL)
+    stack.close()
+
+
+def test_combine_lists_skip_exactly_zero_blocks_and_matrix_states(qd):
+    """Operators that couple only the two halves of the basis (parity-like sectors, exactly-zero diagonal blocks): the combine
+    lists hold half of the (32-row group, 16-column block) entries; states are n x 3 matrices per instance (the three
+    columns of an instance share its coefficient row).  Against the GEMM route and the oracle."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(8)
+    n, k, batch, m = 256, 5, 100, 3
+    ops = _operators(rng, n, "i" * k)
+    half = np.arange(n) < n // 2
+    ops[:, half[:, None] == half[None, :]] = 0.0          # couple only rows of one half with columns of the other
+    stack = qd.Stack(ctx, ops, None, None)
+    sched = FixedStepSchedule([0.0, 0.02], None, 0.01, _rk4_points)
+    table = rng.uniform(-1, 1, (batch, len(sched.times), k))
+    y0 = crand(rng, batch, n, m)
+    comb, cc = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 1)
+    assert cc["rhs_combine"]["launches"] == 8 and cc["rhs_gemm"]["launches"] == 0 and cc["rhs_blocks_gemm"]["launches"] == 0, cc
+    assert cc["combine_info"]["launches"] == (n // 32) * (n // 16) // 2, cc["combine_info"]
+    gemm, cg = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 0)
+    assert cg["rhs_combine"]["launches"] == 0
+    assert_close(comb, gemm, 1e-13)
+    for b in (0, 99):
+        def rhs(t, y, b=b):
+            row = int(np.argmin(np.abs(np.asarray(sched.times) - t)))
+            return orc.generator_rhs(None, ops, table[b, row], None, None, t, y)
+
+        _, yref = orc.rk4_solve(rhs, [0.0, 0.02], y0[b], 0.01)
+        assert_close(comb[b, -1], yref[-1], 1e-11)
+    stack.close()
+
+
+def test_more_operators_than_the_combine_kernels_cover_take_the_gemm_route(qd):
+    """Nine operators with imaginary planes (three groups of four > CMB_MAXQ): the layout is not applicable and the sweep
+    runs on the MFMA GEMM route as before; small sweeps (fewer than combine_min_cols state columns) likewise."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(9)
+    n = 64
+    sched = FixedStepSchedule([0.0, 0.01], None, 0.01, _rk4_points)
+    for k, batch, want_combine in ((9, 300, False), (4, 100, False), (4, 300, True)):
+        stack = qd.Stack(ctx, _operators(rng, n, "i" * k), None, None)
+        table = rng.uniform(-1, 1, (batch, len(sched.times), k))
+        _, cc = _solve(qd, stack, "RK4", sched, table, crand(rng, n, 1), batch, True, 1)
+        assert (cc["rhs_combine"]["launches"] > 0) == want_combine, (k, batch, cc)
+        assert (cc["rhs_gemm"]["launches"] + cc["rhs_blocks_gemm"]["launches"] > 0) != want_combine, (k, batch, cc)
+        stack.close()

@@ -437,9 +437,10 @@ def test_receiving_rank_of_the_stack_broadcast_runs_the_headline_solve(qd):
     model (BASELINE configs[2]: n = 1024, k = 8, rotating_frame = H_d) is sent through ncclBroadcast into a stack
     from midyn_stack_create_empty (midyn_stack_broadcast_from, one-rank communicator); the receiving side re-derives
     plane flags, active-segment lists and -- lazily -- the tile work lists from the RECEIVED buffer.  The product
-    Solver then runs the headline sweep (512 instances x 20 RK4 steps, active pulse window) once on the stack it built
-    and once on the received one: same route (128 x 128 SPARSE work-list tile, same listed tiles and split count,
-    no dense launch) and `np.array_equal` final states; instance 100 against the oracle.  Reference seam:
+    Solver then runs the headline sweep (512 instances x 20 RK4 steps, active pulse window) on the stack it built and on
+    the received one, on the default route (combine + apply: the layout of midyn_combine.h is re-packed from the received
+    buffer) and on the MFMA work-list route (combine=0): same launches, same lists, `np.array_equal` final states;
+    instance 100 against the oracle.  Reference seam:
     solvers/solver_classes.py:568-586 (the sequential instance loop the shards replace)."""
     from oracle import dynamics_oracle as orc
     from qiskit_dynamics_amd import _lib, workloads
@@ -456,14 +457,21 @@ def test_receiving_rank_of_the_stack_broadcast_runs_the_headline_solve(qd):
     y0 = crand(rng, 1024)
     y0 /= np.linalg.norm(y0)
 
-    def run():
-        res = _profiled(ctx, lambda: solver.solve(t_span=t_span, y0=y0, signals=sweeps, method="RK4",
-                                                  max_dt=cfg["max_dt"]))
-        counts = {c: ctx.counters(c) for c in ("rhs_blocks_gemm", "rhs_gemm", "sparse_tile", "sparse_list")}
-        return np.stack([r.y[-1] for r in res]), counts
+    names = ("rhs_combine", "rhs_blocks_gemm", "rhs_gemm", "sparse_tile", "sparse_list", "combine_info", "combine_shape")
 
-    built, c_built = run()
-    assert c_built["rhs_blocks_gemm"]["launches"] == 80 and c_built["rhs_gemm"]["launches"] == 0, c_built
+    def run(combine=1):
+        ctx.set_option("combine", combine)
+        try:
+            res = _profiled(ctx, lambda: solver.solve(t_span=t_span, y0=y0, signals=sweeps, method="RK4",
+                                                      max_dt=cfg["max_dt"]))
+        finally:
+            ctx.set_option("combine", 1)
+        return np.stack([r.y[-1] for r in res]), {c: ctx.counters(c) for c in names}
+
+    built, c_built = run()                       # default route: combine + apply on the sector lists
+    assert c_built["rhs_combine"]["launches"] == 80 and c_built["rhs_blocks_gemm"]["launches"] == 0, c_built
+    built_g, c_built_g = run(combine=0)          # the MFMA work-list route
+    assert c_built_g["rhs_blocks_gemm"]["launches"] == 80 and c_built_g["rhs_gemm"]["launches"] == 0, c_built_g
 
     comm = _lib.Comm(ctx, 1, 0, _lib.Comm.unique_id())
     dst = _lib.Stack.empty(ctx, src.n, src.k, src.has_static, src.has_frame)
@@ -476,12 +484,18 @@ def test_receiving_rank_of_the_stack_broadcast_runs_the_headline_solve(qd):
     solver.model._stack = dst          # the solver of a receiving rank holds the received stack
     try:
         received, c_recv = run()
+        received_g, c_recv_g = run(combine=0)
     finally:
         solver.model._stack = src
-    assert c_recv == c_built or all(c_recv[c]["launches"] == c_built[c]["launches"] for c in c_built), (c_recv, c_built)
-    assert (int(c_recv["sparse_tile"]["launches"]), int(c_recv["sparse_tile"]["ms"])) == (128, 128)
-    assert c_recv["sparse_list"] == c_built["sparse_list"]
+    for got, want in ((c_recv, c_built), (c_recv_g, c_built_g)):
+        for c in ("rhs_combine", "rhs_blocks_gemm", "rhs_gemm"):
+            assert got[c]["launches"] == want[c]["launches"], (c, got, want)
+        for c in ("combine_info", "combine_shape", "sparse_list"):
+            assert got[c] == want[c], (c, got, want)
+    assert (int(c_recv_g["sparse_tile"]["launches"]), int(c_recv_g["sparse_tile"]["ms"])) == (128, 128)
     assert np.array_equal(received, built), f"received stack: max|d| = {np.max(np.abs(received - built)):.3e}"
+    assert np.array_equal(received_g, built_g)
+    assert_close(built, built_g, 1e-13)
     dst.close()
 
     a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], cfg["h_d"])

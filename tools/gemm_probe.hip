@@ -59,7 +59,7 @@ static int run(const GemmArgs& g, hipStream_t s, int reps, float* ms_out) {
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 4096, variant = argc > 2 ? atoi(argv[2]) : 0, splits = argc > 3 ? atoi(argv[3]) : 1;
     const int n = 1024, k = 8, reps = 40;
-    const bool cplx = variant == 2 || variant == 3;
+    const bool cplx = variant == 2 || variant == 3 || variant == 13 || variant == 14;
     srand(7);
     // operators: purely imaginary, coupling rows of one half to columns of the other (variant 0/1); dense complex (2/3)
     std::vector<double2> A((size_t)k * n * n, make_double2(0.0, 0.0));
@@ -112,6 +112,10 @@ int main(int argc, char** argv) {
     else if (variant == 2) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<64, 64, 2, 2, 16, 4, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 6; }
     else if (variant == 4) { st = run<64, 128, 2, 4, 16, 2, true>(g, s, reps, &ms); flops = listed * 64 * 16 * (double)N * 4; }
     else if (variant == 5) { st = run<64, 64, 2, 2, 16, 2, true>(g, s, reps, &ms); flops = listed * 64 * 16 * (double)N * 4; }
+    else if (variant == 11) { st = run<128, 128, 1, 8, 16, 2, true>(g, s, reps, &ms); flops = listed * 128 * 16 * (double)N * 4; }   // 8 waves, 128 x 16 wave tiles: half the scalings per MFMA
+    else if (variant == 12) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<128, 128, 1, 8, 16, 2, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 4; }
+    else if (variant == 13) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<128, 64, 2, 4, 16, 4, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 6; }   // 3M, 8 waves, 64 x 16 wave tiles
+    else if (variant == 14) { g.work_ptr = nullptr; g.work_idx = nullptr; st = run<64, 128, 1, 8, 16, 4, false>(g, s, reps, &ms); flops = (double)k * n * n * N * 6; }
     else if (variant == 9) { st = run<128, 128, 2, 2, 16, 2, true, 1>(g, s, reps, &ms); flops = listed * 128 * 16 * (double)N * 4; }   // 4 waves, 64 x 64 wave tiles
 #ifdef MIDYN_EXPERIMENT_LIST_KERNEL
     else if (variant == 10) {   // the hand-scheduled list kernel (tools/experiments/gemm_list_kernel.h; not adopted)
