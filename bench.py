@@ -1053,7 +1053,7 @@ def main():
                                 "frac": round(ex_k / (avg_k * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
                                 "what": "dense 128x128 MFMA GEMM kernel on the same stack (skip_zero_blocks=0, combine=0): "
                                         "multiplies the exactly-zero blocks too"}
-        avg_d = timed_variant({"skip_zero_planes": 0})
+        avg_d = timed_variant({"skip_zero_planes": 0, "skip_zero_blocks": 0})
         info_d = ctx.counters("combine_info")
         took_combine_d = on_combine and info_d["launches"] > 0 and int(info_d["ms"]) // 100 > 0
         if took_combine_d:
@@ -1073,7 +1073,7 @@ def main():
                            ("no structure exploited (general complex operators): 3M complex multiplication (3 real fp64 "
                             "MFMAs per complex product) inside the solver loop, dense 64x64 tiles")}
         if took_combine_d:
-            avg_3m = timed_variant({"skip_zero_planes": 0, "combine": 0})
+            avg_3m = timed_variant({"skip_zero_planes": 0, "skip_zero_blocks": 0, "combine": 0})
             ex_3m = 6 * stack.n_segments * n * n * b_loc
             dense["mfma_gemm_3m_route"] = {"option": "combine=0", "avg_launch_ms": round(avg_3m, 4),
                                            "rhs_evals_per_s": round(b_loc / (avg_3m * 1e-3), 1),

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
     const int wr = wv % a.wr, wi = wv / a.wr, nwi = waves / a.wr;
     const int rgb = (a.n_row_groups + a.wr - 1) / a.wr;
     const int rg = (blockIdx.x % rgb) * a.wr + wr;
-    if (rg >= a.n_row_groups) return;                      // (splits == 1: no barrier anywhere; splits > 1: wr == 1, the whole
-                                                           //  workgroup shares rg and leaves together)
+    if (rg >= a.n_row_groups) return;                      // (a wave that leaves here never reaches the barrier of the list
+                                                           //  split below; the hardware barrier counts the waves still alive)
     const int col0 = ((blockIdx.x / rgb) * nwi + wi) * (NG * 16);
     const int lb = lane & 15, lq = lane >> 4;
 
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
     }
     if (a.splits > 1) {
         // partial sums of waves 1 .. splits-1 through LDS, added by wave 0 in wave order (bit-reproducible)
-        double* red = reinterpret_cast<double*>(smem_raw);
         constexpr int NV = RT * NG * 8;     // doubles per lane
+        double* red = reinterpret_cast<double*>(smem_raw) + (size_t)wv * (a.splits - 1) * NV * 64;   // this pair's slots
         if (sp > 0) {
             double* mine = red + (size_t)(sp - 1) * NV * 64 + lane;
 #pragma unroll

@@ -154,7 +154,8 @@ def test_headline_shard_512_instances_full_length_vs_oracle(qd, headline):
 @pytest.mark.parametrize("nb", [1024, 2048])
 def test_headline_shards_of_2_and_4_gpus_combine_shapes(qd, headline, nb):
     """The shards of the 4- and 2-GPU runs (1024 / 2048 instances), 20 steps in the active pulse window: 1024 instances run
-    two waves per (row group, column block) pair (list split 2), 2048 four pairs per workgroup without a split; both
+    two waves per (row group, column block) pair (list split 2, two pairs per workgroup), 2048 four pairs per workgroup
+    without a split -- four waves per workgroup, one workgroup per CU either way; both
     against the MFMA work-list route (1e-13) and instance nb - 1 against the oracle."""
     cfg, solver, model = headline
     sweeps = [_signals(qd, cfg, b) for b in range(nb)]
@@ -163,7 +164,7 @@ def test_headline_shards_of_2_and_4_gpus_combine_shapes(qd, headline, nb):
     y0 /= np.linalg.norm(y0)
     comb, c1 = _run(qd, solver, sweeps, [2.4, 2.5], y0, cfg["max_dt"])
     assert c1["rhs_combine"]["launches"] == 80 and c1["rhs_blocks_gemm"]["launches"] == 0, c1
-    want = (1, 2) if nb == 1024 else (4, 1)
+    want = (2, 2) if nb == 1024 else (4, 1)
     assert (int(c1["combine_shape"]["launches"]), int(c1["combine_shape"]["ms"])) == want, c1["combine_shape"]
     lists, c2 = _run(qd, solver, sweeps, [2.4, 2.5], y0, cfg["max_dt"], combine=0)
     assert c2["rhs_blocks_gemm"]["launches"] == 80 and c2["rhs_combine"]["launches"] == 0

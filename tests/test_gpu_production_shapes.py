@@ -490,8 +490,9 @@ def test_receiving_rank_of_the_stack_broadcast_runs_the_headline_solve(qd):
     for got, want in ((c_recv, c_built), (c_recv_g, c_built_g)):
         for c in ("rhs_combine", "rhs_blocks_gemm", "rhs_gemm"):
             assert got[c]["launches"] == want[c]["launches"], (c, got, want)
-        for c in ("combine_info", "combine_shape", "sparse_list"):
+        for c in ("combine_info", "combine_shape"):
             assert got[c] == want[c], (c, got, want)
+    assert c_recv_g["sparse_list"] == c_built_g["sparse_list"]
     assert (int(c_recv_g["sparse_tile"]["launches"]), int(c_recv_g["sparse_tile"]["ms"])) == (128, 128)
     assert np.array_equal(received, built), f"received stack: max|d| = {np.max(np.abs(received - built)):.3e}"
     assert np.array_equal(received_g, built_g)
