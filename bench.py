@@ -1048,7 +1048,22 @@ def main():
         if on_lists or on_combine:
             avg_k = timed_variant({"skip_zero_blocks": 0, "combine": 0} if on_combine else {"skip_zero_blocks": 0})
             ex_k = sum(4 if m in (1, 2) else 8 for m in modes if m != 3) * n * n * b_loc
-            same_model_dense = {"avg_launch_ms": round(avg_k, 4), "rhs_evals_per_s": round(b_loc / (avg_k * 1e-3), 1),
+            no_lists = None
+            if on_combine:     # the default route of a model with the same planes but NO exactly-zero blocks
+                avg_n = timed_variant({"skip_zero_blocks": 0})
+                info_n = ctx.counters("combine_info")
+                code_n = int(info_n["ms"])
+                nq_n = code_n // 100 + (code_n // 10) % 10
+                kinds_n = int(code_n // 100 > 0 or (code_n % 10) & 1) + int((code_n // 10) % 10 > 0 or (code_n % 10) & 2)
+                ex_n = (2.0 * 4 * nq_n + 2.0 * (2 if kinds_n == 1 else 4)) * info_n["launches"] * 16 * 32 * (-(-b_loc // 128) * 128)
+                no_lists = {"option": "skip_zero_blocks=0", "avg_launch_ms": round(avg_n, 4),
+                            "rhs_evals_per_s": round(b_loc / (avg_n * 1e-3), 1),
+                            "executed_tflops": round(ex_n / (avg_n * 1e-3) / 1e12, 3),
+                            "frac": round(ex_n / (avg_n * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                            "what": "combine + apply over ALL (32-row, 16-column) entries: what a model with purely imaginary "
+                                    "generators but no conserved quantity runs at"}
+            same_model_dense = {"default_route_without_zero_block_lists": no_lists,
+                                "avg_launch_ms": round(avg_k, 4), "rhs_evals_per_s": round(b_loc / (avg_k * 1e-3), 1),
                                 "executed_tflops": round(ex_k / (avg_k * 1e-3) / 1e12, 3),
                                 "frac": round(ex_k / (avg_k * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
                                 "what": "dense 128x128 MFMA GEMM kernel on the same stack (skip_zero_blocks=0, combine=0): "
@@ -1112,11 +1127,11 @@ def main():
                               "tflops": round(sus[0], 2), "frac_of_78.6": round(sus[0] / FP64_MFMA_PEAK_TFLOPS, 4),
                               "shader_clock_ghz": round(sus[1], 3), "ms": round(sus[2], 2),
                               "all_zero_operands": {"tflops": round(sus0[0], 2), "shader_clock_ghz": round(sus0[1], 3)},
-                              "note": "bare v_mfma_f64_16x16x4 stream at the contraction kernels' cadence (2 waves per SIMD, "
-                                      "16 accumulator quads) for ~40 ms: with random-mantissa operands the chip clocks to its "
-                                      "power budget below the 2.4 GHz that 78.6 TFLOP/s is quoted at -- this, not 1.0, is what "
-                                      "a kernel that did nothing but MFMAs on real data would reach; roofline.frac stays "
-                                      "against 78.6"},
+                              "note": "bare v_mfma_f64_16x16x4 stream at the contraction kernels' cadence (2 waves per SIMD, 16 "
+                                      "accumulator quads) for ~14 ms, operands with random mantissas and signs, with the shader "
+                                      "clock it sustained (the chip clocks to its power budget; 78.6 TFLOP/s is quoted at "
+                                      "2.4 GHz): what a kernel that did nothing but MFMAs on such data reaches; roofline.frac "
+                                      "stays against 78.6"},
                           "hbm_read_gbs": round(ctx.microbench("hbm_read"), 0),
                           "mall_read_gbs": round(ctx.microbench("mall_read"), 0),
                           "fp64_mfma_and_vector_fma_share_a_pipe": {
@@ -1147,12 +1162,15 @@ def main():
         out["roofline"] = roofline
     if same_model_dense:
         out["dense_kernels_same_model"] = same_model_dense
-        out["value_without_exact_zero_block_skipping"] = same_model_dense["rhs_evals_per_s"]
-        out["value_note"] = ("value = the product's default route: identical arithmetic minus products with operator "
-                             "blocks that are EXACTLY zero (parity sectors of the frame operator), bit-identical states; "
-                             "value_without_exact_zero_block_skipping = the dense kernels on the same stack.  On both "
-                             "routes the static operator in the frame, U^+(G_d - F)U with F = G_d, is exactly zero and "
-                             "inactive (the reference's U^+ G_d U - diag(d) leaves 1e-13 rounding noise there)")
+        nl = same_model_dense.get("default_route_without_zero_block_lists")
+        out["value_without_exact_zero_block_skipping"] = nl["rhs_evals_per_s"] if nl else same_model_dense["rhs_evals_per_s"]
+        out["value_note"] = ("value = the product's default route: the reference's arithmetic (combine the operators with the "
+                             "instance's coefficients, apply to the state) minus products with operator blocks that are "
+                             "EXACTLY zero (parity sectors of the frame operator); value_without_exact_zero_block_skipping = "
+                             "the same route over all blocks.  On both the static operator in the frame, U^+(G_d - F)U "
+                             "with F = G_d, is exactly zero and inactive (the reference's U^+ G_d U - diag(d) leaves 1e-13 "
+                             "rounding noise there).  mfma_gemm_route_same_model / dense_kernels_same_model: the k + 1 GEMM "
+                             "formulation (default until round 3) on the same stack")
     if gemm_route:
         out["mfma_gemm_route_same_model"] = gemm_route
     if projected:
@@ -1162,12 +1180,13 @@ def main():
     if same_model_dense and dense:
         out["cfg3_three_numbers"] = {
             "structured_model_default_route": round(value, 1),
-            "dense_kernels_same_stack": same_model_dense["rhs_evals_per_s"],
+            "same_planes_no_zero_blocks": (same_model_dense.get("default_route_without_zero_block_lists") or same_model_dense)["rhs_evals_per_s"],
             "general_complex_operators": dense["rhs_evals_per_s"],
             "unit": "RHS evals/s on one GPU, 4096 instances",
-            "read_as": "value (the first number) belongs to THIS model: real Hamiltonians in their own eigenbasis with a parity "
-                       "symmetry.  A model with dense complex frame-basis operators (e.g. a random Hermitian frame) runs at "
-                       "the third number; a model with real Hamiltonians but no conserved quantity near the second"}
+            "read_as": "all three on the product's default route (combine + apply).  value (the first number) belongs to THIS "
+                       "model: real Hamiltonians in their own eigenbasis with a parity symmetry.  A model with dense complex "
+                       "frame-basis operators and a static operator (e.g. a random Hermitian frame) runs at the third number; "
+                       "a model with real Hamiltonians but no conserved quantity at the second"}
     if measured_peaks:
         out["measured_peaks"] = measured_peaks
 

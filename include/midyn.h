@@ -63,6 +63,12 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   split_k [1], force_splits [0], force_tile [0 | 64 | 128 | 12864]   tile / split-K choice of the zgemm
  *   splitk_inlaunch [0]   sum the split-K partials inside the contraction launch (measured slower, opt-in)
  *   pair_launch [1]       sparse MFMA route: the two independent products of a Magnus-2 level share one launch
+ *   combine [1]           sweeps (B > 1 instances with their own coefficients, >= combine_min_cols state columns, at most 8
+ *                         operators with a real plane and 8 with an imaginary one): the contraction runs as COMBINE + APPLY
+ *                         (csrc/midyn_combine.h: sum_j c_j[b] G_j per instance by fp64 MFMAs over the operator planes, then
+ *                         the product with the state by vector FMAs -- the reference's order of operations,
+ *                         models/operator_collections.py:101-134) instead of k + 1 GEMMs; 0: the MFMA GEMM routes
+ *   combine_min_cols [256]   ... smallest padded column count of the state block that takes it
  *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage
  *   multi_stream [1]      2..8 state columns at n >= 256: multi-column streaming kernel
  *   tiny_rk4 [1]          small systems: whole fixed-step solve in one persistent launch
@@ -273,10 +279,16 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * "resident_fallbacks": (step ranges a one-launch kernel gave up on and the launch-per-product route re-ran, 0).
  * Two more names describe the LAST launch of the sparse MFMA route: "sparse_tile" -> (BM, BN) of its tile,
  * "sparse_list" -> (listed (panel, K tile, operator) tiles of the stack for that panel height, split count),
- * "sparse_pair" -> (contractions in that launch: 2 when two independent products shared it, ctx option pair_launch). */
+ * "sparse_pair" -> (contractions in that launch: 2 when two independent products shared it, ctx option pair_launch).
+ * "rhs_combine" counts the launches of the COMBINE + APPLY sweep kernel; its last launch is described by
+ * "combine_info" -> (listed (32-row group, 16-column block) entries of the stack, 100 NRE4 + 10 NIM4 + STAT: groups of four
+ * real / imaginary operator planes and the static operator's planes, bit 0 real, bit 1 imaginary) and "combine_shape" ->
+ * ((row group, column block) pairs per workgroup, waves that split the list of one pair). */
 int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);
 int midyn_reset_counters(midyn_ctx* ctx);
-/* Measured ceilings: "mfma_f64" -> out[0] = TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64;
+/* Measured ceilings: "mfma_f64" -> out[0] = TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64; "mfma_f64_sustained"
+ * (operands with random mantissas) / "mfma_f64_sustained_zero" -> out[0] TFLOP/s, out[1] shader clock in GHz, out[2] ms of
+ * a ~14 ms stream at the contraction kernels' cadence (2 waves per SIMD, 16 accumulator quads);
  * "hbm_read" -> GB/s streaming a 4 GiB buffer; "mall_read" -> GB/s re-reading 144 MiB (the size of
  * the cfg-2 operator stack, which fits the 256 MiB Infinity Cache);
  * "fp64_coissue" -> out[0..2] = ms of the same rounds with MFMAs + vector fp64 FMAs interleaved, MFMAs only, FMAs only,

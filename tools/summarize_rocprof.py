@@ -79,9 +79,13 @@ def phase_report(db, line):
     want = sum(c for _, c in seq)
     out = ["## dominant kernel by phase of the traced bench.py run", "",
            f"`{kname}`: {len(disp)} dispatches in the trace, `launch_sequence` of the same run accounts for {want}."]
-    if len(disp) != want:
-        out += ["", "(counts differ: no per-phase split)", ""]
+    if len(disp) < want:
+        out += ["", "(fewer dispatches than the sequence: no per-phase split)", ""]
         return out
+    if len(disp) > want:
+        out += ["", f"(the first {want} dispatches are the sequence; the other {len(disp) - want} belong to later A/B legs of "
+                    "bench.py that run the same kernel on other lists -- e.g. skip_zero_blocks=0 -- and are left out here)"]
+        disp = disp[:want]
     flops = roof.get("executed_mfma_flops_per_launch")
     peak = roof.get("peak")
     out += ["",
