@@ -32,7 +32,11 @@
 
 #ifdef __cplusplus
 extern "C" {
-typedef struct { double re, im; } midyn_complex;
+#if defined(__clang__) || defined(__GNUC__)
+typedef double _Complex midyn_complex;              /* the C type itself (GNU extension in C++): one function type for both views */
+#else
+typedef struct { double re, im; } midyn_complex;    /* layout-compatible stand-in */
+#endif
 #else
 #include <complex.h>
 typedef double _Complex midyn_complex;

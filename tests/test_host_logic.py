@@ -210,9 +210,14 @@ def test_header_is_plain_c_and_symbols_resolve(tmp_path):
     assert p.returncode == 0 and "ABI_OK %d symbols" % len(_lib.ABI_SYMBOLS) in p.stdout, p.stdout + p.stderr
     # and the same header as C++
     cpp = tmp_path / "h.cpp"
-    cpp.write_text('#include "%s"\nint main() { midyn_complex z{1.0, 2.0}; return z.re > 0 ? 0 : 1; }\n'
+    # (midyn_complex is `double _Complex` in both languages -- one function type for the C and the C++ view of every
+    # entry point, which UBSan's function-type check of a C caller insists on -- with the layout of a (re, im) pair)
+    cpp.write_text('#include "%s"\nint main() { midyn_complex z; __real__ z = 1.0; __imag__ z = 2.0;\n'
+                   'static_assert(sizeof(midyn_complex) == 16, "(re, im) pair");\n'
+                   'const double* p = reinterpret_cast<const double*>(&z); return p[0] == 1.0 && p[1] == 2.0 ? 0 : 1; }\n'
                    % os.path.join(ROOT, "include", "midyn.h"))
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-o", str(tmp_path / "h"), str(cpp)], check=True)
+    assert subprocess.run([str(tmp_path / "h")]).returncode == 0
 
 
 def test_signal_algebra_values_match_reference(golden):

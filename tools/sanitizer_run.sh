@@ -1,0 +1,32 @@
+#!/bin/bash
+# Host side of libmidyn.so under AddressSanitizer + UndefinedBehaviorSanitizer (device code is not instrumented).
+# Build (in the CPU container, ~6 min):
+#   mkdir -p build/asan && cd build/asan
+#   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-value -fsanitize=address -fno-gpu-sanitize \
+#         -Xarch_host -fsanitize=undefined -fno-omit-frame-pointer -c -o midyn_asan.o ../../qiskit_dynamics_amd/csrc/midyn.hip
+#   (UBSan for the HOST side only: a plain -fsanitize=undefined also instruments the gfx950 code, and the contraction
+#    kernels then fail to launch -- found with tools/gemm_probe.hip: -O1, -O1 -g and -O1 + ASan are all correct)
+#   hipcc -shared -fsanitize=address,undefined -o libmidyn_asan.so midyn_asan.o -ldl && rm midyn_asan.o
+#   /opt/rocm/lib/llvm/bin/clang -std=c99 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -o abi_solve_asan \
+#         ../../tests/abi_solve.c -ldl -lm
+# Run (on the GPU box, through gpurun):  bash tools/sanitizer_run.sh  -> gpurun_out/sanitizer/
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/sanitizer
+mkdir -p $O
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=1:abort_on_error=0
+export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+HIPRT=/opt/rocm/lib/libamdhip64.so
+RCCL=/opt/rocm/lib/librccl.so.1
+# 1. the C99 host program: context, stack, in-place + out-of-place RCCL broadcast, RHS, RK4, Magnus-2 through the C-ABI
+$R/build/asan/abi_solve_asan $HIPRT $R/build/asan/libmidyn_asan.so $RCCL > $O/abi_solve.log 2>&1
+echo "abi_solve_asan exit $?" >> $O/abi_solve.log
+tail -3 $O/abi_solve.log
+# 2. the Python binding's GPU tests on the sanitized library (ASan runtime preloaded into the interpreter)
+cp $R/qiskit_dynamics_amd/libmidyn.so /tmp/libmidyn_plain.so
+cp $R/build/asan/libmidyn_asan.so $R/qiskit_dynamics_amd/libmidyn.so
+RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
+( cd $R && LD_PRELOAD=$RT MIDYN_HIP_RUNTIME=system timeout 1500 python -m pytest tests/test_gpu_edge_cases.py tests/test_gpu_combine.py tests/test_gpu_resident.py \
+    -m gpu -q -x -p no:cacheprovider > $O/pytest_asan.log 2>&1 ; echo "pytest exit $?" >> $O/pytest_asan.log )
+cp /tmp/libmidyn_plain.so $R/qiskit_dynamics_amd/libmidyn.so
+tail -5 $O/pytest_asan.log
+grep -c "ERROR: AddressSanitizer\|runtime error:" $O/abi_solve.log $O/pytest_asan.log
