@@ -71,7 +71,9 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         operators with a real plane and 8 with an imaginary one): the contraction runs as COMBINE + APPLY
  *                         (csrc/midyn_combine.h: sum_j c_j[b] G_j per instance by fp64 MFMAs over the operator planes, then
  *                         the product with the state by vector FMAs -- the reference's order of operations,
- *                         models/operator_collections.py:101-134) instead of k + 1 GEMMs; 0: the MFMA GEMM routes
+ *                         models/operator_collections.py:101-134) instead of k + 1 GEMMs, where that is the faster
+ *                         formulation (the planes of a kind fill groups of four MFMA slots: at least three quarters of
+ *                         the slots must hold a plane); 2: wherever the kernels apply; 0: the MFMA GEMM routes
  *   combine_min_cols [256]   ... smallest padded column count of the state block that takes it
  *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage
  *   multi_stream [1]      2..8 state columns at n >= 256: multi-column streaming kernel

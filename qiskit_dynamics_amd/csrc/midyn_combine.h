@@ -17,7 +17,8 @@
 //
 // No LDS and no barrier: the operator planes are re-packed once per stack in MFMA A-operand order (rows of a 16-row tile x
 // 4 planes per 512-byte wave load, contiguous per wave through its list of kk blocks), the stage input row y[kk][.] and the
-// static operator element are read straight from memory (16 lanes per address), two kk ahead of their use.
+// static operator elements are read straight from memory one kk step ahead of their use (the state: 16 lanes per address;
+// the static rows: one element per lane, broadcast within the 16-lane row by DPP).
 // Exactly-zero 16-column blocks of a 32-row group are skipped through per-group lists (symmetry sectors).
 #pragma once
 
@@ -79,11 +80,17 @@ __global__ __launch_bounds__(256) void combine_pack_kernel(CombinePackArgs a) {
     }
 }
 
-// 16-instance groups per wave: 4 (64 instances) when the combined operator has one kind of plane only -- purely real or
-// purely imaginary generators, e.g. real Hamiltonians in their eigenbasis -- in two groups (5..8 operators), else 2 (the
-// second kind doubles the combined elements and the static rows a wave holds; 256 registers per lane at two waves per SIMD).
+// Value of lane N (0..15) of this lane's row of 16 lanes, in every lane of the row (DPP row_newbcast, gfx90a+).
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, false);   // (one v_mov_b64_dpp: row_newbcast is the one
+                                                                              //  DPP control the 64-bit ALU ops accept)
+}
+
+// 16-instance groups per wave: 4 (64 instances) up to two plane groups, else 2 (registers: 2 x NG accumulator quad pairs, the
+// combined elements of one plane kind at a time, two sets of prefetched operands; 256 per lane at two waves per SIMD).
 constexpr int combine_ng(int nre4, int nim4, int stat) {
-    return (((nre4 > 0 || (stat & 1)) != (nim4 > 0 || (stat & 2))) && nre4 + nim4 == 2) ? 4 : 2;
+    return nre4 + nim4 <= 2 ? 4 : 2;
 }
 
 // STAT: bit 0 = the static operator has a real plane, bit 1 = an imaginary plane.
@@ -135,12 +142,16 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
     const double* __restrict__ fr = a.frags + (size_t)e0 * (16 * RT * NQ * 64);
     const double2* __restrict__ yb = a.B + col0;
     // static rows lq + 4 r (+ 16 t) of this lane, as doubles (only the planes the static operator has are read)
+    // The static operator (the C input of the combining MFMAs): the 16 lanes of a row (same lq) need the same 4 rows x 2
+    // tiles x 2 planes = 16 doubles per kk.  Each lane fetches ONE of them -- lane lb: row lq + 4 (lb & 3) of tile
+    // (lb >> 2) & 1, plane lb >> 3 -- and the row broadcasts them with DPP (16 lanes reading one address still cost the
+    // texture path a full wave-load each: 8-16 of them per step were 27 % of the 8-plane kernel's time).
     const double* __restrict__ sb = reinterpret_cast<const double*>(a.stat + (size_t)(rg * CMB_ROWS) * a.lda);
-    const unsigned s_lane = (unsigned)(lq * a.lda) * 2u;
+    const unsigned s_lane = (unsigned)((lq + 4 * (lb & 3) + 16 * ((lb >> 2) & 1)) * a.lda) * 2u + (unsigned)(lb >> 3);
 
     double afr[2][RT][NQ];
     double2 yv[2][NG];
-    double svr[2][RT][4], svi[2][RT][4];
+    double sv[2];
     // loads of flat step `sf` (entry sf / 16 of this row group, kk = 16 kb + sf % 16) into buffer b
     auto load = [&](int sf, int kb, int b) {
         const int kk = kb * 16 + (sf & 15);
@@ -152,17 +163,7 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
         const double2* __restrict__ yrow = yb + (size_t)kk * a.ldb;
 #pragma unroll
         for (int g = 0; g < NG; ++g) yv[b][g] = yrow[(unsigned)(16 * g + lb)];
-        if (STAT) {
-            const double* __restrict__ srow = sb + 2 * (size_t)kk;
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double* q = srow + 2 * ((size_t)(t * 16 + 4 * r) * a.lda) + s_lane;
-                    if (STAT & 1) svr[b][t][r] = q[0];
-                    if (STAT & 2) svi[b][t][r] = q[1];
-                }
-        }
+        if (STAT) sv[b] = (sb + 2 * (size_t)kk)[s_lane];
         // (the loads stay HERE, one step ahead of their use: left alone, the scheduler sinks them to their first use to
         // shorten live ranges, and every step then waits for its own loads)
         __builtin_amdgcn_sched_barrier(0);
@@ -176,7 +177,9 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
                 d4 gre[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    gre[g] = (STAT & 1) ? d4{svr[b][t][0], svr[b][t][1], svr[b][t][2], svr[b][t][3]} : d4{0.0, 0.0, 0.0, 0.0};
+                    gre[g] = (STAT & 1) ? (t == 0 ? d4{row_bcast<0>(sv[b]), row_bcast<1>(sv[b]), row_bcast<2>(sv[b]), row_bcast<3>(sv[b])}
+                                                  : d4{row_bcast<4>(sv[b]), row_bcast<5>(sv[b]), row_bcast<6>(sv[b]), row_bcast<7>(sv[b])})
+                                        : d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int q = 0; q < NRE4; ++q)
                         gre[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[b][t][q], cb[g][q], gre[g], 0, 0, 0);
@@ -193,7 +196,9 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
                 d4 gim[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    gim[g] = (STAT & 2) ? d4{svi[b][t][0], svi[b][t][1], svi[b][t][2], svi[b][t][3]} : d4{0.0, 0.0, 0.0, 0.0};
+                    gim[g] = (STAT & 2) ? (t == 0 ? d4{row_bcast<8>(sv[b]), row_bcast<9>(sv[b]), row_bcast<10>(sv[b]), row_bcast<11>(sv[b])}
+                                                  : d4{row_bcast<12>(sv[b]), row_bcast<13>(sv[b]), row_bcast<14>(sv[b]), row_bcast<15>(sv[b])})
+                                        : d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int q = 0; q < NIM4; ++q)
                         gim[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[b][t][NRE4 + q], cb[g][NRE4 + q], gim[g], 0, 0, 0);

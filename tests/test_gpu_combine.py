@@ -7,6 +7,8 @@ against the MFMA GEMM routes (ctx option combine = 0), one test per kernel varia
   * a frame diagonal (phases in the stage input and in the epilogue), ragged dimension (n = 96 -> 128 padded rows),
     300 instances (384 padded columns: four waves split every list and sum through LDS);
   * RK4 (epilogues RK1..4) and the expm action of scipy_expm with magnus_order 1 and 2 (Taylor / Chebyshev epilogues).
+Every variant is forced with ctx option combine = 2; the default (1) takes the kernel only where it is the faster formulation
+(at least three quarters of its plane slots -- groups of four -- must hold a plane): asserted too.
 
 Plus: operators with exactly-zero blocks (lists shorter than the dense ones), matrix-valued states (several columns per
 instance share a coefficient row), a stack with more operators than the kernels cover (falls back to the GEMM route).
@@ -90,9 +92,14 @@ def test_combine_kernel_variant_vs_oracle_and_gemm_route(qd, kinds, static_kind,
     sched = FixedStepSchedule([0.0, 0.03], None, 0.01, _rk4_points)
     table = rng.uniform(-1, 1, (batch, len(sched.times), len(kinds)))
     y0 = crand(rng, batch, n, 1)
-    comb, cc = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 1)
+    comb, cc = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 2)      # 2: wherever the kernel applies
     assert cc["rhs_combine"]["launches"] == 12 and cc["rhs_gemm"]["launches"] == 0 and cc["rhs_blocks_gemm"]["launches"] == 0, cc
     assert int(cc["combine_info"]["ms"]) == 100 * variant[0] + 10 * variant[1] + variant[2], cc["combine_info"]
+    # the default (combine = 1) takes the kernel only where it is the faster formulation (midyn_rk4.inc: plan_uses_combine)
+    planes = sum(2 if kd == "c" else 1 for kd in kinds)          # at least three quarters of the plane slots must be in use
+    pays = 4 * planes >= 3 * 4 * (variant[0] + variant[1])
+    _, cd = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 1)
+    assert (cd["rhs_combine"]["launches"] == 12) == bool(pays), (variant, planes, cd)
     assert int(cc["combine_shape"]["ms"]) == 4, cc["combine_shape"]          # four waves split every list
     gemm, cg = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 0)
     assert cg["rhs_combine"]["launches"] == 0 and cg["rhs_gemm"]["launches"] + cg["rhs_blocks_gemm"]["launches"] == 12, cg

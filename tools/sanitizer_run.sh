@@ -2,13 +2,16 @@
 # Host side of libmidyn.so under AddressSanitizer + UndefinedBehaviorSanitizer (device code is not instrumented).
 # Build (in the CPU container, ~6 min):
 #   mkdir -p build/asan && cd build/asan
-#   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-value -fsanitize=address -fno-gpu-sanitize \
-#         -Xarch_host -fsanitize=undefined -fno-omit-frame-pointer -c -o midyn_asan.o ../../qiskit_dynamics_amd/csrc/midyn.hip
-#   (UBSan for the HOST side only: a plain -fsanitize=undefined also instruments the gfx950 code, and the contraction
-#    kernels then fail to launch -- found with tools/gemm_probe.hip: -O1, -O1 -g and -O1 + ASan are all correct)
+#   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-value -fsanitize=address,undefined -fno-sanitize=function \
+#         -fno-gpu-sanitize -fno-omit-frame-pointer -c -o midyn_asan.o ../../qiskit_dynamics_amd/csrc/midyn.hip
+#   (-fno-sanitize=function: UBSan's function-type check puts a signature word in front of every function, and the HIP
+#    runtime then no longer finds the kernels behind their host stubs -- every templated kernel launch silently does
+#    nothing; found with tools/gemm_probe.hip: -O1, -O1 -g, -O1 + ASan are correct, + UBSan is not, + UBSan without
+#    `function` is.  The C driver below is compiled WITH the check: it verifies that the C view of every entry point it
+#    calls has the function type of the C++ definition -- midyn_complex is `double _Complex` in both for that reason)
 #   hipcc -shared -fsanitize=address,undefined -o libmidyn_asan.so midyn_asan.o -ldl && rm midyn_asan.o
 #   /opt/rocm/lib/llvm/bin/clang -std=c99 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -o abi_solve_asan \
-#         ../../tests/abi_solve.c -ldl -lm
+#         ../../tests/abi_solve.c -ldl -lm -lstdc++   (libstdc++: ASan's __cxa_throw interceptor needs it when RCCL throws inside)
 # Run (on the GPU box, through gpurun):  bash tools/sanitizer_run.sh  -> gpurun_out/sanitizer/
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/sanitizer
