@@ -795,6 +795,9 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: kernel ablation bits (results wrong)")
     ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 | 12864 (kernel A/B testing)")
     ap.add_argument("--opt", action="append", default=[], help="A/B: ctx option NAME=VALUE (repeatable)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the A/B legs of cfg 3 (GEMM route, no zero-block lists, general complex operators): PMC passes, so "
+                         "that the per-dispatch counter averages of the dominant kernel are those of the headline launch only")
     ap.add_argument("--no-projection", action="store_true",
                     help="skip projected_strong_scaling (profiling: keeps shard-sized launches out of the per-kernel averages)")
     ap.add_argument("--dry-ranks", action="store_true",
@@ -1030,7 +1033,7 @@ def main():
     dense = None
     same_model_dense = None
     gemm_route = None
-    if not args.dense and roofline and world == 1 and on_combine:
+    if not args.dense and roofline and world == 1 and on_combine and not args.no_variants:
         # the MFMA GEMM formulation of the same sweep (the default route until round 3): work-list tiles, k + 1 GEMMs
         avg_g = timed_variant({"combine": 0})
         ex_g = None
@@ -1043,7 +1046,7 @@ def main():
                       "frac": round(ex_g / (avg_g * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if ex_g else None,
                       "what": "zgemm_seg_kernel<128,128,...,SPARSE> on the sector work lists: k GEMMs whose results are scaled "
                               "and summed (16 MFMA-FMAs per element against 10 FMAs of combine + apply); same results to rounding"}
-    if not args.dense and roofline and world == 1:
+    if not args.dense and roofline and world == 1 and not args.no_variants:
         plan.close()
         if on_lists or on_combine:
             avg_k = timed_variant({"skip_zero_blocks": 0, "combine": 0} if on_combine else {"skip_zero_blocks": 0})

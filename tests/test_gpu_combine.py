@@ -166,7 +166,7 @@ def test_combine_lists_skip_exactly_zero_blocks_and_matrix_states(qd):
 
     ctx = qd.default_context()
     rng = np.random.default_rng(8)
-    n, k, batch, m = 256, 5, 100, 3
+    n, k, batch, m = 256, 6, 100, 3
     ops = _operators(rng, n, "i" * k)
     half = np.arange(n) < n // 2
     ops[:, half[:, None] == half[None, :]] = 0.0          # couple only rows of one half with columns of the other
