@@ -389,6 +389,54 @@ def profile_pass(ctx, fn, classes):
 ALL_CLASSES = ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", "rhs_blocks", "rhs_blocks_gemm", "rk4_resident")
 
 
+def leg_small_sweeps(qd, workloads, instances=4096, steps=200):
+    """Sweeps of SMALL systems through the product Solver (list mode): chains of three-level transmons in the frame of their
+    static Hamiltonian, DiscreteSignal pulses with carriers -- the sizes pulse-level simulations have.  us per RK4 stage over
+    the device part of the solve on the one-launch kernel (csrc/midyn_combine_sweep.h) and with a launch per stage."""
+    out = {}
+    dt = 0.005
+    t_final = dt * steps
+    rng = np.random.default_rng(7)
+    for levels, sites in ((3, 3), (3, 4)):
+        h_d, ops, freqs = workloads.transmon_chain(levels, sites)
+        n = h_d.shape[0]
+        solver = qd.Solver(static_hamiltonian=h_d, hamiltonian_operators=ops, rotating_frame=h_d)
+        ctx = solver.model._ctx
+        n_smp = max(4, int(round(t_final / 0.05)))
+        lists = [[qd.DiscreteSignal(t_final / n_smp, rng.uniform(0.2, 1.0) * np.hanning(n_smp + 2)[1:-1], carrier_freq=f,
+                                    phase=rng.uniform(0, 2 * np.pi)) for f in freqs] for _ in range(instances)]
+        y0 = np.zeros(n, dtype=complex)
+        y0[0] = 1.0
+
+        def best(reps=3):
+            devs, calls = [], []
+            for _ in range(reps + 1):           # (the first one builds layouts / warms up)
+                t0 = time.perf_counter()
+                res = solver.solve(t_span=[0.0, t_final], y0=y0, signals=lists, method="RK4", max_dt=dt)
+                calls.append(time.perf_counter() - t0)
+                devs.append(res[0].wall_s)
+            return min(devs[1:]), min(calls[1:]), res
+
+        dev1, call1, res = best()
+        ctx.set_option("combine_sweep", 0)
+        try:
+            dev0, call0, ref = best()
+        finally:
+            ctx.set_option("combine_sweep", 1)
+        evals = instances * 4 * steps
+        out[f"{sites}_transmons_n{n}"] = {
+            "instances": instances, "steps": steps, "operators": len(ops),
+            "us_per_stage_one_launch": round(dev1 / (4 * steps) * 1e6, 2),
+            "us_per_stage_launch_per_stage": round(dev0 / (4 * steps) * 1e6, 2),
+            "rhs_evals_per_s_device": round(evals / dev1, 1), "rhs_evals_per_s_whole_call": round(evals / call1, 1),
+            "max_abs_difference_between_the_routes": float(max(np.max(np.abs(a_.y[-1] - b_.y[-1])) for a_, b_ in
+                                                               zip(res[::257], ref[::257]))),
+            "max_norm_deviation": float(max(abs(np.linalg.norm(r.y[-1]) - 1.0) for r in res[::257]))}
+    out["note"] = ("whole RK4 solve of the sweep in ONE launch, 16 instances per workgroup, state in registers, stage input in "
+                   "LDS (combine_sweep_rk4_kernel); device part = midyn_rk4_solve incl. PCIe; DESIGN 4.16")
+    return out
+
+
 def leg_cfg4_diag_frame(qd, ctx, workloads):
     """cfg 4's "second run" of SURVEY 8(d): the same Lindbladian in the diagonal rotating frame diag(H_d), the same 100
     steps through the product's default route (pinned to the oracle at this shape by
@@ -1295,6 +1343,10 @@ def main():
             out["cfg4"]["diag_frame_run"] = leg_cfg4_diag_frame(qd, ctx, workloads)
         except Exception as exc:  # pylint: disable=broad-except
             out["cfg4"] = {"error": repr(exc)}
+        try:
+            out["small_system_sweeps"] = leg_small_sweeps(qd, workloads)
+        except Exception as exc:  # pylint: disable=broad-except
+            out["small_system_sweeps"] = {"error": repr(exc)}
     if want_cfg5:
         # second sharded leg: cfg 5, 1024 instances in total, 1024/N per GPU; the 2.4 GB stack is broadcast
         try:

@@ -75,6 +75,10 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         formulation (the planes of a kind fill groups of four MFMA slots: at least three quarters of
  *                         the slots must hold a plane); 2: wherever the kernels apply; 0: the MFMA GEMM routes
  *   combine_min_cols [256]   ... smallest padded column count of the state block that takes it
+ *   combine_sweep [1]     fixed-step RK4 sweeps (midyn_rk4_solve, B > 1 instances, one state column each) of stacks with that
+ *                         layout and n_pad <= 256: the WHOLE solve in one launch, 16 instances per workgroup, state in
+ *                         registers, stage input in LDS (csrc/midyn_combine_sweep.h); 1: always up to n_pad = 128, above only
+ *                         when the workgroups fill the chip, 2: wherever it applies, 0: never (a launch per RK4 stage)
  *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage
  *   multi_stream [1]      2..8 state columns at n >= 256: multi-column streaming kernel
  *   tiny_rk4 [1]          small systems: whole fixed-step solve in one persistent launch
@@ -289,7 +293,9 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * "rhs_combine" counts the launches of the COMBINE + APPLY sweep kernel; its last launch is described by
  * "combine_info" -> (listed (32-row group, 16-column block) entries of the stack, 100 NRE4 + 10 NIM4 + STAT: groups of four
  * real / imaginary operator planes and the static operator's planes, bit 0 real, bit 1 imaginary) and "combine_shape" ->
- * ((row group, column block) pairs per workgroup, waves that split the list of one pair). */
+ * ((row group, column block) pairs per workgroup, waves that split the list of one pair).  A one-launch RK4 sweep
+ * (combine_sweep) counts as ONE "rhs_combine" launch; "combine_sweep" -> (workgroups of 16 instances, 10 x waves per
+ * workgroup + 16-row tiles per wave) of the last one. */
 int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);
 int midyn_reset_counters(midyn_ctx* ctx);
 /* Measured ceilings: "mfma_f64" -> out[0] = TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64; "mfma_f64_sustained"

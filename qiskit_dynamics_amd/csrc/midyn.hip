@@ -21,6 +21,7 @@
 #include "midyn_kernels.h"
 #include "midyn_resident.h"
 #include "midyn_combine.h"
+#include "midyn_combine_sweep.h"
 
 using namespace midyn;
 

@@ -1,0 +1,370 @@
+// midyn_combine_sweep.h -- fixed-step RK4 sweeps of SMALL dense systems (n_pad <= 256) in ONE launch (round 4).
+//
+// The per-launch route runs a batched evaluation as one kernel: at n = 64 .. 256 and a few thousand instances such a
+// launch holds microseconds of matrix-pipe work, so a solve is bound by launches, by the state going through memory four
+// times per step and -- with 64 instances per wave -- by too few waves to fill the chip.  Trajectories of a sweep are
+// independent (solvers/solver_classes.py:568-586 loops over them), so nothing has to cross workgroups: a workgroup owns 16
+// INSTANCES through ALL steps (fixed_step_solvers.py:43-77, the RK4 step; :406-459, the step loop).
+//
+//   * the evaluation is COMBINE + APPLY of midyn_combine.h on the same re-packed operator planes and zero-block lists
+//     (v_mfma_f64_16x16x4 over 4 planes x 16 rows x 16 instances, then 2 .. 4 vector FMAs per element), one wave per
+//     RT 16-row tiles (RT = 1: n_pad <= 128, RT = 2 above), at n_pad = 64 two waves per tile that split the list and sum
+//     through LDS;
+//   * y and the RK4 accumulator of a wave's rows stay in its registers for the whole solve (RT = 1; at RT = 2 the registers
+//     are taken by the contraction and a stage lasts tens of microseconds: they are read and written once per stage in
+//     the workgroup's own columns of two [n_pad][ld] blocks); the stage input, already phased with the frame phases of the
+//     stage time, is the only vector the waves exchange: two LDS copies [n_pad][16], written by the stage before, one
+//     barrier per stage;
+//   * coefficients c_j[instance] of a stage: one load per plane group and lane from the table S[B][R][k], a stage ahead.
+//
+// 256 workgroups of 16 instances fill the chip at 4096 instances; the time of a stage is the workgroup's matrix-pipe time
+// (n_pad^2 x 16 x (plane slots + 2 .. 4) FMAs on one CU at 64 per clock) plus one to two microseconds of exchange, reduction
+// and stage arithmetic.  Measured (tools/bench_small_sweeps.py, chains of three-level transmons / qubits in the frame of
+// their static Hamiltonian, 4096 instances, us per RK4 stage, this kernel against the per-launch kernels of the same
+// formulation): n = 27: 2.8 / 14.8; n = 64 (6 operators): 8.4 / 20.5; n = 81: 13.4 / 23.7; n = 128 (7): 27 / 33; n = 243: 60 / 84;
+// n = 256 (8): 77 / 89.  With few workgroups the large sizes lose (n = 243, 256 instances: 55 against 19): the host takes this
+// kernel above n_pad = 128 only when its workgroups fill the chip (midyn_rk4.inc: rk4_combine_sweep_one_launch).
+// What did NOT matter, measured one by one: the look-ahead depth beyond a few steps, the coefficient / phase loads of a stage
+// (cold, but a stage ahead), scalar loads in the loop.  What did: 64-bit vector address arithmetic in the kk step (vector
+// integer instructions take issue cycles from the SIMD that feeds the matrix pipe).
+#pragma once
+
+namespace midyn {
+
+struct CombineSweepArgs {
+    const double* frags;      // the stack's COMBINE layout (midyn_combine.h): [entry][kk % 16][tile < 2][group][lane]
+    const int* list_ptr;      // [n_pad / 32 + 1]
+    const int* list_idx;
+    const double2* stat;      // static operator [lda][lda] or nullptr
+    int lda;
+    int plane_col[8 * CMB_MAXQ];
+    int n, n_pad, k, B;
+    int splits;               // waves that share one row tile (1 or 2)
+    const double* S;          // [B][R][k]
+    long long inst_stride;    // R * k
+    const double2* E;         // [R][n_pad] frame phases of the table times, or nullptr
+    const int* rows;          // [nsteps][3] table rows of t, t + h / 2, t + h
+    const double* hs;         // [nsteps]
+    const int* save;          // [nsteps] slot of the saved states the step's result goes to (-1: none), or nullptr
+    int nsteps;
+    const double2* y0;        // [B | 1][n]
+    int y0_shared;
+    double2* out;             // [B][P][n]
+    int P;
+    double2* ybuf;            // RT == 2 (registers at their limit, stages of tens of microseconds): y and the RK4 accumulator of the
+    double2* accbuf;          // workgroup's instances live in memory, [n_pad][ld], ybuf holding y0 at launch; RT == 1: unused
+    int ld;
+};
+
+// Operand look-ahead in kk steps: a step is RT (64 NQ + 42) pipe cycles of one wave against several hundred cycles from
+// the L2 to a register.
+constexpr int sweep_depth(int rt, int nq, int stat) {
+    return rt == 2 ? (nq >= 2 || stat ? 2 : 4) : (nq <= 2 ? 8 : 4);      // (two tiles: registers; their steps are long anyway)
+}
+
+template <int NRE4, int NIM4, int STAT, int RT>
+__global__ __launch_bounds__(512) void combine_sweep_rk4_kernel(const CombineSweepArgs a) {
+    constexpr int NQ = NRE4 + NIM4, D = sweep_depth(RT, NQ, STAT);
+    constexpr bool RE = NRE4 > 0 || (STAT & 1), IM = NIM4 > 0 || (STAT & 2);
+    static_assert(NQ > 0 && NRE4 <= CMB_MAXQ && NIM4 <= CMB_MAXQ && (RT == 1 || RT == 2), "shape");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int np = a.n_pad;
+    double2* const X0 = reinterpret_cast<double2*>(smem_raw);          // two copies of the phased stage input [n_pad][16]
+    double* const red = reinterpret_cast<double*>(X0 + (size_t)2 * np * 16);   // splits == 2: partial sums of the second wave
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sp = wave % a.splits, wt = wave / a.splits;
+    const int row0 = wt * 16 * RT;                       // this wave's rows: row0 + 16 t + lq + 4 r
+    const int rg = row0 >> 5, t0 = (row0 >> 4) & 1;      // row group of the lists, first tile inside it
+    const int lb = lane & 15, lq = lane >> 4;
+    const int inst = blockIdx.x * 16 + lb;
+    const bool live = inst < a.B;
+    const int ic = live ? inst : a.B - 1;
+    const double* __restrict__ Sb = a.S + (size_t)ic * a.inst_stride;
+    int pc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) pc[q] = a.plane_col[4 * q + lq];
+
+    int e0 = a.list_ptr[rg], e1 = a.list_ptr[rg + 1];
+    if (a.splits > 1) {
+        const int len = e1 - e0;
+        e1 = e0 + (int)((long long)len * (sp + 1) / a.splits);
+        e0 = e0 + (int)((long long)len * sp / a.splits);
+    }
+    const int steps = (e1 - e0) * 16;
+    // (wave-uniform bases in scalar registers + one 32-bit lane offset: the loads take the scalar-base form and a step needs no
+    // 64-bit vector address arithmetic -- vector integer work takes issue cycles from the matrix pipe of the SIMD)
+    using gbytes = const __attribute__((address_space(1))) char*;      // (global, so that the loads are not flat ones)
+    auto uniform_ptr = [](const void* p_) {
+        const unsigned long long v = (unsigned long long)p_;
+        return (gbytes)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)v));
+    };
+    const gbytes frb = uniform_ptr(a.frags + (size_t)e0 * (16 * 2 * NQ * 64));
+    // static rows of this lane by DPP (midyn_combine.h): lane lb fetches row lq + 4 (lb & 3) of tile (RT == 2 ? (lb >> 2) & 1 : t0),
+    // plane lb >> 3
+    const gbytes sbb = uniform_ptr(a.stat + (size_t)(rg * CMB_ROWS) * a.lda);
+    const unsigned s_lane = ((unsigned)((lq + 4 * (lb & 3) + 16 * (RT == 2 ? ((lb >> 2) & 1) : t0)) * a.lda) * 2u + (unsigned)(lb >> 3)) * 8u;   // bytes
+
+    // the state of this wave's rows (used by the waves with sp == 0)
+    constexpr int SR = RT == 1 ? 1 : 0;                  // RT == 2: the state lives in memory (ybuf / accbuf)
+    double2 y[RT][4], acc[SR ? RT : 1][4];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 16 * t + lq + 4 * r;
+            y[t][r] = (row < a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)ic * a.n) + row] : make_double2(0.0, 0.0);
+            if constexpr (SR) acc[t][r] = y[t][r];
+        }
+    if (sp == 0) {
+        const double2* Es = a.E ? a.E + (size_t)a.rows[0] * np : nullptr;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 16 * t + lq + 4 * r;
+                X0[(size_t)row * 16 + lb] = Es ? cmul(Es[row], y[t][r]) : y[t][r];
+            }
+    }
+    __syncthreads();
+
+    double afr[D][RT][NQ];
+    double2 yv[D];
+    double sv[D];
+    d4 ore[RT], oim[RT];
+    double cb[NQ], cbn[NQ];
+    // What a stage needs from memory is requested ONE STAGE AHEAD (a stage of a 64-row system is 3 us): the coefficients and
+    // frame phases of the next stage are loaded at the top of this one, the operator fragments of the first D - 1 kk steps by
+    // the look-ahead of the last ones (the fragments are the same every stage).  No scalar loads inside the stage loop -- a
+    // wait for an LDS read with a scalar load outstanding is a wait for everything (lgkmcnt counts both, scalar loads return
+    // out of order): the per-stage scalars (table row, step size, save slot) of 64 stages sit in one register each, lane =
+    // stage, refilled every 32 stages, and are read with v_readlane; the kk blocks of the wave's list likewise.
+    const int nstage = 4 * a.nsteps;
+    int rowv = 0, savev = -1, kbv = 0;
+    double hv = 0.0;
+    auto refill = [&](int base) {
+        int i = base + lane;
+        i = i < nstage ? i : nstage - 1;
+        const int g = i & 3;
+        rowv = a.rows[3 * (i >> 2) + (g == 0 ? 0 : (g == 3 ? 2 : 1))];
+        hv = a.hs[i >> 2];
+        savev = (g == 3 && a.save) ? a.save[i >> 2] : -1;
+    };
+    refill(0);
+    {
+        const int ne = e1 - e0;
+        kbv = ne > 0 ? a.list_idx[e0 + (lane < ne ? lane : ne - 1)] : 0;      // (a share of a list has at most 16 entries)
+    }
+    auto kb_of = [&](int entry) { return __builtin_amdgcn_readlane(kbv, entry); };
+    const int s_first = __builtin_amdgcn_readlane(rowv, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) cb[q] = pc[q] >= 0 ? Sb[(size_t)s_first * a.k + pc[q]] : 0.0;
+    double2 ec[RT][4], en[RT][4];
+    if (RT == 1 && a.E && sp == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ec[0][r] = a.E[(size_t)s_first * np + row0 + lq + 4 * r];
+    }
+    const int kb_first = kb_of(0);
+    // global operands of flat step `sf` (entry sf / 16 of this wave's share of the list) into slot b
+    const unsigned f_lane = (unsigned)((RT == 2 ? 0 : t0) * NQ * 64 + lane) * 8u;      // bytes
+    auto load_g = [&](int sf, int kk, int b) {
+        const gbytes fn = frb + (unsigned)sf * (unsigned)(2 * NQ * 64 * 8);
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) afr[b][t][q] = *(const __attribute__((address_space(1))) double*)(fn + f_lane + (unsigned)((t * NQ + q) * 64 * 8));
+        if (STAT) sv[b] = *(const __attribute__((address_space(1))) double*)(sbb + (unsigned)kk * 16u + s_lane);
+    };
+    if (steps > 0) {
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) load_g(j, kb_first * 16 + j, j);
+    }
+    // all four stages of all steps run through ONE copy of the loops below (stage index 4 st + sg)
+    for (int stage = 0; stage < nstage; ++stage) {
+        const int st = stage >> 2, sg = stage & 3;
+        if ((stage & 31) == 0 && stage > 0) refill(stage);
+        const int sl = stage & 31;
+        const int srow = __builtin_amdgcn_readlane(rowv, sl), nrow = __builtin_amdgcn_readlane(rowv, sl + 1);
+        const long long hb = __double_as_longlong(hv);
+        const double h = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hb >> 32), sl) << 32) |
+                                                          (unsigned)__builtin_amdgcn_readlane((int)hb, sl)));
+        const int save_slot = __builtin_amdgcn_readlane(savev, sl);
+        const double2* __restrict__ X = X0 + (size_t)(sg & 1) * np * 16;          // (four stages: a step starts on copy 0)
+        double2* __restrict__ Xn = X0 + (size_t)((sg & 1) ^ 1) * np * 16;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) cbn[q] = pc[q] >= 0 ? Sb[(size_t)nrow * a.k + pc[q]] : 0.0;
+        // frame phases of the next stage's rows (its input).  One tile per wave: loaded here, ahead of the contraction, and
+        // kept for the result of the next stage; two tiles (n_pad > 128: stages of tens of microseconds, registers at their
+        // limit): both sets after the contraction
+        if (RT == 1 && a.E && sp == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) en[0][r] = a.E[(size_t)nrow * np + row0 + lq + 4 * r];
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            ore[t] = d4{0.0, 0.0, 0.0, 0.0};
+            oim[t] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+        auto load_x = [&](int kk, int b) {
+            yv[b] = X[(size_t)kk * 16 + lb];
+            // (the loads stay HERE, D - 1 steps ahead of their use: left alone, the scheduler sinks them to their first use)
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto static_re = [&](int t, int b) {
+            return (STAT & 1) ? (t == 0 ? d4{row_bcast<0>(sv[b]), row_bcast<1>(sv[b]), row_bcast<2>(sv[b]), row_bcast<3>(sv[b])}
+                                        : d4{row_bcast<4>(sv[b]), row_bcast<5>(sv[b]), row_bcast<6>(sv[b]), row_bcast<7>(sv[b])})
+                              : d4{0.0, 0.0, 0.0, 0.0};
+        };
+        auto static_im = [&](int t, int b) {
+            return (STAT & 2) ? (t == 0 ? d4{row_bcast<8>(sv[b]), row_bcast<9>(sv[b]), row_bcast<10>(sv[b]), row_bcast<11>(sv[b])}
+                                        : d4{row_bcast<12>(sv[b]), row_bcast<13>(sv[b]), row_bcast<14>(sv[b]), row_bcast<15>(sv[b])})
+                              : d4{0.0, 0.0, 0.0, 0.0};
+        };
+        // COMBINE of one kk step (slot b) into g[..][p], APPLY of the step before from g[..][p ^ 1]: a wave with ONE tile has one
+        // chain MFMA(s) -> vector FMAs per step, and in program order every step would wait for its own MFMA; software-pipelined
+        // the FMAs of step s run behind the MFMAs of step s + 1 (PIPE; needs a look-ahead of more than one step)
+        constexpr bool PIPE = D > 2;
+        d4 gre[PIPE ? 2 : 1][RT], gim[PIPE ? 2 : 1][RT];
+        auto combine = [&](int b, int p, int kinds) {      // kinds: bit 0 the real planes, bit 1 the imaginary ones
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                if (RE && (kinds & 1)) {
+                    gre[p][t] = static_re(t, b);
+#pragma unroll
+                    for (int q = 0; q < NRE4; ++q) gre[p][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[b][t][q], cb[q], gre[p][t], 0, 0, 0);
+                }
+                if (IM && (kinds & 2)) {
+                    gim[p][t] = static_im(t, b);
+#pragma unroll
+                    for (int q = 0; q < NIM4; ++q)
+                        gim[p][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[b][t][NRE4 + q], cb[NRE4 + q], gim[p][t], 0, 0, 0);
+                }
+            }
+        };
+        auto apply = [&](int b, int p, int kinds) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (RE && (kinds & 1)) {
+                        ore[t][r] = fma(gre[p][t][r], yv[b].x, ore[t][r]);
+                        oim[t][r] = fma(gre[p][t][r], yv[b].y, oim[t][r]);
+                    }
+                    if (IM && (kinds & 2)) {
+                        ore[t][r] = fma(-gim[p][t][r], yv[b].y, ore[t][r]);
+                        oim[t][r] = fma(gim[p][t][r], yv[b].x, oim[t][r]);
+                    }
+                }
+        };
+        if (steps > 0) {
+            // the look-ahead of D - 1 steps wraps past the end of the list to its first steps: the operator fragments of the
+            // NEXT stage (its state rows are re-read after the barrier)
+#pragma unroll
+            for (int j = 0; j < D - 1; ++j) load_x(kb_first * 16 + j, j);
+            if (PIPE) combine(0, 0, 3);
+            // (steps is a multiple of 16, D divides 16; the last D steps are a copy of the loop body of their own: only there can
+            // the look-ahead pass the end, at positions known at compile time)
+            auto body = [&](int s, bool last) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const int sfw = (last && j >= 1) ? j - 1 : s + j + D - 1;
+                    const int kk = kb_of(sfw >> 4) * 16 + (sfw & 15);
+                    load_g(sfw, kk, (j + D - 1) % D);
+                    load_x(kk, (j + D - 1) % D);
+                    if (PIPE) {
+                        combine((j + 1) % D, (j + 1) & 1, 3);   // (after the last step: the first step of the next stage with this
+                        apply(j, j & 1, 3);                     //  stage's coefficients -- discarded)
+                    } else {                                    // two tiles, two or more plane groups: one plane kind at a time
+                        combine(j, 0, 1);                       // (registers)
+                        apply(j, 0, 1);
+                        combine(j, 0, 2);
+                        apply(j, 0, 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            for (int s = 0; s < steps - D; s += D) body(s, false);
+            body(steps - D, true);
+        }
+        if (a.splits > 1) {
+            double* slot = red + (size_t)wt * (RT * 8 * 64) + lane;
+            if (sp > 0) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        slot[(t * 8 + r) * 64] = ore[t][r];
+                        slot[(t * 8 + 4 + r) * 64] = oim[t][r];
+                    }
+            }
+            __syncthreads();
+            if (sp == 0) {
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ore[t][r] += slot[(t * 8 + r) * 64];
+                        oim[t][r] += slot[(t * 8 + 4 + r) * 64];
+                    }
+            }
+        }
+        if (sp == 0) {
+            // RK4 stage arithmetic (fixed_step_solvers.py:43-77): acc' = (sg == 0 ? y : acc) + wa h k, input of the next stage
+            // y + wc h k; the last stage: y' = acc + h k / 6, which is also the next input
+            const double wa = (sg == 0 || sg == 3) ? h * (1.0 / 6) : h * (1.0 / 3);
+            const double wc = sg == 2 ? h : 0.5 * h;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                double2 yy[4], aa[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 16 * t + lq + 4 * r;
+                    if (RT == 2 && a.E) {
+                        ec[t][r] = a.E[(size_t)srow * np + row];
+                        en[t][r] = a.E[(size_t)nrow * np + row];
+                    }
+                    if constexpr (SR) {
+                        yy[r] = y[t][r];
+                        aa[r] = acc[t][r];
+                    } else {
+                        const size_t idx = (size_t)row * a.ld + blockIdx.x * 16 + lb;
+                        yy[r] = a.ybuf[idx];
+                        aa[r] = a.accbuf[idx];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 16 * t + lq + 4 * r;
+                    const double2 o = make_double2(ore[t][r], oim[t][r]);
+                    const double2 kv = a.E ? cmul_conj_a(ec[t][r], o) : o;
+                    aa[r] = cfma_r(wa, kv, sg == 0 ? yy[r] : aa[r]);
+                    double2 cur = cfma_r(wc, kv, yy[r]);
+                    if (sg == 3) {
+                        yy[r] = aa[r];
+                        cur = aa[r];
+                    }
+                    Xn[(size_t)row * 16 + lb] = a.E ? cmul(en[t][r], cur) : cur;
+                    if constexpr (SR) {
+                        y[t][r] = yy[r];
+                        acc[t][r] = aa[r];
+                    } else {
+                        const size_t idx = (size_t)row * a.ld + blockIdx.x * 16 + lb;
+                        a.accbuf[idx] = aa[r];
+                        if (sg == 3) a.ybuf[idx] = yy[r];
+                    }
+                    if (save_slot >= 0 && live && row < a.n) a.out[((size_t)inst * a.P + save_slot) * a.n + row] = yy[r];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) cb[q] = cbn[q];
+        if (RT == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ec[0][r] = en[0][r];
+        }
+        __syncthreads();      // the next stage's input is complete (and nobody reads the copy it replaces any more)
+    }
+}
+
+}  // namespace midyn

@@ -140,3 +140,28 @@ def lindblad_config(n_qubits=6, n_drives=6, n_diss=4, gamma=1e-3, t_final=5.0, m
     rho0[0, 0] = 1.0
     return dict(h_d=h_d, ops=ops, static_dissipators=diss, rho0=rho0, t_span=[0.0, t_final],
                 max_dt=max_dt, carrier=nu[:n_drives].copy(), t_final=t_final)
+
+
+def transmon_chain(levels, sites, seed=0):
+    """A chain of `sites` oscillators truncated to `levels` levels (three: the transmon of pulse-level simulations):
+    H_d = sum_i w_i N_i + alpha / 2 N_i (N_i - 1) + J sum_i (a_i^+ a_{i+1} + h.c.), one drive a_i + a_i^+ per site.
+    Returns (h_d, drive operators, drive frequencies in GHz); n = levels ** sites."""
+    rng = np.random.default_rng(seed)
+    a = np.diag(np.sqrt(np.arange(1, levels)), 1).astype(complex)
+    num = a.conj().T @ a
+    eye = np.eye(levels)
+
+    def on(op, i):
+        out = np.array([[1.0 + 0j]])
+        for s in range(sites):
+            out = np.kron(out, op if s == i else eye)
+        return out
+
+    w = 2 * np.pi * (5.0 + 0.1 * rng.standard_normal(sites))
+    alpha = -2 * np.pi * 0.3
+    h_d = sum(w[i] * on(num, i) + 0.5 * alpha * on(num @ (num - eye), i) for i in range(sites))
+    for i in range(sites - 1):
+        hop = on(a.conj().T, i) @ on(a, i + 1)
+        h_d = h_d + 2 * np.pi * 0.005 * (hop + hop.conj().T)
+    ops = [2 * np.pi * 0.02 * (on(a, i) + on(a.conj().T, i)) for i in range(sites)]
+    return h_d, ops, w / (2 * np.pi)

@@ -10,6 +10,10 @@ against the MFMA GEMM routes (ctx option combine = 0), one test per kernel varia
 Every variant is forced with ctx option combine = 2; the default (1) takes the kernel only where it is the faster formulation
 (at least three quarters of its plane slots -- groups of four -- must hold a plane): asserted too.
 
+The same 32 variants on the ONE-LAUNCH kernel of RK4 sweeps of small systems (csrc/midyn_combine_sweep.h,
+combine_sweep_rk4_kernel<NRE4, NIM4, STAT, RT>: 16 instances per workgroup through all steps) at n_pad = 64 (two waves per
+row tile), 128 and 256 (two tiles per wave), against the per-launch kernels and the oracle.
+
 Plus: operators with exactly-zero blocks (lists shorter than the dense ones), matrix-valued states (several columns per
 instance share a coefficient row), a stack with more operators than the kernels cover (falls back to the GEMM route).
 The reference computes the same thing per instance as  (G_d + sum_j c_j G_j) y  (models/operator_collections.py:101-134).
@@ -47,9 +51,12 @@ def _operators(rng, n, kinds):
     return np.array(ops)
 
 
-def _solve(qd, stack, method, sched, table, y0, batch, shared, combine, magnus_order=1):
+def _solve(qd, stack, method, sched, table, y0, batch, shared, combine, magnus_order=1, one_launch=0):
+    """one_launch = 0 pins the per-launch kernels (RK4 sweeps of systems with n_pad <= 256 otherwise run on the one-launch kernel
+    of midyn_combine_sweep.h, which has its own tests below)."""
     ctx = qd.default_context()
     ctx.set_option("combine", combine)
+    ctx.set_option("combine_sweep", one_launch)
     ctx.reset_counters()
     ctx.set_option("profile", 1)
     try:
@@ -61,7 +68,9 @@ def _solve(qd, stack, method, sched, table, y0, batch, shared, combine, magnus_o
     finally:
         ctx.set_option("profile", 0)
         ctx.set_option("combine", 1)
-    return ys, {c: ctx.counters(c) for c in ("rhs_combine", "rhs_gemm", "rhs_blocks_gemm", "combine_info", "combine_shape")}
+        ctx.set_option("combine_sweep", 1)
+    return ys, {c: ctx.counters(c) for c in ("rhs_combine", "rhs_gemm", "rhs_blocks_gemm", "combine_info", "combine_shape",
+                                             "combine_sweep")}
 
 
 CASES = [
@@ -205,4 +214,124 @@ def test_more_operators_than_the_combine_kernels_cover_take_the_gemm_route(qd):
         _, cc = _solve(qd, stack, "RK4", sched, table, crand(rng, n, 1), batch, True, 1)
         assert (cc["rhs_combine"]["launches"] > 0) == want_combine, (k, batch, cc)
         assert (cc["rhs_gemm"]["launches"] + cc["rhs_blocks_gemm"]["launches"] > 0) != want_combine, (k, batch, cc)
+        stack.close()
+
+
+# ---- RK4 sweeps of small systems in ONE launch (csrc/midyn_combine_sweep.h) -----------------------------------------------------
+SWEEP_SIZES = ((40, 37), (96, 300), (200, 70), (128, 16), (243, 33))     # (n, instances): n_pad 64 / 128 / 256 / 128 / 256
+
+
+@pytest.mark.parametrize("idx", range(len(CASES)), ids=["%d%d%d" % v for _, _, v in CASES])
+def test_one_launch_sweep_variant_vs_per_launch_route_and_oracle(qd, idx):
+    """Every (NRE4, NIM4, STAT) variant of combine_sweep_rk4_kernel, sizes rotating over the three workgroup shapes; a frame
+    diagonal, per-instance initial states, steps of two different sizes and three saved states (fixed_step_solvers.py:406-459
+    with a t_eval).  The per-launch kernels of the same formulation must agree to rounding, the oracle's RK4 to 1e-11."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    kinds, static_kind, variant = CASES[idx]
+    ctx = qd.default_context()
+    rng = np.random.default_rng(700 + idx)
+    n, batch = SWEEP_SIZES[idx % len(SWEEP_SIZES)]
+    ops = _operators(rng, n, kinds)
+    static = None if static_kind is None else _operators(rng, n, static_kind)[0]
+    fim = rng.normal(size=n) if idx % 3 else None
+    stack = qd.Stack(ctx, ops, static, fim)
+    t_eval = [0.0, 0.013, 0.03]
+    sched = FixedStepSchedule([0.0, 0.03], t_eval, 0.01, _rk4_points)
+    table = rng.uniform(-1, 1, (batch, len(sched.times), len(kinds)))
+    y0 = crand(rng, batch, n, 1)
+    one, c1 = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 2, one_launch=2)      # 2: wherever it applies
+    n_pad = -(-n // 64) * 64
+    rt = 2 if n_pad > 128 else 1
+    waves = n_pad // (16 * rt) * (2 if n_pad == 64 else 1)
+    assert c1["rhs_combine"]["launches"] == 1 and c1["rhs_gemm"]["launches"] == 0 and c1["rhs_blocks_gemm"]["launches"] == 0, c1
+    assert (int(c1["combine_sweep"]["launches"]), int(c1["combine_sweep"]["ms"])) == (-(-batch // 16), 10 * waves + rt), c1["combine_sweep"]
+    assert int(c1["combine_info"]["ms"]) == 100 * variant[0] + 10 * variant[1] + variant[2], c1["combine_info"]
+    per, c0 = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 2, one_launch=0)
+    assert c0["rhs_combine"]["launches"] + c0["rhs_gemm"]["launches"] + c0["rhs_blocks_gemm"]["launches"] == 4 * len(sched.step_h), c0
+    assert one.shape == per.shape == (batch, sched.n_save, n, 1)      # slots: t_span[0], the three t_eval points, t_span[1]
+    assert_close(one, per, 1e-13)
+    d = None if fim is None else 1j * fim
+    times = np.asarray(sched.times)
+    for b in (0, batch // 2, batch - 1):
+        def rhs(t, y, b=b):
+            return orc.generator_rhs(static, ops, table[b, int(np.argmin(np.abs(times - t)))], d, None, t, y)
+
+        _, yref = orc.rk4_solve(rhs, [0.0, 0.03], y0[b, :, 0], 0.01, t_eval)
+        assert_close(one[b, 1:-1, :, 0], yref, 1e-11)
+    stack.close()
+
+
+def test_one_launch_sweep_through_the_solver_with_shared_y0(qd):
+    """The product Solver in list mode (solver_classes.py:556-590): a 4-level, 3-site chain (n = 64) in the frame of its
+    static Hamiltonian, one y0 for the whole sweep, 45 instances; default options take the one-launch kernel; against the per-launch route and the oracle."""
+    from oracle import dynamics_oracle as orc
+
+    levels, sites = 4, 3
+    a = np.diag(np.sqrt(np.arange(1, levels)), 1).astype(complex)
+    num = a.conj().T @ a
+    eye = np.eye(levels)
+
+    def on(op, i):
+        out = np.array([[1.0 + 0j]])
+        for s_ in range(sites):
+            out = np.kron(out, op if s_ == i else eye)
+        return out
+
+    h_d = sum((5.0 + 0.1 * i) * on(num, i) - 0.15 * on(num @ (num - eye), i) for i in range(sites))
+    for i in range(sites - 1):
+        hop = on(a.conj().T, i) @ on(a, i + 1)
+        h_d = h_d + 0.02 * (hop + hop.conj().T)
+    ops = [0.1 * (on(a, i) + on(a.conj().T, i)) for i in range(sites)]
+    solver = qd.Solver(static_hamiltonian=h_d, hamiltonian_operators=ops, rotating_frame=h_d)
+    ctx = solver.model._ctx
+    rng = np.random.default_rng(5)
+    batch = 45
+    lists = [[qd.Signal(float(rng.uniform(0.3, 1.0)), 5.0 + 0.1 * i, float(rng.uniform(0, 6))) for i in range(sites)]
+             for _ in range(batch)]
+    y0 = np.zeros(levels**sites, dtype=complex)
+    y0[0] = 1.0
+    t_span, dt = [0.0, 0.5], 0.01
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    try:
+        res = solver.solve(t_span=t_span, y0=y0, signals=lists, method="RK4", max_dt=dt)
+        c1 = {c: ctx.counters(c) for c in ("rhs_combine", "combine_sweep", "combine_info")}
+        ctx.set_option("combine_sweep", 0)
+        ctx.reset_counters()
+        ref = solver.solve(t_span=t_span, y0=y0, signals=lists, method="RK4", max_dt=dt)
+        c0 = ctx.counters("rhs_combine")
+    finally:
+        ctx.set_option("profile", 0)
+        ctx.set_option("combine_sweep", 1)
+    assert c1["rhs_combine"]["launches"] == 1 and int(c1["combine_sweep"]["launches"]) == 3, c1
+    assert c1["combine_info"]["launches"] <= (64 // 32) * (64 // 16), c1["combine_info"]
+    assert c0["launches"] != 1
+    for b in range(batch):
+        assert_close(res[b].y[-1], ref[b].y[-1], 1e-12)
+    a_d, a_ops, d, basis = orc.hamiltonian_model_build(h_d, np.array(ops), -1j * h_d)
+    for b in (0, 44):
+        def coeffs(t, b=b):
+            return np.array([np.real(sg.complex_value(t)) for sg in lists[b]])
+
+        _, yref = orc.solve_generator_model(a_d, a_ops, d, basis, coeffs, t_span, y0, "RK4", dt)
+        assert_close(res[b].y[-1], yref[-1], SOLVE_TOL)
+    assert np.max([abs(np.linalg.norm(r.y[-1]) - 1.0) for r in res]) < 1e-8
+
+
+def test_one_launch_sweep_is_taken_where_it_is_faster(qd):
+    """Default options (combine_sweep = 1): up to n_pad = 128 every RK4 sweep of a stack with a COMBINE layout runs in one launch;
+    above, only when the workgroups of 16 instances fill the chip (midyn_rk4.inc: rk4_combine_sweep_one_launch): 33 and 2000
+    instances at n = 200 stay on the per-launch kernels, 4096 instances take the one-launch kernel."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(77)
+    sched = FixedStepSchedule([0.0, 0.02], None, 0.01, _rk4_points)
+    for n, batch, want in ((96, 33, True), (40, 300, True), (200, 33, False), (200, 2000, False), (200, 4096, True)):
+        stack = qd.Stack(ctx, _operators(rng, n, "iii"), None, rng.normal(size=n))
+        table = rng.uniform(-1, 1, (batch, len(sched.times), 3))
+        _, cc = _solve(qd, stack, "RK4", sched, table, crand(rng, n, 1), batch, True, 1, one_launch=1)
+        assert (cc["rhs_combine"]["launches"] == 1) == want, (n, batch, cc)
         stack.close()
