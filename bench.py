@@ -423,8 +423,23 @@ def leg_small_sweeps(qd, workloads, instances=4096, steps=200):
             dev0, call0, ref = best()
         finally:
             ctx.set_option("combine_sweep", 1)
+        # the same sweep with scipy_expm (Magnus order 1, same steps): the expm action, one launch / a launch per product
+        e_steps = steps
+        expm = {}
+        for key, opt in (("one_launch", 1), ("launch_per_product", 0)):
+            ctx.set_option("combine_sweep", opt)
+            try:
+                devs = []
+                for _ in range(3):
+                    r_e = solver.solve(t_span=[0.0, t_final], y0=y0, signals=lists, method="scipy_expm", max_dt=dt)
+                    devs.append(r_e[0].wall_s)
+            finally:
+                ctx.set_option("combine_sweep", 1)
+            expm["us_per_step_" + key] = round(min(devs[1:]) / e_steps * 1e6, 2)
+        expm["max_abs_difference_to_the_rk4_result_midpoint_magnus_vs_rk4"] = float(max(np.max(np.abs(a_.y[-1] - b_.y[-1])) for a_, b_ in zip(res[::257], r_e[::257])))
         evals = instances * 4 * steps
         out[f"{sites}_transmons_n{n}"] = {
+            "scipy_expm_magnus1": expm,
             "instances": instances, "steps": steps, "operators": len(ops),
             "us_per_stage_one_launch": round(dev1 / (4 * steps) * 1e6, 2),
             "us_per_stage_launch_per_stage": round(dev0 / (4 * steps) * 1e6, 2),
@@ -432,8 +447,9 @@ def leg_small_sweeps(qd, workloads, instances=4096, steps=200):
             "max_abs_difference_between_the_routes": float(max(np.max(np.abs(a_.y[-1] - b_.y[-1])) for a_, b_ in
                                                                zip(res[::257], ref[::257]))),
             "max_norm_deviation": float(max(abs(np.linalg.norm(r.y[-1]) - 1.0) for r in res[::257]))}
-    out["note"] = ("whole RK4 solve of the sweep in ONE launch, 16 instances per workgroup, state in registers, stage input in "
-                   "LDS (combine_sweep_rk4_kernel); device part = midyn_rk4_solve incl. PCIe; DESIGN 4.16")
+    out["note"] = ("whole RK4 / scipy_expm solve of the sweep in ONE launch, 16 instances per workgroup, state in registers, stage "
+                   "input in LDS (combine_sweep_kernel); device part = midyn_rk4_solve / midyn_expm_solve incl. PCIe, plan set-up "
+                   "and (expm) the host-side choice of the series of every step; DESIGN 4.16")
     return out
 
 

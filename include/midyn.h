@@ -75,10 +75,11 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         formulation (the planes of a kind fill groups of four MFMA slots: at least three quarters of
  *                         the slots must hold a plane); 2: wherever the kernels apply; 0: the MFMA GEMM routes
  *   combine_min_cols [256]   ... smallest padded column count of the state block that takes it
- *   combine_sweep [1]     fixed-step RK4 sweeps (midyn_rk4_solve, B > 1 instances, one state column each) of stacks with that
+ *   combine_sweep [1]     fixed-step RK4 sweeps (midyn_rk4_solve) and scipy_expm sweeps with magnus_order 1 (midyn_expm_solve;
+ *                         B > 1 instances, one state column each) of stacks with that
  *                         layout and n_pad <= 256: the WHOLE solve in one launch, 16 instances per workgroup, state in
  *                         registers, stage input in LDS (csrc/midyn_combine_sweep.h); 1: always up to n_pad = 128, above only
- *                         when the workgroups fill the chip, 2: wherever it applies, 0: never (a launch per RK4 stage)
+ *                         when the workgroups fill the chip, 2: wherever it applies, 0: never (a launch per RK4 stage / series term)
  *   combine_first [1]     one instance, >= 8 columns: form C(t) once, then one n x n x m product per stage
  *   multi_stream [1]      2..8 state columns at n >= 256: multi-column streaming kernel
  *   tiny_rk4 [1]          small systems: whole fixed-step solve in one persistent launch

@@ -1,4 +1,4 @@
-// midyn_combine_sweep.h -- fixed-step RK4 sweeps of SMALL dense systems (n_pad <= 256) in ONE launch (round 4).
+// midyn_combine_sweep.h -- fixed-step RK4 and scipy_expm (Magnus 1) sweeps of SMALL dense systems (n_pad <= 256) in ONE launch (round 4).
 //
 // The per-launch route runs a batched evaluation as one kernel: at n = 64 .. 256 and a few thousand instances such a
 // launch holds microseconds of matrix-pipe work, so a solve is bound by launches, by the state going through memory four
@@ -53,18 +53,33 @@ struct CombineSweepArgs {
     int P;
     double2* ybuf;            // RT == 2 (registers at their limit, stages of tens of microseconds): y and the RK4 accumulator of the
     double2* accbuf;          // workgroup's instances live in memory, [n_pad][ld], ybuf holding y0 at launch; RT == 1: unused
+    double2* buf3;            // ... third state vector of the expm action
     int ld;
+    // MODE 1, the expm ACTION of scipy_expm with magnus_order 1 (fixed_step_solvers.py:80-108,345-363; midyn_action.inc): the
+    // solve as a flat list of series TERMS, one product each -- per term the table row of its step's generator, the scalars of
+    //     w = pw + a G x;  acc += b w      (Taylor: a = h / (s j), b = 1;  Chebyshev: a = (1 | 2) h / rho, b = 2 J_j)
+    // and flags: bit 0 the last term of a series (a repetition of the step), bit 1 ... of the step (frame phases, saved
+    // state: slot in bits 8.., 0xffffff = none), bit 2 Chebyshev recurrence (pw starts from phi_{j-2}); c = the factor of the
+    // series that starts next (J_0 or 1).
+    int nstage;
+    const int* st_row;
+    const int* st_flag;
+    const double* st_a;
+    const double* st_b;
+    const double* st_c;
+    double c_first;
 };
 
 // Operand look-ahead in kk steps: a step is RT (64 NQ + 42) pipe cycles of one wave against several hundred cycles from
 // the L2 to a register.
-constexpr int sweep_depth(int rt, int nq, int stat) {
-    return rt == 2 ? (nq >= 2 || stat ? 2 : 4) : (nq <= 2 ? 8 : 4);      // (two tiles: registers; their steps are long anyway)
+constexpr int sweep_depth(int rt, int nq, int stat, int mode) {
+    return rt == 2 ? (nq >= 2 || stat || mode ? 2 : 4) : (nq <= (mode ? 1 : 2) ? 8 : 4);   // (registers; two tiles: their steps are long anyway)
 }
 
-template <int NRE4, int NIM4, int STAT, int RT>
-__global__ __launch_bounds__(512) void combine_sweep_rk4_kernel(const CombineSweepArgs a) {
-    constexpr int NQ = NRE4 + NIM4, D = sweep_depth(RT, NQ, STAT);
+// MODE 0: fixed-step RK4 (four stages per step); MODE 1: expm action, Magnus order 1 (a stage = a series term).
+template <int NRE4, int NIM4, int STAT, int RT, int MODE>
+__global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepArgs a) {
+    constexpr int NQ = NRE4 + NIM4, D = sweep_depth(RT, NQ, STAT, MODE);
     constexpr bool RE = NRE4 > 0 || (STAT & 1), IM = NIM4 > 0 || (STAT & 2);
     static_assert(NQ > 0 && NRE4 <= CMB_MAXQ && NIM4 <= CMB_MAXQ && (RT == 1 || RT == 2), "shape");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -106,9 +121,11 @@ __global__ __launch_bounds__(512) void combine_sweep_rk4_kernel(const CombineSwe
     const gbytes sbb = uniform_ptr(a.stat + (size_t)(rg * CMB_ROWS) * a.lda);
     const unsigned s_lane = ((unsigned)((lq + 4 * (lb & 3) + 16 * (RT == 2 ? ((lb >> 2) & 1) : t0)) * a.lda) * 2u + (unsigned)(lb >> 3)) * 8u;   // bytes
 
-    // the state of this wave's rows (used by the waves with sp == 0)
-    constexpr int SR = RT == 1 ? 1 : 0;                  // RT == 2: the state lives in memory (ybuf / accbuf)
-    double2 y[RT][4], acc[SR ? RT : 1][4];
+    // the state of this wave's rows (used by the waves with sp == 0).  MODE 0: y, acc of RK4; MODE 1: y = the accumulated
+    // result of the series, acc = phi_{j-1}, pw = phi_{j-2} (Chebyshev) / 0
+    constexpr int SR = RT == 1 ? 1 : 0;                  // RT == 2: the state lives in memory (ybuf / accbuf / buf3)
+    const int first_row = MODE == 1 ? a.st_row[0] : a.rows[0];
+    double2 y[RT][4], acc[SR ? RT : 1][4], pw[(SR && MODE == 1) ? RT : 1][4];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -118,13 +135,27 @@ __global__ __launch_bounds__(512) void combine_sweep_rk4_kernel(const CombineSwe
             if constexpr (SR) acc[t][r] = y[t][r];
         }
     if (sp == 0) {
-        const double2* Es = a.E ? a.E + (size_t)a.rows[0] * np : nullptr;
+        const double2* Es = a.E ? a.E + (size_t)first_row * np : nullptr;
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 16 * t + lq + 4 * r;
-                X0[(size_t)row * 16 + lb] = Es ? cmul(Es[row], y[t][r]) : y[t][r];
+                const double2 v = Es ? cmul(Es[row], y[t][r]) : y[t][r];
+                X0[(size_t)row * 16 + lb] = v;
+                if (MODE == 1) {      // the first series starts from v: result c_first v, phi_0 = v
+                    const double2 cv = make_double2(a.c_first * v.x, a.c_first * v.y);
+                    if constexpr (SR) {
+                        y[t][r] = cv;
+                        acc[t][r] = v;
+                        if constexpr (MODE == 1) pw[t][r] = make_double2(0.0, 0.0);
+                    } else {
+                        const size_t idx = (size_t)row * a.ld + blockIdx.x * 16 + lb;
+                        a.ybuf[idx] = cv;
+                        a.accbuf[idx] = v;
+                        a.buf3[idx] = make_double2(0.0, 0.0);
+                    }
+                }
             }
     }
     __syncthreads();
@@ -140,16 +171,29 @@ __global__ __launch_bounds__(512) void combine_sweep_rk4_kernel(const CombineSwe
     // wait for an LDS read with a scalar load outstanding is a wait for everything (lgkmcnt counts both, scalar loads return
     // out of order): the per-stage scalars (table row, step size, save slot) of 64 stages sit in one register each, lane =
     // stage, refilled every 32 stages, and are read with v_readlane; the kk blocks of the wave's list likewise.
-    const int nstage = 4 * a.nsteps;
-    int rowv = 0, savev = -1, kbv = 0;
-    double hv = 0.0;
+    const int nstage = MODE == 1 ? a.nstage : 4 * a.nsteps;
+    int rowv = 0, savev = -1, kbv = 0;        // (savev: MODE 1 the flags word)
+    double hv = 0.0, bv = 0.0, cv_ = 0.0;     // (hv: MODE 1 the scalar a)
     auto refill = [&](int base) {
         int i = base + lane;
         i = i < nstage ? i : nstage - 1;
-        const int g = i & 3;
-        rowv = a.rows[3 * (i >> 2) + (g == 0 ? 0 : (g == 3 ? 2 : 1))];
-        hv = a.hs[i >> 2];
-        savev = (g == 3 && a.save) ? a.save[i >> 2] : -1;
+        if (MODE == 1) {
+            rowv = a.st_row[i];
+            savev = a.st_flag[i];
+            hv = a.st_a[i];
+            bv = a.st_b[i];
+            cv_ = a.st_c[i];
+        } else {
+            const int g = i & 3;
+            rowv = a.rows[3 * (i >> 2) + (g == 0 ? 0 : (g == 3 ? 2 : 1))];
+            hv = a.hs[i >> 2];
+            savev = (g == 3 && a.save) ? a.save[i >> 2] : -1;
+        }
+    };
+    auto lane_double = [&](double v, int l) {
+        const long long b_ = __double_as_longlong(v);
+        return __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(b_ >> 32), l) << 32) |
+                                                (unsigned)__builtin_amdgcn_readlane((int)b_, l)));
     };
     refill(0);
     {
@@ -182,16 +226,14 @@ __global__ __launch_bounds__(512) void combine_sweep_rk4_kernel(const CombineSwe
     }
     // all four stages of all steps run through ONE copy of the loops below (stage index 4 st + sg)
     for (int stage = 0; stage < nstage; ++stage) {
-        const int st = stage >> 2, sg = stage & 3;
+        const int sg = stage & 3;
         if ((stage & 31) == 0 && stage > 0) refill(stage);
         const int sl = stage & 31;
         const int srow = __builtin_amdgcn_readlane(rowv, sl), nrow = __builtin_amdgcn_readlane(rowv, sl + 1);
-        const long long hb = __double_as_longlong(hv);
-        const double h = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(hb >> 32), sl) << 32) |
-                                                          (unsigned)__builtin_amdgcn_readlane((int)hb, sl)));
-        const int save_slot = __builtin_amdgcn_readlane(savev, sl);
-        const double2* __restrict__ X = X0 + (size_t)(sg & 1) * np * 16;          // (four stages: a step starts on copy 0)
-        double2* __restrict__ Xn = X0 + (size_t)((sg & 1) ^ 1) * np * 16;
+        const double h = lane_double(hv, sl);                  // MODE 1: a
+        const int save_slot = __builtin_amdgcn_readlane(savev, sl);      // MODE 1: flags
+        const double2* __restrict__ X = X0 + (size_t)(stage & 1) * np * 16;          // (RK4: a step starts on copy 0)
+        double2* __restrict__ Xn = X0 + (size_t)((stage & 1) ^ 1) * np * 16;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) cbn[q] = pc[q] >= 0 ? Sb[(size_t)nrow * a.k + pc[q]] : 0.0;
         // frame phases of the next stage's rows (its input).  One tile per wave: loaded here, ahead of the contraction, and
@@ -310,13 +352,19 @@ __global__ __launch_bounds__(512) void combine_sweep_rk4_kernel(const CombineSwe
             }
         }
         if (sp == 0) {
-            // RK4 stage arithmetic (fixed_step_solvers.py:43-77): acc' = (sg == 0 ? y : acc) + wa h k, input of the next stage
-            // y + wc h k; the last stage: y' = acc + h k / 6, which is also the next input
+            // MODE 0, RK4 stage arithmetic (fixed_step_solvers.py:43-77): acc' = (sg == 0 ? y : acc) + wa h k, input of the next
+            // stage y + wc h k; the last stage: y' = acc + h k / 6, which is also the next input.
+            // MODE 1, a series term (midyn_action.inc): w = pw + a G x joins the result with weight b and is the next x; at the end
+            // of a series the result starts the next one -- at the end of a step through the frame phases of both steps.
             const double wa = (sg == 0 || sg == 3) ? h * (1.0 / 6) : h * (1.0 / 3);
             const double wc = sg == 2 ? h : 0.5 * h;
+            const int flags = save_slot;
+            const bool series_end = flags & 1, step_end = flags & 2, cheb = flags & 4;
+            const int eslot = (flags >> 8) == 0xffffff ? -1 : (flags >> 8);
+            const double tb = MODE == 1 ? lane_double(bv, sl) : 0.0, tc = MODE == 1 ? lane_double(cv_, sl) : 0.0;
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
-                double2 yy[4], aa[4];
+                double2 yy[4], aa[4], pp[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = row0 + 16 * t + lq + 4 * r;
@@ -327,33 +375,60 @@ __global__ __launch_bounds__(512) void combine_sweep_rk4_kernel(const CombineSwe
                     if constexpr (SR) {
                         yy[r] = y[t][r];
                         aa[r] = acc[t][r];
+                        if constexpr (MODE == 1) pp[r] = pw[t][r];
                     } else {
                         const size_t idx = (size_t)row * a.ld + blockIdx.x * 16 + lb;
                         yy[r] = a.ybuf[idx];
                         aa[r] = a.accbuf[idx];
+                        if (MODE == 1) pp[r] = a.buf3[idx];
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = row0 + 16 * t + lq + 4 * r;
                     const double2 o = make_double2(ore[t][r], oim[t][r]);
-                    const double2 kv = a.E ? cmul_conj_a(ec[t][r], o) : o;
-                    aa[r] = cfma_r(wa, kv, sg == 0 ? yy[r] : aa[r]);
-                    double2 cur = cfma_r(wc, kv, yy[r]);
-                    if (sg == 3) {
-                        yy[r] = aa[r];
-                        cur = aa[r];
+                    double2 cur;
+                    if (MODE == 0) {
+                        const double2 kv = a.E ? cmul_conj_a(ec[t][r], o) : o;
+                        aa[r] = cfma_r(wa, kv, sg == 0 ? yy[r] : aa[r]);
+                        cur = cfma_r(wc, kv, yy[r]);
+                        if (sg == 3) {
+                            yy[r] = aa[r];
+                            cur = aa[r];
+                        }
+                        if (a.E) cur = cmul(en[t][r], cur);
+                        if (save_slot >= 0 && live && row < a.n) a.out[((size_t)inst * a.P + save_slot) * a.n + row] = yy[r];
+                    } else {
+                        const double2 w = cfma_r(h, o, pp[r]);
+                        double2 res = cfma_r(tb, w, yy[r]);
+                        if (!series_end) {
+                            cur = w;
+                            pp[r] = cheb ? aa[r] : make_double2(0.0, 0.0);
+                            aa[r] = w;
+                            yy[r] = res;
+                        } else {
+                            if (step_end) {
+                                if (a.E) res = cmul_conj_a(ec[t][r], res);
+                                if (eslot >= 0 && live && row < a.n) a.out[((size_t)inst * a.P + eslot) * a.n + row] = res;
+                                if (a.E) res = cmul(en[t][r], res);
+                            }
+                            cur = res;
+                            aa[r] = res;
+                            yy[r] = make_double2(tc * res.x, tc * res.y);
+                            pp[r] = make_double2(0.0, 0.0);
+                        }
                     }
-                    Xn[(size_t)row * 16 + lb] = a.E ? cmul(en[t][r], cur) : cur;
+                    Xn[(size_t)row * 16 + lb] = cur;
                     if constexpr (SR) {
                         y[t][r] = yy[r];
                         acc[t][r] = aa[r];
+                        if constexpr (MODE == 1) pw[t][r] = pp[r];
                     } else {
                         const size_t idx = (size_t)row * a.ld + blockIdx.x * 16 + lb;
                         a.accbuf[idx] = aa[r];
-                        if (sg == 3) a.ybuf[idx] = yy[r];
+                        if (MODE == 1 || sg == 3) a.ybuf[idx] = yy[r];
+                        if (MODE == 1) a.buf3[idx] = pp[r];
                     }
-                    if (save_slot >= 0 && live && row < a.n) a.out[((size_t)inst * a.P + save_slot) * a.n + row] = yy[r];
                 }
             }
         }

@@ -335,3 +335,57 @@ def test_one_launch_sweep_is_taken_where_it_is_faster(qd):
         _, cc = _solve(qd, stack, "RK4", sched, table, crand(rng, n, 1), batch, True, 1, one_launch=1)
         assert (cc["rhs_combine"]["launches"] == 1) == want, (n, batch, cc)
         stack.close()
+
+
+# ---- scipy_expm (Magnus order 1) sweeps of small systems in ONE launch: combine_sweep_kernel<.., MODE 1> ------------------------
+EXPM_CASES = [(40, 37, "iii", None, True), (96, 300, "cccc", "c", True), (200, 70, "iiiiii", "i", True),
+              (128, 16, "rrc", "r", False), (243, 33, "ii", None, True), (64, 50, "cccccccc", "c", False)]
+
+
+@pytest.mark.parametrize("n,batch,kinds,static_kind,framed", EXPM_CASES, ids=[f"n{c[0]}_{c[2]}_{c[3]}" for c in EXPM_CASES])
+def test_one_launch_expm_sweep_vs_per_launch_route_and_oracle(qd, n, batch, kinds, static_kind, framed):
+    """The expm ACTION of scipy_expm with magnus_order 1 (fixed_step_solvers.py:80-108,345-363) for sweeps of small systems: the
+    whole solve as one launch (a stage = a term of the Chebyshev or scaled Taylor series of a step), at the three workgroup
+    shapes, anti-Hermitian generators (Chebyshev series) and general ones (scaled Taylor), steps of two sizes, saved states.
+    Against the per-launch kernels (same series: 1e-12) and the oracle's scipy.linalg.expm solve."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(900 + n + len(kinds))
+    anti = kinds[0] != "r"              # the cases that start with a real-plane operator are general (non-normal) generators
+
+    def make(kind):
+        g = _operators(rng, n, kind)[0] * (0.5 if anti else 0.2)
+        if not anti:
+            return g
+        if kind == "i":                 # -i H with H real symmetric
+            return 1j * (g.imag + g.imag.T) / 2
+        return (g - g.conj().T) / 2
+
+    ops = np.array([make(kd) for kd in kinds])
+    static = None if static_kind is None else make(static_kind)
+    fim = rng.normal(size=n) if framed else None
+    stack = qd.Stack(ctx, ops, static, fim)
+    t_eval = [0.0, 0.07, 0.2]
+    sched = FixedStepSchedule([0.0, 0.2], t_eval, 0.05, _magnus_points(1))
+    table = rng.uniform(-1, 1, (batch, len(sched.times), len(kinds)))
+    y0 = crand(rng, batch, n, 1)
+    one, c1 = _solve(qd, stack, "scipy_expm", sched, table, y0, batch, False, 2, one_launch=2)
+    assert c1["rhs_combine"]["launches"] == 1 and c1["rhs_gemm"]["launches"] == 0 and c1["rhs_blocks_gemm"]["launches"] == 0, c1
+    n_pad = -(-n // 64) * 64
+    rt = 2 if n_pad > 128 else 1
+    waves = n_pad // (16 * rt) * (2 if n_pad == 64 else 1)
+    assert (int(c1["combine_sweep"]["launches"]), int(c1["combine_sweep"]["ms"])) == (-(-batch // 16), 10 * waves + rt), c1["combine_sweep"]
+    per, c0 = _solve(qd, stack, "scipy_expm", sched, table, y0, batch, False, 2, one_launch=0)
+    assert c0["rhs_combine"]["launches"] + c0["rhs_gemm"]["launches"] + c0["rhs_blocks_gemm"]["launches"] > len(sched.step_h), c0
+    assert_close(one, per, 1e-12)
+    d = None if fim is None else 1j * fim
+    times = np.asarray(sched.times)
+    for b in (0, batch - 1):
+        def gen(t, b=b):
+            return orc.generator_evaluate(static, ops, table[b, int(np.argmin(np.abs(times - t)))], d, None, t)
+
+        _, yref = orc.expm_solve(gen, [0.0, 0.2], y0[b, :, 0], 0.05, t_eval, 1)
+        assert_close(one[b, 1:-1, :, 0], yref, SOLVE_TOL)
+    stack.close()

@@ -2086,7 +2086,8 @@ def test_chebyshev_action_sweep_with_frame_and_fallbacks(qd):
     rng = np.random.default_rng(4)
     y0 = crand(rng, 128)
     y0 /= np.linalg.norm(y0)
-    try:
+    ctx.set_option("combine_sweep", 0)      # products are counted as launches here: a launch per series term, not the one-launch
+    try:                                     # kernel of small sweeps (tests/test_gpu_combine.py covers that one)
         for frame, expect_fewer in ((None, True), (cfg["h_d"], None)):
             solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
             fn = lambda: solver.solve(t_span=[0.0, 0.2], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.05)
@@ -2135,6 +2136,7 @@ def test_chebyshev_action_sweep_with_frame_and_fallbacks(qd):
     finally:
         ctx.set_option("chebyshev", 1)
         ctx.set_option("expm_action", 1)
+        ctx.set_option("combine_sweep", 1)
 
 
 @pytest.mark.parametrize("order", [1, 2])

@@ -29,9 +29,11 @@ def main():
     ap.add_argument("--instances", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--repeats", type=int, default=5)
+    ap.add_argument("--method", default="RK4")
+    ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--shapes", default="3x2,3x3,3x4,3x5,2x4,2x6,2x7,2x8")
     args = ap.parse_args()
-    dt = 0.005
+    dt = args.dt
     t_final = dt * args.steps
     rng = np.random.default_rng(7)
     print(f"{'model':>8} {'n':>5} {'k':>3} {'inst':>6} {'steps':>5} | {'device s':>9} {'call s':>8} {'M evals/s (device)':>19} | route")
@@ -52,7 +54,7 @@ def main():
             devs, calls = [], []
             for _ in range(reps):
                 t0 = time.perf_counter()
-                r = solver.solve(t_span=[0.0, t_final], y0=y0, signals=lists, method="RK4", max_dt=dt)
+                r = solver.solve(t_span=[0.0, t_final], y0=y0, signals=lists, method=args.method, max_dt=dt)
                 calls.append(time.perf_counter() - t0)
                 devs.append(r[0].wall_s)
             return r, devs, calls
