@@ -24,7 +24,11 @@
 
 namespace midyn {
 
-constexpr int CMB_MAXQ = 2;     // plane groups (of 4) per kind that have kernels: k <= 8 operators with a plane of that kind
+constexpr int CMB_MAXQ = 2;     // plane groups (of 4) per kind when the stack has planes of both kinds: k <= 8 operators per kind
+constexpr int CMB_MAXQ1 = 4;    // ... of ONE kind only (real-symmetric Hamiltonians: purely imaginary generators): k <= 16
+constexpr bool combine_groups_ok(int nre4, int nim4) {     // (at most 16 plane slots either way: plane_col[8 * CMB_MAXQ])
+    return nre4 + nim4 > 0 && ((nre4 <= CMB_MAXQ && nim4 <= CMB_MAXQ) || (nre4 == 0 && nim4 <= CMB_MAXQ1) || (nim4 == 0 && nre4 <= CMB_MAXQ1));
+}
 constexpr int CMB_ROWS = 32;    // rows per row group (two 16-row MFMA tiles per wave)
 
 struct CombineArgs {
@@ -98,7 +102,7 @@ template <int NRE4, int NIM4, int STAT>
 __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a) {
     constexpr int NQ = NRE4 + NIM4, RT = 2, NG = combine_ng(NRE4, NIM4, STAT);
     constexpr bool RE = NRE4 > 0 || (STAT & 1), IM = NIM4 > 0 || (STAT & 2);
-    static_assert(NQ > 0 && NRE4 <= CMB_MAXQ && NIM4 <= CMB_MAXQ, "plane groups");
+    static_assert(combine_groups_ok(NRE4, NIM4), "plane groups");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -2643,6 +2643,57 @@ __global__ __launch_bounds__(256) void fp64_coissue_kernel(double* sink, int ite
     if (s == 123.456) sink[0] = s;
 }
 
+// Norm bounds of the Magnus generator Omega of every step over the instances of a sweep (expm action, midyn_action.inc):
+// out[3 st + {0, 1, 2}] = max_b of the 1-norm triangle bound, of the larger of the 1- and infinity-norm bounds, and of the
+// bound of the Hermitian part, from the per-segment norms nrm[3][nseg] and the coefficient table S[B][R][k] ON THE DEVICE
+// (a 4096-instance table came back to the host for this loop: 39 MB over PCIe + a strided pass, 7 ms of a 3 ms solve).
+__global__ __launch_bounds__(256) void step_bounds_kernel(const double* __restrict__ S, int B, int R, int k, int nseg, int has_static,
+                                                          const int* __restrict__ rows, const double* __restrict__ hs, int order,
+                                                          const double* __restrict__ nrm, double* __restrict__ out) {
+    const int st = blockIdx.x;
+    const double ah = fabs(hs[st]);
+    const double p2 = 0.14433756729740643;   // sqrt(3) / 12
+    double best[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < B; b += 256) {
+        double gn[2] = {0.0, 0.0}, G[2] = {0.0, 0.0}, Hm[2] = {0.0, 0.0};
+        for (int i = 0; i < order; ++i) {
+            const double* c = S + ((size_t)b * R + rows[3 * st + i]) * k;
+            double ginf = 0.0;
+            for (int seg = 0; seg < nseg; ++seg) {
+                const double cf = (has_static && seg == 0) ? 1.0 : fabs(c[seg - has_static]);
+                gn[i] += cf * nrm[seg];
+                ginf += cf * nrm[nseg + seg];
+                Hm[i] += cf * nrm[2 * nseg + seg];
+            }
+            G[i] = fmax(gn[i], ginf);
+        }
+        double v[3];
+        if (order == 1) {
+            v[0] = ah * gn[0];
+            v[1] = ah * G[0];
+            v[2] = ah * Hm[0];
+        } else {
+            v[0] = 0.5 * ah * (gn[0] + gn[1]) + 2 * p2 * ah * ah * gn[0] * gn[1];
+            v[1] = 0.5 * ah * (G[0] + G[1]) + 2 * p2 * ah * ah * G[0] * G[1];
+            v[2] = 0.5 * ah * (Hm[0] + Hm[1]) + 2 * p2 * ah * ah * (Hm[1] * G[0] + G[1] * Hm[0]);
+        }
+        for (int j = 0; j < 3; ++j) best[j] = (v[j] > best[j] || v[j] != v[j]) ? v[j] : best[j];      // (NaN propagates)
+    }
+    __shared__ double red[3][256];
+    for (int j = 0; j < 3; ++j) red[j][threadIdx.x] = best[j];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int j = 0; j < 3; ++j) {
+                const double o = red[j][threadIdx.x + w], m_ = red[j][threadIdx.x];
+                red[j][threadIdx.x] = (o > m_ || o != o) ? o : m_;
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int j = 0; j < 3; ++j) out[3 * st + j] = red[j][0];
+}
+
 // streaming read of `n16` 16-byte elements (grid-stride, 4 independent loads per thread per round)
 __global__ __launch_bounds__(256) void stream_read_kernel(const double2* src, size_t n16, double* sink) {
     double2 acc = make_double2(0.0, 0.0);

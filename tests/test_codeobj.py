@@ -151,7 +151,7 @@ def test_combine_kernels_keep_scratch_out_of_their_loop(tmp_path):
     text = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, check=True).stdout
     lines = text.split("\n")
     starts = [i for i, l in enumerate(lines) if "rhs_combine_kernel" in l and l.rstrip().endswith(">:")]
-    assert len(starts) == 32
+    assert len(starts) == 48
     for st in starts:
         end = next(i for i in range(st + 1, len(lines)) if lines[i].rstrip().endswith(">:") or i == len(lines) - 1)
         ops = [l.split("//")[0].split() for l in lines[st + 1:end]]

@@ -2,7 +2,7 @@
 against the MFMA GEMM routes (ctx option combine = 0), one test per kernel variant:
 
   * operators with real planes only / imaginary planes only / both / a mix of the three, 2 .. 8 of them, so that every
-    (NRE4, NIM4) in {0, 1, 2}^2 \\ (0, 0) occurs;
+    (NRE4, NIM4) in {0, 1, 2}^2 \\ (0, 0) occurs, and 9 .. 16 operators of ONE kind ((0, 3), (0, 4), (3, 0), (4, 0));
   * no static operator, a real one, an imaginary one, a complex one (STAT 0 .. 3: the C input of the combining MFMAs);
   * a frame diagonal (phases in the stage input and in the epilogue), ragged dimension (n = 96 -> 128 padded rows),
     300 instances (384 padded columns: four waves split every list and sum through LDS);
@@ -83,7 +83,11 @@ CASES = [
     ("rrrrri", None, (2, 1, 0)), ("ccrrr", "r", (2, 1, 1)), ("rrrrrc", "i", (2, 1, 2)), ("ccccr", "c", (2, 1, 3)),
     ("iiiiir", None, (1, 2, 0)), ("cciii", "r", (1, 2, 1)), ("iiiiic", "i", (1, 2, 2)), ("cccci", "c", (1, 2, 3)),
     ("ccccc", None, (2, 2, 0)), ("cccccc", "r", (2, 2, 1)), ("cccccccc", "i", (2, 2, 2)), ("cccccccc", "c", (2, 2, 3)),
+    # one plane kind alone: up to 16 operators (real-symmetric Hamiltonians with more than 8 drives / couplers)
+    ("i" * 10, None, (0, 3, 0)), ("i" * 12, "i", (0, 3, 2)), ("i" * 13, "r", (0, 4, 1)), ("i" * 16, "c", (0, 4, 3)),
+    ("r" * 9, None, (3, 0, 0)), ("r" * 11, "c", (3, 0, 3)), ("r" * 14, "i", (4, 0, 2)), ("r" * 16, "r", (4, 0, 1)),
 ]
+N_BOTH_KINDS = 32        # the first 32 cases: the (NRE4, NIM4) <= (2, 2) variants, which the one-launch kernels of small sweeps have too
 
 
 @pytest.mark.parametrize("kinds,static_kind,variant", CASES, ids=["%d%d%d" % v for _, _, v in CASES])
@@ -200,28 +204,36 @@ def test_combine_lists_skip_exactly_zero_blocks_and_matrix_states(qd):
 
 
 def test_more_operators_than_the_combine_kernels_cover_take_the_gemm_route(qd):
-    """Nine operators with imaginary planes (three groups of four > CMB_MAXQ): the layout is not applicable and the sweep
-    runs on the MFMA GEMM route as before; small sweeps (fewer than combine_min_cols state columns) likewise."""
+    """Nine COMPLEX operators (three groups of four of each kind; more than 8 per kind only go with one kind alone) and 17
+    imaginary ones: the layout is not applicable and the sweep runs on the MFMA GEMM route as before; small sweeps (fewer
+    than combine_min_cols state columns) likewise.  Ten imaginary operators at n = 40: the per-launch kernels have the variant,
+    the one-launch kernel of small sweeps does not and hands the sweep over."""
     from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
 
     ctx = qd.default_context()
     rng = np.random.default_rng(9)
     n = 64
     sched = FixedStepSchedule([0.0, 0.01], None, 0.01, _rk4_points)
-    for k, batch, want_combine in ((9, 300, False), (4, 100, False), (4, 300, True)):
-        stack = qd.Stack(ctx, _operators(rng, n, "i" * k), None, None)
+    for kinds, batch, want_combine in (("c" * 9, 300, False), ("i" * 17, 300, False), ("iiii", 100, False), ("iiii", 300, True)):
+        k = len(kinds)
+        stack = qd.Stack(ctx, _operators(rng, n, kinds), None, None)
         table = rng.uniform(-1, 1, (batch, len(sched.times), k))
         _, cc = _solve(qd, stack, "RK4", sched, table, crand(rng, n, 1), batch, True, 1)
         assert (cc["rhs_combine"]["launches"] > 0) == want_combine, (k, batch, cc)
         assert (cc["rhs_gemm"]["launches"] + cc["rhs_blocks_gemm"]["launches"] > 0) != want_combine, (k, batch, cc)
         stack.close()
+    stack = qd.Stack(ctx, _operators(rng, 40, "i" * 10), None, None)
+    table = rng.uniform(-1, 1, (300, len(sched.times), 10))
+    _, cc = _solve(qd, stack, "RK4", sched, table, crand(rng, 40, 1), 300, True, 1, one_launch=2)
+    assert cc["rhs_combine"]["launches"] == 4 and int(cc["combine_info"]["ms"]) == 30, cc
+    stack.close()
 
 
 # ---- RK4 sweeps of small systems in ONE launch (csrc/midyn_combine_sweep.h) -----------------------------------------------------
 SWEEP_SIZES = ((40, 37), (96, 300), (200, 70), (128, 16), (243, 33))     # (n, instances): n_pad 64 / 128 / 256 / 128 / 256
 
 
-@pytest.mark.parametrize("idx", range(len(CASES)), ids=["%d%d%d" % v for _, _, v in CASES])
+@pytest.mark.parametrize("idx", range(N_BOTH_KINDS), ids=["%d%d%d" % v for _, _, v in CASES[:N_BOTH_KINDS]])
 def test_one_launch_sweep_variant_vs_per_launch_route_and_oracle(qd, idx):
     """Every (NRE4, NIM4, STAT) variant of combine_sweep_rk4_kernel, sizes rotating over the three workgroup shapes; a frame
     diagonal, per-instance initial states, steps of two different sizes and three saved states (fixed_step_solvers.py:406-459
