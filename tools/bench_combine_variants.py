@@ -28,7 +28,8 @@ nr = int(rows.max()) + 1
 y0 = np.zeros((n, 1), complex)
 y0[0] = 1
 for kinds, stat in (("iiiiiiii", None), ("iiiiiiii", "i"), ("iiiiiiii", "c"), ("iiii", None), ("iiii", "i"), ("iiii", "c"), ("cccc", None),
-                    ("cccc", "c"), ("ii", "i"), ("cc", "c"), ("iiiiiicc", "i"), ("cccccccc", None), ("cccccccc", "c")):
+                    ("cccc", "c"), ("ii", "i"), ("cc", "c"), ("iiiiiicc", "i"), ("cccccccc", None), ("cccccccc", "c"),
+                    ("i" * 12, None), ("i" * 16, None), ("i" * 16, "i"), ("r" * 12, "c")):
     st = qd.Stack(ctx, ops(kinds), None if stat is None else ops(stat)[0], None)
     table = rng.uniform(-1, 1, (B, nr, len(kinds)))
     res = {}
@@ -43,5 +44,5 @@ for kinds, stat in (("iiiiiiii", None), ("iiiiiiii", "i"), ("iiiiiiii", "c"), ("
         p.close()
     ctx.set_option("combine", 1)
     info = ctx.counters("combine_info")
-    print(f"{kinds:9s} static {stat}: combine {res[2]:.3f} ms, GEMM route {res[0]:.3f} ms per batched evaluation", flush=True)
+    print(f"{kinds:16s} static {stat}: combine {res[2]:.3f} ms, GEMM route {res[0]:.3f} ms per batched evaluation", flush=True)
     st.close()
