@@ -401,3 +401,48 @@ def test_one_launch_expm_sweep_vs_per_launch_route_and_oracle(qd, n, batch, kind
         _, yref = orc.expm_solve(gen, [0.0, 0.2], y0[b, :, 0], 0.05, t_eval, 1)
         assert_close(one[b, 1:-1, :, 0], yref, SOLVE_TOL)
     stack.close()
+
+
+@pytest.mark.parametrize("method", ["RK4", "scipy_expm"])
+def test_one_launch_sweep_of_a_vectorised_lindbladian(qd, method):
+    """Open systems are small sweeps too: two three-level transmons with relaxation and dephasing, vectorised (N = 81 rows of the
+    superoperator stack, models/lindblad_model.py:436-538), 40 instances with their own drive amplitudes and phases, frame of the
+    static Hamiltonian.  The one-launch kernel (default options) against a launch per stage and against the NON-vectorised solver
+    (n x n products, row f2: other kernels altogether), which is pinned to the reference's goldens elsewhere."""
+    from qiskit_dynamics_amd import workloads
+
+    h_d, ops, freqs = workloads.transmon_chain(3, 2)
+    a = np.diag(np.sqrt(np.arange(1, 3)), 1).astype(complex)
+    eye = np.eye(3)
+    diss = [np.sqrt(0.02) * np.kron(a, eye), np.sqrt(0.03) * np.kron(eye, a), np.sqrt(0.01) * np.kron(a.conj().T @ a, eye)]
+    kw = dict(static_hamiltonian=h_d, hamiltonian_operators=ops, static_dissipators=diss, rotating_frame=h_d)
+    vec = qd.Solver(vectorized=True, **kw)
+    mat = qd.Solver(vectorized=False, **kw)
+    ctx = vec.model._ctx
+    rng = np.random.default_rng(3)
+    batch = 40
+    lists = [[qd.Signal(float(rng.uniform(0.5, 3.0)), float(f), float(rng.uniform(0, 6))) for f in freqs] for _ in range(batch)]
+    rho0 = np.zeros((9, 9), dtype=complex)
+    rho0[0, 0] = 0.7
+    rho0[4, 4] = 0.3
+    rho0[0, 4] = rho0[4, 0] = 0.2
+    t_span, dt = [0.0, 0.4], (0.002 if method == "RK4" else 0.01)
+    ctx.reset_counters()
+    ctx.set_option("profile", 1)
+    try:
+        yv = rho0.flatten(order="F")          # (array input of a vectorised model: the column-stacked state)
+        res = vec.solve(t_span=t_span, y0=yv, signals=lists, method=method, max_dt=dt)
+        c1 = {c: ctx.counters(c) for c in ("rhs_combine", "combine_sweep")}
+        ctx.set_option("combine_sweep", 0)
+        ref = vec.solve(t_span=t_span, y0=yv, signals=lists, method=method, max_dt=dt)
+    finally:
+        ctx.set_option("profile", 0)
+        ctx.set_option("combine_sweep", 1)
+    assert c1["rhs_combine"]["launches"] == 1 and int(c1["combine_sweep"]["launches"]) == 3, c1
+    for b in range(batch):
+        assert_close(res[b].y[-1], ref[b].y[-1], 1e-12)
+    assert max(abs(np.trace(r.y[-1].reshape(9, 9, order="F")) - 1.0) for r in res) < 1e-9
+    if method == "RK4":
+        rm = mat.solve(t_span=t_span, y0=rho0, signals=lists[:6], method="RK4", max_dt=dt)
+        for b in range(6):
+            assert_close(res[b].y[-1].reshape(9, 9, order="F"), rm[b].y[-1], SOLVE_TOL)
