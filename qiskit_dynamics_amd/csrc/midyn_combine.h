@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void combine_pack_kernel(CombinePackArgs a) {
 // Value of lane N (0..15) of this lane's row of 16 lanes, in every lane of the row (DPP row_newbcast, gfx90a+).
 template <int N>
 __device__ __forceinline__ double row_bcast(double v) {
-    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, false);   // (one v_mov_b64_dpp: row_newbcast is the one
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);    // (one v_mov_b64_dpp: row_newbcast is the one
                                                                               //  DPP control the 64-bit ALU ops accept)
 }
 
