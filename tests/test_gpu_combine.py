@@ -446,3 +446,31 @@ def test_one_launch_sweep_of_a_vectorised_lindbladian(qd, method):
         rm = mat.solve(t_span=t_span, y0=rho0, signals=lists[:6], method="RK4", max_dt=dt)
         for b in range(6):
             assert_close(res[b].y[-1].reshape(9, 9, order="F"), rm[b].y[-1], SOLVE_TOL)
+
+
+@pytest.mark.parametrize("method", ["RK4", "scipy_expm"])
+def test_one_launch_sweep_backwards_in_time_and_matrix_states(qd, method):
+    """t_span[1] < t_span[0] (negative steps, fixed_step_solvers.py:639-651) on the one-launch kernel against a launch per
+    stage; matrix-valued states (several columns per instance) are not for that kernel and keep the per-launch kernels."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points, _rk4_points
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(31)
+    n, batch, kinds = 70, 50, "iiic"
+    ops = np.array([(g - g.conj().T) / 2 for g in _operators(rng, n, kinds)])
+    static = _operators(rng, n, "c")[0]
+    static = (static - static.conj().T) / 2
+    stack = qd.Stack(ctx, ops, static, rng.normal(size=n))
+    pts = _rk4_points if method == "RK4" else _magnus_points(1)
+    sched = FixedStepSchedule([0.3, 0.1], [0.3, 0.22, 0.1], 0.02, pts)
+    assert np.all(np.asarray(sched.step_h)[1:-1] < 0)
+    table = rng.uniform(-1, 1, (batch, len(sched.times), len(kinds)))
+    y0 = crand(rng, batch, n, 1)
+    one, c1 = _solve(qd, stack, method, sched, table, y0, batch, False, 2, one_launch=1)
+    per, c0 = _solve(qd, stack, method, sched, table, y0, batch, False, 2, one_launch=0)
+    assert c1["rhs_combine"]["launches"] == 1 and c0["rhs_combine"]["launches"] != 1, (c1, c0)
+    assert_close(one, per, 1e-12)
+    y0m = crand(rng, batch, n, 3)
+    _, cm = _solve(qd, stack, method, sched, table, y0m, batch, False, 2, one_launch=2)
+    assert cm["rhs_combine"]["launches"] + cm["rhs_gemm"]["launches"] + cm["rhs_blocks_gemm"]["launches"] > 1, cm
+    stack.close()
