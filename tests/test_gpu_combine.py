@@ -347,6 +347,18 @@ def test_one_launch_sweep_is_taken_where_it_is_faster(qd):
         _, cc = _solve(qd, stack, "RK4", sched, table, crand(rng, n, 1), batch, True, 1, one_launch=1)
         assert (cc["rhs_combine"]["launches"] == 1) == want, (n, batch, cc)
         stack.close()
+    # 10 .. 16 rows: the persistent one-wave kernel of small systems (class rhs_stream) unless the sweep is large and has a few
+    # operators -- then the MFMA kernel (midyn_rk4.inc: midyn_rk4_solve); same results
+    stack = qd.Stack(ctx, _operators(rng, 16, "iiii"), None, rng.normal(size=16))
+    results = {}
+    for batch, want in ((100, False), (2048, True)):
+        table = rng.uniform(-1, 1, (2048, len(sched.times), 4))[:batch].copy()
+        y0 = crand(np.random.default_rng(5), 16, 1)
+        results[batch], cc = _solve(qd, stack, "RK4", sched, table, y0, batch, True, 1, one_launch=1)
+        assert (cc["rhs_combine"]["launches"] == 1) == want, (batch, cc)
+        one_wave, _ = _solve(qd, stack, "RK4", sched, table, y0, batch, True, 1, one_launch=0)
+        assert_close(results[batch], one_wave, 1e-13)
+    stack.close()
 
 
 # ---- scipy_expm (Magnus order 1) sweeps of small systems in ONE launch: combine_sweep_kernel<.., MODE 1> ------------------------
