@@ -8,8 +8,8 @@
 //
 //   * the evaluation is COMBINE + APPLY of midyn_combine.h on the same re-packed operator planes and zero-block lists
 //     (v_mfma_f64_16x16x4 over 4 planes x 16 rows x 16 instances, then 2 .. 4 vector FMAs per element), one wave per
-//     RT 16-row tiles (RT = 1: n_pad <= 128, RT = 2 above), at n_pad = 64 two waves per tile that split the list and sum
-//     through LDS;
+//     RT 16-row tiles (RT = 1: n_pad <= 128, RT = 2 above), at n_pad = 64 two waves per tile that split the list, exchange
+//     their partial sums through LDS and share the rows of the tile for the stage arithmetic;
 //   * y and the RK4 accumulator of a wave's rows stay in its registers for the whole solve (RT = 1; at RT = 2 the registers
 //     are taken by the contraction and a stage lasts tens of microseconds: they are read and written once per stage in
 //     the workgroup's own columns of two [n_pad][ld] blocks); the stage input, already phased with the frame phases of the
@@ -121,8 +121,11 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
     const gbytes sbb = uniform_ptr(a.stat + (size_t)(rg * CMB_ROWS) * a.lda);
     const unsigned s_lane = ((unsigned)((lq + 4 * (lb & 3) + 16 * (RT == 2 ? ((lb >> 2) & 1) : t0)) * a.lda) * 2u + (unsigned)(lb >> 3)) * 8u;   // bytes
 
-    // the state of this wave's rows (used by the waves with sp == 0).  MODE 0: y, acc of RK4; MODE 1: y = the accumulated
-    // result of the series, acc = phi_{j-1}, pw = phi_{j-2} (Chebyshev) / 0
+    // the state of this wave's rows.  MODE 0: y, acc of RK4; MODE 1: y = the accumulated result of the series, acc = phi_{j-1},
+    // pw = phi_{j-2} (Chebyshev) / 0.  Two waves that split the list of a tile also split its ROWS for everything after the
+    // contraction (register rows r < 2 / r >= 2): each sums the partner's partial results of its own rows and does their stage
+    // arithmetic -- ~100 fp64 vector instructions per tile and stage that one wave did while its partner waited.
+    const int own_lo = a.splits > 1 ? 2 * sp : 0, own_hi = a.splits > 1 ? 2 * sp + 2 : 4;
     constexpr int SR = RT == 1 ? 1 : 0;                  // RT == 2: the state lives in memory (ybuf / accbuf / buf3)
     const int first_row = MODE == 1 ? a.st_row[0] : a.rows[0];
     double2 y[RT][4], acc[SR ? RT : 1][4], pw[(SR && MODE == 1) ? RT : 1][4];
@@ -134,12 +137,13 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
             y[t][r] = (row < a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)ic * a.n) + row] : make_double2(0.0, 0.0);
             if constexpr (SR) acc[t][r] = y[t][r];
         }
-    if (sp == 0) {
+    {
         const double2* Es = a.E ? a.E + (size_t)first_row * np : nullptr;
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (RT == 1 && (r < own_lo || r >= own_hi)) continue;
                 const int row = row0 + 16 * t + lq + 4 * r;
                 const double2 v = Es ? cmul(Es[row], y[t][r]) : y[t][r];
                 X0[(size_t)row * 16 + lb] = v;
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
 #pragma unroll
     for (int q = 0; q < NQ; ++q) cb[q] = pc[q] >= 0 ? Sb[(size_t)s_first * a.k + pc[q]] : 0.0;
     double2 ec[RT][4], en[RT][4];
-    if (RT == 1 && a.E && sp == 0) {
+    if (RT == 1 && a.E) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) ec[0][r] = a.E[(size_t)s_first * np + row0 + lq + 4 * r];
     }
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
         // frame phases of the next stage's rows (its input).  One tile per wave: loaded here, ahead of the contraction, and
         // kept for the result of the next stage; two tiles (n_pad > 128: stages of tens of microseconds, registers at their
         // limit): both sets after the contraction
-        if (RT == 1 && a.E && sp == 0) {
+        if (RT == 1 && a.E) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) en[0][r] = a.E[(size_t)nrow * np + row0 + lq + 4 * r];
         }
@@ -329,29 +333,27 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
             for (int s = 0; s < steps - D; s += D) body(s, false);
             body(steps - D, true);
         }
-        if (a.splits > 1) {
+        if (a.splits > 1) {      // the partner's partial sums of this wave's rows (and this wave's of the partner's rows) through LDS
             double* slot = red + (size_t)wt * (RT * 8 * 64) + lane;
-            if (sp > 0) {
 #pragma unroll
-                for (int t = 0; t < RT; ++t)
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        slot[(t * 8 + r) * 64] = ore[t][r];
-                        slot[(t * 8 + 4 + r) * 64] = oim[t][r];
-                    }
-            }
+                for (int r = 0; r < 4; ++r) {
+                    if (RT == 2 || (r >= own_lo && r < own_hi)) continue;
+                    slot[(t * 8 + r) * 64] = ore[t][r];
+                    slot[(t * 8 + 4 + r) * 64] = oim[t][r];
+                }
             __syncthreads();
-            if (sp == 0) {
 #pragma unroll
-                for (int t = 0; t < RT; ++t)
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ore[t][r] += slot[(t * 8 + r) * 64];
-                        oim[t][r] += slot[(t * 8 + 4 + r) * 64];
-                    }
-            }
+                for (int r = 0; r < 4; ++r) {
+                    if (RT == 1 && (r < own_lo || r >= own_hi)) continue;
+                    ore[t][r] += slot[(t * 8 + r) * 64];
+                    oim[t][r] += slot[(t * 8 + 4 + r) * 64];
+                }
         }
-        if (sp == 0) {
+        {
             // MODE 0, RK4 stage arithmetic (fixed_step_solvers.py:43-77): acc' = (sg == 0 ? y : acc) + wa h k, input of the next
             // stage y + wc h k; the last stage: y' = acc + h k / 6, which is also the next input.
             // MODE 1, a series term (midyn_action.inc): w = pw + a G x joins the result with weight b and is the next x; at the end
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
                 double2 yy[4], aa[4], pp[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (RT == 1 && (r < own_lo || r >= own_hi)) continue;
                     const int row = row0 + 16 * t + lq + 4 * r;
                     if (RT == 2 && a.E) {
                         ec[t][r] = a.E[(size_t)srow * np + row];
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (RT == 1 && (r < own_lo || r >= own_hi)) continue;
                     const int row = row0 + 16 * t + lq + 4 * r;
                     const double2 o = make_double2(ore[t][r], oim[t][r]);
                     double2 cur;
