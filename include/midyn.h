@@ -75,6 +75,9 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         formulation (the planes of a kind fill groups of four MFMA slots: at least three quarters of
  *                         the slots must hold a plane); 2: wherever the kernels apply; 0: the MFMA GEMM routes
  *   combine_min_cols [256]   ... smallest padded column count of the state block that takes it
+ *   combine_occupancy [2]  waves per SIMD the workgroup shape of a SMALL sweep aims at: up to 8 waves split the list of one (row
+ *                         group, instance block) pair and add their accumulators through LDS as a tree; 1: one wave per SIMD,
+ *                         at most 4 waves per pair (the rule until round 4; A/B)
  *   combine_sweep [1]     fixed-step RK4 sweeps (midyn_rk4_solve) and scipy_expm sweeps with magnus_order 1 (midyn_expm_solve;
  *                         B > 1 instances, one state column each) of stacks with that
  *                         layout and n_pad <= 256: the WHOLE solve in one launch, 16 instances per workgroup, state in

@@ -45,8 +45,8 @@ struct CombineArgs {
     int plane_col[8 * CMB_MAXQ];   // coefficient column of plane 4 q + i (first the real-plane groups, then the imaginary ones); -1: padding
     int n_row_groups;
     int wr;                  // waves of a workgroup along the rows (the others along the instances)
-    int splits;              // > 1: that many waves share one (row group, instance block) and split its list (small sweeps: more
-                             // waves than (row group, instance block) pairs are needed to fill the chip); summed through LDS
+    int splits;              // > 1 (a power of two): that many waves share one (row group, instance block) and split its list (small
+                             // sweeps: more waves than (row group, instance block) pairs are needed to fill the chip); summed through LDS
     Epilogue epi;
 };
 
@@ -239,25 +239,27 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
         }
     }
     if (a.splits > 1) {
-        // partial sums of waves 1 .. splits-1 through LDS, added by wave 0 in wave order (bit-reproducible)
+        // partial sums through LDS as a tree: in the round of half h = splits / 2, splits / 4, .., 1 wave sp + h hands its
+        // accumulators to wave sp and leaves (fixed order: bit-reproducible; splits / 2 slots per pair -- 8 waves on one pair
+        // fit 128 KB with 64 instances per wave)
         constexpr int NV = RT * NG * 8;     // doubles per lane
-        double* red = reinterpret_cast<double*>(smem_raw) + (size_t)wv * (a.splits - 1) * NV * 64;   // this pair's slots
-        if (sp > 0) {
-            double* mine = red + (size_t)(sp - 1) * NV * 64 + lane;
+        double* red = reinterpret_cast<double*>(smem_raw) + (size_t)wv * (a.splits >> 1) * NV * 64 + lane;   // this pair's slots
+        for (int h = a.splits >> 1; h >= 1; h >>= 1) {
+            if (sp >= h) {
+                double* mine = red + (size_t)(sp - h) * NV * 64;
 #pragma unroll
-            for (int t = 0; t < RT; ++t)
+                for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int g = 0; g < NG; ++g)
+                    for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        mine[((t * NG + g) * 8 + r) * 64] = ore[t][g][r];
-                        mine[((t * NG + g) * 8 + 4 + r) * 64] = oim[t][g][r];
-                    }
-        }
-        __syncthreads();
-        if (sp > 0) return;
-        for (int z = 1; z < a.splits; ++z) {
-            const double* theirs = red + (size_t)(z - 1) * NV * 64 + lane;
+                        for (int r = 0; r < 4; ++r) {
+                            mine[((t * NG + g) * 8 + r) * 64] = ore[t][g][r];
+                            mine[((t * NG + g) * 8 + 4 + r) * 64] = oim[t][g][r];
+                        }
+            }
+            __syncthreads();
+            if (sp >= h) return;            // (the hardware barrier counts the waves still alive)
+            const double* theirs = red + (size_t)sp * NV * 64;
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
                         ore[t][g][r] += theirs[((t * NG + g) * 8 + r) * 64];
                         oim[t][g][r] += theirs[((t * NG + g) * 8 + 4 + r) * 64];
                     }
+            if (h > 1) __syncthreads();     // the slots are written again in the next round
         }
     }
     store_tile<RT, NG>(a.epi, rg * CMB_ROWS + lq, col0 + lb, ore, oim);

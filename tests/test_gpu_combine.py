@@ -5,7 +5,7 @@ against the MFMA GEMM routes (ctx option combine = 0), one test per kernel varia
     (NRE4, NIM4) in {0, 1, 2}^2 \\ (0, 0) occurs, and 9 .. 16 operators of ONE kind ((0, 3), (0, 4), (3, 0), (4, 0));
   * no static operator, a real one, an imaginary one, a complex one (STAT 0 .. 3: the C input of the combining MFMAs);
   * a frame diagonal (phases in the stage input and in the epilogue), ragged dimension (n = 96 -> 128 padded rows),
-    300 instances (384 padded columns: four waves split every list and sum through LDS);
+    300 instances (384 padded columns: eight waves split every list and sum through LDS as a tree);
   * RK4 (epilogues RK1..4) and the expm action of scipy_expm with magnus_order 1 and 2 (Taylor / Chebyshev epilogues).
 Every variant is forced with ctx option combine = 2; the default (1) takes the kernel only where it is the faster formulation
 (at least three quarters of its plane slots -- groups of four -- must hold a plane): asserted too.
@@ -113,7 +113,7 @@ def test_combine_kernel_variant_vs_oracle_and_gemm_route(qd, kinds, static_kind,
     pays = 4 * planes >= 3 * 4 * (variant[0] + variant[1])
     _, cd = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 1)
     assert (cd["rhs_combine"]["launches"] == 12) == bool(pays), (variant, planes, cd)
-    assert int(cc["combine_shape"]["ms"]) == 4, cc["combine_shape"]          # four waves split every list
+    assert int(cc["combine_shape"]["ms"]) == 8, cc["combine_shape"]          # eight waves split every list (LDS tree)
     gemm, cg = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 0)
     assert cg["rhs_combine"]["launches"] == 0 and cg["rhs_gemm"]["launches"] + cg["rhs_blocks_gemm"]["launches"] == 12, cg
     assert_close(comb, gemm, 1e-13)

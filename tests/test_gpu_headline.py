@@ -130,15 +130,15 @@ def test_headline_sweep_4096_instances_combine_route_vs_oracle_and_gemm_routes(q
 
 def test_headline_shard_512_instances_full_length_vs_oracle(qd, headline):
     """The per-GPU shard of the 8-GPU run (512 instances) over ALL 1000 RK4 steps of cfg 3 through the product Solver: the
-    combine route with FOUR waves splitting the list of every (row group, 64-column block) pair and summing through LDS
-    (256 pairs for 1024 SIMDs); instance 300 against the oracle's 1000 steps, every instance for its norm, and the first
+    combine route with EIGHT waves splitting the list of every (row group, 64-column block) pair and summing through LDS as
+    a tree (256 pairs for 1024 SIMDs, two waves per SIMD); instance 300 against the oracle's 1000 steps, every instance for its norm, and the first
     20 steps against the MFMA work-list route (split-K) and the dense kernels, 1e-13."""
     cfg, solver, model = headline
     nb = 512
     sweeps = [_signals(qd, cfg, b) for b in range(nb)]
     full, c1 = _run(qd, solver, sweeps, cfg["t_span"], cfg["y0"], cfg["max_dt"])
     assert c1["rhs_combine"]["launches"] == 4000 and c1["rhs_gemm"]["launches"] == 0 and c1["rhs_blocks_gemm"]["launches"] == 0, c1
-    assert (int(c1["combine_shape"]["launches"]), int(c1["combine_shape"]["ms"])) == (1, 4), c1["combine_shape"]
+    assert (int(c1["combine_shape"]["launches"]), int(c1["combine_shape"]["ms"])) == (1, 8), c1["combine_shape"]
     assert np.max(np.abs(np.linalg.norm(full, axis=1) - 1.0)) < 1e-8
     assert_close(full[300], _oracle_final(cfg, model, 300, cfg["t_span"], cfg["y0"]), SOLVE_TOL)
     short, _ = _run(qd, solver, sweeps, [2.4, 2.5], cfg["y0"], cfg["max_dt"])
@@ -154,8 +154,8 @@ def test_headline_shard_512_instances_full_length_vs_oracle(qd, headline):
 @pytest.mark.parametrize("nb", [1024, 2048])
 def test_headline_shards_of_2_and_4_gpus_combine_shapes(qd, headline, nb):
     """The shards of the 4- and 2-GPU runs (1024 / 2048 instances), 20 steps in the active pulse window: 1024 instances run
-    two waves per (row group, column block) pair (list split 2, two pairs per workgroup), 2048 four pairs per workgroup
-    without a split -- four waves per workgroup, one workgroup per CU either way; both
+    four waves per (row group, column block) pair (list split 4, two pairs per workgroup), 2048 two waves per pair (four pairs
+    per workgroup) -- eight waves per workgroup = two per SIMD, one workgroup per CU either way; both
     against the MFMA work-list route (1e-13) and instance nb - 1 against the oracle."""
     cfg, solver, model = headline
     sweeps = [_signals(qd, cfg, b) for b in range(nb)]
@@ -164,7 +164,7 @@ def test_headline_shards_of_2_and_4_gpus_combine_shapes(qd, headline, nb):
     y0 /= np.linalg.norm(y0)
     comb, c1 = _run(qd, solver, sweeps, [2.4, 2.5], y0, cfg["max_dt"])
     assert c1["rhs_combine"]["launches"] == 80 and c1["rhs_blocks_gemm"]["launches"] == 0, c1
-    want = (2, 2) if nb == 1024 else (4, 1)
+    want = (2, 4) if nb == 1024 else (4, 2)
     assert (int(c1["combine_shape"]["launches"]), int(c1["combine_shape"]["ms"])) == want, c1["combine_shape"]
     lists, c2 = _run(qd, solver, sweeps, [2.4, 2.5], y0, cfg["max_dt"], combine=0)
     assert c2["rhs_blocks_gemm"]["launches"] == 80 and c2["rhs_combine"]["launches"] == 0
