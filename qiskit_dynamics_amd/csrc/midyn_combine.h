@@ -243,10 +243,12 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
         // accumulators to wave sp and leaves (fixed order: bit-reproducible; splits / 2 slots per pair -- 8 waves on one pair
         // fit 128 KB with 64 instances per wave)
         constexpr int NV = RT * NG * 8;     // doubles per lane
-        double* red = reinterpret_cast<double*>(smem_raw) + (size_t)wv * (a.splits >> 1) * NV * 64 + lane;   // this pair's slots
-        for (int h = a.splits >> 1; h >= 1; h >>= 1) {
+        double* lds = reinterpret_cast<double*>(smem_raw);
+        const unsigned red = (unsigned)(wv * (a.splits >> 1)) * (NV * 64) + lane;   // this pair's slots (32-bit LDS offsets)
+        // one round: false = this wave has handed its sums over and is done
+        auto round = [&](int h) -> bool {
             if (sp >= h) {
-                double* mine = red + (size_t)(sp - h) * NV * 64;
+                double* mine = lds + (red + (unsigned)(sp - h) * (NV * 64));
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -258,8 +260,8 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
                         }
             }
             __syncthreads();
-            if (sp >= h) return;            // (the hardware barrier counts the waves still alive)
-            const double* theirs = red + (size_t)sp * NV * 64;
+            if (sp >= h) return false;      // (the hardware barrier counts the waves still alive)
+            const double* theirs = lds + (red + (unsigned)sp * (NV * 64));
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -269,8 +271,17 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
                         ore[t][g][r] += theirs[((t * NG + g) * 8 + r) * 64];
                         oim[t][g][r] += theirs[((t * NG + g) * 8 + 4 + r) * 64];
                     }
-            if (h > 1) __syncthreads();     // the slots are written again in the next round
+            return true;
+        };
+        if (a.splits >= 8) {
+            if (!round(4)) return;
+            __syncthreads();                // (the slots are written again in the next round)
         }
+        if (a.splits >= 4) {
+            if (!round(2)) return;
+            __syncthreads();
+        }
+        if (!round(1)) return;
     }
     store_tile<RT, NG>(a.epi, rg * CMB_ROWS + lq, col0 + lb, ore, oim);
 }
