@@ -297,7 +297,8 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * "rhs_combine" counts the launches of the COMBINE + APPLY sweep kernel; its last launch is described by
  * "combine_info" -> (listed (32-row group, 16-column block) entries of the stack, 100 NRE4 + 10 NIM4 + STAT: groups of four
  * real / imaginary operator planes and the static operator's planes, bit 0 real, bit 1 imaginary) and "combine_shape" ->
- * ((row group, column block) pairs per workgroup, waves that split the list of one pair).  A one-launch RK4 sweep
+ * ((row group, column block) pairs per workgroup, waves that split the list of one pair), "combine_wave" -> (state columns
+ * per wave of that launch: 64, or 32 for stacks with more than two plane groups and for small sweeps, 0).  A one-launch RK4 sweep
  * (combine_sweep) counts as ONE "rhs_combine" launch; "combine_sweep" -> (workgroups of 16 instances, 10 x waves per
  * workgroup + 16-row tiles per wave) of the last one. */
 int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);

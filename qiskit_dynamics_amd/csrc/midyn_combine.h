@@ -97,10 +97,10 @@ constexpr int combine_ng(int nre4, int nim4, int stat) {
     return nre4 + nim4 <= 2 ? 4 : 2;
 }
 
-// STAT: bit 0 = the static operator has a real plane, bit 1 = an imaginary plane.
-template <int NRE4, int NIM4, int STAT>
-__global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a) {
-    constexpr int NQ = NRE4 + NIM4, RT = 2, NG = combine_ng(NRE4, NIM4, STAT);
+// STAT: bit 0 = the static operator has a real plane, bit 1 = an imaginary plane.  NG: 16-instance groups per wave.
+template <int NRE4, int NIM4, int STAT, int NG>
+__device__ __forceinline__ void combine_body(const CombineArgs& a) {
+    constexpr int NQ = NRE4 + NIM4, RT = 2;
     constexpr bool RE = NRE4 > 0 || (STAT & 1), IM = NIM4 > 0 || (STAT & 2);
     static_assert(combine_groups_ok(NRE4, NIM4), "plane groups");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -284,6 +284,19 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a
         if (!round(1)) return;
     }
     store_tile<RT, NG>(a.epi, rg * CMB_ROWS + lq, col0 + lb, ore, oim);
+}
+
+template <int NRE4, int NIM4, int STAT>
+__global__ __launch_bounds__(512, 2) void rhs_combine_kernel(const CombineArgs a) {
+    combine_body<NRE4, NIM4, STAT, combine_ng(NRE4, NIM4, STAT)>(a);
+}
+
+// The same with 32 instances per wave for stacks of up to two plane groups: sweeps of so few instances that 64-instance
+// waves, even eight to a pair, leave SIMDs without work (n = 1024: below 512 instances) get twice the pairs.
+template <int NRE4, int NIM4, int STAT>
+__global__ __launch_bounds__(512, 2) void rhs_combine_small_kernel(const CombineArgs a) {
+    static_assert(NRE4 + NIM4 <= 2, "the wide variants already run 32 instances per wave");
+    combine_body<NRE4, NIM4, STAT, 2>(a);
 }
 
 }  // namespace midyn

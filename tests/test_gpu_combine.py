@@ -5,7 +5,8 @@ against the MFMA GEMM routes (ctx option combine = 0), one test per kernel varia
     (NRE4, NIM4) in {0, 1, 2}^2 \\ (0, 0) occurs, and 9 .. 16 operators of ONE kind ((0, 3), (0, 4), (3, 0), (4, 0));
   * no static operator, a real one, an imaginary one, a complex one (STAT 0 .. 3: the C input of the combining MFMAs);
   * a frame diagonal (phases in the stage input and in the epilogue), ragged dimension (n = 96 -> 128 padded rows),
-    300 instances (384 padded columns: eight waves split every list and sum through LDS as a tree);
+    300 instances (384 padded columns: eight waves split every list and sum through LDS as a tree; 32 instances per wave --
+    the small-sweep variants -- and, under combine_occupancy = 1, 64 per wave with four waves per list);
   * RK4 (epilogues RK1..4) and the expm action of scipy_expm with magnus_order 1 and 2 (Taylor / Chebyshev epilogues).
 Every variant is forced with ctx option combine = 2; the default (1) takes the kernel only where it is the faster formulation
 (at least three quarters of its plane slots -- groups of four -- must hold a plane): asserted too.
@@ -51,12 +52,13 @@ def _operators(rng, n, kinds):
     return np.array(ops)
 
 
-def _solve(qd, stack, method, sched, table, y0, batch, shared, combine, magnus_order=1, one_launch=0):
+def _solve(qd, stack, method, sched, table, y0, batch, shared, combine, magnus_order=1, one_launch=0, occupancy=2):
     """one_launch = 0 pins the per-launch kernels (RK4 sweeps of systems with n_pad <= 256 otherwise run on the one-launch kernel
     of midyn_combine_sweep.h, which has its own tests below)."""
     ctx = qd.default_context()
     ctx.set_option("combine", combine)
     ctx.set_option("combine_sweep", one_launch)
+    ctx.set_option("combine_occupancy", occupancy)
     ctx.reset_counters()
     ctx.set_option("profile", 1)
     try:
@@ -69,7 +71,8 @@ def _solve(qd, stack, method, sched, table, y0, batch, shared, combine, magnus_o
         ctx.set_option("profile", 0)
         ctx.set_option("combine", 1)
         ctx.set_option("combine_sweep", 1)
-    return ys, {c: ctx.counters(c) for c in ("rhs_combine", "rhs_gemm", "rhs_blocks_gemm", "combine_info", "combine_shape",
+        ctx.set_option("combine_occupancy", 2)
+    return ys, {c: ctx.counters(c) for c in ("rhs_combine", "rhs_gemm", "rhs_blocks_gemm", "combine_info", "combine_shape", "combine_wave",
                                              "combine_sweep")}
 
 
@@ -113,7 +116,15 @@ def test_combine_kernel_variant_vs_oracle_and_gemm_route(qd, kinds, static_kind,
     pays = 4 * planes >= 3 * 4 * (variant[0] + variant[1])
     _, cd = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 1)
     assert (cd["rhs_combine"]["launches"] == 12) == bool(pays), (variant, planes, cd)
-    assert int(cc["combine_shape"]["ms"]) == 8, cc["combine_shape"]          # eight waves split every list (LDS tree)
+    # 48 pairs of (32 rows, 32 columns): eight waves split every list (LDS tree); stacks of up to two plane groups run their
+    # 32-instance variant here (rhs_combine_small_kernel: a sweep too small for 64-instance waves to fill the chip) ...
+    assert (int(cc["combine_shape"]["ms"]), int(cc["combine_wave"]["launches"])) == (8, 32), (cc["combine_shape"], cc["combine_wave"])
+    # ... and their 64-instance variant under the one-wave-per-SIMD rule (combine_occupancy = 1: four waves per pair)
+    wide, cw = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 2, occupancy=1)
+    want_wave = 64 if variant[0] + variant[1] <= 2 else 32
+    assert (int(cw["combine_shape"]["ms"]), int(cw["combine_wave"]["launches"])) == (4, want_wave), (cw["combine_shape"], cw["combine_wave"])
+    assert cw["rhs_combine"]["launches"] == 12 and cw["rhs_gemm"]["launches"] + cw["rhs_blocks_gemm"]["launches"] == 0, cw
+    assert_close(wide, comb, 1e-13)
     gemm, cg = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 0)
     assert cg["rhs_combine"]["launches"] == 0 and cg["rhs_gemm"]["launches"] + cg["rhs_blocks_gemm"]["launches"] == 12, cg
     assert_close(comb, gemm, 1e-13)

@@ -26,7 +26,7 @@ S = 42
 rows = sched.step_rows[:S]
 nr = int(rows.max()) + 1
 y0 = cfg["y0"].reshape(-1, 1)
-sizes = [int(x) for x in sys.argv[1:]] or [128, 256, 512, 1024, 2048, 4096]
+sizes = [int(x) for x in sys.argv[1:]] or [128, 256, 384, 512, 1024, 2048, 4096]
 for B in sizes:
     amps = np.array([workloads.sweep_parameters(b, 8)[0] for b in range(B)])
     phs = np.array([workloads.sweep_parameters(b, 8)[1] for b in range(B)])
@@ -48,9 +48,9 @@ for B in sizes:
             us = ms / (4 * (S - 2)) * 1e3
             best = us if best is None else min(best, us)
         shape = ctx.counters("combine_shape")
-        res[occ] = (round(best, 1), int(shape["launches"]), int(shape["ms"]))
+        res[occ] = (round(best, 1), int(shape["launches"]), int(shape["ms"]), int(ctx.counters("combine_wave")["launches"]))
     ctx.set_option("combine_occupancy", 2)
     ctx.set_option("combine", 1)
     diff = float(np.max(np.abs(outs[1] - outs[2])))
-    print(f"{B:5d} instances: occupancy 1 {res[1][0]:7.1f} us (pairs/workgroup {res[1][1]}, splits {res[1][2]});  "
-          f"occupancy 2 {res[2][0]:7.1f} us (pairs/workgroup {res[2][1]}, splits {res[2][2]});  max|diff| {diff:.1e}", flush=True)
+    print(f"{B:5d} instances: occupancy 1 {res[1][0]:7.1f} us (pairs/workgroup {res[1][1]}, splits {res[1][2]}, {res[1][3]} instances/wave);  "
+          f"occupancy 2 {res[2][0]:7.1f} us (pairs/workgroup {res[2][1]}, splits {res[2][2]}, {res[2][3]} instances/wave);  max|diff| {diff:.1e}", flush=True)
