@@ -1176,8 +1176,9 @@ def main():
             ps = qd.Rk4Plan(stack, times, tab_s, rows, sched.step_h[:total], y0, b_s, True)
             # (warm-up over the first steps, then the best of up to three back-to-back stretches of the same length: a shard's
             # launches are short, and the first ones after a change of kernel shape run at unsettled clocks)
-            w_steps = min(args.warmup, total - 1)
-            ps.run(0, w_steps)
+            w_steps = max(0, min(args.warmup, total - 1))
+            if w_steps:
+                ps.run(0, w_steps)
             ctx.synchronize()
             d_steps = max(1, min(args.steps, (total - w_steps) // 3 or 1, total - w_steps))
             el_p = None
