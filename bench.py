@@ -838,7 +838,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=16,
+                    help="untimed steps before the K timed ones (the first ~60 launches of the contraction run 5-15 %% slower "
+                         "while the clocks settle: profiles/r04_rocprof_bench.md, warm-up row)")
     ap.add_argument("--batch", type=int, default=0,
                     help="sweep instances: the TOTAL over all GPUs (default 4096), or per GPU with --weak")
     ap.add_argument("--weak", action="store_true", help="weak scaling: --batch (4096) instances PER GPU")

@@ -8,9 +8,9 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench.json 2> $O/bench.err
-# (the traced command times the same 40 steps behind the same 4 warm-up steps as the default run: the first dozen launches
+# (the traced command times the same 40 steps behind the same 16 warm-up steps as the default run: the first dozen launches
 # of the dominant kernel run 10-20 % slower while the clocks settle, and a 10-step region would be mostly that)
-B="python $R/bench.py --steps 40 --warmup 4 --repeats 1 --no-cpu-baseline --no-end-to-end --no-projection"
+B="python $R/bench.py --steps 40 --warmup 16 --repeats 1 --no-cpu-baseline --no-end-to-end --no-projection"
 P="python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --no-end-to-end --no-projection --no-variants"
 # (rocprofv3 of ROCm 7.2 sometimes dies inside a PMC pass, and segfaults at exit AFTER writing its database: a pass
 # counts when its .db exists; up to six attempts)
