@@ -63,7 +63,7 @@ struct CombinePackArgs {
     double* frags;
 };
 
-__global__ __launch_bounds__(256) void combine_pack_kernel(CombinePackArgs a) {
+MIDYN_GLOBAL __launch_bounds__(256) void combine_pack_kernel(CombinePackArgs a) {
     const int e = blockIdx.x;
     const int rg = a.ent_rg[e], kb = a.list_idx[e];
     const int per_entry = 16 * 2 * a.nq * 64;
@@ -298,5 +298,36 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_small_kernel(const Combine
     static_assert(NRE4 + NIM4 <= 2, "the wide variants already run 32 instances per wave");
     combine_body<NRE4, NIM4, STAT, 2>(a);
 }
+
+// ---- the instantiations that exist, and where ------------------------------------------------------------------------------
+// libmidyn.so is built from several translation units so that hipcc compiles the kernel families side by side (the device
+// side of ONE unit is compiled serially: five minutes for everything).  The host side of every entry point stays in
+// midyn.hip; a family's kernels are instantiated in its own unit (midyn_tu_combine.hip defines MIDYN_TU_COMBINE), every
+// other unit sees `extern template` declarations of the same list and only takes the kernels' addresses.  A kernel the
+// host code selects but the list does not name is an undefined symbol of the library: __graft_entry__.build() refuses it.
+#define MIDYN_FOR_STAT(X, ...) X(__VA_ARGS__, 0) X(__VA_ARGS__, 1) X(__VA_ARGS__, 2) X(__VA_ARGS__, 3)
+#define MIDYN_COMBINE_PAIRS_UP_TO_TWO_GROUPS(X) \
+    MIDYN_FOR_STAT(X, 0, 1) MIDYN_FOR_STAT(X, 0, 2) MIDYN_FOR_STAT(X, 1, 0) MIDYN_FOR_STAT(X, 2, 0) MIDYN_FOR_STAT(X, 1, 1)
+#define MIDYN_COMBINE_PAIRS_BOTH_KINDS(X) \
+    MIDYN_COMBINE_PAIRS_UP_TO_TWO_GROUPS(X) MIDYN_FOR_STAT(X, 1, 2) MIDYN_FOR_STAT(X, 2, 1) MIDYN_FOR_STAT(X, 2, 2)
+#ifdef MIDYN_TU_COMBINE
+#define MIDYN_COMBINE_EXTERN
+#else
+#define MIDYN_COMBINE_EXTERN extern
+#endif
+#ifdef MIDYN_TU_COMBINE_WIDE     // midyn_tu_combine_wide.hip: three / four groups of one kind, and the 32-instance waves of small sweeps
+#define MIDYN_COMBINE_WIDE_EXTERN
+#else
+#define MIDYN_COMBINE_WIDE_EXTERN extern
+#endif
+#define MIDYN_X(R_, I_, S_) MIDYN_COMBINE_EXTERN template __global__ void rhs_combine_kernel<R_, I_, S_>(const CombineArgs);
+MIDYN_COMBINE_PAIRS_BOTH_KINDS(MIDYN_X)
+#undef MIDYN_X
+#define MIDYN_X(R_, I_, S_) MIDYN_COMBINE_WIDE_EXTERN template __global__ void rhs_combine_kernel<R_, I_, S_>(const CombineArgs);
+MIDYN_FOR_STAT(MIDYN_X, 0, 3) MIDYN_FOR_STAT(MIDYN_X, 0, 4) MIDYN_FOR_STAT(MIDYN_X, 3, 0) MIDYN_FOR_STAT(MIDYN_X, 4, 0)
+#undef MIDYN_X
+#define MIDYN_X(R_, I_, S_) MIDYN_COMBINE_WIDE_EXTERN template __global__ void rhs_combine_small_kernel<R_, I_, S_>(const CombineArgs);
+MIDYN_COMBINE_PAIRS_UP_TO_TWO_GROUPS(MIDYN_X)
+#undef MIDYN_X
 
 }  // namespace midyn

@@ -446,4 +446,25 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
     }
 }
 
+// ---- the instantiations that exist (see the end of midyn_combine.h): midyn_tu_combine_sweep{,_expm}.hip define them -------
+#define MIDYN_SWEEP_FOR_RT(X, M_, ...) X(__VA_ARGS__, 1, M_) X(__VA_ARGS__, 2, M_)
+#define MIDYN_X0(R_, I_, S_) MIDYN_SWEEP_FOR_RT(MIDYN_X, 0, R_, I_, S_)
+#define MIDYN_X1(R_, I_, S_) MIDYN_SWEEP_FOR_RT(MIDYN_X, 1, R_, I_, S_)
+#ifdef MIDYN_TU_COMBINE_SWEEP_RK4
+#define MIDYN_X(R_, I_, S_, T_, M_) template __global__ void combine_sweep_kernel<R_, I_, S_, T_, M_>(const CombineSweepArgs);
+#else
+#define MIDYN_X(R_, I_, S_, T_, M_) extern template __global__ void combine_sweep_kernel<R_, I_, S_, T_, M_>(const CombineSweepArgs);
+#endif
+MIDYN_COMBINE_PAIRS_BOTH_KINDS(MIDYN_X0)
+#undef MIDYN_X
+#ifdef MIDYN_TU_COMBINE_SWEEP_EXPM
+#define MIDYN_X(R_, I_, S_, T_, M_) template __global__ void combine_sweep_kernel<R_, I_, S_, T_, M_>(const CombineSweepArgs);
+#else
+#define MIDYN_X(R_, I_, S_, T_, M_) extern template __global__ void combine_sweep_kernel<R_, I_, S_, T_, M_>(const CombineSweepArgs);
+#endif
+MIDYN_COMBINE_PAIRS_BOTH_KINDS(MIDYN_X1)
+#undef MIDYN_X
+#undef MIDYN_X0
+#undef MIDYN_X1
+
 }  // namespace midyn

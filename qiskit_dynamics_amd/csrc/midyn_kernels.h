@@ -25,6 +25,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Kernels that are not templates exist once, in midyn.hip; the translation units that only instantiate a kernel family
+// (midyn_tu_*.hip define MIDYN_FAMILY_TU; see the end of this file) see them as templates nobody instantiates.
+#ifdef MIDYN_FAMILY_TU
+#define MIDYN_GLOBAL template <int MIDYN_NOT_IN_THIS_UNIT = 0> __global__
+#else
+#define MIDYN_GLOBAL __global__
+#endif
+
 namespace midyn {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1580,7 +1588,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void zgemm_plane_kernel(PlaneArgs 
 }
 
 // planes[act][i] = non-zero plane of active segment `act` (mode 1: real part, mode 2: imaginary part)
-__global__ __launch_bounds__(256) void extract_planes_kernel(const double2* ops, const int* seg_act, int n_act,
+MIDYN_GLOBAL __launch_bounds__(256) void extract_planes_kernel(const double2* ops, const int* seg_act, int n_act,
                                                              size_t plane, double* planes) {
     const size_t total = plane * n_act;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
@@ -1651,7 +1659,7 @@ struct GenArgs {
     const double* scale_vec; // optional per-instance factor on top of `scale` (step sizes)
 };
 
-__global__ __launch_bounds__(256) void gen_eval_kernel(GenArgs a) {
+MIDYN_GLOBAL __launch_bounds__(256) void gen_eval_kernel(GenArgs a) {
     const int n = a.n_pad;
     const size_t plane = (size_t)n * n;
     const size_t total = plane * (a.batch > 0 ? a.batch : 1);
@@ -1691,7 +1699,7 @@ struct LinArgs {
     double2* out;
 };
 
-__global__ __launch_bounds__(256) void lincomb_kernel(LinArgs a) {
+MIDYN_GLOBAL __launch_bounds__(256) void lincomb_kernel(LinArgs a) {
     const size_t plane = (size_t)a.n * a.n;
     const size_t total = plane * (a.batch > 0 ? a.batch : 1);
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
@@ -1712,7 +1720,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(LinArgs a) {
 }
 
 // E[r][i] = exp(i * frame_im[i] * times[r])  (rotating_frame.py:255,350: exp(frame_diag * t))
-__global__ __launch_bounds__(256) void phase_table_kernel(const double* frame_im, const double* times,
+MIDYN_GLOBAL __launch_bounds__(256) void phase_table_kernel(const double* frame_im, const double* times,
                                                           int n_pad, int rows, double2* E) {
     const size_t total = (size_t)rows * n_pad;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
@@ -1764,7 +1772,7 @@ struct SigTableArgs {
     double* S;                    // [B][R][k]
 };
 
-__global__ __launch_bounds__(256) void signal_table_kernel(SigTableArgs a) {
+MIDYN_GLOBAL __launch_bounds__(256) void signal_table_kernel(SigTableArgs a) {
 // the reference rounds the carrier product, the phase addition and the two products of the real part
 // separately: no FMA contraction in this kernel
 #pragma clang fp contract(off)
@@ -1801,7 +1809,7 @@ __global__ __launch_bounds__(256) void signal_table_kernel(SigTableArgs a) {
 
 // out[i][0..w) = src[rows[i]][0..w)  (rows of the coefficient table / of the phase table gathered
 // into the order of a batch of time steps)
-__global__ __launch_bounds__(256) void gather_rows_kernel(const double* src, const int* rows, int count,
+MIDYN_GLOBAL __launch_bounds__(256) void gather_rows_kernel(const double* src, const int* rows, int count,
                                                           int w, double* out) {
     const size_t total = (size_t)count * w;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -1813,7 +1821,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const double* src, con
 // Host batch layout [B][n][m] (or shared [n][m]) -> state pool [n_pad][ldy] with instance b in the
 // 64-aligned column block b*mpad .. b*mpad+m (every instance is its own GEMM operand), and back from
 // the ping-pong half flags[b] of the pool.
-__global__ __launch_bounds__(256) void scatter_padded_kernel(const double2* src, int shared, int B, int n, int m,
+MIDYN_GLOBAL __launch_bounds__(256) void scatter_padded_kernel(const double2* src, int shared, int B, int n, int m,
                                                              int mpad, int ldy, double2* y) {
     const size_t total = (size_t)B * n * m;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -1825,7 +1833,7 @@ __global__ __launch_bounds__(256) void scatter_padded_kernel(const double2* src,
     }
 }
 
-__global__ __launch_bounds__(256) void gather_padded_kernel(const double2* y, const int* flags, size_t half, int B,
+MIDYN_GLOBAL __launch_bounds__(256) void gather_padded_kernel(const double2* y, const int* flags, size_t half, int B,
                                                             int n, int m, int mpad, int ldy, double2* dst) {
     const size_t total = (size_t)B * n * m;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -1839,7 +1847,7 @@ __global__ __launch_bounds__(256) void gather_padded_kernel(const double2* y, co
 
 // A[t][j] = (mono[t][j], 0) for t < nb, j < M;  A[t][M] = (1, 0) when a constant term follows the
 // M expansion terms; zero padding elsewhere (row f4: GEMM operand of the polynomial evaluation)
-__global__ __launch_bounds__(256) void mono_operand_kernel(const double* mono, int nb, int M, int has_const,
+MIDYN_GLOBAL __launch_bounds__(256) void mono_operand_kernel(const double* mono, int nb, int M, int has_const,
                                                            int T, int K, double2* A) {
     const size_t total = (size_t)T * K;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -1856,7 +1864,7 @@ __global__ __launch_bounds__(256) void mono_operand_kernel(const double* mono, i
 
 // Host batch layout [B][n][m] (or shared [n][m]) -> device column block [n_pad][ld]; also writes the
 // pre-phased copy yin = E o y.  Padding rows/cols are zeroed by the caller (memset).
-__global__ __launch_bounds__(256) void scatter_state_kernel(const double2* src, int shared, int B, int n,
+MIDYN_GLOBAL __launch_bounds__(256) void scatter_state_kernel(const double2* src, int shared, int B, int n,
                                                             int m, int ld, const double2* e,
                                                             double2* y, double2* yin) {
     const size_t total = (size_t)B * n * m;
@@ -1874,7 +1882,7 @@ __global__ __launch_bounds__(256) void scatter_state_kernel(const double2* src, 
 }
 
 // device column block [n_pad][ld] -> out[b][slot][i][j] with out laid out [B][P][n][m]
-__global__ __launch_bounds__(256) void gather_state_kernel(const double2* y, int B, int n, int m, int ld,
+MIDYN_GLOBAL __launch_bounds__(256) void gather_state_kernel(const double2* y, int B, int n, int m, int ld,
                                                            int P, int slot, double2* out) {
     const size_t total = (size_t)B * n * m;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
@@ -2085,7 +2093,7 @@ constexpr int TINY_CQ = 2;  // coefficient values fetched per lane: supports 3 k
         nxt = nn;                                                                                 \
     }
 
-__global__ __launch_bounds__(256) void tiny_rk4_kernel(TinyArgs a) {
+MIDYN_GLOBAL __launch_bounds__(256) void tiny_rk4_kernel(TinyArgs a) {
     MIDYN_TINY_PROLOGUE
     MIDYN_TINY_PIPE_PROLOGUE
     for (int st = a.step_begin; st < a.step_end; ++st) {
@@ -2116,7 +2124,7 @@ __global__ __launch_bounds__(256) void tiny_rk4_kernel(TinyArgs a) {
 // order 1: Omega v = h G(t1) v;  order 2: h/2 (g1 v + g2 v) + sqrt(3)/12 h^2 (g2 g1 v - g1 g2 v).
 // deg[st] < 0: Chebyshev series with K = -deg[st] terms in sc[st] repetitions, rho[st] the norm bound of Omega and
 // cheb[st * cheb_stride + k] = J_k(rho / sc) (see the Chebyshev paragraph of expm_action_solve).
-__global__ __launch_bounds__(256) void tiny_expm_kernel(TinyArgs a, int magnus_order, const int* deg, const int* sc,
+MIDYN_GLOBAL __launch_bounds__(256) void tiny_expm_kernel(TinyArgs a, int magnus_order, const int* deg, const int* sc,
                                                         const double* rho, const double* cheb, int cheb_stride) {
     MIDYN_TINY_PROLOGUE
     const double p2 = 0.14433756729740643;  // sqrt(3) / 12
@@ -2199,7 +2207,7 @@ __global__ __launch_bounds__(256) void tiny_expm_kernel(TinyArgs a, int magnus_o
 // (leading dimension ldv); Hm is the (m+1) x m Hessenberg matrix in a 64 x 64 row-major block.
 // ------------------------------------------------------------------------------------------------
 // hc[i] = v_i^H w for i < cnt (one workgroup per i); add != 0 accumulates into Hm[i][j] instead of setting it
-__global__ __launch_bounds__(256) void krylov_dot_kernel(const double2* V, int ldv, const double2* w, int n, int j,
+MIDYN_GLOBAL __launch_bounds__(256) void krylov_dot_kernel(const double2* V, int ldv, const double2* w, int n, int j,
                                                          int add, double2* hc, double2* Hm) {
     const int i = blockIdx.x;
     const double2* v = V + (size_t)i * ldv;
@@ -2231,7 +2239,7 @@ __global__ __launch_bounds__(256) void krylov_dot_kernel(const double2* V, int l
 }
 
 // out[r] = base[r] + sign * sum_{i < cnt} coef[i * cstride] v_i[r]     (base may be out itself or nullptr)
-__global__ __launch_bounds__(256) void krylov_axpy_kernel(const double2* V, int ldv, const double2* coef, int cstride,
+MIDYN_GLOBAL __launch_bounds__(256) void krylov_axpy_kernel(const double2* V, int ldv, const double2* coef, int cstride,
                                                           int cnt, double sign, const double2* base, int n,
                                                           double2* out) {
     for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
@@ -2248,7 +2256,7 @@ __global__ __launch_bounds__(256) void krylov_axpy_kernel(const double2* V, int 
 
 // nrm = ||w||_2 (one workgroup); stores it to *nrm_out and, when Hm != nullptr, to Hm[j+1][j]; then
 // vnext = w / nrm (nrm == 0: vnext = 0, the subspace is invariant)
-__global__ __launch_bounds__(1024) void krylov_norm_scale_kernel(const double2* w, int n, int j, double2* Hm,
+MIDYN_GLOBAL __launch_bounds__(1024) void krylov_norm_scale_kernel(const double2* w, int n, int j, double2* Hm,
                                                                  double* nrm_out, double2* vnext) {
     double acc = 0.0;
     for (int r = threadIdx.x; r < n; r += 1024) {
@@ -2275,7 +2283,7 @@ __global__ __launch_bounds__(1024) void krylov_norm_scale_kernel(const double2* 
 }
 
 // small = h * Hm[0..m)[0..m), zero elsewhere (64 x 64 block that dev_expm_inplace exponentiates)
-__global__ __launch_bounds__(256) void krylov_small_kernel(const double2* Hm, int m, double h, double2* small) {
+MIDYN_GLOBAL __launch_bounds__(256) void krylov_small_kernel(const double2* Hm, int m, double h, double2* small) {
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 64 * 64; idx += gridDim.x * 256) {
         const int i = idx >> 6, j = idx & 63;
         const double2 v = (i < m && j < m) ? Hm[idx] : make_double2(0.0, 0.0);
@@ -2284,7 +2292,7 @@ __global__ __launch_bounds__(256) void krylov_small_kernel(const double2* Hm, in
 }
 
 // Saad's a-posteriori estimate  beta * |h h_{m+1,m}| * |e_m^T expm(h H_m) e_1|  -> err[0]; err[1] = beta
-__global__ void krylov_err_kernel(const double2* E, const double2* Hm, int m, double h, const double* beta, double* err) {
+MIDYN_GLOBAL void krylov_err_kernel(const double2* E, const double2* Hm, int m, double h, const double* beta, double* err) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const double2 e = E[(size_t)(m - 1) * 64];
         const double hn = Hm[(size_t)m * 64 + (m - 1)].x;
@@ -2294,13 +2302,13 @@ __global__ void krylov_err_kernel(const double2* E, const double2* Hm, int m, do
 }
 
 // coef[i] = beta * E[i][0]
-__global__ void krylov_coef_kernel(const double2* E, int m, const double* beta, double2* coef) {
+MIDYN_GLOBAL void krylov_coef_kernel(const double2* E, int m, const double* beta, double2* coef) {
     const int i = threadIdx.x;
     if (i < m) coef[i] = make_double2(beta[0] * E[(size_t)i * 64].x, beta[0] * E[(size_t)i * 64].y);
 }
 
 // yin = E o y  (re-phasing when a step starts from a time that is not the previous step's end)
-__global__ __launch_bounds__(256) void rephase_kernel(const double2* y, const double2* e, int n_pad, int ld,
+MIDYN_GLOBAL __launch_bounds__(256) void rephase_kernel(const double2* y, const double2* e, int n_pad, int ld,
                                                       double2* yin) {
     const size_t total = (size_t)n_pad * ld;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
@@ -2311,7 +2319,7 @@ __global__ __launch_bounds__(256) void rephase_kernel(const double2* y, const do
 }
 
 // dst = a * src (state blocks)
-__global__ __launch_bounds__(256) void scale_copy_kernel(const double2* src, double a, size_t total, double2* dst) {
+MIDYN_GLOBAL __launch_bounds__(256) void scale_copy_kernel(const double2* src, double a, size_t total, double2* dst) {
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const double2 v = src[idx];
         dst[idx] = make_double2(a * v.x, a * v.y);
@@ -2323,7 +2331,7 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const double2* src, dou
 // Optionally also writes the two phased copies of w the next term's products read (wp0 = e0 o w, wp1 = e1 o w).
 // z / beta: the Chebyshev recurrence of the same action, w = (...) + z (phi_{k+1} = 2 B phi_k + phi_{k-1}; z may alias
 // w), acc += beta w; the Taylor series passes z = nullptr, beta = 1.
-__global__ __launch_bounds__(256) void magnus2_term_kernel(const double2* u1, const double2* u2, const double2* v1,
+MIDYN_GLOBAL __launch_bounds__(256) void magnus2_term_kernel(const double2* u1, const double2* u2, const double2* v1,
                                                            const double2* v2, double a, double b, size_t total,
                                                            double2* w, double2* acc, const double2* e0,
                                                            const double2* e1, int ld, double2* wp0, double2* wp1,
@@ -2352,7 +2360,7 @@ __global__ __launch_bounds__(256) void magnus2_term_kernel(const double2* u1, co
 //   kind 0:  -i (I (x) A - A^T (x) I)                                    (vec_commutator)
 //   kind 1:  conj(L) (x) L - (I (x) L^+L + (L^+L)^T (x) I) / 2           (vec_dissipator; ldl = L^+L)
 // accumulate != 0 adds to what `out` holds.  Plain multiplies and adds in numpy's order (no contraction).
-__global__ __launch_bounds__(256) void vec_lindblad_kernel(int n, int ld, const double2* a, int kind, const double2* ldl,
+MIDYN_GLOBAL __launch_bounds__(256) void vec_lindblad_kernel(int n, int ld, const double2* a, int kind, const double2* ldl,
                                                            double2* out, int accumulate) {
 #pragma clang fp contract(off)
     const size_t N = (size_t)n * n, total = N * N;
@@ -2379,7 +2387,7 @@ __global__ __launch_bounds__(256) void vec_lindblad_kernel(int n, int ld, const 
 }
 
 // a += b over [rows][cols] blocks of leading dimension ld (static superoperator = commutator part + dissipator sum)
-__global__ __launch_bounds__(256) void add_padded_kernel(double2* a, const double2* b, int rows, int cols, int ld) {
+MIDYN_GLOBAL __launch_bounds__(256) void add_padded_kernel(double2* a, const double2* b, int rows, int cols, int ld) {
 #pragma clang fp contract(off)
     const size_t total = (size_t)rows * cols;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
@@ -2389,7 +2397,7 @@ __global__ __launch_bounds__(256) void add_padded_kernel(double2* a, const doubl
 }
 
 // flags[2*seg + 0/1] = 1 if any real / imaginary part of segment seg is non zero
-__global__ __launch_bounds__(256) void plane_flags_kernel(const double2* ops, size_t plane, int nseg,
+MIDYN_GLOBAL __launch_bounds__(256) void plane_flags_kernel(const double2* ops, size_t plane, int nseg,
                                                           int* flags) {
     const size_t total = plane * nseg;
     int fr = 0, fi = 0;
@@ -2418,7 +2426,7 @@ __global__ __launch_bounds__(256) void plane_flags_kernel(const double2* ops, si
 // map[(seg * nrb + rb) * ncb + cb] = 1 when the 16 x 16 block (rb, cb) of operator segment seg holds a
 // non-zero entry (nrb = ncb = n_pad / 16; the map is zeroed by the caller; every writer stores 1).
 // grid (nrb, nseg): one workgroup per 16-row strip.
-__global__ __launch_bounds__(256) void block_map_kernel(const double2* ops, int n_pad, unsigned char* map) {
+MIDYN_GLOBAL __launch_bounds__(256) void block_map_kernel(const double2* ops, int n_pad, unsigned char* map) {
     const int rb = blockIdx.x, seg = blockIdx.y;
     const int nb = n_pad / 16;
     const double2* base = ops + (size_t)seg * n_pad * n_pad + (size_t)rb * 16 * n_pad;
@@ -2432,7 +2440,7 @@ __global__ __launch_bounds__(256) void block_map_kernel(const double2* ops, int 
 // partial column abs sums of [n][n] matrices (ld n): sums[(mat * nchunk + z) * n + c] = sum over the
 // rows of chunk z of |A[r][c]|; the host adds the chunks (fixed order) and takes max_c = the 1-norm.
 // grid (ceil(n/256), batch, nchunk): enough workgroups to stream a large matrix at HBM rate.
-__global__ __launch_bounds__(256) void colsum_kernel(const double2* A, int n, int nchunk, double* sums) {
+MIDYN_GLOBAL __launch_bounds__(256) void colsum_kernel(const double2* A, int n, int nchunk, double* sums) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
     const double2* Ab = A + (size_t)blockIdx.y * n * n;   // blockIdx.y: matrix of a batch
@@ -2448,7 +2456,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const double2* A, int n, in
 
 // The same partial column sums for |A^T| (mode 1: the infinity norm of A as the 1-norm of A^T) and for the
 // Hermitian part |A + A^dagger| / 2 (mode 2); one-off per operator stack, so the strided transposed reads are fine.
-__global__ __launch_bounds__(256) void colsum_mode_kernel(const double2* A, int n, int nchunk, int mode, double* sums) {
+MIDYN_GLOBAL __launch_bounds__(256) void colsum_mode_kernel(const double2* A, int n, int nchunk, int mode, double* sums) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
     const double2* Ab = A + (size_t)blockIdx.y * n * n;
@@ -2471,7 +2479,7 @@ __global__ __launch_bounds__(256) void colsum_mode_kernel(const double2* A, int 
 // Frobenius norm of A + A^dagger in fixed-order pieces (the host adds them).  For the generators -iH of a
 // Hamiltonian model this is || H - H^dagger ||_F^2, i.e. the reference's Hermiticity validation
 // (models/hamiltonian_model.py:98-104) evaluated where the operators already are.
-__global__ __launch_bounds__(256) void antiherm_defect_kernel(const double2* A, int n, int nchunk, double* partial) {
+MIDYN_GLOBAL __launch_bounds__(256) void antiherm_defect_kernel(const double2* A, int n, int nchunk, double* partial) {
     const double2* Ab = A + (size_t)blockIdx.y * n * n;
     const int rows = (n + nchunk - 1) / nchunk;
     const int r0 = blockIdx.x * rows, r1 = min(n, r0 + rows);
@@ -2491,7 +2499,7 @@ __global__ __launch_bounds__(256) void antiherm_defect_kernel(const double2* A, 
 }
 
 // pad copy: src [rows][cols] (ld src_ld) -> dst (ld dst_ld), both complex
-__global__ __launch_bounds__(256) void copy2d_kernel(const double2* src, int src_ld, double2* dst, int dst_ld,
+MIDYN_GLOBAL __launch_bounds__(256) void copy2d_kernel(const double2* src, int src_ld, double2* dst, int dst_ld,
                                                      int rows, int cols) {
     const size_t total = (size_t)rows * cols;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
@@ -2504,7 +2512,7 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const double2* src, int src
 
 // X[a][b] *= e_a * conj(e_b)  (dir = +1: operator OUT of the frame, rotating_frame.py:397-436 with -t)
 //           or conj(e_a) * e_b (dir = -1: operator INTO the frame, :372-395), e = exp(d t); in place or to dst
-__global__ __launch_bounds__(256) void frame_mask_kernel(const double2* src, const double2* e, int n_pad, int dir,
+MIDYN_GLOBAL __launch_bounds__(256) void frame_mask_kernel(const double2* src, const double2* e, int n_pad, int dir,
                                                          double2* dst) {
     const size_t total = (size_t)n_pad * n_pad;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total;
@@ -2519,7 +2527,7 @@ __global__ __launch_bounds__(256) void frame_mask_kernel(const double2* src, con
 
 // Batched forms for a chunk of instances (matrices back to back, one phase row shared by the chunk):
 // frame mask of every matrix, and T_b *= gamma_b (gamma_b = coeff[b * stride + j]: a dynamic dissipator's rate)
-__global__ __launch_bounds__(256) void frame_mask_batch_kernel(const double2* src, const double2* e, int n_pad, int dir,
+MIDYN_GLOBAL __launch_bounds__(256) void frame_mask_batch_kernel(const double2* src, const double2* e, int n_pad, int dir,
                                                                int batch, double2* dst) {
     const size_t plane = (size_t)n_pad * n_pad, total = plane * batch;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
@@ -2532,7 +2540,7 @@ __global__ __launch_bounds__(256) void frame_mask_batch_kernel(const double2* sr
     }
 }
 
-__global__ __launch_bounds__(256) void scale_batch_kernel(double2* x, size_t plane, int batch, const double* coeff,
+MIDYN_GLOBAL __launch_bounds__(256) void scale_batch_kernel(double2* x, size_t plane, int batch, const double* coeff,
                                                           long long stride) {
     const size_t total = plane * batch;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
@@ -2542,7 +2550,7 @@ __global__ __launch_bounds__(256) void scale_batch_kernel(double2* x, size_t pla
 }
 
 // out[b][slot][i][j] = Y[b][i][j] (padded [np][np] -> [n][n]) for a chunk of instances
-__global__ __launch_bounds__(256) void save_density_kernel(const double2* Y, int np, int n, int batch, int P, int slot,
+MIDYN_GLOBAL __launch_bounds__(256) void save_density_kernel(const double2* Y, int np, int n, int batch, int P, int slot,
                                                            double2* out) {
     const size_t nn = (size_t)n * n, total = nn * batch;
     for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (size_t)gridDim.x * 256) {
@@ -2582,7 +2590,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* sink, int iters)
 // chip clocks to its power budget: a dense fp64 MFMA stream on such operands sustains a lower shader clock than the
 // 2.4 GHz the 78.6 TFLOP/s peak is quoted at (operands that are all zero, or nearly constant as in mfma_peak_kernel,
 // toggle few bits and keep the full clock).  sink[1], sink[2] = shader cycles and 100 MHz ticks of one workgroup.
-__global__ __launch_bounds__(512, 2) void mfma_sustained_kernel(double* sink, int iters, int random_operands) {
+MIDYN_GLOBAL __launch_bounds__(512, 2) void mfma_sustained_kernel(double* sink, int iters, int random_operands) {
     const long long c0 = clock64(), w0 = wall_clock64();
     d4 acc[16];
 #pragma unroll
@@ -2647,7 +2655,7 @@ __global__ __launch_bounds__(256) void fp64_coissue_kernel(double* sink, int ite
 // out[3 st + {0, 1, 2}] = max_b of the 1-norm triangle bound, of the larger of the 1- and infinity-norm bounds, and of the
 // bound of the Hermitian part, from the per-segment norms nrm[3][nseg] and the coefficient table S[B][R][k] ON THE DEVICE
 // (a 4096-instance table came back to the host for this loop: 39 MB over PCIe + a strided pass, 7 ms of a 3 ms solve).
-__global__ __launch_bounds__(256) void step_bounds_kernel(const double* __restrict__ S, int B, int R, int k, int nseg, int has_static,
+MIDYN_GLOBAL __launch_bounds__(256) void step_bounds_kernel(const double* __restrict__ S, int B, int R, int k, int nseg, int has_static,
                                                           const int* __restrict__ rows, const double* __restrict__ hs, int order,
                                                           const double* __restrict__ nrm, double* __restrict__ out) {
     const int st = blockIdx.x;
@@ -2695,7 +2703,7 @@ __global__ __launch_bounds__(256) void step_bounds_kernel(const double* __restri
 }
 
 // streaming read of `n16` 16-byte elements (grid-stride, 4 independent loads per thread per round)
-__global__ __launch_bounds__(256) void stream_read_kernel(const double2* src, size_t n16, double* sink) {
+MIDYN_GLOBAL __launch_bounds__(256) void stream_read_kernel(const double2* src, size_t n16, double* sink) {
     double2 acc = make_double2(0.0, 0.0);
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -2710,5 +2718,54 @@ __global__ __launch_bounds__(256) void stream_read_kernel(const double2* src, si
     }
     if (acc.x == 123.456 && acc.y == 654.321) sink[0] = acc.x;
 }
+
+// ---- the instantiations of the MFMA contraction kernels that exist, and where -----------------------------------------------
+// libmidyn.so is built from several translation units so that hipcc compiles the kernel families side by side (the device
+// side of ONE unit is compiled serially: five minutes for everything in round 4).  The host side of every entry point stays
+// in midyn.hip; a family's kernels are instantiated in its own unit (midyn_tu_gemm_dense.hip defines MIDYN_TU_GEMM_DENSE,
+// midyn_tu_gemm_lists.hip MIDYN_TU_GEMM_LISTS, midyn_tu_gemm_pairs.hip MIDYN_TU_GEMM_PAIRS), every other unit sees `extern template` declarations of the same list and
+// only takes the kernels' addresses.  A kernel the host code selects but the list does not name is an undefined symbol of
+// the library: __graft_entry__.build() refuses it.
+#define MIDYN_FOR_PLANE_MODE(X, ...) X(__VA_ARGS__, 0) X(__VA_ARGS__, 1) X(__VA_ARGS__, 2) X(__VA_ARGS__, 3)
+#define MIDYN_GEMM_PAIR_TILES(X)                                                                                    \
+    MIDYN_FOR_PLANE_MODE(X, 128, 128, 2, 4, 16) MIDYN_FOR_PLANE_MODE(X, 64, 64, 2, 2, 16) MIDYN_FOR_PLANE_MODE(X, 32, 128, 1, 4, 16) \
+    MIDYN_FOR_PLANE_MODE(X, 32, 64, 1, 2, 16) MIDYN_FOR_PLANE_MODE(X, 16, 128, 1, 4, 16) MIDYN_FOR_PLANE_MODE(X, 16, 64, 1, 2, 16)
+#define MIDYN_GEMM_TILES(X) MIDYN_GEMM_PAIR_TILES(X) MIDYN_FOR_PLANE_MODE(X, 128, 64, 2, 2, 8)
+#ifdef MIDYN_TU_GEMM_DENSE
+#define MIDYN_GEMM_DENSE_EXTERN
+#else
+#define MIDYN_GEMM_DENSE_EXTERN extern
+#endif
+#ifdef MIDYN_TU_GEMM_LISTS
+#define MIDYN_GEMM_LISTS_EXTERN
+#else
+#define MIDYN_GEMM_LISTS_EXTERN extern
+#endif
+#ifdef MIDYN_TU_GEMM_PAIRS
+#define MIDYN_GEMM_PAIRS_EXTERN
+#else
+#define MIDYN_GEMM_PAIRS_EXTERN extern
+#endif
+#define MIDYN_X(BM_, BN_, WM_, WN_, BK_, MODE_) \
+    MIDYN_GEMM_DENSE_EXTERN template __global__ void zgemm_seg_kernel<BM_, BN_, WM_, WN_, BK_, MODE_, 2, false>(GemmArgs);
+MIDYN_GEMM_TILES(MIDYN_X)
+MIDYN_X(64, 64, 2, 2, 16, 4)      // 3M: three accumulator sets fit the registers on the 64 x 64 tile only
+#undef MIDYN_X
+#define MIDYN_X(BM_, BN_, WM_, WN_, BK_, MODE_) \
+    MIDYN_GEMM_LISTS_EXTERN template __global__ void zgemm_seg_kernel<BM_, BN_, WM_, WN_, BK_, MODE_, 2, true>(GemmArgs);
+MIDYN_GEMM_TILES(MIDYN_X)
+#undef MIDYN_X
+#define MIDYN_X(BM_, BN_, WM_, WN_, BK_, MODE_) \
+    MIDYN_GEMM_PAIRS_EXTERN template __global__ void zgemm_seg_pair_kernel<BM_, BN_, WM_, WN_, BK_, MODE_, 2, true>(GemmPair);
+MIDYN_GEMM_PAIR_TILES(MIDYN_X)
+#undef MIDYN_X
+#define MIDYN_X(MODE_) \
+    MIDYN_GEMM_DENSE_EXTERN template __global__ void splitk_reduce_kernel<MODE_, 0>(const double2*, int, int, int, Epilogue);  \
+    MIDYN_GEMM_DENSE_EXTERN template __global__ void splitk_reduce_kernel<MODE_, 2>(const double2*, int, int, int, Epilogue);  \
+    MIDYN_GEMM_DENSE_EXTERN template __global__ void splitk_reduce_kernel<MODE_, 4>(const double2*, int, int, int, Epilogue);  \
+    MIDYN_GEMM_DENSE_EXTERN template __global__ void splitk_reduce_kernel<MODE_, 8>(const double2*, int, int, int, Epilogue);  \
+    MIDYN_GEMM_DENSE_EXTERN template __global__ void splitk_reduce_kernel<MODE_, 16>(const double2*, int, int, int, Epilogue);
+MIDYN_X(EPI_PLAIN) MIDYN_X(EPI_RHS) MIDYN_X(EPI_RK1) MIDYN_X(EPI_RK2) MIDYN_X(EPI_RK3) MIDYN_X(EPI_RK4) MIDYN_X(EPI_TAYLOR) MIDYN_X(EPI_CHEB)
+#undef MIDYN_X
 
 }  // namespace midyn

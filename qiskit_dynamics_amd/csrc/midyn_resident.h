@@ -767,7 +767,7 @@ struct SweepArgs {
 };
 
 // D[st][r] = E[rows[3 st + 1]][r] o conj(E[rows[3 st]][r]): the frame phase between the two Gauss points of every step
-__global__ __launch_bounds__(256) void sweep_dtable_kernel(const double2* __restrict__ E, const int* __restrict__ rows, int nsteps, int np,
+MIDYN_GLOBAL __launch_bounds__(256) void sweep_dtable_kernel(const double2* __restrict__ E, const int* __restrict__ rows, int nsteps, int np,
                                                            double2* __restrict__ Dt) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)nsteps * np) return;
@@ -1422,5 +1422,43 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
         }
     }
 }
+
+// ---- the instantiations that exist (see the end of midyn_kernels.h): midyn_tu_sweep.hip defines MIDYN_TU_SWEEP (the
+// one-workgroup-per-instance sweep kernels), midyn_tu_resident.hip MIDYN_TU_RESIDENT (the single-trajectory kernels) -------
+#ifdef MIDYN_TU_SWEEP
+#define MIDYN_SWEEP_EXTERN
+#else
+#define MIDYN_SWEEP_EXTERN extern
+#endif
+#ifdef MIDYN_TU_RESIDENT
+#define MIDYN_RESIDENT_EXTERN
+#else
+#define MIDYN_RESIDENT_EXTERN extern
+#endif
+#define MIDYN_FOR_ELEMENT_FORM(X, ...) X(__VA_ARGS__, 0) X(__VA_ARGS__, 1) X(__VA_ARGS__, 2)
+#define MIDYN_SWEEP_SHAPES(X)   /* (rows per thread, threads) x element form */                                 \
+    MIDYN_FOR_ELEMENT_FORM(X, 1, 256) MIDYN_FOR_ELEMENT_FORM(X, 1, 512) MIDYN_FOR_ELEMENT_FORM(X, 1, 1024) \
+    MIDYN_FOR_ELEMENT_FORM(X, 2, 1024) MIDYN_FOR_ELEMENT_FORM(X, 3, 1024) MIDYN_FOR_ELEMENT_FORM(X, 4, 1024)
+#define MIDYN_X(R_, T_, P_)                                                                           \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_kernel<1, R_, T_, P_>(const SweepArgs);   \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_kernel<2, R_, T_, P_>(const SweepArgs);   \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_rk4_kernel<R_, T_, P_>(const SweepArgs);
+MIDYN_SWEEP_SHAPES(MIDYN_X)
+#undef MIDYN_X
+MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_split_kernel<1, 1>(const SweepSplitArgs);
+MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_split_kernel<1, 2>(const SweepSplitArgs);
+MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_split_kernel<2, 1>(const SweepSplitArgs);
+MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_split_kernel<2, 2>(const SweepSplitArgs);
+#define MIDYN_X(NE_, W_) \
+    MIDYN_RESIDENT_EXTERN template __global__ void rk4_resident_kernel<NE_, W_, false>(const ResidentArgs); \
+    MIDYN_RESIDENT_EXTERN template __global__ void rk4_resident_kernel<NE_, W_, true>(const ResidentArgs);
+MIDYN_X(2, 4) MIDYN_X(2, 8) MIDYN_X(4, 4) MIDYN_X(4, 8) MIDYN_X(8, 4) MIDYN_X(8, 8) MIDYN_X(16, 4) MIDYN_X(16, 8)
+#undef MIDYN_X
+#define MIDYN_X(M_) \
+    MIDYN_RESIDENT_EXTERN template __global__ void ell_resident_kernel<M_, 4>(const EllArgs); \
+    MIDYN_RESIDENT_EXTERN template __global__ void ell_resident_kernel<M_, 8>(const EllArgs); \
+    MIDYN_RESIDENT_EXTERN template __global__ void ell_resident_kernel<M_, 16>(const EllArgs);
+MIDYN_X(0) MIDYN_X(1)
+#undef MIDYN_X
 
 }  // namespace midyn

@@ -11,22 +11,43 @@ import msgpack
 BUNDLE_MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
-def extract_code_object(path, arch="gfx950"):
+def extract_code_objects(path, arch="gfx950"):
+    """The gfx950 code object of every offload bundle in the file: libmidyn.so is linked from several translation units
+    (midyn.hip + one per kernel family) and carries one bundle per unit."""
     data = open(path, "rb").read()
-    at = data.find(BUNDLE_MAGIC)
-    if at < 0:
-        raise ValueError(f"{path}: no clang offload bundle")
-    p = at + len(BUNDLE_MAGIC)
-    (count,) = struct.unpack_from("<Q", data, p)
-    p += 8
-    for _ in range(count):
-        off, size, tlen = struct.unpack_from("<QQQ", data, p)
-        p += 24
-        triple = data[p:p + tlen].decode()
-        p += tlen
-        if arch in triple and size:
-            return data[at + off:at + off + size]
-    raise ValueError(f"{path}: no {arch} entry in the offload bundle")
+    found, at = [], data.find(BUNDLE_MAGIC)
+    while at >= 0:
+        p = at + len(BUNDLE_MAGIC)
+        (count,) = struct.unpack_from("<Q", data, p)
+        p += 8
+        for _ in range(count):
+            off, size, tlen = struct.unpack_from("<QQQ", data, p)
+            p += 24
+            triple = data[p:p + tlen].decode()
+            p += tlen
+            if arch in triple and size:
+                found.append(data[at + off:at + off + size])
+        at = data.find(BUNDLE_MAGIC, at + 1)
+    if not found:
+        raise ValueError(f"{path}: no {arch} entry in any clang offload bundle")
+    return found
+
+
+def extract_code_object(path, arch="gfx950"):
+    """The first gfx950 code object (the unit linked first: midyn.hip)."""
+    return extract_code_objects(path, arch)[0]
+
+
+def disassembly(path, tmp_path, objdump="/opt/rocm/lib/llvm/bin/llvm-objdump"):
+    """llvm-objdump -d of every gfx950 code object in the library, concatenated."""
+    import subprocess
+
+    text = []
+    for i, elf in enumerate(extract_code_objects(path)):
+        co = tmp_path / f"midyn_{i}.co"
+        co.write_bytes(elf)
+        text.append(subprocess.run([objdump, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, check=True).stdout)
+    return "\n".join(text)
 
 
 def kernel_metadata(elf):
@@ -56,4 +77,11 @@ def kernel_metadata(elf):
 
 
 def library_kernels(path):
-    return kernel_metadata(extract_code_object(path))
+    kernels = {}
+    for elf in extract_code_objects(path):
+        unit = kernel_metadata(elf)
+        twice = set(unit) & set(kernels)
+        if twice:
+            raise ValueError(f"kernels instantiated in two translation units: {sorted(twice)[:3]}")
+        kernels.update(unit)
+    return kernels

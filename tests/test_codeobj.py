@@ -93,9 +93,7 @@ def _tile_loop(symbol_fragment, tmp_path):
     """Instructions between the first and the last MFMA of the kernel whose mangled name contains the fragment."""
     import subprocess
 
-    co = tmp_path / "midyn.co"
-    co.write_bytes(codeobj.extract_code_object(LIB))
-    text = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, check=True).stdout
+    text = codeobj.disassembly(LIB, tmp_path, OBJDUMP)
     lines = text.split("\n")
     start = next(i for i, l in enumerate(lines) if symbol_fragment in l and l.rstrip().endswith(">:"))
     end = next(i for i in range(start + 1, len(lines)) if lines[i].rstrip().endswith(">:"))
@@ -146,9 +144,7 @@ def test_combine_kernels_keep_scratch_out_of_their_loop(tmp_path):
 
     if not os.path.exists(LIB):
         pytest.skip("libmidyn.so has not been built")
-    co = tmp_path / "midyn.co"
-    co.write_bytes(codeobj.extract_code_object(LIB))
-    text = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, check=True).stdout
+    text = codeobj.disassembly(LIB, tmp_path, OBJDUMP)
     lines = text.split("\n")
     starts = [i for i, l in enumerate(lines) if "rhs_combine_kernel" in l and l.rstrip().endswith(">:")]
     assert len(starts) == 48
@@ -174,9 +170,7 @@ def test_sweep_kernels_keep_scratch_out_of_their_contraction_loops(tmp_path):
 
     if not os.path.exists(LIB):
         pytest.skip("libmidyn.so has not been built")
-    co = tmp_path / "midyn.co"
-    co.write_bytes(codeobj.extract_code_object(LIB))
-    text = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True, check=True).stdout
+    text = codeobj.disassembly(LIB, tmp_path, OBJDUMP)
     lines = text.split("\n")
     starts = [i for i, l in enumerate(lines) if "combine_sweep_kernelILi" in l and l.rstrip().endswith(">:")]
     assert len(starts) == 128

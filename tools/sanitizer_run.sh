@@ -1,15 +1,17 @@
 #!/bin/bash
 # Host side of libmidyn.so under AddressSanitizer + UndefinedBehaviorSanitizer (device code is not instrumented).
-# Build (in the CPU container, ~6 min):
+# Build (in the CPU container, ~2 min; one object per translation unit: midyn.hip + the kernel-family units midyn_tu_*.hip):
 #   mkdir -p build/asan && cd build/asan
-#   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-value -fsanitize=address,undefined -fno-sanitize=function \
-#         -fno-gpu-sanitize -fno-omit-frame-pointer -c -o midyn_asan.o ../../qiskit_dynamics_amd/csrc/midyn.hip
+#   for u in ../../qiskit_dynamics_amd/csrc/midyn.hip ../../qiskit_dynamics_amd/csrc/midyn_tu_*.hip; do
+#     hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -Wno-unused-value -Wno-unused-function -fsanitize=address,undefined \
+#           -fno-sanitize=function -fno-gpu-sanitize -fno-omit-frame-pointer -c -o $(basename $u .hip)_asan.o $u &
+#   done; wait
 #   (-fno-sanitize=function: UBSan's function-type check puts a signature word in front of every function, and the HIP
 #    runtime then no longer finds the kernels behind their host stubs -- every templated kernel launch silently does
 #    nothing; found with tools/gemm_probe.hip: -O1, -O1 -g, -O1 + ASan are correct, + UBSan is not, + UBSan without
 #    `function` is.  The C driver below is compiled WITH the check: it verifies that the C view of every entry point it
 #    calls has the function type of the C++ definition -- midyn_complex is `double _Complex` in both for that reason)
-#   hipcc -shared -fsanitize=address,undefined -o libmidyn_asan.so midyn_asan.o -ldl && rm midyn_asan.o
+#   hipcc -shared -fsanitize=address,undefined -o libmidyn_asan.so midyn*_asan.o -ldl && rm midyn*_asan.o
 #   /opt/rocm/lib/llvm/bin/clang -std=c99 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -o abi_solve_asan \
 #         ../../tests/abi_solve.c -ldl -lm -lstdc++   (libstdc++: ASan's __cxa_throw interceptor needs it when RCCL throws inside)
 # Run (on the GPU box, through gpurun):  bash tools/sanitizer_run.sh  -> gpurun_out/sanitizer/
