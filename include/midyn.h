@@ -112,6 +112,8 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *   profile [0]           record HIP-event kernel times (midyn_get_counters)
  *   stream_variant, plane_kernel, prefer_duo, ablate          A/B and profiling switches */
 int midyn_ctx_set_option(midyn_ctx* ctx, const char* name, long long value);
+/* The present value of an option: what a caller that changes one for a while puts back afterwards (unknown name: error). */
+int midyn_ctx_get_option(midyn_ctx* ctx, const char* name, long long* value);
 
 /* ---- operator stack ----------------------------------------------------------------------
  * Replaces OperatorCollection.__init__ (models/operator_collections.py:54-81): the device-resident
@@ -300,7 +302,10 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * ((row group, column block) pairs per workgroup, waves that split the list of one pair), "combine_wave" -> (state columns
  * per wave of that launch: 64, or 32 for stacks with more than two plane groups and for small sweeps, 0).  A one-launch RK4 sweep
  * (combine_sweep) counts as ONE "rhs_combine" launch; "combine_sweep" -> (workgroups of 16 instances, 10 x waves per
- * workgroup + 16-row tiles per wave) of the last one. */
+ * workgroup + 16-row tiles per wave) of the last one.
+ * "flops:<class>" -> (real floating-point operations the dense MFMA contraction launches of that class executed while
+ * `profile` was on -- per complex multiply-add 8 with four real products, 6 with three (3M), 4 for a one-plane operand --, 0):
+ * what bench.py divides by the class's kernel time for the rooflines of the dense expm and the Lindblad products. */
 int midyn_get_counters(midyn_ctx* ctx, const char* name, double* out);
 int midyn_reset_counters(midyn_ctx* ctx);
 /* Measured ceilings: "mfma_f64" -> out[0] = TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64; "mfma_f64_sustained"
@@ -342,7 +347,12 @@ int midyn_stack_broadcast(midyn_stack* stack, void* nccl_comm, int root);
  * rank -- the root too -- receives into `dst` (same shape, normally from midyn_stack_create_empty) and derives its
  * host-side lists from the received content, exactly as a non-root rank of midyn_stack_broadcast does.  With a
  * one-rank communicator it is a copy through RCCL plus the receiving side, i.e. a single GPU can run what ranks
- * 1..N-1 run.  midyn_stack_broadcast(s, comm, root) == midyn_stack_broadcast_from(s, s, comm, root). */
+ * 1..N-1 run.  midyn_stack_broadcast(s, comm, root) == midyn_stack_broadcast_from(s, s, comm, root).
+ * Errors and the other ranks: EVERY rank of the communicator must make the call (it is a collective).  A shape that
+ * does not match the root's -- which only the rank that has it can see -- does not leave the others hanging: the ranks
+ * first exchange 48 bytes (the root's shape to everybody, the minimum of everybody's verdict back), and either all of
+ * them broadcast the buffer or none does and each returns non-zero.  What still hangs, as with any collective: a rank
+ * that never calls, or that fails before the handshake (NULL arguments, no librccl, root out of range). */
 int midyn_stack_broadcast_from(midyn_stack* dst, midyn_stack* src, void* nccl_comm, int root);
 
 #ifdef __cplusplus

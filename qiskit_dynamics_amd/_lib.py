@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libmidyn.so")
 # every symbol include/midyn.h declares (__graft_entry__.build() and tests/test_host_logic.py check the .so exports all of them; tests/abi_probe.c compiles the header as plain C)
 ABI_SYMBOLS = [
     "midyn_ctx_create", "midyn_ctx_destroy", "midyn_ctx_synchronize", "midyn_last_error",
-    "midyn_ctx_set_option", "midyn_stack_packed_bytes", "midyn_stack_create", "midyn_stack_create_lindblad",
+    "midyn_ctx_set_option", "midyn_ctx_get_option", "midyn_stack_packed_bytes", "midyn_stack_create", "midyn_stack_create_lindblad",
     "midyn_stack_adopt", "midyn_stack_antiherm_defect",
     "midyn_stack_destroy", "midyn_stack_info", "midyn_stack_segment_modes", "midyn_eval_generator", "midyn_eval_rhs",
     "midyn_rk4_solve", "midyn_expm", "midyn_expm_solve", "midyn_zgemm", "midyn_rk4_plan_create",
@@ -131,6 +131,7 @@ def load():
         lib.midyn_ctx_destroy.argtypes = [_vp]
         lib.midyn_ctx_synchronize.argtypes = [_vp]
         lib.midyn_ctx_set_option.argtypes = [_vp, ctypes.c_char_p, _cll]
+        lib.midyn_ctx_get_option.argtypes = [_vp, ctypes.c_char_p, P(_cll)]
         lib.midyn_stack_packed_bytes.argtypes = [_ci, _ci, _ci, P(ctypes.c_size_t)]
         lib.midyn_stack_create.argtypes = [_vp, _ci, _ci, _vp, _vp, _vp, _vp, P(_vp)]
         lib.midyn_stack_adopt.argtypes = [_vp, _ci, _ci, _ci, _ci, _vp, P(_vp)]
@@ -223,6 +224,28 @@ class Context:
     def set_option(self, name: str, value: int):
         self.check(self.lib.midyn_ctx_set_option(self.handle, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        out = _cll(0)
+        self.check(self.lib.midyn_ctx_get_option(self.handle, name.encode(), ctypes.byref(out)))
+        return int(out.value)
+
+    def options(self, **values):
+        """Context manager: the given options for the duration of a `with` block, their PREVIOUS values afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            before = {name: self.get_option(name) for name in values}
+            try:
+                for name, val in values.items():
+                    self.set_option(name, val)
+                yield self
+            finally:
+                for name, val in before.items():
+                    self.set_option(name, val)
+
+        return scope()
+
     def synchronize(self):
         self.check(self.lib.midyn_ctx_synchronize(self.handle))
 
@@ -230,6 +253,12 @@ class Context:
         out = (ctypes.c_double * 2)()
         self.check(self.lib.midyn_get_counters(self.handle, name.encode(), out))
         return {"launches": out[0], "ms": out[1]}
+
+    def executed_flops(self, name: str) -> float:
+        """Real flops the dense MFMA contraction launches of counter class `name` executed while `profile` was on."""
+        out = (ctypes.c_double * 2)()
+        self.check(self.lib.midyn_get_counters(self.handle, ("flops:" + name).encode(), out))
+        return float(out[0])
 
     def microbench(self, name: str, full: bool = False):
         out = (ctypes.c_double * 4)()

@@ -111,8 +111,8 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a) {
     const int wr = wv % a.wr, wi = wv / a.wr, nwi = waves / a.wr;
     const int rgb = (a.n_row_groups + a.wr - 1) / a.wr;
     const int rg = (blockIdx.x % rgb) * a.wr + wr;
-    if (rg >= a.n_row_groups) return;                      // (a wave that leaves here never reaches the barrier of the list
-                                                           //  split below; the hardware barrier counts the waves still alive)
+    // (rg < n_row_groups for every wave: launch_combine makes a.wr a divisor of the row-group count, so no wave of a
+    //  workgroup leaves before the barriers of the list split below)
     const int col0 = ((blockIdx.x / rgb) * nwi + wi) * (NG * 16);
     const int lb = lane & 15, lq = lane >> 4;
 
@@ -245,9 +245,11 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a) {
         constexpr int NV = RT * NG * 8;     // doubles per lane
         double* lds = reinterpret_cast<double*>(smem_raw);
         const unsigned red = (unsigned)(wv * (a.splits >> 1)) * (NV * 64) + lane;   // this pair's slots (32-bit LDS offsets)
-        // one round: false = this wave has handed its sums over and is done
-        auto round = [&](int h) -> bool {
-            if (sp >= h) {
+        // one round; a wave that has handed its sums over stays for the remaining barriers (every wave of the workgroup
+        // reaches every __syncthreads(): nothing here relies on how the hardware counts waves that have ended)
+        bool alive = true;                  // wave-uniform (sp is)
+        auto round = [&](int h) {
+            if (alive && sp >= h) {
                 double* mine = lds + (red + (unsigned)(sp - h) * (NV * 64));
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
@@ -260,28 +262,30 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a) {
                         }
             }
             __syncthreads();
-            if (sp >= h) return false;      // (the hardware barrier counts the waves still alive)
-            const double* theirs = lds + (red + (unsigned)sp * (NV * 64));
+            if (sp >= h) alive = false;
+            if (alive) {
+                const double* theirs = lds + (red + (unsigned)sp * (NV * 64));
 #pragma unroll
-            for (int t = 0; t < RT; ++t)
+                for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int g = 0; g < NG; ++g)
+                    for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ore[t][g][r] += theirs[((t * NG + g) * 8 + r) * 64];
-                        oim[t][g][r] += theirs[((t * NG + g) * 8 + 4 + r) * 64];
-                    }
-            return true;
+                        for (int r = 0; r < 4; ++r) {
+                            ore[t][g][r] += theirs[((t * NG + g) * 8 + r) * 64];
+                            oim[t][g][r] += theirs[((t * NG + g) * 8 + 4 + r) * 64];
+                        }
+            }
         };
         if (a.splits >= 8) {
-            if (!round(4)) return;
+            round(4);
             __syncthreads();                // (the slots are written again in the next round)
         }
         if (a.splits >= 4) {
-            if (!round(2)) return;
+            round(2);
             __syncthreads();
         }
-        if (!round(1)) return;
+        round(1);
+        if (!alive) return;
     }
     store_tile<RT, NG>(a.epi, rg * CMB_ROWS + lq, col0 + lb, ore, oim);
 }

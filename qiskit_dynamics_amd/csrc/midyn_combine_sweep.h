@@ -59,7 +59,7 @@ struct CombineSweepArgs {
     // solve as a flat list of series TERMS, one product each -- per term the table row of its step's generator, the scalars of
     //     w = pw + a G x;  acc += b w      (Taylor: a = h / (s j), b = 1;  Chebyshev: a = (1 | 2) h / rho, b = 2 J_j)
     // and flags: bit 0 the last term of a series (a repetition of the step), bit 1 ... of the step (frame phases, saved
-    // state: slot in bits 8.., 0xffffff = none), bit 2 Chebyshev recurrence (pw starts from phi_{j-2}); c = the factor of the
+    // state: slot + 1 in bits 8.., 0 = none), bit 2 Chebyshev recurrence (pw starts from phi_{j-2}); c = the factor of the
     // series that starts next (J_0 or 1).
     int nstage;
     const int* st_row;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
             const double wc = sg == 2 ? h : 0.5 * h;
             const int flags = save_slot;
             const bool series_end = flags & 1, step_end = flags & 2, cheb = flags & 4;
-            const int eslot = (flags >> 8) == 0xffffff ? -1 : (flags >> 8);
+            const int eslot = (int)((unsigned)flags >> 8) - 1;      // (bits 8..: save slot + 1, 0 = none)
             const double tb = MODE == 1 ? lane_double(bv, sl) : 0.0, tc = MODE == 1 ? lane_double(cv_, sl) : 0.0;
 #pragma unroll
             for (int t = 0; t < RT; ++t) {

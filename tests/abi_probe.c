@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     midyn_complex z = 1.0 + 2.0 * I; /* C99 complex is the ABI element type */
     (void)z;
     CHECK(midyn_ctx_create); CHECK(midyn_ctx_destroy); CHECK(midyn_ctx_synchronize); CHECK(midyn_last_error);
-    CHECK(midyn_ctx_set_option); CHECK(midyn_stack_packed_bytes); CHECK(midyn_stack_create);
+    CHECK(midyn_ctx_set_option); CHECK(midyn_ctx_get_option); CHECK(midyn_stack_packed_bytes); CHECK(midyn_stack_create);
     CHECK(midyn_stack_adopt); CHECK(midyn_stack_destroy); CHECK(midyn_stack_info);
     CHECK(midyn_stack_segment_modes); CHECK(midyn_eval_generator); CHECK(midyn_eval_rhs);
     CHECK(midyn_rk4_solve); CHECK(midyn_expm); CHECK(midyn_expm_solve); CHECK(midyn_zgemm);

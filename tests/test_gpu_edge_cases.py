@@ -225,3 +225,26 @@ def test_measurement_only_option_is_refused_without_the_debug_environment(qd, mo
         ctx.set_option("resident_exchange_only", 1)
     finally:
         ctx.set_option("resident_exchange_only", 0)
+
+
+def test_options_are_readable_and_scoped_changes_restore_the_previous_value(qd):
+    """midyn_ctx_get_option / Context.options: a caller that changes an option for one solve puts back the value it FOUND --
+    `combine_occupancy` defaults to 2, `combine_min_cols` to 256: restoring "1" (round 4's test helper) would have changed
+    them for every later user of the shared context."""
+    ctx = qd.default_context()
+    defaults = {name: ctx.get_option(name) for name in ("combine", "combine_occupancy", "combine_min_cols", "skip_zero_blocks",
+                                                        "complex_3m", "resident_spin_limit", "ell_sweep_split", "profile")}
+    assert defaults["combine"] == 1 and defaults["combine_occupancy"] == 2 and defaults["profile"] == 0
+    assert defaults["resident_spin_limit"] == 1 << 21
+    with ctx.options(combine=0, combine_occupancy=1, combine_min_cols=512, complex_3m=2, profile=1):
+        assert ctx.get_option("combine") == 0 and ctx.get_option("combine_occupancy") == 1
+        assert ctx.get_option("combine_min_cols") == 512 and ctx.get_option("complex_3m") == 2 and ctx.get_option("profile") == 1
+        with ctx.options(combine=2):
+            assert ctx.get_option("combine") == 2
+        assert ctx.get_option("combine") == 0
+    assert {name: ctx.get_option(name) for name in defaults} == defaults
+    with pytest.raises(qd.DynamicsError, match="unknown option"):
+        ctx.get_option("no_such_option")
+    with pytest.raises(qd.DynamicsError, match="unknown option"):
+        with ctx.options(no_such_option=1):
+            pass

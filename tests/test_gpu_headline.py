@@ -78,16 +78,9 @@ def _oracle_final(cfg, model, b, t_span, y0):
 def _run(qd, solver, sweeps, t_span, y0, max_dt, **options):
     """(final states, counters) of one product solve under ctx options (restored afterwards)."""
     ctx = qd.default_context()
-    for name, val in options.items():
-        ctx.set_option(name, val)
     ctx.reset_counters()
-    ctx.set_option("profile", 1)
-    try:
+    with ctx.options(profile=1, **options):      # every option back to the value it HAD, whatever its default is
         res = solver.solve(t_span=t_span, y0=y0, signals=sweeps, method="RK4", max_dt=max_dt)
-    finally:
-        ctx.set_option("profile", 0)
-        for name in options:
-            ctx.set_option(name, 1)
     counts = {c: ctx.counters(c) for c in ("rhs_combine", "rhs_blocks_gemm", "rhs_gemm", "sparse_tile", "sparse_list",
                                            "combine_info", "combine_shape")}
     return np.stack([r.y[-1] for r in res]), counts

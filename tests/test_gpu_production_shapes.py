@@ -794,3 +794,96 @@ def test_symmetry_sectors_many_uneven_sectors_and_operators_without_selection_ru
                                                    [0.0, 0.3], y0s[b], method, kw["max_dt"],
                                                    magnus_order=kw.get("magnus_order", 1))
                 assert_close(res[b].y[-1], ref[-1], SOLVE_TOL)
+
+
+SWEEP_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["MIDYN_ROOT"])
+import numpy as np
+import torch.distributed as dist
+import qiskit_dynamics_amd as qd
+from qiskit_dynamics_amd import workloads
+from qiskit_dynamics_amd.distributed import init_process_group_from_env, shard_bounds, solve_sweep
+
+rank, world = init_process_group_from_env(backend="gloo")     # both ranks compute on THE GPU (device 0), gloo carries the results
+assert world == 2
+cfg = workloads.schrodinger_config(n_qubits=5, n_drives=3, t_final=1.0, max_dt=0.01)
+solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+
+
+def signals_of(b):
+    amps, phases = workloads.sweep_parameters(b, 3)
+    return [qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, ph) for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+
+
+rng = np.random.default_rng(77)
+for n_inst, kw in ((5, dict(method="RK4", max_dt=0.01)), (1, dict(method="RK4", max_dt=0.01)),
+                   (4, dict(method="scipy_expm", max_dt=0.05, magnus_order=2))):
+    sweeps = [signals_of(b) for b in range(n_inst)]
+    y_list = []
+    for b in range(n_inst):
+        v = rng.standard_normal(32) + 1j * rng.standard_normal(32)
+        y_list.append(v / np.linalg.norm(v))
+    t_span = [0.0, 0.3]
+    # the one-rank answer, computed by THIS rank with the same Solver: one list-mode solve of all instances
+    ref = solver.solve(t_span=t_span, y0=y_list, signals=sweeps, **kw)
+    ref = ref if isinstance(ref, list) else [ref]
+    lo, hi = shard_bounds(n_inst, rank, world)
+    full = solve_sweep(solver, t_span, y_list, sweeps, gather="all", **kw)
+    assert len(full) == n_inst
+    for b in range(n_inst):
+        assert np.array_equal(full[b].t, ref[b].t)
+        # an instance's trajectory does not depend on which other instances share its batched launch: same bits
+        assert np.array_equal(full[b].y, ref[b].y), (rank, n_inst, b, float(np.max(np.abs(full[b].y - ref[b].y))))
+    at_root = solve_sweep(solver, t_span, y_list, sweeps, gather="root", root=1, **kw)
+    if rank == 1:
+        assert len(at_root) == n_inst and all(np.array_equal(at_root[b].y, ref[b].y) for b in range(n_inst))
+    else:
+        assert at_root is None
+    off, own = solve_sweep(solver, t_span, y_list, sweeps, gather="none", **kw)
+    assert off == lo and len(own) == hi - lo
+    for i, r_ in enumerate(own):
+        assert np.array_equal(r_.y, ref[lo + i].y)
+    # a state shared by all instances
+    shared = solve_sweep(solver, t_span, cfg["y0"], sweeps, gather="all", **kw)
+    one = solver.solve(t_span=t_span, y0=cfg["y0"], signals=sweeps, **kw)
+    one = one if isinstance(one, list) else [one]
+    assert all(np.array_equal(shared[b].y, one[b].y) for b in range(n_inst))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok", flush=True)
+'''
+
+
+def test_solve_sweep_with_the_real_solver_on_two_ranks_sharing_the_gpu(tmp_path):
+    """`distributed.solve_sweep` (the sharded Solver.solve list mode of SURVEY 8(e); reference loop:
+    solvers/solver_classes.py:568-586) with the PRODUCT Solver under two ranks -- both on this GPU, gloo rendezvous, as
+    bench.py's MIDYN_BENCH_SHARE_GPU mode does: uneven shards (5 instances = 3 + 2), fewer instances than ranks (1),
+    per-instance and shared initial states, RK4 and Magnus-2 `scipy_expm`, gather = "all" / "root" / "none" -- every
+    result `array_equal` to the one-rank list-mode solve of the same instances."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "sweep_worker.py"
+    script.write_text(SWEEP_WORKER)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MIDYN_ROOT=root)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate()[0] + "\n[timeout]")
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {rank} ok" in out, f"rank {rank}:\n{out[-3000:]}"
