@@ -635,20 +635,21 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
         return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2,
                                 y0, count, True)
 
-    def measure(sweep_kernel):
-        ctx.set_option("ell_sweep", 1 if sweep_kernel else 0)
-        try:
+    def measure(sweep_kernel, duo=1):
+        with ctx.options(ell_sweep=1 if sweep_kernel else 0, ell_sweep_duo=duo):
             run()
             ctx.synchronize()
-            t0_ = time.perf_counter()
-            ctx.timer_start()
-            ys_ = run()
-            dev_ = ctx.timer_stop()
-            wall_ = time.perf_counter() - t0_
+            best = None
+            for _ in range(3 if sweep_kernel else 1):       # (best of three: a 4 ms solve next to 21 MB of PCIe)
+                t0_ = time.perf_counter()
+                ctx.timer_start()
+                ys_ = run()
+                dev_ = ctx.timer_stop()
+                wall_ = time.perf_counter() - t0_
+                if best is None or wall_ < best[2]:
+                    best = (ys_, dev_, wall_)
             cs_ = profile_pass(ctx, run, ALL_CLASSES) if with_profile else None
-        finally:
-            ctx.set_option("ell_sweep", 1)
-        return ys_, dev_, wall_, cs_
+        return best[0], best[1], best[2], cs_
 
     ys, dev_ms, wall, cs = measure(True)            # the product's default route
     n_steps = len(sched.step_h)
@@ -675,14 +676,28 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
             flops = terms * count * 2 * slots * n * 2 * 4
             lds_bytes = terms * count * 2 * slots * n * 2 * 16
             l2_bytes = terms * count * 2 * slots * n * elem_bytes
-            busy = min(count, 256)
+            parts = int(ctx.counters("sweep_split")["launches"])   # workgroups per instance
+            busy = min(count * parts, 256)
             form_name = {0: "general: 4 B column + 8 B value", 1: "packed: column | sign, one magnitude per slot",
                          2: "direct: LDS address of the operand, one signed magnitude per slot"}[form]
-            out["route"] = ("ell_sweep_kernel<2,4,1024,%d>: ONE launch, one workgroup (1024 threads) per instance through "
-                            "all steps; staged vectors in LDS, operator elements (%s) from L2, series vectors the passes "
-                            "do not touch in a per-instance stash" % (form, form_name))
+            if parts == 2:
+                cross = ctx.counters("sweep_cross")
+                kname = "ell_sweep_duo_kernel<2, 2, 1024, %d>" % form
+                out["route"] = ("%s: ONE launch, TWO workgroups (1024 threads, half of the rows each) per instance through all "
+                                "steps; each stages its half of an operand vector in LDS and applies the %d of %d operator slots "
+                                "that stay inside the half while the partner's half arrives (per-wave round flags; payload slots in "
+                                "device memory that stay in the L2 the partners share -- plain stores, sc1 loads -- or are written "
+                                "through when they sit on different XCDs), then the %d slots that reach across; operator elements "
+                                "(%s) from L2; series vectors in registers"
+                                % (kname, int(cross["ms"] - cross["launches"]), int(cross["ms"]), int(cross["launches"]), form_name))
+            else:
+                kname = "ell_sweep_kernel<2, 4, 1024, %d>" % form
+                out["route"] = ("%s: ONE launch, one workgroup (1024 threads) per instance through "
+                                "all steps; staged vectors in LDS, operator elements (%s) from L2, series vectors the passes "
+                                "do not touch in a per-instance stash" % (kname, form_name))
+            out["workgroups_per_instance"] = parts
             out["roofline"] = {
-                "kernel": "ell_sweep_kernel<2, 4, 1024, %d>" % form, "bound": "lds",
+                "kernel": kname, "bound": "lds",
                 "achieved": round(lds_bytes / (k_ms * 1e-3) / 1e9, 1),
                 "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s",
                 "frac": round(lds_bytes / (k_ms * 1e-3) / 1e9 / LDS_PEAK_GBS, 4), "traffic": None,
@@ -696,9 +711,18 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
                 "l2_operator_bytes_per_launch": l2_bytes,
                 "l2_operator_gbs": round(l2_bytes / (k_ms * 1e-3) / 1e9, 1),
                 "note": "achieved = bytes gathered from LDS (16 B per operator slot, row and operand vector) / kernel "
-                        "time; peak = 256 B per clock and CU (ds_read_b128, MI355X_MICROARCH.md) x 256 CUs x 2.4 GHz; one "
-                        "workgroup per instance, so a 128-instance shard occupies 128 of the 256 CUs (frac_of_the_busy_cus)."
-                        "  Vector fp64, no MFMA: the operators have at most 19 non-zeros per row"}
+                        "time; peak = 256 B per clock and CU (ds_read_b128, MI355X_MICROARCH.md) x 256 CUs x 2.4 GHz; "
+                        "cus_busy = instances x workgroups per instance (one workgroup per CU: LDS); frac_of_the_busy_cus "
+                        "prices the same bytes against those CUs only.  Vector fp64, no MFMA: the operators have at most "
+                        "19 non-zeros per row"}
+            if parts == 2:     # round 3's kernel beside it: one workgroup per instance (what a shard of more than 128 instances runs)
+                ys1, dev1, wall1, cs1 = measure(True, duo=0)
+                out["one_workgroup_per_instance_route"] = {
+                    "kernel": "ell_sweep_kernel<2, 4, 1024, %d>" % form, "solve_s": round(wall1, 4),
+                    "ms_per_step": round(wall1 / n_steps * 1e3, 4), "stream_ms_per_step": round(dev1 / n_steps, 4),
+                    "kernel_ms_per_step": round(cs1["rk4_resident"]["ms"] / n_steps, 4),
+                    "us_per_term": round(cs1["rk4_resident"]["ms"] * 1e3 / max(terms, 1), 2), "cus_busy": min(count, 256),
+                    "max_abs_difference_to_the_default_route": float(np.max(np.abs(ys - ys1)))}
         else:
             out["roofline"] = cfg5_roofline(ctx, stack, cs, count, stack.n, n_steps, wall, count)
         if took_sweep:     # the work-list MFMA route beside it
@@ -982,11 +1006,13 @@ def leg_parallel_in_time(qd, ctx, workloads, n_qubits=4, steps=1000):
     amps, phases = workloads.sweep_parameters(0, n_qubits)
     sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph) for a, nu, ph in zip(amps, cfg["carrier"], phases)]
 
+    y0_vec = cfg["rho0"].flatten(order="F")      # (a vectorised model takes the column-stacked density matrix)
+
     def solve(method):
         best, r_ = 1e9, None
         for _ in range(3):
             t0 = time.perf_counter()
-            r_ = solver.solve(t_span=cfg["t_span"], y0=cfg["rho0"], signals=sigs, method=method, max_dt=cfg["max_dt"])
+            r_ = solver.solve(t_span=cfg["t_span"], y0=y0_vec, signals=sigs, method=method, max_dt=cfg["max_dt"])
             best = min(best, time.perf_counter() - t0)
         return best, r_
 
@@ -995,14 +1021,14 @@ def leg_parallel_in_time(qd, ctx, workloads, n_qubits=4, steps=1000):
     ctx.reset_counters()
     ctx.set_option("profile", 1)
     try:
-        solver.solve(t_span=cfg["t_span"], y0=cfg["rho0"], signals=sigs, method="hip_expm_parallel", max_dt=cfg["max_dt"])
+        solver.solve(t_span=cfg["t_span"], y0=y0_vec, signals=sigs, method="hip_expm_parallel", max_dt=cfg["max_dt"])
         ctx.synchronize()
         cz, cg, ce = ctx.counters("zgemm"), ctx.counters("gen_eval"), ctx.counters("elementwise")
         flops = ctx.executed_flops("zgemm")
     finally:
         ctx.set_option("profile", 0)
     # CPU: the reference's sequential loop (generator by tensordot, scipy.linalg.expm, matvec) on the superoperators, 20 steps
-    s_d, s_ops = orc.vectorized_lindblad_stack(cfg["h_d"], cfg["ops"], len(cfg["static_dissipators"]), cfg["static_dissipators"])[:2]
+    s_d, s_ops = orc.vectorized_lindblad_stack(cfg["h_d"], cfg["ops"], cfg["static_dissipators"], None)
     threads = 8
     n_cpu = 20
 
@@ -1016,7 +1042,7 @@ def leg_parallel_in_time(qd, ctx, workloads, n_qubits=4, steps=1000):
         for i in range(n_cpu):
             y = scipy.linalg.expm(orc.magnus_terms(gen, 2.4 + i * cfg["max_dt"], cfg["max_dt"], 1)) @ y
         cpu_s = (time.perf_counter() - t0) / n_cpu
-    rho = r_par.y[-1]
+    rho = r_par.y[-1].reshape(n, n, order="F")
     return {
         "workload": f"{n_qubits}-qubit vectorised Lindbladian (N = {n * n}), {n_qubits} drives, {len(cfg['static_dissipators'])} "
                     f"dissipators, no frame, scipy_expm magnus_order 1, {steps} steps, ONE trajectory",

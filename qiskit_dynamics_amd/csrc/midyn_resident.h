@@ -745,6 +745,8 @@ struct SweepArgs {
     const double* mag;        // [wsp]
     int wsp;
     int wre;                  // slots [0, wre) hold real-plane values, [wre, wsp) imaginary-plane values
+    int wre_loc, wim_loc;     // two workgroups per instance (ell_sweep_duo_kernel): slots [0, wre_loc) and [wre, wim_loc) reference
+                              // columns in the row's OWN half of the vector only (stack_ell_layout orders them first)
     int n, n_pad, has_static, k, nseg;
     const double* S;          // [B][R][k]
     long long inst_stride;    // R * k
@@ -790,19 +792,26 @@ __device__ __forceinline__ unsigned sweep_boff(const int tid, const int i_, cons
 // Two straight-line loops, no selects: the real-plane slots (A x = v x), then the imaginary-plane slots
 // (A = i v: A x = v (-x.y, x.x)).  X1 / X2: the LDS copies of the operand vectors (sweep_lds: their base; PACKED 2
 // elements are byte addresses relative to it, X2 operands 32768 bytes behind their X1 operands).
-template <int ORDER, int SWEEP_RPT, int TH, int PACKED, int PFD = MIDYN_SWEEP_PREFETCH, bool KEEP_O2 = false>
+// PART (two workgroups per instance): 0 all slots; 1 the slots whose operands lie in the workgroup's own half (the sums
+// start here); 2 the remaining slots (the sums continue).  row0: first row of the workgroup (rows row0 + tid + TH i).
+template <int ORDER, int SWEEP_RPT, int TH, int PACKED, int PFD = MIDYN_SWEEP_PREFETCH, bool KEEP_O2 = false, int PART = 0>
 __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* cab, const double2* sweep_lds, const double2* X1,
                                            const double2* X2, const int tid, const bool swapped, double2 (&o1)[SWEEP_RPT],
-                                           double2 (&o2)[SWEEP_RPT], const double scale2 = 1.0) {   // scale2: factor of the second sum
+                                           double2 (&o2)[SWEEP_RPT], const double scale2 = 1.0,   // scale2: factor of the second sum
+                                           const unsigned row0 = 0, const int re_lo = 0, const int re_hi = 0, const int im_lo = 0,
+                                           const int im_hi = 0) {      // PART 3: the real-plane slots [re_lo, re_hi) and the imaginary-
+                                                                        // plane slots [im_lo, im_hi); the sums continue
     const int np = a.n_pad;
     const unsigned unp = (unsigned)np;
     auto boff = [&](const int i_, const int shift) { return sweep_boff<TH>(tid, i_, shift); };
-#define ROW(i_) ((unsigned)(tid + TH * (i_)))
+#define ROW(i_) (row0 + (unsigned)(tid + TH * (i_)))
 
+    if (PART != 2 && PART != 3) {
 #pragma unroll
-    for (int i = 0; i < SWEEP_RPT; ++i) {
-        o1[i] = make_double2(0.0, 0.0);
-        if (!KEEP_O2) o2[i] = make_double2(0.0, 0.0);     // KEEP_O2: the caller has put a start value into the second sum
+        for (int i = 0; i < SWEEP_RPT; ++i) {
+            o1[i] = make_double2(0.0, 0.0);
+            if (!KEEP_O2) o2[i] = make_double2(0.0, 0.0);     // KEEP_O2: the caller has put a start value into the second sum
+        }
     }
 #if MIDYN_SWEEP_ABLATE == 1   // profiling only: no operator pass at all
     for (int i = 0; i < SWEEP_RPT; ++i) { o1[i] = X1[tid + TH * i]; o2[i] = X2[tid + TH * i]; }
@@ -824,10 +833,10 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
                 c_[i] = (int)((((unsigned)e_ * unp + ROW(i)) * 2654435761u) >> 8) & (np - 1);
                 v_[i] = 1e-3;
             } else if (PACKED) {
-                c_[i] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.pk + (size_t)e_ * unp) + boff(i, 2));
+                c_[i] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.pk + ((size_t)e_ * unp + row0)) + boff(i, 2));
             } else {
-                c_[i] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.col + (size_t)e_ * unp) + boff(i, 2));
-                v_[i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.val + (size_t)e_ * unp) + boff(i, 3));
+                c_[i] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.col + ((size_t)e_ * unp + row0)) + boff(i, 2));
+                v_[i] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.val + ((size_t)e_ * unp + row0)) + boff(i, 3));
             }
         }
     };
@@ -913,8 +922,19 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
     // in the loop below.  Order 2 has no registers for the second buffer (27 spills, 26.9 vs 19.3 us per term); order 1
     // has them and gains nothing (5.45 vs 5.33): the waves of a CU already overlap each other's phases as far as the LDS
     // pipeline lets them.)
-    MIDYN_SWEEP_K_RANGE(false, 0, a.wre)
-    MIDYN_SWEEP_K_RANGE(true, a.wre, a.wsp)
+    if (PART == 0) {
+        MIDYN_SWEEP_K_RANGE(false, 0, a.wre)
+        MIDYN_SWEEP_K_RANGE(true, a.wre, a.wsp)
+    } else if (PART == 1) {
+        MIDYN_SWEEP_K_RANGE(false, 0, a.wre_loc)
+        MIDYN_SWEEP_K_RANGE(true, a.wre, a.wim_loc)
+    } else if (PART == 2) {
+        MIDYN_SWEEP_K_RANGE(false, a.wre_loc, a.wre)
+        MIDYN_SWEEP_K_RANGE(true, a.wim_loc, a.wsp)
+    } else {
+        MIDYN_SWEEP_K_RANGE(false, re_lo, re_hi)
+        MIDYN_SWEEP_K_RANGE(true, im_lo, im_hi)
+    }
 #undef MIDYN_SWEEP_K_RANGE
 #undef MIDYN_SWEEP_K_SLOT
 #undef ROW
@@ -1074,6 +1094,321 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
 #undef AT16
 #undef ACC
 #undef CUR
+
+
+// ------------------------------------------------------------------------------------------------
+// ell_sweep_duo_kernel<ORDER, RPT, TH, PACKED>: TWO workgroups per instance (round 5) -- the 128-instance cfg 5 shard of an
+// 8-GPU run on all 256 CUs.  What round 2's split kernel (below) paid for the second workgroup was the exchange: every
+// operand vector all-gathered between the partners BEFORE the pass that needs it, through write-through stores of payload
+// AND re-arming sentinels -- 74 MB per series term over the fabric for 256 workgroups, 7 us per all-gather at cfg 5's
+// size: what the halved pass saves.  Here:
+//   * each workgroup owns half of the rows (n_pad / 2 = TH RPT) and stages ITS half of an operand vector in LDS at once;
+//   * stack_ell_layout orders the operator slots so that those whose operands lie in the row's own half come first
+//     (a_.wre_loc / a_.wim_loc) -- operators built from Pauli strings couple the halves through the strings that flip the
+//     top qubit only: 2 of cfg 5's 19 slots -- and the pass runs those slots first (sweep_pass<.., PART 1>) while the
+//     partner's half is on its way; then the partner's rows are copied into the other half of the LDS vectors and the few
+//     slots that reach across follow (PART 2);
+//   * the hand-off is per WAVE: thread tid of one workgroup needs exactly the rows thread tid of the other has published
+//     (the same tid + TH i of the other half), so wave w waits for wave w of its partner and for nobody else.  A wave
+//     stores its rows into the round's payload slot, drains its stores (s_waitcnt vmcnt(0)) and then sets its flag word
+//     to the round number; the reader polls that ONE word (sc1 load), then reads the payload with sc1 (L1-bypassing)
+//     loads.  Rounds alternate between a one-vector and a two-vector slot (order 2; order 1: two one-vector slots), and
+//     a slot is written again two rounds later, after the writer has seen the reader's flag of the round in between --
+//     which the reader sets after it has finished reading.  Monotonic round numbers: nothing is re-armed;
+//   * the partners of an instance compare their XCC ids once (agent-scope words).  On ONE XCD -- where the observed
+//     b % 8 dispatch puts them (part_major), but nothing depends on it -- they share the L2, so payload and flag are PLAIN
+//     stores that stay in that L2 and the sc1 loads of the reader are served by it: no fabric traffic at all.  On
+//     different XCDs the stores are write-through (sc1), the same protocol (cdna_hip_programming.md G16, form R1).
+// With half the rows per thread the series vectors of order 2 fit the registers again (no stash in device memory), and
+// the frame picture, the packed element forms and the commutator-free Magnus-2 term are ell_sweep_kernel's.
+// Both workgroups of every instance must be resident at once (one per CU: LDS): cooperative launch, bounded waits, and the
+// host falls back to ell_sweep_kernel when a wait gives up (midyn_action.inc).
+// ------------------------------------------------------------------------------------------------
+struct SweepDuoArgs {
+    SweepArgs a;
+    double2* ring;              // [B][3 vectors][n_pad] payload slots
+    int* flags;                 // [B][2 halves][DUO_FLAG_WORDS]: [0, 16) round number per wave, [16] XCC id + 1; all zero at launch
+    int* err;
+    unsigned spin_limit;        // polls after which a wait gives up
+    int part_major;             // 1: blocks [p B, (p + 1) B) hold half p of every instance (B a multiple of 8: the partners of an
+                                // instance on one XCD under the observed b % 8 dispatch -- a speed matter only)
+    int ablate;                 // profiling only (results wrong): 1 no exchange at all, 2 write-through stores on one XCD too,
+                                // 4 no local slots, 8 no crossing slots
+};
+constexpr int DUO_FLAG_WORDS = 32;
+
+typedef unsigned int sweep_u4 __attribute__((ext_vector_type(4)));
+
+template <int ORDER, int SWEEP_RPT, int TH, int PACKED>
+__global__ __launch_bounds__(TH) void ell_sweep_duo_kernel(const SweepDuoArgs da) {
+    static_assert(PACKED == 1 || PACKED == 2, "packed element forms only");
+    const SweepArgs& a = da.a;
+    extern __shared__ __attribute__((aligned(16))) double2 sweep_lds[];
+    __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];
+    __shared__ int stag[SWEEP_MAX_SLOTS];
+    const int tid = threadIdx.x, np = a.n_pad;
+    const unsigned unp = (unsigned)np;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = gridDim.x >> 1;
+    const int b = da.part_major ? (int)(blockIdx.x % nb) : (int)(blockIdx.x >> 1);
+    const int part = da.part_major ? (int)(blockIdx.x / nb) : (int)(blockIdx.x & 1);
+    const unsigned half = unp >> 1;                             // = TH * SWEEP_RPT rows per workgroup
+    const unsigned row0 = part ? half : 0u, prow0 = part ? 0u : half;
+    const int lstride = np + 1;
+    double2* const X1 = sweep_lds;
+    double2* const X2 = PACKED == 2 ? sweep_lds + 2048 : sweep_lds + lstride;
+    auto xrow = [&](const unsigned r_) { return PACKED == 2 ? ((r_ >> 11) << 12) | (r_ & 2047u) : r_; };   // index of column r_ in X1 / X2
+    auto boff = [&](const int i_, const int shift) { return sweep_boff<TH>(tid, i_, shift); };   // (see sweep_boff)
+    auto rowof = [&](const int i_) {   // tid + TH i_, opaque to the optimiser: no address derived from it is hoisted out of the loops
+        unsigned r_ = (unsigned)(tid + TH * i_);
+        asm volatile("" : "+v"(r_));
+        return r_;
+    };
+#define AT16(base_, i_) (*reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base_) + boff(i_, 4)))
+    // the payload slots of this instance through a buffer descriptor (16-byte loads / stores; aux 16 = sc1)
+    const size_t ring_doubles2 = (size_t)3 * np;
+    const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double2*>(da.ring) + (size_t)b * ring_doubles2, 0, (int)(ring_doubles2 * sizeof(double2)), 0x00020000);
+    auto ring_off = [&](const int slot, const unsigned row) { return (unsigned)((slot * np + (int)row) << 4); };
+    int* const my_flags = da.flags + ((size_t)b * 2 + part) * DUO_FLAG_WORDS;
+    int* const partner_flags = da.flags + ((size_t)b * 2 + (1 - part)) * DUO_FLAG_WORDS;
+    bool dead = false;
+    // a bounded wait for a word of the partner to reach `want` (every lane loads the same word)
+    auto wait_word = [&](int* word, const int want) {
+        unsigned spins = 0;
+        for (;;) {
+            if (dead) return 0;
+            const int got = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got >= want) return got;
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+            if ((spins & 1023u) == 0 && __hip_atomic_load(da.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) spins = da.spin_limit;
+            if (spins >= da.spin_limit) {
+                __hip_atomic_store(da.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                dead = true;
+            }
+        }
+    };
+    // do the partners share an XCD (one L2)?  Each publishes its XCC id + 1 once and reads the other's.
+    bool one_l2 = false;
+    if (!(da.ablate & 1)) {
+        unsigned xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 15u;
+        if (tid == 0) __hip_atomic_store(my_flags + 16, (int)xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int theirs = wait_word(partner_flags + 16, 1);
+        one_l2 = !dead && theirs == (int)xcc + 1 && !(da.ablate & 2);
+    }
+    const double p2 = 0.14433756729740643;   // sqrt(3) / 12
+    double2 pw[SWEEP_RPT], acc[SWEEP_RPT], cur[SWEEP_RPT];
+#pragma unroll
+    for (int i = 0; i < SWEEP_RPT; ++i) {
+        const unsigned r = row0 + rowof(i);
+        acc[i] = (r < (unsigned)a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + r] : make_double2(0.0, 0.0);
+        cur[i] = pw[i] = make_double2(0.0, 0.0);
+    }
+    for (int e = tid; e < a.wsp; e += TH) stag[e] = a.tags[e];
+    if (tid == 0 && PACKED != 2) {
+        X1[np] = make_double2(0.0, 0.0);
+        if (ORDER == 2) X2[np] = make_double2(0.0, 0.0);
+    }
+    // Operator slots in the order they are applied: the local ones (real plane, then imaginary plane), then the crossing ones.
+    const int n_loc = a.wre_loc + (a.wim_loc - a.wre), n_all = a.wsp;
+    // the slots [j_lo, j_hi) of that order (sweep_pass with explicit ranges; the sums o1 / o2 continue)
+    auto run_slots = [&](const int j_lo, const int j_hi, const bool swapped, const bool keep, const double scale2,
+                         double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
+        if (j_lo >= j_hi) return;
+        int re_lo, re_hi, im_lo, im_hi;
+        if (j_hi <= n_loc) {
+            const int nre = a.wre_loc;
+            re_lo = j_lo < nre ? j_lo : nre;
+            re_hi = j_hi < nre ? j_hi : nre;
+            im_lo = a.wre + (j_lo > nre ? j_lo - nre : 0);
+            im_hi = a.wre + (j_hi > nre ? j_hi - nre : 0);
+        } else {                           // (the crossing slots: all of them)
+            re_lo = a.wre_loc;
+            re_hi = a.wre;
+            im_lo = a.wim_loc;
+            im_hi = a.wsp;
+        }
+        if (keep) sweep_pass<ORDER, SWEEP_RPT, TH, PACKED, MIDYN_SWEEP_PREFETCH, true, 3>(a, cab, sweep_lds, X1, X2, tid, swapped, o1, o2, scale2, row0, re_lo, re_hi, im_lo, im_hi);
+        else sweep_pass<ORDER, SWEEP_RPT, TH, PACKED, MIDYN_SWEEP_PREFETCH, false, 3>(a, cab, sweep_lds, X1, X2, tid, swapped, o1, o2, 1.0, row0, re_lo, re_hi, im_lo, im_hi);
+    };
+    int rr = 0;       // exchange rounds so far
+    // One exchange round and the pass it feeds.  in1 / in2: this thread's rows of the operand vectors as the operators see
+    // them (X1 / X2 forms).  nv = 1: one vector travels (in1) and the X2 form of the partner's rows is dtab o in1 (dtab: the
+    // frame phase between the Gauss points of this step; use_dp false: none); nv = 2: both forms travel.
+    // keep: o2 continues from its start value (its sum scaled by scale2); else both sums start at zero.
+    auto exchange_and_pass = [&](const double2 (&in1)[SWEEP_RPT], const double2 (&in2)[SWEEP_RPT], const int nv,
+                                 const double2* dtab, const bool use_dp, const bool swapped, const bool keep,
+                                 const double scale2, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
+        const int slot = ORDER == 2 ? (nv == 2 ? 1 : 0) : (rr & 1);      // payload slot(s) of this round
+        const bool exch = !(da.ablate & 1);
+        __syncthreads();                   // every reader of the LDS copies of the previous pass is done
+#pragma unroll
+        for (int i = 0; i < SWEEP_RPT; ++i) {
+            const unsigned r = row0 + rowof(i);
+            if (exch) {
+#pragma unroll
+                for (int v = 0; v < ORDER; ++v) {
+                    if (v >= nv) continue;
+                    const double2 z = v ? in2[i] : in1[i];
+                    sweep_u4 w;
+                    const unsigned long long zx = (unsigned long long)__double_as_longlong(z.x), zy = (unsigned long long)__double_as_longlong(z.y);
+                    w.x = (unsigned)zx; w.y = (unsigned)(zx >> 32); w.z = (unsigned)zy; w.w = (unsigned)(zy >> 32);
+                    if (one_l2) __builtin_amdgcn_raw_buffer_store_b128(w, ring, (int)ring_off(slot + v, r), 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(w, ring, (int)ring_off(slot + v, r), 0, 16);
+                }
+            }
+            X1[xrow(r)] = in1[i];
+            if (ORDER == 2) X2[xrow(r)] = in2[i];
+            o1[i] = make_double2(0.0, 0.0);
+            if (!keep) o2[i] = make_double2(0.0, 0.0);
+        }
+        __syncthreads();
+        ++rr;
+        // This wave's rows have reached memory (the L2 both partners share, or written through): its flag says so.  (Measured:
+        // splitting the local slots in three parts around the flag store and the partner's loads -- so that the store
+        // acknowledgement and the load latency would hide behind slots -- is SLOWER, 17.2 against 15.4 us per term at 128
+        // instances: every part restarts the element prefetch and drains it again; profiles/r05_cfg5_duo.md.)
+        if (exch) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((tid & 63) == 0) {
+                // (one L2: a store that stays in it -- workgroup scope lowers to sc0, which keeps the line; agent scope writes through)
+                if (one_l2) __hip_atomic_store(my_flags + wave, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_store(my_flags + wave, rr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // the slots that stay inside this half, while the partner's half is on its way
+        run_slots(0, (da.ablate & 4) ? 0 : n_loc, swapped, keep, scale2, o1, o2);
+        // the partner's rows prow0 + tid + TH i: published by ITS thread tid, i.e. by its wave `wave`
+        if (exch) {
+            (void)wait_word(partner_flags + wave, rr);
+            asm volatile("" ::: "memory");          // (compiler: the payload is read after the flag, not before)
+            sweep_u4 w[SWEEP_RPT][ORDER];
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                const unsigned r = prow0 + rowof(i);
+#pragma unroll
+                for (int v = 0; v < ORDER; ++v)
+                    if (v < nv) w[i][v] = __builtin_amdgcn_raw_buffer_load_b128(ring, (int)ring_off(slot + v, r), 0, 16);
+            }
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                const unsigned r = prow0 + rowof(i);
+                auto unpack = [](const sweep_u4 q) {
+                    return make_double2(__longlong_as_double((long long)(((unsigned long long)q.y << 32) | q.x)),
+                                        __longlong_as_double((long long)(((unsigned long long)q.w << 32) | q.z)));
+                };
+                const double2 xa = unpack(w[i][0]);
+                X1[xrow(r)] = xa;
+                if (ORDER == 2) X2[xrow(r)] = nv == 2 ? unpack(w[i][ORDER - 1]) : (use_dp ? cmul(AT16(dtab + prow0, i), xa) : xa);
+            }
+        }
+        __syncthreads();
+        if (!(da.ablate & 8)) run_slots(n_loc, n_all, swapped, keep, scale2, o1, o2);
+    };
+    for (int st = 0; st < a.nsteps; ++st) {
+        const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];
+        const double h = a.hs[st];
+        __syncthreads();   // the previous step's readers of the coefficients are done (and stag is written)
+        for (int e = tid; e < a.wsp; e += TH) {
+            const int seg = stag[e] & 63;
+            const bool stat = a.has_static && seg == 0;
+            const double* Sb = a.S + (size_t)b * a.inst_stride;
+            const double mg = a.mag[e];     // PACKED 2: signed
+            cab[e] = make_double2(mg * (stat ? 1.0 : Sb[(size_t)r0 * a.k + seg - a.has_static]),
+                                  (ORDER == 2) ? mg * (stat ? 1.0 : Sb[(size_t)r1 * a.k + seg - a.has_static]) : 0.0);
+        }
+        const double2* const E0 = a.E ? a.E + (size_t)r0 * np : nullptr;
+        const bool framed2 = a.E && ORDER == 2;
+        // the frame phase between the two Gauss points of this step for this thread's rows (the partner's rows: read with the payload)
+        const double2* const dtab = framed2 ? a.Dt + (size_t)st * np : nullptr;
+        constexpr bool DM_REG = true;
+        double2 dmr[DM_REG ? SWEEP_RPT : 1];
+        if (DM_REG) {
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) dmr[DM_REG ? i : 0] = framed2 ? AT16(dtab + row0, i) : make_double2(1.0, 0.0);
+        }
+        auto dm = [&](const int i_) { return DM_REG ? dmr[DM_REG ? i_ : 0] : AT16(dtab + row0, i_); };
+        const int Ks = a.ser_K[st], reps = a.ser_reps[st];
+        const bool cheb = Ks > 0;
+        const int K = cheb ? Ks : -Ks;
+        const double par = a.ser_par[st];
+        const double* coef = a.coef + (size_t)st * a.stride;
+        const int slot = a.save ? a.save[st] : -1;
+        for (int rep = 0; rep < reps; ++rep) {
+            const double c0 = cheb ? coef[0] : 1.0;
+            // start of a series: phi_0 = the accumulated result (into the frame picture of the first Gauss point at the
+            // first repetition: y~ = E(t1) o y)
+#pragma unroll
+            for (int i = 0; i < SWEEP_RPT; ++i) {
+                double2 v = acc[i];
+                if (rep == 0 && a.E) v = cmul(AT16(E0 + row0, i), v);
+                cur[i] = v;
+                acc[i] = make_double2(c0 * v.x, c0 * v.y);
+                pw[i] = make_double2(0.0, 0.0);      // Chebyshev: phi_{j-2};  Taylor: nothing
+            }
+            for (int j = 1; j <= K; ++j) {
+                const double f = cheb ? (j == 1 ? 1.0 : 2.0) / par : 1.0 / (par * (double)j);
+                double2 o1[SWEEP_RPT], o2[SWEEP_RPT], in2[SWEEP_RPT];
+                if (ORDER == 2) {
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) in2[i] = framed2 ? cmul(dm(i), cur[i]) : cur[i];
+                }
+                // o1 = C(t1) v~, o2 = C(t2) (D v~)
+                exchange_and_pass(cur, ORDER == 2 ? in2 : cur, 1, dtab, framed2, false, false, 1.0, o1, o2);
+                double2 w[SWEEP_RPT];
+                if (ORDER == 2) {
+                    const double ca = 0.5 * h * f, cb = p2 * h * h * f;
+                    double2 du1[SWEEP_RPT], u2[SWEEP_RPT], m0[SWEEP_RPT];
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) {
+                        const double2 u1 = o1[i];
+                        u2[i] = o2[i];
+                        du1[i] = u1;
+                        if (framed2) {
+                            u2[i] = cmul_conj_a(dm(i), o2[i]);
+                            du1[i] = cmul(dm(i), u1);       // for g2~ = conj(D) C(t2) D
+                        }
+                        // the term so far, m = phi_{j-2} + ca (u1 + u2), rides through the second pass INSIDE its second sum
+                        // (start value -m, the sum scaled by cb: cb v1 - o2 then IS m + cb (v1 - g1~ u2))
+                        m0[i] = make_double2(-(pw[i].x + ca * (u1.x + u2[i].x)), -(pw[i].y + ca * (u1.y + u2[i].y)));
+                    }
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) o2[i] = m0[i];
+                    exchange_and_pass(du1, u2, 2, dtab, false, true, true, cb, o1, o2);     // o1 = C(t2) (D u1), o2 = -m + cb C(t1) u2
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) {
+                        const double2 v1 = framed2 ? cmul_conj_a(dm(i), o1[i]) : o1[i];
+                        w[i] = make_double2(cb * v1.x - o2[i].x, cb * v1.y - o2[i].y);
+                    }
+                } else {
+                    const double ca = h * f;
+#pragma unroll
+                    for (int i = 0; i < SWEEP_RPT; ++i) w[i] = cfma_r(ca, o1[i], pw[i]);
+                }
+                // end of the term: w joins the result and is the next term's input; the old phi_{j-1} is the next phi_{j-2}
+                const bool last = j == K;
+                const double cj = cheb ? 2.0 * coef[j] : 1.0;
+#pragma unroll
+                for (int i = 0; i < SWEEP_RPT; ++i) {
+                    const unsigned r = row0 + rowof(i);
+                    double2 ac = cfma_r(cj, w[i], acc[i]);
+                    if (!last) {
+                        pw[i] = cheb ? cur[i] : make_double2(0.0, 0.0);
+                        cur[i] = w[i];
+                    } else if (rep + 1 == reps) {    // out of the frame picture; saved states
+                        if (a.E) ac = cmul_conj_a(AT16(E0 + row0, i), ac);
+                        if (slot >= 0 && r < (unsigned)a.n) a.out[((size_t)b * a.P + slot) * a.n + r] = ac;
+                    }
+                    acc[i] = ac;
+                }
+            }
+        }
+    }
+}
+#undef AT16
 
 
 // ------------------------------------------------------------------------------------------------
@@ -1444,6 +1779,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
     MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_kernel<2, R_, T_, P_>(const SweepArgs);   \
     MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_rk4_kernel<R_, T_, P_>(const SweepArgs);
 MIDYN_SWEEP_SHAPES(MIDYN_X)
+#undef MIDYN_X
+#define MIDYN_X(O_, P_)                                                                                   \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_duo_kernel<O_, 2, 1024, P_>(const SweepDuoArgs);  \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_duo_kernel<O_, 1, 1024, P_>(const SweepDuoArgs);  \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_duo_kernel<O_, 1, 512, P_>(const SweepDuoArgs);   \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_duo_kernel<O_, 1, 256, P_>(const SweepDuoArgs);
+MIDYN_X(1, 1) MIDYN_X(1, 2) MIDYN_X(2, 1) MIDYN_X(2, 2)
 #undef MIDYN_X
 MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_split_kernel<1, 1>(const SweepSplitArgs);
 MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_split_kernel<1, 2>(const SweepSplitArgs);

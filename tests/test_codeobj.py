@@ -36,7 +36,10 @@ DEFAULT_ROUTE = (
     "rk4_resident_kernelILi2ELi8ELb0EE",
     "rk4_resident_kernelILi4ELi8ELb0EE",
     "ell_resident_kernelILi1ELi8EE",                             # cfg 4
-    "ell_sweep_kernelILi2ELi4ELi1024ELi2EE",                     # cfg 5 (direct element form)
+    "ell_sweep_duo_kernelILi2ELi2ELi1024ELi2EE",                 # cfg 5 shard (round 5): two workgroups per instance
+    "ell_sweep_duo_kernelILi2ELi2ELi1024ELi1EE",
+    "ell_sweep_duo_kernelILi1ELi2ELi1024ELi2EE",
+    "ell_sweep_kernelILi2ELi4ELi1024ELi2EE",                     # cfg 5, more than 128 instances per GPU (direct element form)
     "ell_sweep_kernelILi2ELi4ELi1024ELi1EE",
     "ell_sweep_kernelILi2ELi4ELi1024ELi0EE",
     "ell_sweep_kernelILi2ELi3ELi1024ELi0EE",
@@ -79,7 +82,7 @@ def test_no_kernel_of_a_default_route_spills_registers(kernels):
 def test_register_budgets_of_the_one_workgroup_per_cu_kernels(kernels):
     """1024-thread workgroups get 128 registers per lane, 512-thread ones 256 (one workgroup per CU)."""
     for name, k in kernels.items():
-        if "ell_sweep_kernelILi" in name and "ELi1024E" in name or "ell_sweep_rk4_kernel" in name and "ELi1024E" in name:
+        if ("ell_sweep_kernelILi" in name or "ell_sweep_rk4_kernel" in name or "ell_sweep_duo_kernel" in name) and "ELi1024E" in name:
             assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 128, (name, k[".vgpr_count"])
         if "rk4_resident_kernelILi" in name and "ELi8EL" in name:
             assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256, (name, k[".vgpr_count"])

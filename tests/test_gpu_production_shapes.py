@@ -51,14 +51,17 @@ def _profiled(ctx, fn):
         ctx.set_option("profile", 0)
 
 
-@pytest.mark.parametrize("route", ["default", "mfma_work_lists"])
+@pytest.mark.parametrize("route", ["default", "one_workgroup_per_instance", "mfma_work_lists"])
 def test_cfg5_shard_vs_oracle(qd, route):
     """BASELINE cfg 5, the per-GPU shard of the 8-GPU run: 12 qubits (n = 4096), k = 8, diagonal rotating frame,
     scipy_expm with magnus_order = 2, max_dt = 0.25, T = 5 -> ALL 20 steps, 128 instances in ONE batched device
     solve, dense random y0.  Two routes, each asserted through the launch counters:
 
-      * "default": what the product (and bench.py's cfg5 leg) runs -- ONE launch of ell_sweep_kernel<2,4,1024,2>
-        (counter "rk4_resident" == 1 launch, "sweep_split" == (1 workgroup per instance, element form 2 = direct));
+      * "default": what the product (and bench.py's cfg5 leg) runs -- ONE launch of ell_sweep_duo_kernel<2,2,1024,2>: two
+        workgroups per instance, 256 workgroups for the 128 instances (counter "rk4_resident" == 1 launch, "sweep_split" ==
+        (2 workgroups per instance, element form 2 = direct), "sweep_cross" == (2 of the 19 slots reach across the halves: the drive and the XX coupling of the top qubit));
+      * "one_workgroup_per_instance": option ell_sweep_duo = 0, round 3's ell_sweep_kernel<2,4,1024,2> (what a shard of more
+        than 128 instances runs);
       * "mfma_work_lists": option ell_sweep = 0, the SPARSE MFMA work-list contraction ("rhs_blocks_gemm").
 
     Instances 0, 63 and 127 are compared with a CPU evaluation of the same 20 steps that uses the ORACLE's generators
@@ -80,16 +83,18 @@ def test_cfg5_shard_vs_oracle(qd, route):
     y0 /= np.linalg.norm(y0)
     h, t_final = 0.25, 5.0
     gave_up_before = ctx.counters("resident_fallbacks")["launches"]
-    ctx.set_option("ell_sweep", 1 if route == "default" else 0)
-    try:
+    with ctx.options(ell_sweep=0 if route == "mfma_work_lists" else 1, ell_sweep_duo=1 if route == "default" else 0):
         res = _profiled(ctx, lambda: solver.solve(t_span=[0.0, t_final], y0=y0, signals=sweeps, method="scipy_expm",
                                                   max_dt=h, magnus_order=2))
-    finally:
-        ctx.set_option("ell_sweep", 1)
-    if route == "default":
+    if route != "mfma_work_lists":
         assert ctx.counters("rk4_resident")["launches"] == 1, "the one-launch sweep kernel did not take the solve"
         split = ctx.counters("sweep_split")
-        assert (int(split["launches"]), int(split["ms"])) == (1, 2), f"not ell_sweep_kernel<2,4,1024,2>: {split}"
+        if route == "default":
+            assert (int(split["launches"]), int(split["ms"])) == (2, 2), f"not ell_sweep_duo_kernel<2,2,1024,2>: {split}"
+            cross = ctx.counters("sweep_cross")
+            assert (int(cross["launches"]), int(cross["ms"])) == (2, 19), cross
+        else:
+            assert (int(split["launches"]), int(split["ms"])) == (1, 2), f"not ell_sweep_kernel<2,4,1024,2>: {split}"
         assert ctx.counters("rhs_blocks_gemm")["launches"] == 0
         assert ctx.counters("resident_fallbacks")["launches"] == gave_up_before, "the sweep kernel gave up"
     else:

@@ -392,26 +392,27 @@ def test_one_workgroup_per_instance_sweep_kernel(qd, nq, nb, order):
     y0 = crand(rng, 2**nq)
     y0 /= np.linalg.norm(y0)
     sig = sweeps if nb > 1 else sweeps[0]
-    out, launches, split = {}, {}, {}
-    for flag in (1, 2, 0):       # 1: one workgroup per instance; 2: several (ell_sweep_split = 3); 0: per-launch route
-        ctx.set_option("ell_sweep", 1 if flag else 0)
-        ctx.set_option("ell_sweep_split", 3 if flag == 2 else 0)
-        ctx.reset_counters()
-        ctx.set_option("profile", 1)
-        try:
+    out, launches, split, cross = {}, {}, {}, {}
+    # 1: one workgroup per instance; 2: several, operand vectors all-gathered (ell_sweep_split = 3); 3: the default -- two
+    # workgroups per instance with the exchange behind the local slots (ell_sweep_duo_kernel, n >= 512); 0: per-launch route
+    for flag in (1, 2, 3, 0):
+        with ctx.options(ell_sweep=1 if flag else 0, ell_sweep_split=3 if flag == 2 else 0, ell_sweep_duo=1 if flag == 3 else 0,
+                         profile=1):
+            ctx.reset_counters()
             r = solver.solve(t_span=[0.0, 0.4], y0=y0, signals=sig, method="scipy_expm", max_dt=0.05, magnus_order=order,
                              t_eval=[0.0, 0.15, 0.4])
-        finally:
-            ctx.set_option("profile", 0)
-            ctx.set_option("ell_sweep", 1)
-            ctx.set_option("ell_sweep_split", 1)
-        launches[flag] = ctx.counters("rk4_resident")["launches"]
-        split[flag] = ctx.counters("sweep_split")["launches"]
+            launches[flag] = ctx.counters("rk4_resident")["launches"]
+            split[flag] = ctx.counters("sweep_split")["launches"]
+            cross[flag] = ctx.counters("sweep_cross")
         out[flag] = np.stack([x.y for x in r]) if nb > 1 else r.y[None]
-    assert launches[1] == 1 and launches[2] == 1 and launches[0] == 0, launches
+    assert launches[1] == 1 and launches[2] == 1 and launches[3] == 1 and launches[0] == 0, launches
     assert split[1] == 1 and split[2] == (2 if nq >= 11 else 1), split      # n = 2048: two workgroups of 1024 rows each
+    assert split[3] == (2 if nq >= 9 else 1), split                          # (n = 256: too small to share)
+    if nq >= 9:      # the chain couples the halves of the vector through the strings that flip the top qubit (qubit 0 is the
+        assert cross[3]["launches"] == 2, cross[3]      # most significant bit): its drive and its XX coupling -- 2 slots
     assert_close(out[1], out[0], 1e-12)
     assert_close(out[2], out[0], 1e-12)
+    assert_close(out[3], out[0], 1e-12)
     a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
     for b in (sorted({0, nb // 2, nb - 1}) if nq <= 10 else [nb - 1]):     # (a 2048 x 2048 expm per step on the host)
         _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
@@ -538,24 +539,23 @@ def test_sweep_kernel_four_workgroups_per_instance_at_full_size(qd):
     solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
                        rotating_frame=np.diag(cfg["h_d"]).real.copy(), validate=False)
     out, split = {}, {}
-    for tag, sweep, parts in (("four", 1, 3), ("one", 1, 1), ("per_launch", 0, 1)):
-        ctx.set_option("ell_sweep", sweep)
-        ctx.set_option("ell_sweep_split", parts)
-        ctx.reset_counters()
-        ctx.set_option("profile", 1)
-        try:
+    for tag, sweep, parts, duo in (("four", 1, 3, 0), ("one", 1, 1, 0), ("two", 1, 1, 1), ("per_launch", 0, 1, 1)):
+        with ctx.options(ell_sweep=sweep, ell_sweep_split=parts, ell_sweep_duo=duo, profile=1):
+            ctx.reset_counters()
             r = solver.solve(t_span=[0.0, 1.0], y0=cfg["y0"], signals=sweeps, method="scipy_expm", max_dt=0.25,
                              magnus_order=2, t_eval=[0.0, 0.5, 1.0])
-        finally:
-            ctx.set_option("profile", 0)
-            ctx.set_option("ell_sweep", 1)
-            ctx.set_option("ell_sweep_split", 1)
-        assert ctx.counters("rk4_resident")["launches"] == (1 if sweep else 0)
-        split[tag] = (ctx.counters("sweep_split")["launches"], ctx.counters("sweep_split")["ms"])
+            assert ctx.counters("rk4_resident")["launches"] == (1 if sweep else 0)
+            split[tag] = (ctx.counters("sweep_split")["launches"], ctx.counters("sweep_split")["ms"])
+            if tag == "two":
+                cross = ctx.counters("sweep_cross")
         out[tag] = np.stack([x.y for x in r])
     assert split["four"][0] == 4 and split["one"] == (1, 2), split     # (workgroups per instance, element form: 2 = direct)
+    # the default for this stack: two workgroups per instance, TWO of the 19 slots (the drive of the top qubit and its XX
+    # coupling) reach into the partner's half
+    assert split["two"] == (2, 2) and (cross["launches"], cross["ms"]) == (2, 19), (split, cross)
     assert_close(out["four"], out["per_launch"], 1e-12)
     assert_close(out["one"], out["per_launch"], 1e-12)
+    assert_close(out["two"], out["per_launch"], 1e-12)
     assert np.max(np.abs(np.linalg.norm(out["four"][:, -1], axis=1) - 1.0)) < 1e-12
 
 
@@ -603,22 +603,21 @@ def test_sweep_kernel_element_forms(qd, kind, form, nq, order):
     y0 = crand(rng, 2**nq)
     y0 /= np.linalg.norm(y0)
     out, forms = {}, {}
-    for tag, opts in (("default", {}), ("general", {"ell_sweep_packed": 0}), ("per_launch", {"ell_sweep": 0})):
-        for name, val in opts.items():
-            ctx.set_option(name, val)
-        ctx.reset_counters()
-        ctx.set_option("profile", 1)
-        try:
+    parts = {}
+    for tag, opts in (("default", {}), ("one_workgroup", {"ell_sweep_duo": 0}), ("general", {"ell_sweep_packed": 0}),
+                      ("per_launch", {"ell_sweep": 0})):
+        with ctx.options(profile=1, **opts):
+            ctx.reset_counters()
             r = solver.solve(t_span=[0.0, 0.4], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.05, magnus_order=order,
                              t_eval=[0.0, 0.15, 0.4])
-        finally:
-            ctx.set_option("profile", 0)
-            for name in opts:
-                ctx.set_option(name, 1)
-        assert ctx.counters("rk4_resident")["launches"] == (0 if tag == "per_launch" else 1)
-        forms[tag] = ctx.counters("sweep_split")["ms"]
+            assert ctx.counters("rk4_resident")["launches"] == (0 if tag == "per_launch" else 1)
+            forms[tag] = ctx.counters("sweep_split")["ms"]
+            parts[tag] = ctx.counters("sweep_split")["launches"]
         out[tag] = np.stack([x.y for x in r])
-    assert forms["default"] == form and forms["general"] == 0, forms
+    assert forms["default"] == form and forms["one_workgroup"] == form and forms["general"] == 0, forms
+    # the packed forms of a small sweep share an instance between two workgroups by default (ell_sweep_duo_kernel)
+    assert parts["default"] == (2 if form else 1) and parts["one_workgroup"] == 1, parts
+    assert_close(out["default"], out["one_workgroup"], 1e-12)
     assert_close(out["default"], out["general"], 1e-12)
     assert_close(out["default"], out["per_launch"], 1e-12)
     a_d, a, d, basis = orc.hamiltonian_model_build(h_d, ops, frame)
@@ -730,7 +729,7 @@ def test_small_sweep_of_a_dense_model_runs_as_single_trajectories(qd):
         assert_close(res[b].y, y_ref, SOLVE_TOL)
 
 
-@pytest.mark.parametrize("route", ["dense_rk4", "ell_rk4", "ell_expm", "sweep_split"])
+@pytest.mark.parametrize("route", ["dense_rk4", "ell_rk4", "ell_expm", "sweep_split", "sweep_duo"])
 def test_one_launch_kernels_fall_back_when_a_wait_gives_up(qd, route):
     """The one-launch kernels wait for each other's data inside the launch.  With the spin limit forced to zero every wait
     whose first poll finds a word missing gives up (what a launch that is not co-resident after all, or a GPU shared with
@@ -747,14 +746,14 @@ def test_one_launch_kernels_fall_back_when_a_wait_gives_up(qd, route):
         frame, method, kw = h_d, "RK4", dict(max_dt=0.01)
         carrier = np.array([1.0, 2.0, 3.0])
     else:                               # ELL stacks: the 9-qubit chain in its diagonal frame
-        cfg = W.schrodinger_config(n_qubits=9 if route != "sweep_split" else 12, n_drives=8, t_final=1.0, max_dt=0.05)
+        cfg = W.schrodinger_config(n_qubits={"sweep_split": 12, "sweep_duo": 10}.get(route, 9), n_drives=8, t_final=1.0, max_dt=0.05)
         h_d, ops, carrier = cfg["h_d"], cfg["ops"], cfg["carrier"]
         n, k = h_d.shape[0], len(ops)
         frame = np.diag(h_d).real.copy()
         method, kw = ("RK4", dict(max_dt=0.01)) if route == "ell_rk4" else ("scipy_expm", dict(max_dt=0.05))
-        if route == "sweep_split":
+        if route in ("sweep_split", "sweep_duo"):
             kw["magnus_order"] = 2
-    nb = 3 if route == "sweep_split" else 1
+    nb = 3 if route in ("sweep_split", "sweep_duo") else 1
     sweeps = []
     for b in range(nb):
         amps, phases = W.sweep_parameters(b, k)
@@ -770,6 +769,7 @@ def test_one_launch_kernels_fall_back_when_a_wait_gives_up(qd, route):
         ctx.set_option("resident_spin_limit", limit)
         if route == "sweep_split":
             ctx.set_option("ell_sweep_split", 3)
+        ctx.set_option("ell_sweep_duo", 1 if route == "sweep_duo" else 0)
         before = ctx.counters("resident_fallbacks")["launches"]
         ctx.reset_counters()
         ctx.set_option("profile", 1)
@@ -779,7 +779,10 @@ def test_one_launch_kernels_fall_back_when_a_wait_gives_up(qd, route):
             ctx.set_option("profile", 0)
             ctx.set_option("resident_spin_limit", -1)
             ctx.set_option("ell_sweep_split", 1)
+            ctx.set_option("ell_sweep_duo", 1)
         assert ctx.counters("rk4_resident")["launches"] >= 1, "the one-launch route was not taken"
+        if route == "sweep_duo" and tag == "healthy":
+            assert ctx.counters("sweep_split")["launches"] == 2
         fallbacks[tag] = ctx.counters("resident_fallbacks")["launches"] - before
         runs[tag] = np.stack([x.y[-1] for x in r]) if nb > 1 else r.y[-1][None]
     assert fallbacks["healthy"] == 0 and fallbacks["gives_up"] >= 1, fallbacks
@@ -787,5 +790,5 @@ def test_one_launch_kernels_fall_back_when_a_wait_gives_up(qd, route):
     if route != "sweep_split":          # (n = 4096: the healthy route is pinned against the oracle elsewhere)
         a_d, a, d, basis = orc.hamiltonian_model_build(h_d, ops, frame)
         _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt: np.array([np.real(s(tt)) for s in sweeps[0]]),
-                                           t_span, y0, method, kw["max_dt"])
+                                           t_span, y0, method, kw["max_dt"], magnus_order=kw.get("magnus_order", 1))
         assert_close(runs["gives_up"][0], ref[-1], SOLVE_TOL)
