@@ -13,7 +13,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 

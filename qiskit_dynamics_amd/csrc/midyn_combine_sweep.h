@@ -96,9 +96,21 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
     const bool live = inst < a.B;
     const int ic = live ? inst : a.B - 1;
     const double* __restrict__ Sb = a.S + (size_t)ic * a.inst_stride;
-    int pc[NQ];
+    // coefficient column of this lane's plane of group q.  Two tiles with three or four plane groups (256 registers, all in
+    // use) read it from the kernel arguments where it is needed -- once per stage -- through an index the optimiser cannot see
+    // through: held in registers across the stages it was the value hipcc parked in scratch.
+    constexpr bool PC_REG = !(RT == 2 && NQ >= 3);
+    int pc[PC_REG ? NQ : 1];
+    if (PC_REG) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) pc[q] = a.plane_col[4 * q + lq];
+        for (int q = 0; q < NQ; ++q) pc[PC_REG ? q : 0] = a.plane_col[4 * q + lq];
+    }
+    auto pc_of = [&](const int q) {
+        if (PC_REG) return pc[PC_REG ? q : 0];
+        int idx = 4 * q + lq;
+        asm volatile("" : "+v"(idx));
+        return a.plane_col[idx];
+    };
 
     int e0 = a.list_ptr[rg], e1 = a.list_ptr[rg + 1];
     if (a.splits > 1) {
@@ -207,7 +219,10 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
     auto kb_of = [&](int entry) { return __builtin_amdgcn_readlane(kbv, entry); };
     const int s_first = __builtin_amdgcn_readlane(rowv, 0);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) cb[q] = pc[q] >= 0 ? Sb[(size_t)s_first * a.k + pc[q]] : 0.0;
+    for (int q = 0; q < NQ; ++q) {
+        const int pcq = pc_of(q);
+        cb[q] = pcq >= 0 ? Sb[(size_t)s_first * a.k + pcq] : 0.0;
+    }
     double2 ec[RT][4], en[RT][4];
     if (RT == 1 && a.E) {
 #pragma unroll
@@ -238,8 +253,16 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
         const int save_slot = __builtin_amdgcn_readlane(savev, sl);      // MODE 1: flags
         const double2* __restrict__ X = X0 + (size_t)(stage & 1) * np * 16;          // (RK4: a step starts on copy 0)
         double2* __restrict__ Xn = X0 + (size_t)((stage & 1) ^ 1) * np * 16;
+        // (two tiles with three or four plane groups sit at the 256 registers of a 512-thread workgroup: they ask for the next
+        // coefficients after the contraction, where they arrive behind the stage arithmetic, instead of holding them through it)
+        constexpr bool CBN_LATE = RT == 2 && NQ >= 3;
+        if (!CBN_LATE) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) cbn[q] = pc[q] >= 0 ? Sb[(size_t)nrow * a.k + pc[q]] : 0.0;
+            for (int q = 0; q < NQ; ++q) {
+                const int pcq = pc_of(q);
+                cbn[q] = pcq >= 0 ? Sb[(size_t)nrow * a.k + pcq] : 0.0;
+            }
+        }
         // frame phases of the next stage's rows (its input).  One tile per wave: loaded here, ahead of the contraction, and
         // kept for the result of the next stage; two tiles (n_pad > 128: stages of tens of microseconds, registers at their
         // limit): both sets after the contraction
@@ -333,6 +356,13 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
             for (int s = 0; s < steps - D; s += D) body(s, false);
             body(steps - D, true);
         }
+        if (CBN_LATE) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int pcq = pc_of(q);
+                cbn[q] = pcq >= 0 ? Sb[(size_t)nrow * a.k + pcq] : 0.0;
+            }
+        }
         if (a.splits > 1) {      // the partner's partial sums of this wave's rows (and this wave's of the partner's rows) through LDS
             double* slot = red + (size_t)wt * (RT * 8 * 64) + lane;
 #pragma unroll
@@ -370,7 +400,8 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (RT == 1 && (r < own_lo || r >= own_hi)) continue;
-                    const int row = row0 + 16 * t + lq + 4 * r;
+                    int row = row0 + 16 * t + lq + 4 * r;
+                    if (RT == 2) asm volatile("" : "+v"(row));    // (no 64-bit address of a (row, array) pair is carried through the stage loop)
                     if (RT == 2 && a.E) {
                         ec[t][r] = a.E[(size_t)srow * np + row];
                         en[t][r] = a.E[(size_t)nrow * np + row];
@@ -389,7 +420,8 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (RT == 1 && (r < own_lo || r >= own_hi)) continue;
-                    const int row = row0 + 16 * t + lq + 4 * r;
+                    int row = row0 + 16 * t + lq + 4 * r;
+                    if (RT == 2) asm volatile("" : "+v"(row));
                     const double2 o = make_double2(ore[t][r], oim[t][r]);
                     double2 cur;
                     if (MODE == 0) {
@@ -434,6 +466,9 @@ __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepAr
                         if (MODE == 1) a.buf3[idx] = pp[r];
                     }
                 }
+                // two tiles: one tile's state and phases at a time (left alone, the scheduler starts the loads of the second tile
+                // before the arithmetic of the first and the larger variants park values in scratch)
+                if (RT == 2) __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
