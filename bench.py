@@ -1149,7 +1149,7 @@ def main():
     ap.add_argument("--complex-3m", type=int, default=-1, help="A/B: ctx option complex_3m (0 | 1 | 2)")
     ap.add_argument("--plane-kernel", action="store_true", help="A/B: planar two-tiles-per-barrier kernel (opt-in)")
     ap.add_argument("--ablate", type=int, default=0, help="profiling only: kernel ablation bits (results wrong)")
-    ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 | 12864 (kernel A/B testing)")
+    ap.add_argument("--force-tile", type=int, default=0, help="0 auto | 64 | 128 (kernel A/B testing)")
     ap.add_argument("--opt", action="append", default=[], help="A/B: ctx option NAME=VALUE (repeatable)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the A/B legs of cfg 3 (GEMM route, no zero-block lists, general complex operators): PMC passes, so "
@@ -1370,9 +1370,7 @@ def main():
 
     def timed_variant(options, steps_=10):
         """ms per launch of the same sweep on a fresh plan created under `options` (routes are chosen at plan creation)."""
-        for name_, val_ in options.items():
-            ctx.set_option(name_, val_)
-        try:
+        with ctx.options(**options):         # (every option back to the value it had)
             pv = qd.Rk4Plan(stack, times, table, rows, sched.step_h[:total], y0, b_loc, True)
             w_steps = max(1, min(2, total - 1))
             d_steps = max(1, min(args.steps, steps_, total - w_steps))
@@ -1382,9 +1380,6 @@ def main():
             pv.run(w_steps, w_steps + d_steps)
             ms_ = ctx.timer_stop() / (4 * d_steps)
             pv.close()
-        finally:
-            for name_ in options:
-                ctx.set_option(name_, 1)
         return ms_
 
     # ---- the same sweep without the symmetry-sector work lists, and as general dense-complex operators ----------
@@ -1438,7 +1433,16 @@ def main():
             ex_d = (2.0 * 4 * nq_d + 8.0) * info_d["launches"] * 16 * 32 * (-(-b_loc // 128) * 128)
         else:
             ex_d = 6 * stack.n_segments * n * n * b_loc   # 3M: 3 real MFMA products per complex product
-        dense = {"avg_launch_ms": round(avg_d, 4), "rhs_evals_per_s": round(b_loc / (avg_d * 1e-3), 1),
+        wide_d = None
+        if took_combine_d:      # A/B: 64 instances per wave on one wave per SIMD (rhs_combine_wide_kernel) instead of two 32-instance waves
+            avg_w = timed_variant({"skip_zero_planes": 0, "skip_zero_blocks": 0, "combine_wide": 1})
+            if int(ctx.counters("combine_wave")["launches"]) == 64:
+                wide_d = {"option": "combine_wide=1", "kernel": "rhs_combine_wide_kernel<2, 2, 3>", "avg_launch_ms": round(avg_w, 4),
+                          "rhs_evals_per_s": round(b_loc / (avg_w * 1e-3), 1),
+                          "frac": round(ex_d / (avg_w * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                          "frac_survey_8d_useful": round(useful / (avg_w * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
+        dense = {"one_wave_per_simd_64_instance_waves": wide_d,
+                 "avg_launch_ms": round(avg_d, 4), "rhs_evals_per_s": round(b_loc / (avg_d * 1e-3), 1),
                  "useful_tflops": round(useful / (avg_d * 1e-3) / 1e12, 3),
                  "frac_survey_8d_useful": round(useful / (avg_d * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
                  "executed_tflops": round(ex_d / (avg_d * 1e-3) / 1e12, 3),

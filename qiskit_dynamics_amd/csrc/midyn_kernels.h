@@ -2730,7 +2730,7 @@ MIDYN_GLOBAL __launch_bounds__(256) void stream_read_kernel(const double2* src, 
 #define MIDYN_GEMM_PAIR_TILES(X)                                                                                    \
     MIDYN_FOR_PLANE_MODE(X, 128, 128, 2, 4, 16) MIDYN_FOR_PLANE_MODE(X, 64, 64, 2, 2, 16) MIDYN_FOR_PLANE_MODE(X, 32, 128, 1, 4, 16) \
     MIDYN_FOR_PLANE_MODE(X, 32, 64, 1, 2, 16) MIDYN_FOR_PLANE_MODE(X, 16, 128, 1, 4, 16) MIDYN_FOR_PLANE_MODE(X, 16, 64, 1, 2, 16)
-#define MIDYN_GEMM_TILES(X) MIDYN_GEMM_PAIR_TILES(X) MIDYN_FOR_PLANE_MODE(X, 128, 64, 2, 2, 8)
+#define MIDYN_GEMM_TILES(X) MIDYN_GEMM_PAIR_TILES(X)     // (the 128 x 64 x 8 two-per-CU tile of round 2's A/B is no longer built: nothing selects it)
 #ifdef MIDYN_TU_GEMM_DENSE
 #define MIDYN_GEMM_DENSE_EXTERN
 #else

@@ -37,7 +37,6 @@ DEFAULT_ROUTE = (
     "ell_sweep_kernelILi2ELi4ELi1024ELi2EE",                     # cfg 5, more than 128 instances per GPU (direct element form)
     "ell_sweep_kernelILi2ELi4ELi1024ELi1EE",
     "ell_sweep_kernelILi2ELi4ELi1024ELi0EE",
-    "ell_sweep_kernelILi2ELi3ELi1024ELi0EE",
     "ell_sweep_kernelILi1ELi4ELi1024ELi2EE",
     "ell_sweep_rk4_kernelILi4ELi1024ELi2EE",
     "ell_sweep_rk4_kernelILi4ELi1024ELi0EE",

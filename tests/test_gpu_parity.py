@@ -33,7 +33,7 @@ def crand(rng, *shape):
 # ------------------------------------------------------------------------------------------------
 # MFMA zgemm: layout, transposition, padding, both tile configurations
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [0, 64, 128, 12864])
+@pytest.mark.parametrize("tile", [0, 64, 128])
 @pytest.mark.parametrize("shape", [(5, 7, 3), (64, 64, 64), (130, 70, 200), (256, 384, 128),
                                    (1, 1, 1), (16, 300, 17)])
 def test_zgemm(qd, shape, tile):
@@ -569,7 +569,7 @@ def test_rk4_plan_matches_solve(qd, cfg2):
     assert_close(plan.fetch(), ref, 1e-13)
     plan.close()
     # every MFMA tile configuration gives the same states (different summation orders only)
-    for tile in (64, 128, 12864):
+    for tile in (64, 128):
         stack.ctx.set_option("force_tile", tile)
         try:
             got = stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save,
