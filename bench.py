@@ -1433,15 +1433,7 @@ def main():
             ex_d = (2.0 * 4 * nq_d + 8.0) * info_d["launches"] * 16 * 32 * (-(-b_loc // 128) * 128)
         else:
             ex_d = 6 * stack.n_segments * n * n * b_loc   # 3M: 3 real MFMA products per complex product
-        wide_d = None
-        if took_combine_d:      # A/B: 64 instances per wave on one wave per SIMD (rhs_combine_wide_kernel) instead of two 32-instance waves
-            avg_w = timed_variant({"skip_zero_planes": 0, "skip_zero_blocks": 0, "combine_wide": 1})
-            if int(ctx.counters("combine_wave")["launches"]) == 64:
-                wide_d = {"option": "combine_wide=1", "kernel": "rhs_combine_wide_kernel<2, 2, 3>", "avg_launch_ms": round(avg_w, 4),
-                          "rhs_evals_per_s": round(b_loc / (avg_w * 1e-3), 1),
-                          "frac": round(ex_d / (avg_w * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
-                          "frac_survey_8d_useful": round(useful / (avg_w * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)}
-        dense = {"one_wave_per_simd_64_instance_waves": wide_d,
+        dense = {"one_wave_per_simd_64_instance_waves": "measured in round 5 and not kept: rhs_combine_wide_kernel<2, 2, 3> 3.27 ms per launch against 2.82 (profiles/r05_summary.md)",
                  "avg_launch_ms": round(avg_d, 4), "rhs_evals_per_s": round(b_loc / (avg_d * 1e-3), 1),
                  "useful_tflops": round(useful / (avg_d * 1e-3) / 1e12, 3),
                  "frac_survey_8d_useful": round(useful / (avg_d * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),

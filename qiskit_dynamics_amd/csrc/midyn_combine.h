@@ -303,15 +303,10 @@ __global__ __launch_bounds__(512, 2) void rhs_combine_small_kernel(const Combine
     combine_body<NRE4, NIM4, STAT, 2>(a);
 }
 
-// 64 instances per wave for stacks with three or four plane groups of BOTH kinds (general complex operators): the accumulators
-// of two row tiles x four instance groups are 128 registers, the operands of two steps 100 more -- one wave per SIMD (256-thread
-// workgroups, 512 registers a lane) where rhs_combine_kernel runs two waves of 32 instances each: half the operand loads per
-// MFMA, no partner wave to hide a load behind (the loads are a step ahead).  A/B: ctx option combine_wide.
-template <int NRE4, int NIM4, int STAT>
-__global__ __launch_bounds__(256, 1) void rhs_combine_wide_kernel(const CombineArgs a) {
-    static_assert(NRE4 > 0 && NIM4 > 0 && NRE4 + NIM4 >= 3, "the variants whose rhs_combine_kernel runs 32 instances per wave");
-    combine_body<NRE4, NIM4, STAT, 4>(a);
-}
+// (Measured in round 5 and not kept: 64 instances per wave for stacks with three or four plane groups of both kinds on ONE wave
+// per SIMD -- 256-thread workgroups, 292 registers a lane, no spill, half the operand loads per MFMA.  General complex operators +
+// static operator, n = 1024, 4096 instances: 3.27 ms per evaluation against 2.82 ms for two 32-instance waves per SIMD
+// (profiles/r05_summary.md): without a partner wave every MFMA -> vector FMA dependency and every load that is late shows.)
 
 // ---- the instantiations that exist, and where ------------------------------------------------------------------------------
 // libmidyn.so is built from several translation units so that hipcc compiles the kernel families side by side (the device
@@ -339,9 +334,6 @@ MIDYN_COMBINE_PAIRS_BOTH_KINDS(MIDYN_X)
 #undef MIDYN_X
 #define MIDYN_X(R_, I_, S_) MIDYN_COMBINE_WIDE_EXTERN template __global__ void rhs_combine_kernel<R_, I_, S_>(const CombineArgs);
 MIDYN_FOR_STAT(MIDYN_X, 0, 3) MIDYN_FOR_STAT(MIDYN_X, 0, 4) MIDYN_FOR_STAT(MIDYN_X, 3, 0) MIDYN_FOR_STAT(MIDYN_X, 4, 0)
-#undef MIDYN_X
-#define MIDYN_X(R_, I_, S_) MIDYN_COMBINE_WIDE_EXTERN template __global__ void rhs_combine_wide_kernel<R_, I_, S_>(const CombineArgs);
-MIDYN_FOR_STAT(MIDYN_X, 1, 2) MIDYN_FOR_STAT(MIDYN_X, 2, 1) MIDYN_FOR_STAT(MIDYN_X, 2, 2)
 #undef MIDYN_X
 #define MIDYN_X(R_, I_, S_) MIDYN_COMBINE_WIDE_EXTERN template __global__ void rhs_combine_small_kernel<R_, I_, S_>(const CombineArgs);
 MIDYN_COMBINE_PAIRS_UP_TO_TWO_GROUPS(MIDYN_X)

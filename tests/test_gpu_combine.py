@@ -139,45 +139,6 @@ def test_combine_kernel_variant_vs_oracle_and_gemm_route(qd, kinds, static_kind,
     stack.close()
 
 
-@pytest.mark.parametrize("kinds,static_kind,variant", [("iiiiir", None, (1, 2, 0)), ("ccrrr", "r", (2, 1, 1)), ("cccccc", "i", (2, 2, 2)),
-                                                        ("cccccccc", "c", (2, 2, 3))], ids=["120", "211", "222", "223"])
-def test_combine_wide_kernel_one_wave_per_simd(qd, kinds, static_kind, variant):
-    """rhs_combine_wide_kernel<NRE4, NIM4, STAT> (ctx option combine_wide = 1): stacks with three or four plane groups of both
-    kinds on 64-instance waves, one wave per SIMD, for sweeps large enough to fill the chip that way (n = 250 -> 8 row groups,
-    8192 instances) -- against the default (two 32-instance waves per SIMD; same sums in the same order: equal to rounding of
-    nothing, i.e. bit for bit) and the oracle."""
-    from oracle import dynamics_oracle as orc
-    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
-
-    ctx = qd.default_context()
-    rng = np.random.default_rng(sum(variant) * 7 + len(kinds))
-    n, batch = 250, 8192
-    ops = _operators(rng, n, kinds) * 0.4
-    static = None if static_kind is None else _operators(rng, n, static_kind)[0] * 0.4
-    fim = rng.normal(size=n)
-    stack = qd.Stack(ctx, ops, static, fim)
-    sched = FixedStepSchedule([0.0, 0.02], None, 0.01, _rk4_points)
-    table = rng.uniform(-1, 1, (batch, len(sched.times), len(kinds)))
-    y0 = crand(rng, batch, n, 1)
-    runs = {}
-    for tag, wide in (("default", 0), ("wide", 1)):
-        with ctx.options(combine_wide=wide):
-            runs[tag], cc = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 2)
-        assert cc["rhs_combine"]["launches"] == 8 and cc["rhs_gemm"]["launches"] + cc["rhs_blocks_gemm"]["launches"] == 0, cc
-        assert int(cc["combine_info"]["ms"]) == 100 * variant[0] + 10 * variant[1] + variant[2], cc["combine_info"]
-        assert int(cc["combine_wave"]["launches"]) == (64 if wide else 32), (tag, cc["combine_wave"])
-    assert np.array_equal(runs["wide"], runs["default"])
-    d = 1j * fim
-    for b in (0, 4097, 8191):
-        def rhs(t, y, b=b):
-            row = int(np.argmin(np.abs(np.asarray(sched.times) - t)))
-            return orc.generator_rhs(static, ops, table[b, row], d, None, t, y)
-
-        _, yref = orc.rk4_solve(rhs, [0.0, 0.02], y0[b, :, 0], 0.01)
-        assert_close(runs["wide"][b, -1, :, 0], yref[-1], 1e-11)
-    stack.close()
-
-
 @pytest.mark.parametrize("magnus_order", [1, 2])
 def test_combine_route_inside_the_expm_action(qd, magnus_order):
     """scipy_expm through the expm ACTION (Taylor / Chebyshev series of products, fixed_step_solvers.py:80-108,345-363): every
