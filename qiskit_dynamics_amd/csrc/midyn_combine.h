@@ -24,11 +24,14 @@
 
 namespace midyn {
 
-constexpr int CMB_MAXQ = 2;     // plane groups (of 4) per kind when the stack has planes of both kinds: k <= 8 operators per kind
+constexpr int CMB_MAXQ = 3;     // plane groups (of 4) per kind when the stack has planes of both kinds: k <= 12 operators per kind (round 5: was 2)
 constexpr int CMB_MAXQ1 = 4;    // ... of ONE kind only (real-symmetric Hamiltonians: purely imaginary generators): k <= 16
-constexpr bool combine_groups_ok(int nre4, int nim4) {     // (at most 16 plane slots either way: plane_col[8 * CMB_MAXQ])
+constexpr int CMB_SLOTS = 8 * CMB_MAXQ;   // plane slots of the widest layouts ((3, 3): 24; one kind alone: 16)
+constexpr bool combine_groups_ok(int nre4, int nim4) {
     return nre4 + nim4 > 0 && ((nre4 <= CMB_MAXQ && nim4 <= CMB_MAXQ) || (nre4 == 0 && nim4 <= CMB_MAXQ1) || (nim4 == 0 && nre4 <= CMB_MAXQ1));
 }
+// the one-launch kernels of small systems (midyn_combine_sweep.h) exist for up to two groups per kind
+constexpr bool combine_sweep_groups_ok(int nre4, int nim4) { return nre4 + nim4 > 0 && nre4 <= 2 && nim4 <= 2; }
 constexpr int CMB_ROWS = 32;    // rows per row group (two 16-row MFMA tiles per wave)
 
 struct CombineArgs {
@@ -42,7 +45,7 @@ struct CombineArgs {
     const double* coeff;     // [instance][inst_stride]: coefficient row of this evaluation
     long long inst_stride;
     int m_cols, n_inst;
-    int plane_col[8 * CMB_MAXQ];   // coefficient column of plane 4 q + i (first the real-plane groups, then the imaginary ones); -1: padding
+    int plane_col[CMB_SLOTS];   // coefficient column of plane 4 q + i (first the real-plane groups, then the imaginary ones); -1: padding
     int n_row_groups;
     int wr;                  // waves of a workgroup along the rows (the others along the instances)
     int splits;              // > 1 (a power of two): that many waves share one (row group, instance block) and split its list (small
@@ -58,8 +61,8 @@ struct CombinePackArgs {
     const int* ent_rg;       // row group of every entry
     const int* list_idx;
     int nq;                  // NRE4 + NIM4
-    int plane_seg[8 * CMB_MAXQ];
-    int plane_im[8 * CMB_MAXQ];
+    int plane_seg[CMB_SLOTS];
+    int plane_im[CMB_SLOTS];
     double* frags;
 };
 
@@ -334,6 +337,14 @@ MIDYN_COMBINE_PAIRS_BOTH_KINDS(MIDYN_X)
 #undef MIDYN_X
 #define MIDYN_X(R_, I_, S_) MIDYN_COMBINE_WIDE_EXTERN template __global__ void rhs_combine_kernel<R_, I_, S_>(const CombineArgs);
 MIDYN_FOR_STAT(MIDYN_X, 0, 3) MIDYN_FOR_STAT(MIDYN_X, 0, 4) MIDYN_FOR_STAT(MIDYN_X, 3, 0) MIDYN_FOR_STAT(MIDYN_X, 4, 0)
+#undef MIDYN_X
+#ifdef MIDYN_TU_COMBINE_MANY     // midyn_tu_combine_many.hip: 9 - 12 operators per kind with planes of both kinds (a third group)
+#define MIDYN_COMBINE_MANY_EXTERN
+#else
+#define MIDYN_COMBINE_MANY_EXTERN extern
+#endif
+#define MIDYN_X(R_, I_, S_) MIDYN_COMBINE_MANY_EXTERN template __global__ void rhs_combine_kernel<R_, I_, S_>(const CombineArgs);
+MIDYN_FOR_STAT(MIDYN_X, 3, 1) MIDYN_FOR_STAT(MIDYN_X, 3, 2) MIDYN_FOR_STAT(MIDYN_X, 3, 3) MIDYN_FOR_STAT(MIDYN_X, 1, 3) MIDYN_FOR_STAT(MIDYN_X, 2, 3)
 #undef MIDYN_X
 #define MIDYN_X(R_, I_, S_) MIDYN_COMBINE_WIDE_EXTERN template __global__ void rhs_combine_small_kernel<R_, I_, S_>(const CombineArgs);
 MIDYN_COMBINE_PAIRS_UP_TO_TWO_GROUPS(MIDYN_X)

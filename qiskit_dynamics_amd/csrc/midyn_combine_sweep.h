@@ -37,7 +37,7 @@ struct CombineSweepArgs {
     const int* list_idx;
     const double2* stat;      // static operator [lda][lda] or nullptr
     int lda;
-    int plane_col[8 * CMB_MAXQ];
+    int plane_col[16];          // (up to two groups per kind: combine_sweep_groups_ok)
     int n, n_pad, k, B;
     int splits;               // waves that share one row tile (1 or 2)
     const double* S;          // [B][R][k]
@@ -81,7 +81,7 @@ template <int NRE4, int NIM4, int STAT, int RT, int MODE>
 __global__ __launch_bounds__(512) void combine_sweep_kernel(const CombineSweepArgs a) {
     constexpr int NQ = NRE4 + NIM4, D = sweep_depth(RT, NQ, STAT, MODE);
     constexpr bool RE = NRE4 > 0 || (STAT & 1), IM = NIM4 > 0 || (STAT & 2);
-    static_assert(combine_groups_ok(NRE4, NIM4) && (RT == 1 || RT == 2), "shape");
+    static_assert(combine_sweep_groups_ok(NRE4, NIM4) && (RT == 1 || RT == 2), "shape");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int np = a.n_pad;
     double2* const X0 = reinterpret_cast<double2*>(smem_raw);          // two copies of the phased stage input [n_pad][16]

@@ -143,7 +143,7 @@ def test_combine_kernels_keep_scratch_out_of_their_loop(tmp_path):
     text = codeobj.disassembly(LIB, tmp_path, OBJDUMP)
     lines = text.split("\n")
     starts = [i for i, l in enumerate(lines) if "rhs_combine_kernel" in l and l.rstrip().endswith(">:")]
-    assert len(starts) == 48
+    assert len(starts) == 68
     for st in starts:
         end = next(i for i in range(st + 1, len(lines)) if lines[i].rstrip().endswith(">:") or i == len(lines) - 1)
         ops = [l.split("//")[0].split() for l in lines[st + 1:end]]

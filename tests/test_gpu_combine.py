@@ -2,7 +2,8 @@
 against the MFMA GEMM routes (ctx option combine = 0), one test per kernel variant:
 
   * operators with real planes only / imaginary planes only / both / a mix of the three, 2 .. 8 of them, so that every
-    (NRE4, NIM4) in {0, 1, 2}^2 \\ (0, 0) occurs, and 9 .. 16 operators of ONE kind ((0, 3), (0, 4), (3, 0), (4, 0));
+    (NRE4, NIM4) in {0, 1, 2}^2 \\ (0, 0) occurs, 9 .. 16 operators of ONE kind ((0, 3), (0, 4), (3, 0), (4, 0)), and 9 .. 12 of a
+    kind beside planes of the other ((3, 1), (3, 2), (3, 3), (1, 3), (2, 3));
   * no static operator, a real one, an imaginary one, a complex one (STAT 0 .. 3: the C input of the combining MFMAs);
   * a frame diagonal (phases in the stage input and in the epilogue), ragged dimension (n = 96 -> 128 padded rows),
     300 instances (384 padded columns: eight waves split every list and sum through LDS as a tree; 32 instances per wave --
@@ -89,6 +90,9 @@ CASES = [
     # one plane kind alone: up to 16 operators (real-symmetric Hamiltonians with more than 8 drives / couplers)
     ("i" * 10, None, (0, 3, 0)), ("i" * 12, "i", (0, 3, 2)), ("i" * 13, "r", (0, 4, 1)), ("i" * 16, "c", (0, 4, 3)),
     ("r" * 9, None, (3, 0, 0)), ("r" * 11, "c", (3, 0, 3)), ("r" * 14, "i", (4, 0, 2)), ("r" * 16, "r", (4, 0, 1)),
+    # both kinds, 9 .. 12 operators of a kind (round 5: a third plane group beside planes of the other kind)
+    ("c" * 9, None, (3, 3, 0)), ("c" * 12, "c", (3, 3, 3)), ("c" * 10, "r", (3, 3, 1)),
+    ("r" * 9 + "ii", "i", (3, 1, 2)), ("c" * 5 + "r" * 5, None, (3, 2, 0)), ("i" * 10 + "c", "c", (1, 3, 3)), ("c" * 8 + "iii", "r", (2, 3, 1)),
 ]
 N_BOTH_KINDS = 32        # the first 32 cases: the (NRE4, NIM4) <= (2, 2) variants, which the one-launch kernels of small sweeps have too
 
@@ -215,7 +219,7 @@ def test_combine_lists_skip_exactly_zero_blocks_and_matrix_states(qd):
 
 
 def test_more_operators_than_the_combine_kernels_cover_take_the_gemm_route(qd):
-    """Nine COMPLEX operators (three groups of four of each kind; more than 8 per kind only go with one kind alone) and 17
+    """Thirteen COMPLEX operators (four groups of four of each kind; more than 12 per kind only go with one kind alone) and 17
     imaginary ones: the layout is not applicable and the sweep runs on the MFMA GEMM route as before; small sweeps (fewer
     than combine_min_cols state columns) likewise.  Ten imaginary operators at n = 40: the per-launch kernels have the variant,
     the one-launch kernel of small sweeps does not and hands the sweep over."""
@@ -225,7 +229,8 @@ def test_more_operators_than_the_combine_kernels_cover_take_the_gemm_route(qd):
     rng = np.random.default_rng(9)
     n = 64
     sched = FixedStepSchedule([0.0, 0.01], None, 0.01, _rk4_points)
-    for kinds, batch, want_combine in (("c" * 9, 300, False), ("i" * 17, 300, False), ("iiii", 100, False), ("iiii", 300, True)):
+    for kinds, batch, want_combine in (("c" * 13, 300, False), ("i" * 17, 300, False), ("iiii", 100, False), ("iiii", 300, True),
+                                       ("c" * 9, 300, True)):
         k = len(kinds)
         stack = qd.Stack(ctx, _operators(rng, n, kinds), None, None)
         table = rng.uniform(-1, 1, (batch, len(sched.times), k))

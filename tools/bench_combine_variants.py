@@ -29,7 +29,8 @@ y0 = np.zeros((n, 1), complex)
 y0[0] = 1
 for kinds, stat in (("iiiiiiii", None), ("iiiiiiii", "i"), ("iiiiiiii", "c"), ("iiii", None), ("iiii", "i"), ("iiii", "c"), ("cccc", None),
                     ("cccc", "c"), ("ii", "i"), ("cc", "c"), ("iiiiiicc", "i"), ("cccccccc", None), ("cccccccc", "c"),
-                    ("i" * 12, None), ("i" * 16, None), ("i" * 16, "i"), ("r" * 12, "c")):
+                    ("i" * 12, None), ("i" * 16, None), ("i" * 16, "i"), ("r" * 12, "c"),
+                    ("c" * 9, None), ("c" * 12, "c"), ("c" * 8 + "iii", None), ("c" * 13, None)):     # (round 5: a third group beside the other kind; 13: GEMM)
     st = qd.Stack(ctx, ops(kinds), None if stat is None else ops(stat)[0], None)
     table = rng.uniform(-1, 1, (B, nr, len(kinds)))
     res = {}
