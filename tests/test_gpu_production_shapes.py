@@ -638,6 +638,32 @@ def test_bench_two_ranks_share_one_gpu():
     assert out["roofline"]["frac"] <= 1.0
 
 
+def test_bench_two_ranks_share_one_gpu_with_the_sharded_cfg5_leg():
+    """The same two self-spawned ranks WITH the second sharded leg of `bench.py --gpus N`: BASELINE configs[4] (n = 4096,
+    Magnus-2, 1024 instances in total), 512 instances per rank -- every rank builds the 2.4 GB stack (one GPU: no RCCL
+    between them), solves its shard, the slowest rank's time is the leg's."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIDYN_BENCH_SHARE_GPU="1")
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--repeats", "1", "--no-projection", "--no-variants"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2
+    leg = out["sharded_cfg5"]
+    assert "error" not in leg, leg
+    assert leg["instances_total"] == 1024 and leg["instances_per_gpu"] == 512 and leg["n_gpus"] == 2
+    assert leg["max_norm_deviation_rank0"] < 1e-10 and leg["instance_steps_per_s"] > 1e4
+
+
 def test_c_program_drives_the_hot_path_through_the_c_abi(tmp_path):
     """tests/abi_solve.c: a C99 host (gcc, dlopen of ONE HIP runtime + librccl + libmidyn.so, no Python objects, no
     torch) creates a context and an operator stack, broadcasts it on a one-rank RCCL communicator, evaluates the RHS,
