@@ -117,7 +117,8 @@ def test_combine_kernel_variant_vs_oracle_and_gemm_route(qd, kinds, static_kind,
     assert int(cc["combine_info"]["ms"]) == 100 * variant[0] + 10 * variant[1] + variant[2], cc["combine_info"]
     # the default (combine = 1) takes the kernel only where it is the faster formulation (midyn_rk4.inc: plan_uses_combine)
     planes = sum(2 if kd == "c" else 1 for kd in kinds)          # at least three quarters of the plane slots must be in use
-    pays = 4 * planes >= 3 * 4 * (variant[0] + variant[1])
+    nq = variant[0] + variant[1]                                 # (five and six groups: seven eighths)
+    pays = 8 * planes >= 7 * 4 * nq if nq >= 5 else 4 * planes >= 3 * 4 * nq
     _, cd = _solve(qd, stack, "RK4", sched, table, y0, batch, False, 1)
     assert (cd["rhs_combine"]["launches"] == 12) == bool(pays), (variant, planes, cd)
     # 48 pairs of (32 rows, 32 columns): eight waves split every list (LDS tree); stacks of up to two plane groups run their
@@ -230,7 +231,7 @@ def test_more_operators_than_the_combine_kernels_cover_take_the_gemm_route(qd):
     n = 64
     sched = FixedStepSchedule([0.0, 0.01], None, 0.01, _rk4_points)
     for kinds, batch, want_combine in (("c" * 13, 300, False), ("i" * 17, 300, False), ("iiii", 100, False), ("iiii", 300, True),
-                                       ("c" * 9, 300, True)):
+                                       ("c" * 9, 300, False), ("c" * 11, 300, True)):
         k = len(kinds)
         stack = qd.Stack(ctx, _operators(rng, n, kinds), None, None)
         table = rng.uniform(-1, 1, (batch, len(sched.times), k))
