@@ -672,15 +672,28 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
             # per term and instance: 2 passes over the operator slots of every row; a pass gathers 2 complex numbers
             # from LDS and does 2 real x complex multiply-adds per slot and reads one operator element from L2
             form = int(ctx.counters("sweep_split")["ms"])          # 0 general (12 B elements), 1 packed, 2 direct (4 B)
-            elem_bytes = 12 if form == 0 else 4
+            elem_bytes = {0: 12, 1: 4, 2: 4, 3: 0}[form]
             flops = terms * count * 2 * slots * n * 2 * 4
             lds_bytes = terms * count * 2 * slots * n * 2 * 16
             l2_bytes = terms * count * 2 * slots * n * elem_bytes
             parts = int(ctx.counters("sweep_split")["launches"])   # workgroups per instance
             busy = min(count * parts, 256)
             form_name = {0: "general: 4 B column + 8 B value", 1: "packed: column | sign, one magnitude per slot",
-                         2: "direct: LDS address of the operand, one signed magnitude per slot"}[form]
-            if parts == 2:
+                         2: "direct: LDS address of the operand, one signed magnitude per slot",
+                         3: "none: one signed magnitude and one flip mask per slot, column = row ^ flip"}[form]
+            if parts == 2 and form == 3:
+                cross = ctx.counters("sweep_cross")
+                kname = "ell_flip_duo_kernel<2, 2, 1024>"
+                out["route"] = ("%s: ONE launch, TWO workgroups (1024 threads, half of the rows each) per instance through all steps; "
+                                "NO operator elements are read (every slot of this stack has one signed magnitude and one flip mask: "
+                                "the LDS address of an operand is the thread's own address XOR a per-slot constant; coefficients and "
+                                "flip masks through v_readlane from lane-held copies); each workgroup stages ITS half of an operand "
+                                "vector in LDS and applies the %d of %d slots that stay inside the half; the %d slots that reach across "
+                                "read their operands straight from the partner's payload (one set of 16-byte sc1 loads shared by the "
+                                "slots, issued inside the slot loop after half of the local slots, per-wave round flags; payload in the "
+                                "L2 the partners share -- plain stores -- or written through on different XCDs); series vectors in registers"
+                                % (kname, int(cross["ms"] - cross["launches"]), int(cross["ms"]), int(cross["launches"])))
+            elif parts == 2:
                 cross = ctx.counters("sweep_cross")
                 kname = "ell_sweep_duo_kernel<2, 2, 1024, %d>" % form
                 out["route"] = ("%s: ONE launch, TWO workgroups (1024 threads, half of the rows each) per instance through all "
@@ -715,10 +728,18 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
                         "cus_busy = instances x workgroups per instance (one workgroup per CU: LDS); frac_of_the_busy_cus "
                         "prices the same bytes against those CUs only.  Vector fp64, no MFMA: the operators have at most "
                         "19 non-zeros per row"}
+            if parts == 2 and form == 3:     # the two-workgroup kernel WITH operator elements beside it (ell_sweep_flip = 0)
+                with ctx.options(ell_sweep_flip=0):
+                    ys3, dev3, wall3, cs3 = measure(True)
+                out["two_workgroups_with_elements_route"] = {
+                    "kernel": "ell_sweep_duo_kernel<2, 2, 1024, 2>", "solve_s": round(wall3, 4),
+                    "ms_per_step": round(wall3 / n_steps * 1e3, 4), "kernel_ms_per_step": round(cs3["rk4_resident"]["ms"] / n_steps, 4),
+                    "us_per_term": round(cs3["rk4_resident"]["ms"] * 1e3 / max(terms, 1), 2), "cus_busy": busy,
+                    "max_abs_difference_to_the_default_route": float(np.max(np.abs(ys - ys3)))}
             if parts == 2:     # round 3's kernel beside it: one workgroup per instance (what a shard of more than 128 instances runs)
                 ys1, dev1, wall1, cs1 = measure(True, duo=0)
                 out["one_workgroup_per_instance_route"] = {
-                    "kernel": "ell_sweep_kernel<2, 4, 1024, %d>" % form, "solve_s": round(wall1, 4),
+                    "kernel": "ell_sweep_kernel<2, 4, 1024, %d>" % min(form, 2), "solve_s": round(wall1, 4),
                     "ms_per_step": round(wall1 / n_steps * 1e3, 4), "stream_ms_per_step": round(dev1 / n_steps, 4),
                     "kernel_ms_per_step": round(cs1["rk4_resident"]["ms"] / n_steps, 4),
                     "us_per_term": round(cs1["rk4_resident"]["ms"] * 1e3 / max(terms, 1), 2), "cus_busy": min(count, 256),

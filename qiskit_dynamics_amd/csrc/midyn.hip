@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,7 @@
 #include "../../include/midyn.h"
 #include "midyn_kernels.h"
 #include "midyn_resident.h"
+#include "midyn_flip.h"
 #include "midyn_combine.h"
 #include "midyn_combine_sweep.h"
 

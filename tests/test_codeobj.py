@@ -31,7 +31,10 @@ DEFAULT_ROUTE = (
     "rk4_resident_kernelILi2ELi8ELb0EE",
     "rk4_resident_kernelILi4ELi8ELb0EE",
     "ell_resident_kernelILi1ELi8EE",                             # cfg 4
-    "ell_sweep_duo_kernelILi2ELi2ELi1024ELi2EE",                 # cfg 5 shard (round 5): two workgroups per instance
+    "ell_flip_duo_kernelILi2ELi2ELi1024EE",                      # cfg 5 shard (round 5): two workgroups per instance, no operator elements
+    "ell_flip_duo_kernelILi1ELi2ELi1024EE",
+    "ell_flip_duo_kernelILi2ELi1ELi512EE",
+    "ell_sweep_duo_kernelILi2ELi2ELi1024ELi2EE",                 # ... with 4-byte elements (several flip masks in a slot)
     "ell_sweep_duo_kernelILi2ELi2ELi1024ELi1EE",
     "ell_sweep_duo_kernelILi1ELi2ELi1024ELi2EE",
     "ell_sweep_kernelILi2ELi4ELi1024ELi2EE",                     # cfg 5, more than 128 instances per GPU (direct element form)
@@ -75,10 +78,46 @@ def test_no_kernel_of_a_default_route_spills_registers(kernels):
 def test_register_budgets_of_the_one_workgroup_per_cu_kernels(kernels):
     """1024-thread workgroups get 128 registers per lane, 512-thread ones 256 (one workgroup per CU)."""
     for name, k in kernels.items():
-        if ("ell_sweep_kernelILi" in name or "ell_sweep_rk4_kernel" in name or "ell_sweep_duo_kernel" in name) and "ELi1024E" in name:
+        if ("ell_sweep_kernelILi" in name or "ell_sweep_rk4_kernel" in name or "ell_sweep_duo_kernel" in name or
+                "ell_flip_duo_kernel" in name) and "ELi1024E" in name:
             assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 128, (name, k[".vgpr_count"])
         if "rk4_resident_kernelILi" in name and "ELi8EL" in name:
             assert k[".vgpr_count"] + k.get(".agpr_count", 0) <= 256, (name, k[".vgpr_count"])
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="llvm-objdump of the ROCm image not found")
+def test_slot_loops_of_the_flip_kernel_wait_for_lds_only(tmp_path):
+    """ell_flip_duo_kernel<2, 2, 1024> (cfg 5 shard): a slot loop is readlanes, four LDS gathers, eight multiply-adds -- no
+    operator element is loaded, and NO `s_waitcnt vmcnt` sits between the gathers of a slot and the loop's back edge (hipcc put a
+    vmcnt(0) in front of the loops that follow the loads of the crossing operands, and one inside every slot loop when a path
+    with unconsumed loads reached the next pass: the exchange's latency, exposed; csrc/midyn_flip.h)."""
+    text = codeobj.disassembly(LIB, tmp_path, "/opt/rocm/lib/llvm/bin/llvm-objdump")
+    lines = text.split("\n")
+    start = next(i for i, l in enumerate(lines) if "ell_flip_duo_kernelILi2ELi2ELi1024EE" in l and l.rstrip().endswith(">:"))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].rstrip().endswith(">:"))
+    ops = [l.split("//")[0].split() for l in lines[start + 1:end]]
+    ops = [o for o in ops if o]
+    assert not any(o[0].startswith("scratch_") for o in ops)
+    # slot loops: a run of four ds_read_b128 followed (within 40 instructions) by a backward s_cbranch_scc1
+    loops = 0
+    i = 0
+    while i < len(ops):
+        if ops[i][0] == "ds_read_b128":
+            reads = [j for j in range(i, min(i + 12, len(ops))) if ops[j][0] == "ds_read_b128"]
+            if len(reads) >= 4:
+                tail = next((j for j in range(reads[3], min(reads[3] + 40, len(ops)))
+                             if ops[j][0] in ("s_cbranch_scc1", "s_cbranch_scc0") and int(ops[j][1]) > 60000), None)
+                if tail is not None:
+                    body = ops[reads[0]:tail]
+                    assert not any(o[0] == "s_waitcnt" and "vmcnt" in " ".join(o) for o in body), body
+                    assert not any(o[0].startswith(("global_load", "buffer_load")) for o in body), body
+                    assert sum(o[0] in ("v_fma_f64", "v_fmac_f64_e32") for o in body) == 8, body
+                    loops += 1
+                    i = tail
+            i = max(i + 1, reads[-1] + 1) if len(reads) >= 4 and tail is None else i + 1
+        else:
+            i += 1
+    assert loops >= 8, loops          # two planes x four parts of the local slots, two passes per term (+ order-1 tail)
 
 
 # ---- the tile loop of the MFMA contraction: every VALU instruction in it takes matrix-pipe cycles -------------------------

@@ -51,15 +51,19 @@ def _profiled(ctx, fn):
         ctx.set_option("profile", 0)
 
 
-@pytest.mark.parametrize("route", ["default", "one_workgroup_per_instance", "mfma_work_lists"])
+@pytest.mark.parametrize("route", ["default", "two_workgroups_with_elements", "one_workgroup_per_instance", "mfma_work_lists"])
 def test_cfg5_shard_vs_oracle(qd, route):
     """BASELINE cfg 5, the per-GPU shard of the 8-GPU run: 12 qubits (n = 4096), k = 8, diagonal rotating frame,
     scipy_expm with magnus_order = 2, max_dt = 0.25, T = 5 -> ALL 20 steps, 128 instances in ONE batched device
     solve, dense random y0.  Two routes, each asserted through the launch counters:
 
-      * "default": what the product (and bench.py's cfg5 leg) runs -- ONE launch of ell_sweep_duo_kernel<2,2,1024,2>: two
-        workgroups per instance, 256 workgroups for the 128 instances (counter "rk4_resident" == 1 launch, "sweep_split" ==
-        (2 workgroups per instance, element form 2 = direct), "sweep_cross" == (2 of the 19 slots reach across the halves: the drive and the XX coupling of the top qubit));
+      * "default": what the product (and bench.py's cfg5 leg) runs -- ONE launch of ell_flip_duo_kernel<2,2,1024>: two
+        workgroups per instance, 256 workgroups for the 128 instances, no operator elements at all (every slot of this stack has
+        one signed magnitude and one flip mask, column = row ^ flip) (counter "rk4_resident" == 1 launch, "sweep_split" ==
+        (2 workgroups per instance, element form 3 = flip masks), "sweep_cross" == (2 of the 19 slots reach across the halves:
+        the drive and the XX coupling of the top qubit));
+      * "two_workgroups_with_elements": option ell_sweep_flip = 0, ell_sweep_duo_kernel<2,2,1024,2> (4-byte elements from L2:
+        what a stack with one magnitude but several flip masks per slot runs);
       * "one_workgroup_per_instance": option ell_sweep_duo = 0, round 3's ell_sweep_kernel<2,4,1024,2> (what a shard of more
         than 128 instances runs);
       * "mfma_work_lists": option ell_sweep = 0, the SPARSE MFMA work-list contraction ("rhs_blocks_gemm").
@@ -83,14 +87,17 @@ def test_cfg5_shard_vs_oracle(qd, route):
     y0 /= np.linalg.norm(y0)
     h, t_final = 0.25, 5.0
     gave_up_before = ctx.counters("resident_fallbacks")["launches"]
-    with ctx.options(ell_sweep=0 if route == "mfma_work_lists" else 1, ell_sweep_duo=1 if route == "default" else 0):
+    duo = route in ("default", "two_workgroups_with_elements")
+    with ctx.options(ell_sweep=0 if route == "mfma_work_lists" else 1, ell_sweep_duo=1 if duo else 0,
+                     ell_sweep_flip=1 if route == "default" else 0):
         res = _profiled(ctx, lambda: solver.solve(t_span=[0.0, t_final], y0=y0, signals=sweeps, method="scipy_expm",
                                                   max_dt=h, magnus_order=2))
     if route != "mfma_work_lists":
         assert ctx.counters("rk4_resident")["launches"] == 1, "the one-launch sweep kernel did not take the solve"
         split = ctx.counters("sweep_split")
-        if route == "default":
-            assert (int(split["launches"]), int(split["ms"])) == (2, 2), f"not ell_sweep_duo_kernel<2,2,1024,2>: {split}"
+        if duo:
+            form = 3 if route == "default" else 2
+            assert (int(split["launches"]), int(split["ms"])) == (2, form), f"not the two-workgroup kernel of element form {form}: {split}"
             cross = ctx.counters("sweep_cross")
             assert (int(cross["launches"]), int(cross["ms"])) == (2, 19), cross
         else:

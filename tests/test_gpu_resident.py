@@ -539,8 +539,9 @@ def test_sweep_kernel_four_workgroups_per_instance_at_full_size(qd):
     solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
                        rotating_frame=np.diag(cfg["h_d"]).real.copy(), validate=False)
     out, split = {}, {}
-    for tag, sweep, parts, duo in (("four", 1, 3, 0), ("one", 1, 1, 0), ("two", 1, 1, 1), ("per_launch", 0, 1, 1)):
-        with ctx.options(ell_sweep=sweep, ell_sweep_split=parts, ell_sweep_duo=duo, profile=1):
+    for tag, sweep, parts, duo, flip in (("four", 1, 3, 0, 1), ("one", 1, 1, 0, 1), ("two", 1, 1, 1, 1), ("two_elements", 1, 1, 1, 0),
+                                         ("per_launch", 0, 1, 1, 1)):
+        with ctx.options(ell_sweep=sweep, ell_sweep_split=parts, ell_sweep_duo=duo, ell_sweep_flip=flip, profile=1):
             ctx.reset_counters()
             r = solver.solve(t_span=[0.0, 1.0], y0=cfg["y0"], signals=sweeps, method="scipy_expm", max_dt=0.25,
                              magnus_order=2, t_eval=[0.0, 0.5, 1.0])
@@ -550,9 +551,11 @@ def test_sweep_kernel_four_workgroups_per_instance_at_full_size(qd):
                 cross = ctx.counters("sweep_cross")
         out[tag] = np.stack([x.y for x in r])
     assert split["four"][0] == 4 and split["one"] == (1, 2), split     # (workgroups per instance, element form: 2 = direct)
-    # the default for this stack: two workgroups per instance, TWO of the 19 slots (the drive of the top qubit and its XX
-    # coupling) reach into the partner's half
-    assert split["two"] == (2, 2) and (cross["launches"], cross["ms"]) == (2, 19), (split, cross)
+    # the default for this stack: two workgroups per instance, no operator elements (form 3: one flip mask per slot), TWO of the
+    # 19 slots (the drive of the top qubit and its XX coupling) reach into the partner's half; with elements: form 2
+    assert split["two"] == (2, 3) and (cross["launches"], cross["ms"]) == (2, 19), (split, cross)
+    assert split["two_elements"] == (2, 2), split
+    assert_close(out["two_elements"], out["per_launch"], 1e-12)
     assert_close(out["four"], out["per_launch"], 1e-12)
     assert_close(out["one"], out["per_launch"], 1e-12)
     assert_close(out["two"], out["per_launch"], 1e-12)
@@ -604,8 +607,8 @@ def test_sweep_kernel_element_forms(qd, kind, form, nq, order):
     y0 /= np.linalg.norm(y0)
     out, forms = {}, {}
     parts = {}
-    for tag, opts in (("default", {}), ("one_workgroup", {"ell_sweep_duo": 0}), ("general", {"ell_sweep_packed": 0}),
-                      ("per_launch", {"ell_sweep": 0})):
+    for tag, opts in (("default", {}), ("with_elements", {"ell_sweep_flip": 0}), ("one_workgroup", {"ell_sweep_duo": 0}),
+                      ("general", {"ell_sweep_packed": 0}), ("per_launch", {"ell_sweep": 0})):
         with ctx.options(profile=1, **opts):
             ctx.reset_counters()
             r = solver.solve(t_span=[0.0, 0.4], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.05, magnus_order=order,
@@ -614,9 +617,13 @@ def test_sweep_kernel_element_forms(qd, kind, form, nq, order):
             forms[tag] = ctx.counters("sweep_split")["ms"]
             parts[tag] = ctx.counters("sweep_split")["launches"]
         out[tag] = np.stack([x.y for x in r])
-    assert forms["default"] == form and forms["one_workgroup"] == form and forms["general"] == 0, forms
-    # the packed forms of a small sweep share an instance between two workgroups by default (ell_sweep_duo_kernel)
-    assert parts["default"] == (2 if form else 1) and parts["one_workgroup"] == 1, parts
+    # the "direct" stacks (XX couplings, X drives) also have ONE flip mask per slot: their two-workgroup kernel reads no operator
+    # elements at all (form 3, ell_flip_duo_kernel); option ell_sweep_flip = 0 keeps the 4-byte elements
+    assert forms["default"] == (3 if form == 2 else form) and forms["with_elements"] == form, forms
+    assert forms["one_workgroup"] == form and forms["general"] == 0, forms
+    # the packed forms of a small sweep share an instance between two workgroups by default
+    assert parts["default"] == (2 if form else 1) and parts["with_elements"] == parts["default"] and parts["one_workgroup"] == 1, parts
+    assert_close(out["default"], out["with_elements"], 1e-12)
     assert_close(out["default"], out["one_workgroup"], 1e-12)
     assert_close(out["default"], out["general"], 1e-12)
     assert_close(out["default"], out["per_launch"], 1e-12)
@@ -625,6 +632,88 @@ def test_sweep_kernel_element_forms(qd, kind, form, nq, order):
         _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
                                            [0.0, 0.4], y0, "scipy_expm", 0.05, t_eval=[0.0, 0.15, 0.4], magnus_order=order)
         assert_close(out["default"][b], ref, SOLVE_TOL)
+
+
+@pytest.mark.parametrize("nq,order,framed,seed", [(9, 2, True, 1), (10, 2, True, 2), (10, 1, True, 3), (11, 2, False, 4),
+                                                  (12, 2, True, 5), (11, 1, False, 6), (9, 1, True, 7)])
+def test_flip_kernel_random_x_strings(qd, nq, order, framed, seed):
+    """Operators that are sums of RANDOM Pauli-X strings (flip masks anywhere: several crossing slots, partners in other waves,
+    other threads, other row indices; several sets of crossing operands): every slot of the stack has one signed magnitude and
+    one flip mask, so the two-workgroup kernel without operator elements takes the sweep (ell_flip_duo_kernel, element form 3)
+    -- against the same kernel family with elements (ell_sweep_flip = 0), one workgroup per instance, the launch-per-product
+    route and the oracle (reference: fixed_step_solvers.py:345-363)."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads as W
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(100 + seed)
+    n = 2**nq
+    rows = np.arange(n)
+
+    def xstring(mask):
+        m = np.zeros((n, n))
+        m[rows, rows ^ mask] = 1.0
+        return m
+
+    top = n >> 1
+    k = 3
+    used = set()
+
+    def fresh_mask(force_top):
+        while True:
+            mask = int(rng.integers(1, n))
+            mask = (mask | top) if force_top else mask
+            if mask not in used:
+                used.add(mask)
+                return mask
+
+    ops = []
+    for j in range(k):
+        op = np.zeros((n, n))
+        for t in range(3):
+            op += (0.3 + 0.2 * t + 0.05 * j) * (-1.0) ** t * xstring(fresh_mask(force_top=(t == 0)))
+        ops.append(2 * np.pi * 0.02 * op)
+    ops = np.stack(ops).astype(complex)
+    diag = 2 * np.pi * rng.uniform(0.0, 0.5, n) if framed else np.zeros(n)    # (the diagonal goes into the frame)
+    h_d = np.diag(diag).astype(complex)
+    for t in range(2):
+        h_d += 2 * np.pi * 0.004 * (t + 1) * xstring(fresh_mask(force_top=(t == 1)))
+    carrier = rng.uniform(0.2, 0.5, k)
+    nb = 5
+    sweeps = []
+    for b in range(nb):
+        amps, phases = W.sweep_parameters(b, k)
+        sweeps.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.5) ** 2) / 2.0), nu, ph)
+                       for a, nu, ph in zip(amps, carrier, phases)])
+    frame = diag.copy() if framed else None
+    solver = qd.Solver(static_hamiltonian=h_d, hamiltonian_operators=ops, rotating_frame=frame)
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    out, forms, parts = {}, {}, {}
+    for tag, opts in (("default", {}), ("with_elements", {"ell_sweep_flip": 0}), ("one_workgroup", {"ell_sweep_duo": 0}),
+                      ("per_launch", {"ell_sweep": 0})):
+        with ctx.options(profile=1, **opts):
+            ctx.reset_counters()
+            r = solver.solve(t_span=[0.0, 0.4], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.05, magnus_order=order,
+                             t_eval=[0.0, 0.15, 0.4])
+            assert ctx.counters("rk4_resident")["launches"] == (0 if tag == "per_launch" else 1)
+            forms[tag] = ctx.counters("sweep_split")["ms"]
+            parts[tag] = ctx.counters("sweep_split")["launches"]
+            if tag == "default":
+                cross = ctx.counters("sweep_cross")
+        out[tag] = np.stack([x.y for x in r])
+    assert (forms["default"], parts["default"]) == (3, 2), (forms, parts)
+    assert (forms["with_elements"], parts["with_elements"]) == (2, 2) and parts["one_workgroup"] == 1, (forms, parts)
+    assert cross["launches"] >= k + 1, cross        # every operator and the static part have a string that flips the top qubit
+    assert_close(out["default"], out["with_elements"], 1e-12)
+    assert_close(out["default"], out["one_workgroup"], 1e-12)
+    assert_close(out["default"], out["per_launch"], 1e-12)
+    if nq <= 10:        # (dense scipy expm per step on the CPU: seconds at n = 1024, minutes beyond)
+        a_d, a, d, basis = orc.hamiltonian_model_build(h_d, ops, frame)
+        for b in (0, nb - 1):
+            _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
+                                               [0.0, 0.4], y0, "scipy_expm", 0.05, t_eval=[0.0, 0.15, 0.4], magnus_order=order)
+            assert_close(out["default"][b], ref, SOLVE_TOL)
 
 
 def test_resident_kernel_rows_without_any_operator(qd):

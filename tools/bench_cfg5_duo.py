@@ -1,5 +1,5 @@
 """cfg 5 shard (n = 4096, Magnus 2, 20 steps): kernel time of the sweep kernels per series term -- one workgroup per instance
-(ell_sweep_kernel), two (ell_sweep_duo_kernel), and the duo kernel with parts switched off (ctx option `ablate`, results
+(ell_sweep_kernel), two with operator elements (ell_sweep_duo_kernel), two without (ell_flip_duo_kernel), and the two-workgroup kernels with parts switched off (ctx option `ablate`, results
 wrong: 1 no exchange, 2 write-through stores although the partners share an XCD, 4 no local slots, 8 no crossing slots).
     python tools/bench_cfg5_duo.py [instances ...]          (on the GPU box)"""
 import json
@@ -26,10 +26,13 @@ for count in [int(x) for x in sys.argv[1:]] or [128, 64, 16]:
         return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2, y0, count, True)
 
     ref = None
-    for tag, opts in (("one_workgroup", dict(ell_sweep_duo=0)), ("duo", {}), ("duo_write_through", dict(ablate=2)),
-                      ("duo_no_exchange", dict(ablate=1)), ("duo_no_local_slots", dict(ablate=4)),
-                      ("duo_no_crossing_slots", dict(ablate=8)), ("duo_exchange_only", dict(ablate=12)),
-                      ("duo_nothing", dict(ablate=13))):
+    fl = dict(ell_sweep_flip=0)
+    for tag, opts in (("one_workgroup", dict(ell_sweep_duo=0)), ("duo", dict(fl)), ("flip", {}),
+                      ("flip_write_through", dict(ablate=2)), ("flip_no_exchange", dict(ablate=1)),
+                      ("flip_no_local_slots", dict(ablate=4)), ("flip_no_crossing_slots", dict(ablate=8)),
+                      ("flip_no_ack_wait", dict(ablate=16)), ("flip_no_flag_poll", dict(ablate=32)), ("flip_nothing", dict(ablate=13)),
+                      ("duo_write_through", dict(fl, ablate=2)), ("duo_no_exchange", dict(fl, ablate=1)),
+                      ("duo_exchange_only", dict(fl, ablate=12)), ("duo_nothing", dict(fl, ablate=13))):
         with ctx.options(**opts):
             run()
             best = 1e9

@@ -1,0 +1,22 @@
+"""Where the wall clock of a cfg 5 shard solve goes on the host (MIDYN_TIMING=1 prints the marks of expm_action_solve).
+    MIDYN_TIMING=1 python tools/cfg5_host_timing.py          (on the GPU box)"""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import bench
+import qiskit_dynamics_amd as qd
+from qiskit_dynamics_amd import workloads
+from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+ctx = qd.default_context(0)
+cfg = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
+ops, static, fim, _ = bench.build_diag_frame_stack(cfg)
+stack = qd.Stack(ctx, ops, static, fim)
+sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(2))
+y0 = cfg["y0"].reshape(-1, 1)
+count = 128
+table, _, _ = bench.sweep_table(workloads, sched.times, 0, count, 8, cfg["carrier"], cfg["t_final"])
+def run():
+    return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2, y0, count, True)
+for i in range(4):
+    t0 = time.perf_counter(); ys = run(); t1 = time.perf_counter()
+    print("solve wall %.1f us" % ((t1 - t0) * 1e6), ys.shape, file=sys.stderr, flush=True)
