@@ -100,6 +100,12 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         <= CUs (n_pad = 4096); the partners all-gather every operand vector through a sentinel-polled
  *                         ring.  2: also 2 workgroups per instance; 3: packed stacks too (measured slower than the
  *                         packed one-workgroup kernel at every shard size); 0: never
+ *   ell_sweep_duo [1]     ... small shards (2 x instances <= CUs) of stacks WITH a packed form, n_pad a power of two in
+ *                         [512, 4096]: TWO workgroups per instance, half of the rows each; the slots that stay inside a
+ *                         half run while the partner's half arrives through the L2 the two share (ell_sweep_duo_kernel); 0: never
+ *   ell_sweep_flip [1]    ... and when every slot of the stack also has ONE flip mask (column = row ^ flip in every row:
+ *                         sums of Pauli strings without Z factors), the two-workgroup kernel that reads no operator
+ *                         elements at all (csrc/midyn_flip.h: ell_flip_duo_kernel); 0: ell_sweep_duo_kernel
  *   resident_spin_limit [2^21]   polls a wait inside a one-launch kernel (rk4_resident, ell_resident, ell_sweep_split)
  *                         may take before it gives up; the solve then re-runs the step range on the launch-per-product
  *                         route by itself (counter "resident_fallbacks").  -1 restores the default; 0 = give up at the

@@ -26,6 +26,14 @@
 #pragma once
 #include <type_traits>
 
+#ifndef MIDYN_FLIP_ABLATE
+#define MIDYN_FLIP_ABLATE 0
+#endif
+#ifndef MIDYN_FLIP_SMEM
+#define MIDYN_FLIP_SMEM 1     // slot coefficients through the scalar cache (0: v_readlane from lane-held copies)
+#endif
+#define MIDYN_CONST_AS __attribute__((address_space(4)))
+
 namespace midyn {
 
 typedef double flip_d2 __attribute__((ext_vector_type(2)));
@@ -190,6 +198,30 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
     // loads issued before it are still in flight (s_waitcnt vmcnt(0) in the preheader: the whole latency, exposed), but not
     // around the back edge of a loop that issues them itself.  (All three steps inside one loop over all local slots cost
     // 1 us per term in scalar compares: a slot is twenty instructions.)
+    // The two coefficients of slot j as the current pass uses them (pass_swapped: the second pass of a term applies the
+    // coefficient sets the other way round).  MIDYN_FLIP_SMEM: one 16-byte scalar load per slot from the table of this
+    // (instance, step) -- requested before the slot's gathers and waited for with them (lgkmcnt), no VALU instruction; the
+    // flip mask, which the gathers need FIRST, stays a v_readlane.  (Measured, cfg 5 shard, the slot loops alone: with the
+    // gathers removed they still took 6.0 of their 6.7 us per term -- eight multiply-adds, five v_readlane and two XORs per slot
+    // are the bound, not the LDS; the scale of the second sum went into the staged operand for the same reason.)
+    bool pass_swapped = false;
+    const MIDYN_CONST_AS flip_d2* ccab = nullptr;     // the coefficient table of this (instance, step)
+    auto coef_a = [&](const int j) {
+#if MIDYN_FLIP_SMEM
+        const flip_d2 cc = ccab[j];
+        return pass_swapped ? cc.y : cc.x;
+#else
+        return lane_f64(wa_l, j);
+#endif
+    };
+    auto coef_b = [&](const int j) {
+#if MIDYN_FLIP_SMEM
+        const flip_d2 cc = ccab[j];
+        return pass_swapped ? cc.x : cc.y;
+#else
+        return lane_f64(wb_l, j);
+#endif
+    };
     unsigned la[RPT];           // LDS byte address of this thread's rows
 #pragma unroll
     for (int i = 0; i < RPT; ++i) la[i] = (unsigned)(tid + TH * i) << 4;
@@ -201,11 +233,24 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
             double2 x1[RPT], x2[RPT];
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
+#if MIDYN_FLIP_ABLATE == 2       // profiling only: no gathers
+                x1[i] = make_double2(__hiloint2double((int)xm, (int)la[i]), 1.0);
+                x2[i] = x1[i];
+#else
                 const char* q = lds + (la[i] ^ xm);
                 x1[i] = *reinterpret_cast<const double2*>(q);
                 x2[i] = ORDER == 2 ? *reinterpret_cast<const double2*>(q + 32768) : x1[i];
+#endif
             }
-            slot_fma(IM, lane_f64(wa_l, j), ORDER == 2 ? lane_f64(wb_l, j) : 0.0, x1, x2, o1, o2);
+#if MIDYN_FLIP_ABLATE == 1           // profiling only: one add per gathered operand instead of the multiply-adds
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                o1[i].x += x1[i].x + x1[i].y;
+                o2[i].x += x2[i].x + x2[i].y;
+            }
+#else
+            slot_fma(IM, coef_a(j), ORDER == 2 ? coef_b(j) : 0.0, x1, x2, o1, o2);
+#endif
         }
     };
     auto run_local = [&](const int j_lo, const int j_hi, auto& hook, double2 (&o1)[RPT], double2 (&o2)[RPT]) {
@@ -223,9 +268,14 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
                                  const bool use_dp, const bool swapped, const bool keep, const double scale2,
                                  double2 (&o1)[RPT], double2 (&o2)[RPT]) {
         const int slot = ORDER == 2 ? (nv == 2 ? 1 : 0) : (rr & 1);      // payload slot(s) of this round
+        // (the scale of the second sum is applied to its OPERAND -- staged and published scaled -- not to every slot's coefficient)
         const double sc2 = keep ? scale2 : 1.0;
+        pass_swapped = swapped;
         wa_l = swapped ? cy_l : cx_l;
-        wb_l = (swapped ? cx_l : cy_l) * sc2;
+        wb_l = swapped ? cx_l : cy_l;
+        double2 in2s[RPT];
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) in2s[i] = keep ? make_double2(sc2 * in2[i].x, sc2 * in2[i].y) : in2[i];
         if (exch) {                        // the rows leave first: nothing below needs them before the partner does
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
@@ -233,7 +283,7 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
 #pragma unroll
                 for (int v = 0; v < ORDER; ++v) {
                     if (v >= nv) continue;
-                    const double2 z = v ? in2[i] : in1[i];
+                    const double2 z = v ? in2s[i] : in1[i];
                     sweep_u4 w;
                     const unsigned long long zx = (unsigned long long)__double_as_longlong(z.x), zy = (unsigned long long)__double_as_longlong(z.y);
                     w.x = (unsigned)zx; w.y = (unsigned)(zx >> 32); w.z = (unsigned)zy; w.w = (unsigned)(zy >> 32);
@@ -247,7 +297,7 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
         for (int i = 0; i < RPT; ++i) {
             const unsigned l = rowof(i);
             *reinterpret_cast<double2*>(lds + (l << 4)) = in1[i];
-            if (ORDER == 2) *reinterpret_cast<double2*>(lds + (l << 4) + 32768) = in2[i];
+            if (ORDER == 2) *reinterpret_cast<double2*>(lds + (l << 4) + 32768) = in2s[i];
             o1[i] = make_double2(0.0, 0.0);
             if (!keep) o2[i] = make_double2(0.0, 0.0);
         }
@@ -298,9 +348,8 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
             }
             unpacked = true;
         };
-        auto cross_apply = [&](const int j) {
+        auto cross_apply = [&](const int j, const double ca, const double cb) {
             const int mt = lane_i32(meta_l, j);
-            const double ca = lane_f64(wa_l, j), cb = ORDER == 2 ? lane_f64(wb_l, j) : 0.0;
             const unsigned m = (unsigned)(mt & 0x7fffffff);
             const int ft = (int)(m & (unsigned)(TH - 1)), fi = (int)((m >> LOG_TH) & (unsigned)(RPT - 1));
             if (ft != ft_loaded) cross_load(ft);
@@ -349,13 +398,21 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
                 cross_load(ft0);
             }
         };
+        const int c3 = (a.ablate & 128) ? cut[2] + 1 : ((a.ablate & 256) ? (3 * n_loc) / 4 : cut[3]);
         run_local(cut[0], cut[1], nothing, o1, o2);
         if (!flagged) raise_flag();
         run_local(cut[1], cut[2], nothing, o1, o2);
-        run_local(cut[2], cut[3], ask, o1, o2);
-        run_local(cut[3], cut[4], fetch, o1, o2);
-        if (xc)
-            for (int jc = n_loc; jc < n_all; ++jc) cross_apply(jc);
+        run_local(cut[2], c3, ask, o1, o2);
+        run_local(c3, cut[4], fetch, o1, o2);
+        if (xc && !(a.ablate & 64)) {
+            // (the coefficients of the first two crossing slots are asked for together, before the wait for the operands: a scalar
+            // load in front of every crossing slot was 0.4 us per term, all waves of the workgroup waiting for it at once)
+            const int j0 = n_loc, j1 = n_loc + 1 < n_all ? n_loc + 1 : n_loc;
+            const double ca0 = coef_a(j0), cb0 = ORDER == 2 ? coef_b(j0) : 0.0, ca1 = coef_a(j1), cb1 = ORDER == 2 ? coef_b(j1) : 0.0;
+            cross_apply(j0, ca0, cb0);
+            if (j1 > j0) cross_apply(j1, ca1, cb1);
+            for (int jc = n_loc + 2; jc < n_all; ++jc) cross_apply(jc, coef_a(jc), ORDER == 2 ? coef_b(jc) : 0.0);
+        }
         // (nothing is in flight here -- said in a form the compiler's counter model reads: otherwise a path on which loaded
         // operands were never consumed reaches the next pass, and the slot loops that reuse their registers wait for vmcnt(0),
         // i.e. for the acknowledgement of the stores issued just before them)
@@ -364,7 +421,8 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
     for (int st = 0; st < a.nsteps; ++st) {
         const int r0 = a.rows[3 * st];
         const double h = a.hs[st];
-        if (lane < n_all) {
+        ccab = (const MIDYN_CONST_AS flip_d2*)(a.cab + ((size_t)b * a.nsteps + st) * a.wsp);
+        if (!MIDYN_FLIP_SMEM && lane < n_all) {
             const flip_d2 cc = a.cab[((size_t)b * a.nsteps + st) * a.wsp + lane];
             cx_l = cc.x;
             cy_l = cc.y;
