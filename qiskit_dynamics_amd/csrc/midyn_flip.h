@@ -354,16 +354,45 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
             const int ft = (int)(m & (unsigned)(TH - 1)), fi = (int)((m >> LOG_TH) & (unsigned)(RPT - 1));
             if (ft != ft_loaded) cross_load(ft);
             if (!unpacked) cross_unpack();
-            if (RPT == 2 && fi) {       // (the slot flips the row index too: the same rows, swapped)
-                double2 y1[RPT], y2[RPT];
+            if (a.ablate & 512) {       // profiling only: the wait for the operands and one add, no multiply-adds
+                o1[0].x += xb1[0].x + xb2[RPT - 1].y;
+                return;
+            }
+            // Four straight-line variants (plane x row flip), every multiply-add IN PLACE (v_fmac_f64 through asm): written with
+            // fma() the variants leave their sums in different registers and the merge costs eight 64-bit moves per variant --
+            // the two crossing slots of cfg 5 took 1.0 us per term that way, as much as six local slots.
+            auto fmac = [](double& acc, const double c, const double x) { asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(acc) : "s"(c), "v"(x)); };
+            const double na = -ca, nb = -cb;
+            auto block = [&](auto im_tag, auto fi_tag) {
+                constexpr bool IM = decltype(im_tag)::value;
+                constexpr int FI = decltype(fi_tag)::value;
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) {
-                    y1[i] = xb1[RPT - 1 - i];
-                    y2[i] = xb2[RPT - 1 - i];
+                    const double2 x1 = xb1[i ^ FI], x2 = xb2[i ^ FI];
+                    if (IM) {
+                        fmac(o1[i].x, na, x1.y);
+                        fmac(o1[i].y, ca, x1.x);
+                        if (ORDER == 2) {
+                            fmac(o2[i].x, nb, x2.y);
+                            fmac(o2[i].y, cb, x2.x);
+                        }
+                    } else {
+                        fmac(o1[i].x, ca, x1.x);
+                        fmac(o1[i].y, ca, x1.y);
+                        if (ORDER == 2) {
+                            fmac(o2[i].x, cb, x2.x);
+                            fmac(o2[i].y, cb, x2.y);
+                        }
+                    }
                 }
-                slot_fma(mt < 0, ca, cb, y1, y2, o1, o2);
+            };
+            const bool im = mt < 0;
+            if (RPT == 2 && fi) {       // (the slot flips the row index too: the same rows, swapped)
+                if (im) block(std::true_type(), std::integral_constant<int, RPT == 2 ? 1 : 0>());
+                else block(std::false_type(), std::integral_constant<int, RPT == 2 ? 1 : 0>());
             } else {
-                slot_fma(mt < 0, ca, cb, xb1, xb2, o1, o2);
+                if (im) block(std::true_type(), std::integral_constant<int, 0>());
+                else block(std::false_type(), std::integral_constant<int, 0>());
             }
         };
         const bool xc = exch && !dead && !(a.ablate & 8);
@@ -412,6 +441,7 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
             cross_apply(j0, ca0, cb0);
             if (j1 > j0) cross_apply(j1, ca1, cb1);
             for (int jc = n_loc + 2; jc < n_all; ++jc) cross_apply(jc, coef_a(jc), ORDER == 2 ? coef_b(jc) : 0.0);
+            // (from lane-held copies through v_readlane instead: the same 10.2 us per term)
         }
         // (nothing is in flight here -- said in a form the compiler's counter model reads: otherwise a path on which loaded
         // operands were never consumed reaches the next pass, and the slot loops that reuse their registers wait for vmcnt(0),
