@@ -739,7 +739,7 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
             if parts == 2:     # round 3's kernel beside it: one workgroup per instance (what a shard of more than 128 instances runs)
                 ys1, dev1, wall1, cs1 = measure(True, duo=0)
                 out["one_workgroup_per_instance_route"] = {
-                    "kernel": "ell_sweep_kernel<2, 4, 1024, %d>" % min(form, 2), "solve_s": round(wall1, 4),
+                    "kernel": "ell_sweep_kernel<2, 4, 1024, %d>" % form, "solve_s": round(wall1, 4),
                     "ms_per_step": round(wall1 / n_steps * 1e3, 4), "stream_ms_per_step": round(dev1 / n_steps, 4),
                     "kernel_ms_per_step": round(cs1["rk4_resident"]["ms"] / n_steps, 4),
                     "us_per_term": round(cs1["rk4_resident"]["ms"] * 1e3 / max(terms, 1), 2), "cus_busy": min(count, 256),

@@ -222,9 +222,15 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
         return lane_f64(wb_l, j);
 #endif
     };
-    unsigned la[RPT];           // LDS byte address of this thread's rows
+    // LDS byte address of this thread's rows as an INTEGER in the LDS address space: (la ^ flip) is then the operand's address with
+    // no addition of the (link-time) base of the dynamic LDS per gather -- two of a slot's thirteen vector instructions.  XOR and
+    // base commute only when the base has no bit below 64 KB: this kernel declares no static LDS (base 0); checked once.
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds_base = (unsigned)(size_t)(lds_char*)flip_lds;
+    if (lds_base & 0xffffu) __builtin_trap();
+    unsigned la[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) la[i] = (unsigned)(tid + TH * i) << 4;
+    for (int i = 0; i < RPT; ++i) la[i] = lds_base + ((unsigned)(tid + TH * i) << 4);
     auto run_plane = [&](const int j_lo, const int j_hi, auto im_tag, const int j_ev, auto& hook, double2 (&o1)[RPT], double2 (&o2)[RPT]) {
         constexpr bool IM = decltype(im_tag)::value;
         for (int j = j_lo; j < j_hi; ++j) {
@@ -237,9 +243,11 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
                 x1[i] = make_double2(__hiloint2double((int)xm, (int)la[i]), 1.0);
                 x2[i] = x1[i];
 #else
-                const char* q = lds + (la[i] ^ xm);
-                x1[i] = *reinterpret_cast<const double2*>(q);
-                x2[i] = ORDER == 2 ? *reinterpret_cast<const double2*>(q + 32768) : x1[i];
+                typedef __attribute__((address_space(3))) const flip_d2 lds_d2;
+                lds_d2* q = (lds_d2*)(size_t)(la[i] ^ xm);
+                const flip_d2 g1 = q[0], g2 = ORDER == 2 ? q[2048] : g1;       // (X2: 32768 bytes behind)
+                x1[i] = make_double2(g1.x, g1.y);
+                x2[i] = make_double2(g2.x, g2.y);
 #endif
             }
 #if MIDYN_FLIP_ABLATE == 1           // profiling only: one add per gathered operand instead of the multiply-adds

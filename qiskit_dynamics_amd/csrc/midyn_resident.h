@@ -729,6 +729,9 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
 //   * All global addresses are a uniform base plus a 32-bit byte offset that passes through an empty asm at every use;
 //     otherwise hipcc hoists the 64-bit address of every (array, row) pair out of the step loop and spills them.
 // ------------------------------------------------------------------------------------------------
+#ifndef MIDYN_CONST_AS
+#define MIDYN_CONST_AS __attribute__((address_space(4)))
+#endif
 constexpr int SWEEP_THREADS = 1024;
 constexpr int SWEEP_MAX_RPT = 4;      // rows per thread (template parameter RPT): n_pad = 1024 * RPT <= 4096
 constexpr int SWEEP_MAX_SLOTS = 256;  // grouped slots per row at most
@@ -822,7 +825,17 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
     // those of slot e0 + s + PF as soon as it has been copied out (the slot loop is unrolled by PF).
     // (measured, us per term, cfg 5 shape, none / 2 / 3 stages: direct form 19.9 / 18.1 / 19.3, packed 23.6 / 21.3 / 22.6; the
     // 12-byte elements of the general form do not have the registers: 31.7 / 35.2 / 40.3)
-    constexpr bool PFON = PACKED != 0 && PFD > 0;
+    constexpr bool PFON = (PACKED == 1 || PACKED == 2) && PFD > 0;     // (PACKED 3: there are no elements to fetch)
+    // PACKED 3 (every slot has ONE flip mask, column = row ^ flip: csrc/midyn_flip.h): the LDS byte address of an operand is the
+    // thread's own address XOR a per-slot constant, read through the scalar cache (a.pk: [wsp] flips in the chunked layout)
+    unsigned lax[PACKED == 3 ? SWEEP_RPT : 1];
+    if (PACKED == 3) {
+#pragma unroll
+        for (int i = 0; i < SWEEP_RPT; ++i) {
+            const unsigned r_ = row0 + (unsigned)(tid + TH * i);
+            lax[PACKED == 3 ? i : 0] = (((r_ >> 11) << 12) | (r_ & 2047u)) << 4;
+        }
+    }
     constexpr int PF = PFON ? PFD : 1;
     int cn[PF][SWEEP_RPT];
     double vn[PF][SWEEP_RPT];
@@ -832,6 +845,8 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
             if (MIDYN_SWEEP_ABLATE == 3) {
                 c_[i] = (int)((((unsigned)e_ * unp + ROW(i)) * 2654435761u) >> 8) & (np - 1);
                 v_[i] = 1e-3;
+            } else if (PACKED == 3) {
+                c_[i] = 0;
             } else if (PACKED) {
                 c_[i] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(a.pk + ((size_t)e_ * unp + row0)) + boff(i, 2));
             } else {
@@ -846,15 +861,16 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
         const double ca = swapped ? cc.y : cc.x, cb = (swapped ? cc.x : cc.y) * (KEEP_O2 ? scale2 : 1.0); \
         int cl[SWEEP_RPT];                                                                       \
         double va[SWEEP_RPT];                                                                    \
-        if (!PFON) fetch(e, cn[S_], vn[S_]);                                                 \
+        if (!PFON && PACKED != 3) fetch(e, cn[S_], vn[S_]);                                  \
+        const unsigned xm_ = PACKED == 3 ? (unsigned)((const MIDYN_CONST_AS int*)(a.pk))[e] : 0u; \
         _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
-            cl[i] = cn[S_][i];                                                                   \
+            cl[i] = PACKED == 3 ? (int)(lax[PACKED == 3 ? i : 0] ^ xm_) : cn[S_][i];             \
             if (PACKED == 0) va[i] = vn[S_][i];                                                    \
         }                                                                                        \
         if (PFON && e + PF < hi) fetch(e + PF, cn[S_], vn[S_]);                              \
         double2 x1[SWEEP_RPT], x2[SWEEP_RPT];                                                    \
         _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
-            if (PACKED == 2) {   /* the element IS the LDS byte address of its X1 operand */          \
+            if (PACKED >= 2) {   /* the element IS the LDS byte address of its X1 operand */          \
                 const char* q = reinterpret_cast<const char*>(sweep_lds) +                       \
                                 (MIDYN_SWEEP_ABLATE == 2 ? (unsigned)((cl[i] & 48) + (tid << 4)) : (unsigned)cl[i]); \
                 x1[i] = *reinterpret_cast<const double2*>(q);                                    \
@@ -868,7 +884,7 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
         }                                                                                        \
         _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
             double wa = ca, wb = cb;                                                             \
-            if (PACKED == 2) {                                                                   \
+            if (PACKED >= 2) {                                                                   \
             } else if (PACKED == 1) {   /* the sign of the element goes into the gathered operand (in place) */ \
                 const long long sgn = (long long)(((unsigned long long)(unsigned)cl[i] & 0x80000000ull) << 32); \
                 x1[i].x = __longlong_as_double(__double_as_longlong(x1[i].x) ^ sgn);             \
@@ -951,8 +967,8 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
     // the X2 operand of a column sits 32768 bytes behind its X1 operand -- an immediate offset of the same address.
     const int lstride = np + 1;
     double2* const X1 = sweep_lds;
-    double2* const X2 = PACKED == 2 ? sweep_lds + 2048 : sweep_lds + lstride;
-    auto xrow = [&](const int r_) { return PACKED == 2 ? ((r_ >> 11) << 12) | (r_ & 2047) : r_; };   // index of column r_ in X1 / X2
+    double2* const X2 = PACKED >= 2 ? sweep_lds + 2048 : sweep_lds + lstride;
+    auto xrow = [&](const int r_) { return PACKED >= 2 ? ((r_ >> 11) << 12) | (r_ & 2047) : r_; };   // index of column r_ in X1 / X2
     auto rowof = [&](const int i_) {   // tid + TH i_, opaque to the optimiser (see boff below: nothing derived from it is hoisted)
         int r_ = tid + TH * i_;
         asm volatile("" : "+v"(r_));
@@ -978,7 +994,7 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
         ACC(i) = (r < a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + r] : make_double2(0.0, 0.0);
     }
     for (int e = tid; e < a.wsp; e += TH) stag[e] = a.tags[e];
-    if (tid == 0 && PACKED != 2) {
+    if (tid == 0 && PACKED < 2) {
         X1[np] = make_double2(0.0, 0.0);
         if (ORDER == 2) X2[np] = make_double2(0.0, 0.0);
     }
@@ -1779,6 +1795,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
     MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_kernel<2, R_, T_, P_>(const SweepArgs);   \
     MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_rk4_kernel<R_, T_, P_>(const SweepArgs);
 MIDYN_SWEEP_SHAPES(MIDYN_X)
+#undef MIDYN_X
+#define MIDYN_X(R_, T_)   /* element form 3 (flip masks, no elements): the expm sweeps */                          \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_kernel<1, R_, T_, 3>(const SweepArgs);   \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_kernel<2, R_, T_, 3>(const SweepArgs);
+MIDYN_X(1, 256) MIDYN_X(1, 512) MIDYN_X(1, 1024) MIDYN_X(2, 1024) MIDYN_X(4, 1024)
 #undef MIDYN_X
 #define MIDYN_X(O_, P_)                                                                                   \
     MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_duo_kernel<O_, 2, 1024, P_>(const SweepDuoArgs);  \

@@ -37,7 +37,8 @@ DEFAULT_ROUTE = (
     "ell_sweep_duo_kernelILi2ELi2ELi1024ELi2EE",                 # ... with 4-byte elements (several flip masks in a slot)
     "ell_sweep_duo_kernelILi2ELi2ELi1024ELi1EE",
     "ell_sweep_duo_kernelILi1ELi2ELi1024ELi2EE",
-    "ell_sweep_kernelILi2ELi4ELi1024ELi2EE",                     # cfg 5, more than 128 instances per GPU (direct element form)
+    "ell_sweep_kernelILi2ELi4ELi1024ELi3EE",                     # cfg 5, more than 128 instances per GPU (no operator elements)
+    "ell_sweep_kernelILi2ELi4ELi1024ELi2EE",                     # ... direct element form
     "ell_sweep_kernelILi2ELi4ELi1024ELi1EE",
     "ell_sweep_kernelILi2ELi4ELi1024ELi0EE",
     "ell_sweep_kernelILi1ELi4ELi1024ELi2EE",

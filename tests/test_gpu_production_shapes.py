@@ -51,7 +51,8 @@ def _profiled(ctx, fn):
         ctx.set_option("profile", 0)
 
 
-@pytest.mark.parametrize("route", ["default", "two_workgroups_with_elements", "one_workgroup_per_instance", "mfma_work_lists"])
+@pytest.mark.parametrize("route", ["default", "two_workgroups_with_elements", "one_workgroup_per_instance",
+                                   "one_workgroup_with_elements", "mfma_work_lists"])
 def test_cfg5_shard_vs_oracle(qd, route):
     """BASELINE cfg 5, the per-GPU shard of the 8-GPU run: 12 qubits (n = 4096), k = 8, diagonal rotating frame,
     scipy_expm with magnus_order = 2, max_dt = 0.25, T = 5 -> ALL 20 steps, 128 instances in ONE batched device
@@ -64,8 +65,9 @@ def test_cfg5_shard_vs_oracle(qd, route):
         the drive and the XX coupling of the top qubit));
       * "two_workgroups_with_elements": option ell_sweep_flip = 0, ell_sweep_duo_kernel<2,2,1024,2> (4-byte elements from L2:
         what a stack with one magnitude but several flip masks per slot runs);
-      * "one_workgroup_per_instance": option ell_sweep_duo = 0, round 3's ell_sweep_kernel<2,4,1024,2> (what a shard of more
-        than 128 instances runs);
+      * "one_workgroup_per_instance": option ell_sweep_duo = 0, ell_sweep_kernel<2,4,1024,3> (what a shard of more than 128
+        instances runs: round 3's kernel without operator elements); "one_workgroup_with_elements": also ell_sweep_flip = 0,
+        round 3's ell_sweep_kernel<2,4,1024,2>;
       * "mfma_work_lists": option ell_sweep = 0, the SPARSE MFMA work-list contraction ("rhs_blocks_gemm").
 
     Instances 0, 63 and 127 are compared with a CPU evaluation of the same 20 steps that uses the ORACLE's generators
@@ -89,7 +91,7 @@ def test_cfg5_shard_vs_oracle(qd, route):
     gave_up_before = ctx.counters("resident_fallbacks")["launches"]
     duo = route in ("default", "two_workgroups_with_elements")
     with ctx.options(ell_sweep=0 if route == "mfma_work_lists" else 1, ell_sweep_duo=1 if duo else 0,
-                     ell_sweep_flip=1 if route == "default" else 0):
+                     ell_sweep_flip=1 if route in ("default", "one_workgroup_per_instance") else 0):
         res = _profiled(ctx, lambda: solver.solve(t_span=[0.0, t_final], y0=y0, signals=sweeps, method="scipy_expm",
                                                   max_dt=h, magnus_order=2))
     if route != "mfma_work_lists":
@@ -101,7 +103,8 @@ def test_cfg5_shard_vs_oracle(qd, route):
             cross = ctx.counters("sweep_cross")
             assert (int(cross["launches"]), int(cross["ms"])) == (2, 19), cross
         else:
-            assert (int(split["launches"]), int(split["ms"])) == (1, 2), f"not ell_sweep_kernel<2,4,1024,2>: {split}"
+            form = 3 if route == "one_workgroup_per_instance" else 2
+            assert (int(split["launches"]), int(split["ms"])) == (1, form), f"not ell_sweep_kernel<2,4,1024,{form}>: {split}"
         assert ctx.counters("rhs_blocks_gemm")["launches"] == 0
         assert ctx.counters("resident_fallbacks")["launches"] == gave_up_before, "the sweep kernel gave up"
     else:

@@ -550,7 +550,7 @@ def test_sweep_kernel_four_workgroups_per_instance_at_full_size(qd):
             if tag == "two":
                 cross = ctx.counters("sweep_cross")
         out[tag] = np.stack([x.y for x in r])
-    assert split["four"][0] == 4 and split["one"] == (1, 2), split     # (workgroups per instance, element form: 2 = direct)
+    assert split["four"][0] == 4 and split["one"] == (1, 3), split     # (workgroups per instance, element form: 3 = flip masks only)
     # the default for this stack: two workgroups per instance, no operator elements (form 3: one flip mask per slot), TWO of the
     # 19 slots (the drive of the top qubit and its XX coupling) reach into the partner's half; with elements: form 2
     assert split["two"] == (2, 3) and (cross["launches"], cross["ms"]) == (2, 19), (split, cross)
@@ -608,6 +608,7 @@ def test_sweep_kernel_element_forms(qd, kind, form, nq, order):
     out, forms = {}, {}
     parts = {}
     for tag, opts in (("default", {}), ("with_elements", {"ell_sweep_flip": 0}), ("one_workgroup", {"ell_sweep_duo": 0}),
+                      ("one_workgroup_with_elements", {"ell_sweep_duo": 0, "ell_sweep_flip": 0}),
                       ("general", {"ell_sweep_packed": 0}), ("per_launch", {"ell_sweep": 0})):
         with ctx.options(profile=1, **opts):
             ctx.reset_counters()
@@ -620,11 +621,13 @@ def test_sweep_kernel_element_forms(qd, kind, form, nq, order):
     # the "direct" stacks (XX couplings, X drives) also have ONE flip mask per slot: their two-workgroup kernel reads no operator
     # elements at all (form 3, ell_flip_duo_kernel); option ell_sweep_flip = 0 keeps the 4-byte elements
     assert forms["default"] == (3 if form == 2 else form) and forms["with_elements"] == form, forms
-    assert forms["one_workgroup"] == form and forms["general"] == 0, forms
+    assert forms["one_workgroup"] == (3 if form == 2 else form) and forms["general"] == 0, forms
     # the packed forms of a small sweep share an instance between two workgroups by default
     assert parts["default"] == (2 if form else 1) and parts["with_elements"] == parts["default"] and parts["one_workgroup"] == 1, parts
+    assert forms["one_workgroup_with_elements"] == form and parts["one_workgroup_with_elements"] == 1, (forms, parts)
     assert_close(out["default"], out["with_elements"], 1e-12)
     assert_close(out["default"], out["one_workgroup"], 1e-12)
+    assert_close(out["default"], out["one_workgroup_with_elements"], 1e-12)
     assert_close(out["default"], out["general"], 1e-12)
     assert_close(out["default"], out["per_launch"], 1e-12)
     a_d, a, d, basis = orc.hamiltonian_model_build(h_d, ops, frame)
@@ -691,7 +694,7 @@ def test_flip_kernel_random_x_strings(qd, nq, order, framed, seed):
     y0 /= np.linalg.norm(y0)
     out, forms, parts = {}, {}, {}
     for tag, opts in (("default", {}), ("with_elements", {"ell_sweep_flip": 0}), ("one_workgroup", {"ell_sweep_duo": 0}),
-                      ("per_launch", {"ell_sweep": 0})):
+                      ("one_workgroup_with_elements", {"ell_sweep_duo": 0, "ell_sweep_flip": 0}), ("per_launch", {"ell_sweep": 0})):
         with ctx.options(profile=1, **opts):
             ctx.reset_counters()
             r = solver.solve(t_span=[0.0, 0.4], y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.05, magnus_order=order,
@@ -703,7 +706,10 @@ def test_flip_kernel_random_x_strings(qd, nq, order, framed, seed):
                 cross = ctx.counters("sweep_cross")
         out[tag] = np.stack([x.y for x in r])
     assert (forms["default"], parts["default"]) == (3, 2), (forms, parts)
-    assert (forms["with_elements"], parts["with_elements"]) == (2, 2) and parts["one_workgroup"] == 1, (forms, parts)
+    assert (forms["with_elements"], parts["with_elements"]) == (2, 2), (forms, parts)
+    assert (forms["one_workgroup"], parts["one_workgroup"]) == (3, 1), (forms, parts)          # ell_sweep_kernel<.., 3>
+    assert (forms["one_workgroup_with_elements"], parts["one_workgroup_with_elements"]) == (2, 1), (forms, parts)
+    assert_close(out["default"], out["one_workgroup_with_elements"], 1e-12)
     assert cross["launches"] >= k + 1, cross        # every operator and the static part have a string that flips the top qubit
     assert_close(out["default"], out["with_elements"], 1e-12)
     assert_close(out["default"], out["one_workgroup"], 1e-12)
