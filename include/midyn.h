@@ -297,7 +297,7 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * out[0] = launches, out[1] = total ms (events are only recorded when profiling is enabled with
  * midyn_ctx_set_option(ctx, "profile", 1); it adds two event records per launch).
  * "sweep_series" describes the last ell_sweep_kernel launch: (series terms per instance summed over the steps, operator
- * slots per row); "sweep_split": (workgroups per instance of that launch, element form 0 general / 1 packed / 2 direct);
+ * slots per row); "sweep_split": (workgroups per instance of that launch, element form 0 general / 1 packed / 2 direct / 3 none: flip masks);
  * "resident_fallbacks": (step ranges a one-launch kernel gave up on and the launch-per-product route re-ran, 0).
  * Two more names describe the LAST launch of the sparse MFMA route: "sparse_tile" -> (BM, BN) of its tile,
  * "sparse_list" -> (listed (panel, K tile, operator) tiles of the stack for that panel height, split count),

@@ -20,3 +20,10 @@ def run():
 for i in range(4):
     t0 = time.perf_counter(); ys = run(); t1 = time.perf_counter()
     print("solve wall %.1f us" % ((t1 - t0) * 1e6), ys.shape, file=sys.stderr, flush=True)
+# ... and the same shard after a 1024-instance solve of the same stack (the order of bench.py's projection leg)
+table_all, _, _ = bench.sweep_table(workloads, sched.times, 0, 1024, 8, cfg["carrier"], cfg["t_final"])
+stack.expm_solve(sched.times, table_all, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2, y0, 1024, True)
+print("--- after the 1024-instance solve", file=sys.stderr, flush=True)
+for i in range(4):
+    t0 = time.perf_counter(); ys = run(); t1 = time.perf_counter()
+    print("solve wall %.1f us" % ((t1 - t0) * 1e6), ys.shape, file=sys.stderr, flush=True)
