@@ -802,7 +802,7 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
                                            const double2* X2, const int tid, const bool swapped, double2 (&o1)[SWEEP_RPT],
                                            double2 (&o2)[SWEEP_RPT], const double scale2 = 1.0,   // scale2: factor of the second sum
                                            const unsigned row0 = 0, const int re_lo = 0, const int re_hi = 0, const int im_lo = 0,
-                                           const int im_hi = 0) {      // PART 3: the real-plane slots [re_lo, re_hi) and the imaginary-
+                                           const int im_hi = 0, const int flip_lane = 0) {      // PART 3: the real-plane slots [re_lo, re_hi) and the imaginary-
                                                                         // plane slots [im_lo, im_hi); the sums continue
     const int np = a.n_pad;
     const unsigned unp = (unsigned)np;
@@ -826,14 +826,22 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
     // (measured, us per term, cfg 5 shape, none / 2 / 3 stages: direct form 19.9 / 18.1 / 19.3, packed 23.6 / 21.3 / 22.6; the
     // 12-byte elements of the general form do not have the registers: 31.7 / 35.2 / 40.3)
     constexpr bool PFON = (PACKED == 1 || PACKED == 2) && PFD > 0;     // (PACKED 3: there are no elements to fetch)
-    // PACKED 3 (every slot has ONE flip mask, column = row ^ flip: csrc/midyn_flip.h): the LDS byte address of an operand is the
-    // thread's own address XOR a per-slot constant, read through the scalar cache (a.pk: [wsp] flips in the chunked layout)
+    // PACKED 3 (every slot has ONE flip mask, column = row ^ flip: csrc/midyn_flip.h): the LDS address of an operand is the
+    // thread's own address XOR a per-slot constant -- lane e of flip_lane holds the constant of slot e (at most 64 slots; loaded
+    // once per kernel), one v_readlane per slot: a scalar load there put its round trip in front of every slot's gathers.
+    // Addresses are integers of the LDS address space: no addition of the vectors' base per gather; XOR and base commute
+    // because the vectors start at a multiple of 64 KB (the kernel keeps its small tables BEHIND them; checked).
+    typedef __attribute__((address_space(3))) char lds_char_t;
+    typedef double lds_d2v __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const lds_d2v lds_d2_t;
     unsigned lax[PACKED == 3 ? SWEEP_RPT : 1];
     if (PACKED == 3) {
+        const unsigned base_ = (unsigned)(size_t)(lds_char_t*)const_cast<double2*>(sweep_lds);
+        if (base_ & 0xffffu) __builtin_trap();
 #pragma unroll
         for (int i = 0; i < SWEEP_RPT; ++i) {
             const unsigned r_ = row0 + (unsigned)(tid + TH * i);
-            lax[PACKED == 3 ? i : 0] = (((r_ >> 11) << 12) | (r_ & 2047u)) << 4;
+            lax[PACKED == 3 ? i : 0] = base_ + ((((r_ >> 11) << 12) | (r_ & 2047u)) << 4);
         }
     }
     constexpr int PF = PFON ? PFD : 1;
@@ -862,7 +870,7 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
         int cl[SWEEP_RPT];                                                                       \
         double va[SWEEP_RPT];                                                                    \
         if (!PFON && PACKED != 3) fetch(e, cn[S_], vn[S_]);                                  \
-        const unsigned xm_ = PACKED == 3 ? (unsigned)((const MIDYN_CONST_AS int*)(a.pk))[e] : 0u; \
+        const unsigned xm_ = PACKED == 3 ? (unsigned)__builtin_amdgcn_readlane(flip_lane, e) : 0u; \
         _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
             cl[i] = PACKED == 3 ? (int)(lax[PACKED == 3 ? i : 0] ^ xm_) : cn[S_][i];             \
             if (PACKED == 0) va[i] = vn[S_][i];                                                    \
@@ -870,7 +878,12 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
         if (PFON && e + PF < hi) fetch(e + PF, cn[S_], vn[S_]);                              \
         double2 x1[SWEEP_RPT], x2[SWEEP_RPT];                                                    \
         _Pragma("unroll") for (int i = 0; i < SWEEP_RPT; ++i) {                                  \
-            if (PACKED >= 2) {   /* the element IS the LDS byte address of its X1 operand */          \
+            if (PACKED == 3) {   /* own address ^ flip, in the LDS address space */                   \
+                lds_d2_t* q3 = (lds_d2_t*)(size_t)(unsigned)cl[i];                               \
+                const lds_d2v g1 = q3[0], g2 = ORDER == 2 ? q3[2048] : g1;                       \
+                x1[i] = make_double2(g1.x, g1.y);                                                \
+                if (ORDER == 2) x2[i] = make_double2(g2.x, g2.y);                                \
+            } else if (PACKED >= 2) {   /* the element IS the LDS byte address of its X1 operand */   \
                 const char* q = reinterpret_cast<const char*>(sweep_lds) +                       \
                                 (MIDYN_SWEEP_ABLATE == 2 ? (unsigned)((cl[i] & 48) + (tid << 4)) : (unsigned)cl[i]); \
                 x1[i] = *reinterpret_cast<const double2*>(q);                                    \
@@ -959,8 +972,15 @@ __device__ __forceinline__ void sweep_pass(const SweepArgs& a, const double2* ca
 template <int ORDER, int SWEEP_RPT, int TH, int PACKED>
 __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) double2 sweep_lds[];
-    __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];   // per slot: (c1, c2) of its segment (x magnitude), this step
-    __shared__ int stag[SWEEP_MAX_SLOTS];                                    // per slot: segment | plane << 8
+    // per slot: (c1, c2) of its segment (x magnitude) of this step, and segment | plane << 8.  PACKED 3: BEHIND the vectors in the
+    // dynamic LDS (no static LDS: the vectors start at LDS address 0, see sweep_pass); else static arrays
+    __shared__ __attribute__((aligned(16))) double2 cab_static[PACKED == 3 ? 1 : SWEEP_MAX_SLOTS];
+    __shared__ int stag_static[PACKED == 3 ? 1 : SWEEP_MAX_SLOTS];
+    const size_t vec_bytes_ = (size_t)((a.n_pad + 2047) / 2048) * 65536;
+    double2* const cab = PACKED == 3 ? reinterpret_cast<double2*>(reinterpret_cast<char*>(sweep_lds) + vec_bytes_) : cab_static;
+    int* const stag = PACKED == 3 ? reinterpret_cast<int*>(reinterpret_cast<char*>(sweep_lds) + vec_bytes_ + SWEEP_MAX_SLOTS * sizeof(double2))
+                                  : stag_static;
+    const int flip_lane = (PACKED == 3 && (threadIdx.x & 63) < a.wsp) ? a.pk[threadIdx.x & 63] : 0;
     const int tid = threadIdx.x, b = blockIdx.x, np = a.n_pad;
     // LDS copies of the vectors the operators are applied to.  PACKED 0 / 1: X1[np + 1], X2[np + 1] ([np] = the zero
     // slot of unused packed elements).  PACKED 2: chunks of 2048 columns, [X1 chunk | X2 chunk] of 32 KB each, so that
@@ -999,11 +1019,11 @@ __global__ __launch_bounds__(TH) void ell_sweep_kernel(const SweepArgs a) {
         if (ORDER == 2) X2[np] = make_double2(0.0, 0.0);
     }
     auto pass = [&](const bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT]) {
-        sweep_pass<ORDER, SWEEP_RPT, TH, PACKED>(a, cab, sweep_lds, X1, X2, tid, swapped, o1, o2);
+        sweep_pass<ORDER, SWEEP_RPT, TH, PACKED>(a, cab, sweep_lds, X1, X2, tid, swapped, o1, o2, 1.0, 0, 0, 0, 0, 0, flip_lane);
     };
     auto pass_keep = [&](const bool swapped, double2 (&o1)[SWEEP_RPT], double2 (&o2)[SWEEP_RPT], const double scale2) {
         // o2 continues from its start value, its sum scaled by scale2
-        sweep_pass<ORDER, SWEEP_RPT, TH, PACKED, MIDYN_SWEEP_PREFETCH, true>(a, cab, sweep_lds, X1, X2, tid, swapped, o1, o2, scale2);
+        sweep_pass<ORDER, SWEEP_RPT, TH, PACKED, MIDYN_SWEEP_PREFETCH, true>(a, cab, sweep_lds, X1, X2, tid, swapped, o1, o2, scale2, 0, 0, 0, 0, 0, flip_lane);
     };
     for (int st = 0; st < a.nsteps; ++st) {
         const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1];

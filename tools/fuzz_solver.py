@@ -105,10 +105,97 @@ def run_case(qd, orc, seed, verbose=True):
     return ok
 
 
+def run_pauli_case(qd, orc, seed, verbose=True):
+    """Models built from random PAULI STRINGS on 8 .. 10 qubits in the computational basis with a diagonal frame (or none and
+    no diagonal): very sparse stacks -- the one-launch sweep kernels with their element forms: strings of X only (one signed
+    magnitude and one flip mask per slot: no operator elements at all, ell_flip_duo_kernel / ell_sweep_kernel<.., 3>), X and Z
+    (one magnitude, signs per row: packed), Y too (imaginary planes), equal or different magnitudes inside an operator."""
+    rng = np.random.default_rng(90_000 + seed)
+    nq = int(rng.choice([8, 9, 10], p=[0.4, 0.4, 0.2]))
+    n = 2**nq
+    rows = np.arange(n)
+    kind = ["x", "xz", "xyz"][int(rng.choice([0, 1, 2], p=[0.5, 0.25, 0.25]))]
+    k = int(rng.integers(1, 5))
+    framed = bool(rng.integers(0, 2))
+    batch = int(rng.choice([1, 2, 5, 33, 128], p=[0.1, 0.2, 0.3, 0.25, 0.15]))
+    method = ["RK4", "scipy_expm"][int(rng.choice([0, 1], p=[0.3, 0.7]))]
+    mo = int(rng.integers(1, 3))
+    same_mag = bool(rng.integers(0, 2))
+    used = set()
+
+    def string():
+        # one Pauli letter per qubit: X flips, Y flips with the factor i (-1)^(column bit), Z gives the sign (-1)^(bit)
+        while True:
+            letters = rng.choice(4, size=nq, p={"x": [0.6, 0.4, 0.0, 0.0], "xz": [0.5, 0.3, 0.0, 0.2], "xyz": [0.4, 0.25, 0.15, 0.2]}[kind])
+            if rng.random() < 0.4:
+                letters[nq - 1] = 1                  # (X on the top qubit: crosses the halves of the two-workgroup kernels)
+            xm = sum(1 << q for q in range(nq) if letters[q] == 1)
+            ym = sum(1 << q for q in range(nq) if letters[q] == 2)
+            zm = sum(1 << q for q in range(nq) if letters[q] == 3)
+            if (xm | ym) == 0 or (xm, ym, zm) in used:          # (diagonal strings belong to the frame)
+                continue
+            used.add((xm, ym, zm))
+            cols = rows ^ (xm | ym)
+            par = lambda v: np.array([bin(int(x)).count("1") & 1 for x in v])
+            val = (1j) ** bin(ym).count("1") * (-1.0) ** par(cols & ym) * (-1.0) ** par(rows & zm)
+            mat = np.zeros((n, n), dtype=complex)
+            mat[rows, cols] = val
+            return mat
+
+    def operator(scale):
+        op = np.zeros((n, n), dtype=complex)
+        for t in range(int(rng.integers(1, 4))):
+            mag = 1.0 if same_mag else 0.5 + 0.25 * t
+            op += mag * (-1.0) ** int(rng.integers(0, 2)) * string()
+        return scale * op
+
+    h_ops = np.array([operator(2 * np.pi * 0.03) for _ in range(k)])
+    diag = 2 * np.pi * rng.uniform(0.0, 0.4, n) if framed else np.zeros(n)
+    h_static = np.diag(diag).astype(complex) + (operator(2 * np.pi * 0.005) if rng.integers(0, 2) else 0.0)
+    frame = diag.copy() if framed else None
+    span = 0.3
+    t_span = [0.0, span]
+    max_dt = 0.02 if method == "RK4" else 0.06
+    sig_sets = []
+    for _ in range(batch):
+        amps, nus, phs = rng.uniform(-1, 1, k), rng.uniform(0, 1, k), rng.uniform(-3, 3, k)
+        sigs = [qd.Signal(lambda t, a=a: a * np.cos(0.7 * t) + 0j, nu, ph) for a, nu, ph in zip(amps, nus, phs)]
+
+        def coeff(t, amps=amps, nus=nus, phs=phs):
+            return np.array([orc.signal_sum_value(np.array([a * np.cos(0.7 * t) + 0j]), [nu], [ph], t) for a, nu, ph in zip(amps, nus, phs)])
+        sig_sets.append((sigs, coeff))
+    y0 = crand(rng, n)
+    y0 /= np.linalg.norm(y0)
+    ctx = qd.default_context()
+    t0 = time.perf_counter()
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, rotating_frame=frame)
+    kwargs = dict(method=method, max_dt=max_dt)
+    if method == "scipy_expm":
+        kwargs["magnus_order"] = mo
+    if batch > 1:
+        res = solver.solve(t_span=t_span, y0=y0, signals=[s for s, _ in sig_sets], **kwargs)
+    else:
+        res = [solver.solve(t_span=t_span, y0=y0, signals=sig_sets[0][0], **kwargs)]
+    wall = time.perf_counter() - t0
+    split = ctx.counters("sweep_split")
+    a_d, a, d, basis = orc.hamiltonian_model_build(h_static, h_ops, frame)
+    err = 0.0
+    for b in sorted({0, batch - 1}):
+        _, y_ref = orc.solve_generator_model(a_d, a, d, basis, sig_sets[b][1], t_span, y0, method, max_dt, magnus_order=mo)
+        err = max(err, float(np.max(np.abs(res[b].y - y_ref)) / (1.0 + np.max(np.abs(y_ref)))))
+    ok = err < 1e-9
+    if verbose or not ok:
+        print(f"seed {seed:5d} {'ok  ' if ok else 'FAIL'} pauli nq={nq} kind={kind:3s} k={k} framed={int(framed)} same_mag={int(same_mag)} "
+              f"B={batch:3d} {method}{mo if method != 'RK4' else ''}: oracle {err:.1e} "
+              f"[last sweep launch: {int(split['launches'])} workgroup(s) per instance, element form {int(split['ms'])}] {wall:.2f}s", flush=True)
+    return ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--pauli", action="store_true", help="models built from random Pauli strings (very sparse stacks)")
     args = ap.parse_args()
     import qiskit_dynamics_amd as qd
     from oracle import dynamics_oracle as orc
@@ -117,7 +204,7 @@ def main():
     bad = []
     for s in range(args.seed, args.seed + args.cases):
         try:
-            if not run_case(qd, orc, s):
+            if not (run_pauli_case if args.pauli else run_case)(qd, orc, s):
                 bad.append(s)
         except Exception as exc:
             print(f"seed {s:5d} EXC  {type(exc).__name__}: {exc}", flush=True)
