@@ -185,6 +185,81 @@ def load():
         return lib
 
 
+# ---- result arrays in pinned host memory -------------------------------------------------------------------------------
+# A solve's results come back over PCIe into an array the binding allocates.  Into pageable memory the runtime stages the
+# copy, and a fresh NumPy array takes its page faults inside it: the 8.4 MB of a cfg 5 shard (BASELINE configs[4]) cost
+# 0.19-0.38 ms depending on where the allocator put the array -- of a 2.5 ms solve.  Large results therefore live in PINNED
+# blocks (hipHostMalloc: the device writes them directly) that return to a small cache when the last view of the array is
+# collected.  MIDYN_PINNED_RESULTS=0 (or a failed hipHostMalloc): plain np.empty.
+_PINNED_MIN_BYTES = 1 << 20        # below: the copy is latency, not bandwidth
+_PINNED_MAX_BYTES = 256 << 20      # above: page-locking that much for as long as the caller keeps the result is not ours to decide
+_PINNED_CACHE_MAX = 1 << 30
+_pinned_cache = {}          # nbytes -> [pointers]
+_pinned_cached_bytes = 0
+_pinned_lock = threading.Lock()
+_hiprt = None
+
+
+def _hip_runtime():
+    global _hiprt
+    if _hiprt is None:
+        rt = ctypes.CDLL(HIP_RUNTIME)          # (already loaded RTLD_GLOBAL by _preload_hip_runtime: the same instance)
+        rt.hipHostMalloc.argtypes = [ctypes.POINTER(_vp), ctypes.c_size_t, ctypes.c_uint]
+        rt.hipHostMalloc.restype = _ci
+        rt.hipHostFree.argtypes = [_vp]
+        rt.hipHostFree.restype = _ci
+        _hiprt = rt
+    return _hiprt
+
+
+class _PinnedBlock:
+    """Owns one pinned block; gives it back to the cache (or to the runtime) when collected."""
+
+    __slots__ = ("ptr", "nbytes")
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+
+    def __del__(self):
+        global _pinned_cached_bytes
+        try:
+            with _pinned_lock:
+                if _pinned_cached_bytes + self.nbytes <= _PINNED_CACHE_MAX:
+                    _pinned_cache.setdefault(self.nbytes, []).append(self.ptr)
+                    _pinned_cached_bytes += self.nbytes
+                    return
+            _hip_runtime().hipHostFree(_vp(self.ptr))
+        except Exception:  # pylint: disable=broad-except
+            pass               # (interpreter shutdown: the process is going away with its pinned memory)
+
+
+def result_array(shape, dtype=np.complex128):
+    """An uninitialised C-contiguous array for results the device writes: pinned host memory when large."""
+    global _pinned_cached_bytes
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if (nbytes < _PINNED_MIN_BYTES or nbytes > _PINNED_MAX_BYTES or os.environ.get("MIDYN_PINNED_RESULTS", "1") == "0"
+            or HIP_RUNTIME is None):
+        return np.empty(shape, dtype=dtype)
+    ptr = None
+    with _pinned_lock:
+        blocks = _pinned_cache.get(nbytes)
+        if blocks:
+            ptr = blocks.pop()
+            _pinned_cached_bytes -= nbytes
+    if ptr is None:
+        p = _vp()
+        try:
+            if _hip_runtime().hipHostMalloc(ctypes.byref(p), nbytes, 0) != 0 or not p.value:
+                return np.empty(shape, dtype=dtype)
+        except (OSError, AttributeError):
+            return np.empty(shape, dtype=dtype)
+        ptr = p.value
+    buf = (ctypes.c_char * nbytes).from_address(ptr)
+    buf._midyn_block = _PinnedBlock(ptr, nbytes)      # lives exactly as long as the buffer every view of the array refers to
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -529,7 +604,7 @@ class Stack:
         times, r, table, step_rows, step_h, step_save, nsteps, y0 = self._solve_args(
             times, table, step_rows, step_h, step_save, y0, batch)
         m = y0.shape[-1]
-        out = np.empty((batch, n_save, self.n, m), dtype=np.complex128)
+        out = result_array((batch, n_save, self.n, m))
         self.ctx.check(self.ctx.lib.midyn_rk4_solve(
             self.handle, batch, m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows), _ptr(step_h),
             _ptr(step_save), n_save, _ptr(y0), int(bool(y0_shared)), _ptr(out)))
@@ -540,7 +615,7 @@ class Stack:
         times, r, table, step_rows, step_h, step_save, nsteps, y0 = self._solve_args(
             times, table, step_rows, step_h, step_save, y0, batch)
         m = y0.shape[-1]
-        out = np.empty((batch, n_save, self.n, m), dtype=np.complex128)
+        out = result_array((batch, n_save, self.n, m))
         self.ctx.check(self.ctx.lib.midyn_expm_solve(
             self.handle, batch, m, r, _ptr(times), _ptr(table), nsteps, _ptr(step_rows), _ptr(step_h),
             _ptr(step_save), n_save, int(magnus_order), _ptr(y0), int(bool(y0_shared)), _ptr(out)))

@@ -248,3 +248,41 @@ def test_options_are_readable_and_scoped_changes_restore_the_previous_value(qd):
     with pytest.raises(qd.DynamicsError, match="unknown option"):
         with ctx.options(no_such_option=1):
             pass
+
+
+@pytest.mark.gpu
+def test_results_in_pinned_arrays_survive_later_solves(qd):
+    """Large results come back in pinned host blocks that are recycled when collected: an array a caller still holds must keep
+    its values through later solves, and two live results never share memory."""
+    import gc
+
+    from qiskit_dynamics_amd import _lib as L
+    from qiskit_dynamics_amd import workloads
+
+    ctx = qd.default_context()
+    cfg = workloads.schrodinger_config(n_qubits=8, n_drives=4)
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=np.diag(cfg["h_d"]).real.copy())
+    stack = solver.model.stack
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+    sched = FixedStepSchedule([0.0, 0.1], None, 0.01, _rk4_points)
+    batch, k = 300, stack.k
+    rng = np.random.default_rng(5)
+    y0 = cfg["y0"].reshape(-1, 1)
+
+    def solve(seed):
+        table = np.random.default_rng(seed).uniform(-1, 1, (batch, len(sched.times), k))
+        return stack.rk4_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, y0, batch, True)
+
+    a = solve(1)
+    assert a.nbytes >= L._PINNED_MIN_BYTES
+    if stack.slot is None:          # (a stack with a row permutation returns a re-ordered copy of the pinned array)
+        assert a.base is not None, "the result is not in a pinned block"
+    keep = a.copy()
+    b = solve(2)
+    assert not np.shares_memory(a, b)
+    del b
+    gc.collect()
+    c = solve(3)                    # (may reuse b's block, never a's)
+    assert not np.shares_memory(a, c)
+    assert np.array_equal(a, keep)
+    assert np.array_equal(solve(1), keep)

@@ -493,3 +493,58 @@ def test_result_bookkeeping_fields():
     for order in (1, 2, 3):
         assert S._result_extras(Model(), "scipy_expm", order, 20, 0.0)["nfev"] == order * 20
         assert S._result_extras(Model(), "hip_expm_parallel", order, 20, 0.0)["nfev"] == order * 20
+
+
+def test_result_arrays_in_pinned_blocks_ownership(monkeypatch):
+    """binding: large result arrays live in pinned blocks (hipHostMalloc) that return to a cache when the LAST view is collected
+    and are handed out again -- never while a view is alive; small results are plain NumPy arrays.  (A fake allocator: no GPU.)"""
+    import ctypes
+    import gc
+
+    from qiskit_dynamics_amd import _lib as L
+
+    class FakeRuntime:
+        def __init__(self):
+            self.live, self.freed = {}, []
+
+        def hipHostMalloc(self, pp, n, flags):
+            b = ctypes.create_string_buffer(n)
+            self.live[ctypes.addressof(b)] = b
+            ctypes.cast(pp, ctypes.POINTER(ctypes.c_void_p))[0] = ctypes.addressof(b)
+            return 0
+
+        def hipHostFree(self, p):
+            self.freed.append(p.value)
+            return 0
+
+    rt = FakeRuntime()
+    monkeypatch.setattr(L, "_hiprt", rt)
+    monkeypatch.setattr(L, "HIP_RUNTIME", "fake")
+    monkeypatch.setattr(L, "_pinned_cache", {})
+    monkeypatch.setattr(L, "_pinned_cached_bytes", 0)
+    shape, nbytes = (16, 2, 4096, 1), 16 * 2 * 4096 * 16
+    a = L.result_array(shape)
+    assert a.shape == shape and a.dtype == np.complex128 and a.flags.c_contiguous and a.flags.writeable
+    a[...] = 1 + 2j
+    view = a[1:3]
+    b = L.result_array(shape)
+    assert not np.shares_memory(a, b)
+    addr = a.ctypes.data
+    del a
+    gc.collect()
+    assert view[0, 0, 0, 0] == 1 + 2j and not L._pinned_cache.get(nbytes)          # a view keeps the block
+    del view
+    gc.collect()
+    assert L._pinned_cache[nbytes] == [addr]
+    c = L.result_array(shape)
+    assert c.ctypes.data == addr                                                    # handed out again
+    assert L.result_array((3, 3)).base is None                                      # small: plain NumPy
+    monkeypatch.setenv("MIDYN_PINNED_RESULTS", "0")
+    assert L.result_array(shape).base is None
+    monkeypatch.delenv("MIDYN_PINNED_RESULTS")
+    monkeypatch.setattr(L, "_PINNED_CACHE_MAX", 0)                                  # a full cache: the block goes back to the runtime
+    del c
+    gc.collect()
+    assert rt.freed == [addr]
+    del b
+    gc.collect()
