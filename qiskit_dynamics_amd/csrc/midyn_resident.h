@@ -1464,11 +1464,18 @@ __global__ __launch_bounds__(TH) void ell_sweep_duo_kernel(const SweepDuoArgs da
 template <int SWEEP_RPT, int TH, int PACKED>
 __global__ __launch_bounds__(TH) void ell_sweep_rk4_kernel(const SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) double2 sweep_lds[];
-    __shared__ __attribute__((aligned(16))) double2 cab[SWEEP_MAX_SLOTS];   // per slot: (coefficient of its segment at the stage time x magnitude, -)
-    __shared__ int stag[SWEEP_MAX_SLOTS];
+    // per slot: (coefficient of its segment at the stage time x magnitude, -), and segment | plane << 8.  PACKED 3: behind the
+    // vector in the dynamic LDS (no static LDS: the vector starts at LDS address 0, see sweep_pass)
+    __shared__ __attribute__((aligned(16))) double2 cab_static[PACKED == 3 ? 1 : SWEEP_MAX_SLOTS];
+    __shared__ int stag_static[PACKED == 3 ? 1 : SWEEP_MAX_SLOTS];
     const int tid = threadIdx.x, b = blockIdx.x, np = a.n_pad;
-    double2* const X1 = sweep_lds;            // layouts as in ell_sweep_kernel (PACKED 2: chunks of 2048 columns)
-    auto xrow = [&](const int r_) { return PACKED == 2 ? ((r_ >> 11) << 12) | (r_ & 2047) : r_; };
+    double2* const X1 = sweep_lds;            // layouts as in ell_sweep_kernel (PACKED 2 / 3: chunks of 2048 columns)
+    const size_t vec_bytes_ = (size_t)((a.n_pad + 2047) / 2048) * 65536 - 32768;
+    double2* const cab = PACKED == 3 ? reinterpret_cast<double2*>(reinterpret_cast<char*>(sweep_lds) + vec_bytes_) : cab_static;
+    int* const stag = PACKED == 3 ? reinterpret_cast<int*>(reinterpret_cast<char*>(sweep_lds) + vec_bytes_ + SWEEP_MAX_SLOTS * sizeof(double2))
+                                  : stag_static;
+    const int flip_lane = (PACKED == 3 && (threadIdx.x & 63) < a.wsp) ? a.pk[threadIdx.x & 63] : 0;
+    auto xrow = [&](const int r_) { return PACKED >= 2 ? ((r_ >> 11) << 12) | (r_ & 2047) : r_; };
     auto boff = [&](const int i_, const int shift) { return sweep_boff<TH>(tid, i_, shift); };
     double2 y[SWEEP_RPT], acc[SWEEP_RPT], cur[SWEEP_RPT];
 #pragma unroll
@@ -1478,7 +1485,7 @@ __global__ __launch_bounds__(TH) void ell_sweep_rk4_kernel(const SweepArgs a) {
         acc[i] = cur[i] = y[i];
     }
     for (int e = tid; e < a.wsp; e += TH) stag[e] = a.tags[e];
-    if (tid == 0 && PACKED != 2) X1[np] = make_double2(0.0, 0.0);
+    if (tid == 0 && PACKED < 2) X1[np] = make_double2(0.0, 0.0);
     const double* Sb = a.S + (size_t)b * a.inst_stride;
     for (int st = 0; st < a.nsteps; ++st) {
         const int r0 = a.rows[3 * st], r1 = a.rows[3 * st + 1], r2 = a.rows[3 * st + 2];
@@ -1500,7 +1507,7 @@ __global__ __launch_bounds__(TH) void ell_sweep_rk4_kernel(const SweepArgs a) {
             }
             __syncthreads();
             double2 o1[SWEEP_RPT], o2[SWEEP_RPT];
-            sweep_pass<1, SWEEP_RPT, TH, PACKED, (SWEEP_RPT < 4 ? MIDYN_SWEEP_PREFETCH : 0)>(a, cab, sweep_lds, X1, X1, tid, false, o1, o2);   // (four rows per thread: no registers for the element ring)
+            sweep_pass<1, SWEEP_RPT, TH, PACKED, (SWEEP_RPT < 4 ? MIDYN_SWEEP_PREFETCH : 0)>(a, cab, sweep_lds, X1, X1, tid, false, o1, o2, 1.0, 0, 0, 0, 0, 0, flip_lane);   // (four rows per thread: no registers for the element ring)
 #pragma unroll
             for (int i = 0; i < SWEEP_RPT; ++i) {
                 const double2 kk = Es ? cmul_conj_a(*reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Es) + boff(i, 4)), o1[i]) : o1[i];
@@ -1816,9 +1823,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void ell_sweep_split_kernel(const Sw
     MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_rk4_kernel<R_, T_, P_>(const SweepArgs);
 MIDYN_SWEEP_SHAPES(MIDYN_X)
 #undef MIDYN_X
-#define MIDYN_X(R_, T_)   /* element form 3 (flip masks, no elements): the expm sweeps */                          \
+#define MIDYN_X(R_, T_)   /* element form 3 (flip masks, no elements) */                                           \
     MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_kernel<1, R_, T_, 3>(const SweepArgs);   \
-    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_kernel<2, R_, T_, 3>(const SweepArgs);
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_kernel<2, R_, T_, 3>(const SweepArgs);   \
+    MIDYN_SWEEP_EXTERN template __global__ void ell_sweep_rk4_kernel<R_, T_, 3>(const SweepArgs);
 MIDYN_X(1, 256) MIDYN_X(1, 512) MIDYN_X(1, 1024) MIDYN_X(2, 1024) MIDYN_X(4, 1024)
 #undef MIDYN_X
 #define MIDYN_X(O_, P_)                                                                                   \

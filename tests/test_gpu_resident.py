@@ -720,6 +720,22 @@ def test_flip_kernel_random_x_strings(qd, nq, order, framed, seed):
             _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt, b=b: np.array([np.real(s(tt)) for s in sweeps[b]]),
                                                [0.0, 0.4], y0, "scipy_expm", 0.05, t_eval=[0.0, 0.15, 0.4], magnus_order=order)
             assert_close(out["default"][b], ref, SOLVE_TOL)
+    # the RK4 sweep of the same model: ell_sweep_rk4_kernel<.., 3> (no operator elements) against the kernel with elements, the
+    # launch-per-stage route and (small sizes) the oracle
+    rk, rk_forms = {}, {}
+    for tag, opts in (("default", {}), ("with_elements", {"ell_sweep_flip": 0}), ("per_launch", {"ell_sweep": 0})):
+        with ctx.options(profile=1, **opts):
+            ctx.reset_counters()
+            r = solver.solve(t_span=[0.0, 0.2], y0=y0, signals=sweeps, method="RK4", max_dt=0.01)
+            rk_forms[tag] = (ctx.counters("rk4_resident")["launches"], ctx.counters("sweep_split")["ms"])
+        rk[tag] = np.stack([x.y for x in r])
+    assert rk_forms["default"] == (1, 3) and rk_forms["with_elements"] == (1, 2) and rk_forms["per_launch"][0] == 0, rk_forms
+    assert_close(rk["default"], rk["with_elements"], 1e-12)
+    assert_close(rk["default"], rk["per_launch"], 1e-12)
+    if nq <= 10:
+        _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt: np.array([np.real(s(tt)) for s in sweeps[0]]),
+                                           [0.0, 0.2], y0, "RK4", 0.01)
+        assert_close(rk["default"][0], ref, SOLVE_TOL)
 
 
 def test_resident_kernel_rows_without_any_operator(qd):

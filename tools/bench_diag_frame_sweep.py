@@ -49,6 +49,18 @@ c = ctx.counters("rk4_resident")
 if c["launches"]:
     out["one_launch_sweep_kernel"] = {"kernel_ms_per_step": round(c["ms"] / n_st, 4),
                                       "rhs_evals_per_s_in_the_kernel": round(4 * B * n_st / (c["ms"] * 1e-3)),
+                                      "element_form": int(ctx.counters("sweep_split")["ms"]),
                                       "max_abs_difference_to_work_lists": float(np.max(np.abs(ys[:, -1, :, 0] - ref)))}
+    # the same kernel WITH operator elements (option ell_sweep_flip = 0): interleaved, minimum of three
+    best = {}
+    for rnd in range(3):
+        for flag in (1, 0):
+            with ctx.options(ell_sweep_flip=flag, profile=1):
+                ctx.reset_counters()
+                run()
+                ms = ctx.counters("rk4_resident")["ms"]
+                form = int(ctx.counters("sweep_split")["ms"])
+            best[form] = min(best.get(form, 1e9), ms)
+    out["one_launch_sweep_kernel"]["rhs_evals_per_s_by_element_form"] = {f: round(4 * B * n_st / (ms * 1e-3)) for f, ms in best.items()}
 print(json.dumps({"what": f"cfg3 model in the diagonal frame diag(H_d), {B} instances, RK4 (block-sparse stack), "
                           f"{steps} timed steps, inputs resident", **out}))
