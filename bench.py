@@ -32,6 +32,8 @@ Objects on the line besides the contract fields:
   cfg4, cfg5                  the vectorised-Lindblad / 12-qubit Magnus-2 configurations with their own rooflines
                               (executed work of the work lists AND the 8(d) dense-form price, labelled)
   sharded_cfg5                second sharded leg: the 1024-instance cfg-5 sweep, 1024/N per GPU
+  diag_frame_rk4_sweep        the headline model set up in the diagonal frame diag(H_d) (sparse operators): the one-launch RK4 sweep
+                              kernel without operator elements -- NOT `value`, which is BASELINE's full-frame configuration
   cpu_baseline                the NumPy oracle on the host cores (rank 0, N = 1), bounded sample
 """
 import argparse
@@ -387,6 +389,64 @@ def profile_pass(ctx, fn, classes):
 
 
 ALL_CLASSES = ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", "rhs_blocks", "rhs_blocks_gemm", "rk4_resident")
+
+
+def leg_diag_frame_sweep(qd, ctx, workloads, instances=4096, steps=40):
+    """The headline model set up in the DIAGONAL frame diag(H_d) instead of the full frame H_d (the same physics: results agree
+    out of the frame; a choice the reference leaves to the user, models/rotating_frame.py): the operators stay in the computational
+    basis -- ~20 non-zeros per row, every ELL slot one signed magnitude and one flip mask -- and the RK4 sweep is ONE launch of
+    ell_sweep_rk4_kernel<1, 1024, 3> (no operator elements, csrc/midyn_flip.h / midyn_resident.h).  Kernel time from the library's
+    HIP-event counters; the same kernel with 4-byte elements (option ell_sweep_flip = 0) and the work-list route beside it."""
+    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
+
+    cfg = workloads.schrodinger_config()
+    frame = RotatingFrame(np.diag(cfg["h_d"]).real.copy())
+    stack = qd.Stack(ctx, -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(frame.frame_diag), frame.frame_diag_imag)
+    sched = FixedStepSchedule(cfg["t_span"], None, 0.005, _rk4_points)
+    rows = sched.step_rows[:steps]
+    nr = int(rows.max()) + 1
+    k = cfg["ops"].shape[0]
+    pars = [workloads.sweep_parameters(b, k) for b in range(instances)]
+    table = workloads.gaussian_coefficient_table(sched.times[:nr], np.array([p[0] for p in pars]), np.array([p[1] for p in pars]),
+                                                 cfg["carrier"], 5.0)
+    y0 = cfg["y0"].reshape(-1, 1)
+    save = np.full(steps, -1, dtype=np.int32)
+    save[-1] = 1
+
+    def run():
+        return stack.rk4_solve(sched.times[:nr], table, rows, sched.step_h[:steps], save, 2, y0, instances, True)
+
+    best, out_y = {}, {}
+    for rnd in range(3):                       # interleaved, minimum per element form
+        for flag in (1, 0):
+            with ctx.options(ell_sweep_flip=flag, profile=1):
+                ctx.reset_counters()
+                ys = run()
+                ms = ctx.counters("rk4_resident")["ms"]
+                form = int(ctx.counters("sweep_split")["ms"])
+            best[form] = min(best.get(form, 1e9), ms)
+            out_y[form] = ys
+    with ctx.options(ell_sweep=0):
+        t0 = time.perf_counter()
+        ref = run()
+        wall_lists = time.perf_counter() - t0
+    form = max(best)
+    evals = 4.0 * instances * steps
+    out = {"workload": "the headline model (10 qubits, n = 1024, 8 drives) in the diagonal frame diag(H_d), %d instances x %d RK4 "
+                       "steps in ONE launch, inputs resident" % (instances, steps),
+           "kernel": "ell_sweep_rk4_kernel<1, 1024, %d>" % form, "element_form": form,
+           "rhs_evals_per_s_in_the_kernel": round(evals / (best[form] * 1e-3)),
+           "kernel_ms_per_step": round(best[form] / steps, 4),
+           "with_4_byte_elements_rhs_evals_per_s": round(evals / (best[min(best)] * 1e-3)) if len(best) > 1 else None,
+           "work_list_route_rhs_evals_per_s_wall": round(evals / wall_lists),
+           "max_abs_difference_to_the_work_list_route": float(np.max(np.abs(out_y[form] - ref))),
+           "max_abs_difference_between_the_element_forms": float(np.max(np.abs(out_y[form] - out_y[min(best)]))),
+           "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(out_y[form][:, -1, :, 0], axis=1) - 1.0))),
+           "note": "NOT the headline number: `value` is measured in the full frame H_d of BASELINE's configuration (dense frame-basis "
+                   "operators, MFMA combine + apply).  This key shows what the same physics costs when the user keeps the operators "
+                   "sparse; parity: tests/test_gpu_resident.py (element forms, random flip masks) and tools/fuzz_solver.py --pauli"}
+    return out
 
 
 def leg_small_sweeps(qd, workloads, instances=4096, steps=200):
@@ -1688,6 +1748,10 @@ def main():
             out["small_system_sweeps"] = leg_small_sweeps(qd, workloads)
         except Exception as exc:  # pylint: disable=broad-except
             out["small_system_sweeps"] = {"error": repr(exc)}
+        try:
+            out["diag_frame_rk4_sweep"] = leg_diag_frame_sweep(qd, ctx, workloads)
+        except Exception as exc:  # pylint: disable=broad-except
+            out["diag_frame_rk4_sweep"] = {"error": repr(exc)}
         # rows a11 / f2 / f3 / f4 of SURVEY section 8 on the driver's line: throughput, roofline of the dominant kernel from the
         # library's own counters, and the CPU algorithm on this host beside each
         for key_, leg_ in (("dense_expm", lambda: leg_dense_expm(qd, ctx)),
