@@ -10,17 +10,20 @@
 //   * the LDS address of an operand is the thread's own address XOR a per-slot constant: no element array, no L2 stream of
 //     4 bytes per (slot, row) and pass (311 KB per pass and instance at cfg 5), no register ring that prefetches it -- and
 //     the wave's vector-memory counter belongs to the exchange alone;
-//   * so the exchange can be spread over the pass without draining anything: the slots that stay inside the half are applied
-//     in parts -- the store acknowledgement and the flag store follow the first, the partner's flag and the loads of the
-//     first crossing slot's operands the second, and every crossing slot's loads land while another part runs.  With element loads in the slot loop this split LOST
+//   * so the exchange can be spread over the pass without draining anything: the rows are published before the first barrier;
+//     the store acknowledgement and the flag store follow the first eighth of the local slots; the partner's flag is asked for,
+//     without waiting, after 5/16 of them; the loads of the crossing operands leave after half of them (inside the slot loop:
+//     see run_plane) and land behind the other half.  With element loads in the slot loop this split LOST
 //     (profiles/r05_cfg5_duo.md, v3b: every part restarted and drained the element prefetch);
-//   * the few slots that cross the halves read their operands STRAIGHT from the partner's payload (row ^ flip: 16-byte
-//     loads into registers): the partner's half is never staged in LDS -- one barrier and (RPT x ORDER) ds_write_b128 per
-//     thread and pass less, and the workgroup holds only its own half in LDS (64 KB at n = 4096);
-//   * slot coefficients and flip masks are wave-uniform: lane j of every wave holds those of slot j (at most 64 slots; loaded
-//     once per step from a table a small kernel fills per (instance, step, slot) before the launch) and a slot takes them with
-//     five v_readlane_b32 -- no LDS broadcast per slot (one ds_read_b128 in five of the old pass), no scalar-cache round
-//     trip in the slot loop (tried first: the loads of the next slot sink behind this slot's waits, lgkmcnt being shared).
+//   * the few slots that cross the halves read their operands STRAIGHT from the partner's payload (ONE set of 16-byte loads
+//     into registers for all crossing slots whose flips share their thread bits): the partner's half is never staged in LDS --
+//     one barrier and (RPT x ORDER) ds_write_b128 per thread and pass less, and the workgroup holds only its own half in LDS
+//     (64 KB at n = 4096);
+//   * the slot loops are bound by their VECTOR instructions, not by the LDS (ablations in profiles/r05_cfg5_duo.md), so a
+//     slot carries as few as possible: its flip mask through ONE v_readlane_b32 from a lane-held copy (lane j: slot j; at
+//     most 64 slots), its two coefficients through ONE 16-byte scalar load (constant address space) from a table a small
+//     kernel fills per (instance, step, slot) before the launch, requested before the slot's gathers and waited for with them;
+//     gathers addressed in the LDS address space (no base add); the scale of the second sum in the staged operand.
 // Protocol, flags, payload slots, one-L2 detection, give-up behaviour: ell_sweep_duo_kernel's.  A wave that reads rows of
 // another wave of its partner (a crossing flip with bits above the lane bits) waits for THAT wave's flag.
 #pragma once
