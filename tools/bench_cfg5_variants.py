@@ -2,9 +2,10 @@
 their ablations, five INTERLEAVED rounds over the variants, minimum per variant (a kernel measured right after a slower one
 runs ~1 us per term slower for a few launches: sequential best-of-three comparisons drift).
     python tools/bench_cfg5_variants.py [variant ...]          (on the GPU box)"""
+import os
 import sys
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import qiskit_dynamics_amd as qd  # noqa: E402
 from qiskit_dynamics_amd import workloads  # noqa: E402
