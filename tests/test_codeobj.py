@@ -121,6 +121,17 @@ def test_slot_loops_of_the_flip_kernel_wait_for_lds_only(tmp_path):
     assert loops >= 8, loops          # two planes x four parts of the local slots, two passes per term (+ order-1 tail)
 
 
+def test_flip_form_kernels_declare_no_static_lds(kernels):
+    """The kernels of element form 3 address their gathers as (own LDS address) ^ flip without adding the base of the dynamic LDS:
+    that base must be 0, i.e. the kernel may not declare static LDS (they trap otherwise; csrc/midyn_flip.h, sweep_pass)."""
+    found = 0
+    for name, k in kernels.items():
+        if "ell_flip_duo_kernel" in name or (("ell_sweep_kernelILi" in name or "ell_sweep_rk4_kernelILi" in name) and "ELi3EEEv" in name):
+            assert k.get(".group_segment_fixed_size", 0) == 0, (name, k.get(".group_segment_fixed_size"))
+            found += 1
+    assert found >= 8 + 10 + 5, found       # 8 flip duo variants, 10 expm sweep variants, 5 RK4 sweep variants of form 3
+
+
 # ---- the tile loop of the MFMA contraction: every VALU instruction in it takes matrix-pipe cycles -------------------------
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
