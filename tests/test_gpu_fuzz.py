@@ -27,3 +27,18 @@ def test_random_shapes_default_routes_vs_reference_routes_and_oracle(block):
     qd.default_context()
     bad = [seed for seed in range(10 * block, 10 * block + 10) if not fuzz_routes.run_case(qd, orc, seed, verbose=False)]
     assert not bad, f"failing seeds: {bad} (python tools/fuzz_routes.py --seed <s> --cases 1)"
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_random_lindblad_models_vs_oracle(block):
+    """tools/fuzz_lindblad.py: random open-system models (vectorised and matrix form, every operator-group pattern, no / diagonal /
+    full frame, single solves and sweeps, RK4 and scipy_expm with Magnus order 1 .. 3) through Solver.solve against the oracle's
+    restatement of models/lindblad_model.py:100-212,410-538 and models/operator_collections.py:451-567,851-1061 at 1e-9."""
+    import fuzz_lindblad
+    import qiskit_dynamics_amd as qd
+    from oracle import dynamics_oracle as orc
+
+    qd.default_context()
+    bad = [seed for seed in range(1000 + 12 * block, 1000 + 12 * block + 12)
+           if not fuzz_lindblad.run_case(qd, orc, seed, verbose=False)[0]]
+    assert not bad, f"failing seeds: {bad} (python tools/fuzz_lindblad.py --seed <s> --cases 1)"
