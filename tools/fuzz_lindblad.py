@@ -6,7 +6,7 @@ Per case: dimension 2 .. 24 (superoperator dimension 4 .. 576), static Hamiltoni
 signals, 0 .. 3 static dissipators, 0 .. 2 dissipator operators with (real) signals -- at least one group of each side is
 drawn so that the model is neither empty nor closed --, no / diagonal / full rotating frame, vectorized or not, a single solve
 or a sweep of 2 .. 40 instances (own signals; own or shared initial density matrix), forwards or backwards, optional t_eval,
-RK4 (both forms) or scipy_expm with Magnus order 1 .. 3 (vectorised form: the reference raises for the matrix form,
+RK4 (both forms) or scipy_expm with Magnus order 1 .. 3, sequential or parallel in time (vectorised form: the reference raises for the matrix form,
 solvers/solver_functions.py:334-337 -- checked too).  The oracle side: oracle.lindblad_model_build -> frame-basis groups;
 vectorised: vectorized_lindblad_stack + vectorized_frame_diag through solve_generator_model(kind="lindblad_vec");
 matrix form: lindblad_rhs through rk4_solve with the frame-basis maps of solver_functions.py:376-450.
@@ -65,6 +65,11 @@ def run_case(qd, orc, seed, verbose=True):
     t_span = [span, 0.0] if backwards else [0.0, span]
     t_eval = None if rng.integers(0, 2) else sorted(rng.uniform(0, span, 2), reverse=backwards)
     max_dt = 0.01 if method == "RK4" else 0.05
+    # a quarter of the vectorised cases take the parallel-in-time form of their method (row f3:
+    # solvers/fixed_step_solvers.py:222-258,524-613; the same linear map per step, the products re-associated -- compared
+    # with the oracle's sequential loop at the same 1e-9)
+    parallel = vectorized and rng.random() < 0.25
+    dev_method = {"RK4": "hip_RK4_parallel", "scipy_expm": "hip_expm_parallel"}[method] if parallel else method
 
     def make_sigs():
         """(signals as Solver.solve takes them, ham coefficient function, dissipator coefficient function)"""
@@ -100,7 +105,7 @@ def run_case(qd, orc, seed, verbose=True):
 
     solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops, static_dissipators=n_stat,
                        dissipator_operators=l_ops, rotating_frame=frame, vectorized=vectorized)
-    kw = dict(method=method, max_dt=max_dt, t_eval=t_eval)
+    kw = dict(method=dev_method, max_dt=max_dt, t_eval=t_eval)
     if method == "scipy_expm":
         kw["magnus_order"] = mo
     t0 = time.perf_counter()
@@ -153,7 +158,7 @@ def run_case(qd, orc, seed, verbose=True):
         herm_dev = max(herm_dev, float(np.abs(fin - fin.conj().T).max()))
     ok = worst < 1e-9
     line = (f"seed {seed:5d} {'ok  ' if ok else 'FAIL'} n={n:2d} {'vec' if vectorized else 'mat'} Hd={int(has_static)} kh={k_h} "
-            f"ns={n_s} kl={k_l} frame={frame_kind:4s} B={batch:2d} {method}{mo if method == 'scipy_expm' else ''} "
+            f"ns={n_s} kl={k_l} frame={frame_kind:4s} B={batch:2d} {dev_method}{mo if method == 'scipy_expm' else ''} "
             f"{'bwd' if backwards else 'fwd'} t_eval={'y' if t_eval is not None else 'n'} y0={'shared' if shared_y0 else 'own'}: "
             f"oracle {worst:.1e} trace {tr_dev:.1e} herm {herm_dev:.1e}{extra} {dt_dev:.2f}s")
     if verbose:
