@@ -94,7 +94,13 @@ MIDYN_GLOBAL __launch_bounds__(256) void flip_cab_kernel(const double* __restric
 
 template <int ORDER, int RPT, int TH>
 __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double2 flip_lds[];   // own half: X1 [half] (| X2 32768 bytes behind, order 2)
+    // own half: X1 [half] (| X2 32768 bytes behind, order 2), TWICE: the copies of consecutive passes alternate between two buffers
+    // FLIP_BUF bytes apart, so a pass writes its operands while slower waves still gather those of the pass before -- ONE barrier
+    // per pass (behind the writes) instead of two (round 5, last session: the barrier in front of the writes cost 0.45 us of a
+    // 10.9 us term on the cfg 5 shard, tools/bench_cfg5_variants.py no_barrier1).  Safe with one barrier: a wave that writes
+    // buffer p & 1 for pass p + 2 has passed the barrier of pass p + 1, which every wave reaches after its gathers of pass p.
+    extern __shared__ __attribute__((aligned(16))) double2 flip_lds[];
+    constexpr unsigned FLIP_BUF = ORDER == 2 ? 65536u : 32768u;
     const int tid = threadIdx.x, np = a.n_pad;
     const unsigned unp = (unsigned)np;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,10 +236,11 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
     // base commute only when the base has no bit below 64 KB: this kernel declares no static LDS (base 0); checked once.
     typedef __attribute__((address_space(3))) char lds_char;
     const unsigned lds_base = (unsigned)(size_t)(lds_char*)flip_lds;
-    if (lds_base & 0xffffu) __builtin_trap();
+    if (lds_base & 0x1ffffu) __builtin_trap();     // (bit 16 too: the buffer toggle)
     unsigned la[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) la[i] = lds_base + ((unsigned)(tid + TH * i) << 4);
+    for (int i = 0; i < RPT; ++i) la[i] = (lds_base + ((unsigned)(tid + TH * i) << 4)) ^ FLIP_BUF;   // (the first pass toggles it back)
+    unsigned boff = FLIP_BUF;       // byte offset of the buffer the current pass reads
     auto run_plane = [&](const int j_lo, const int j_hi, auto im_tag, const int j_ev, auto& hook, double2 (&o1)[RPT], double2 (&o2)[RPT]) {
         constexpr bool IM = decltype(im_tag)::value;
         for (int j = j_lo; j < j_hi; ++j) {
@@ -303,12 +310,13 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
                 }
             }
         }
-        __syncthreads();                   // every reader of the LDS copies of the previous pass is done
+        boff ^= FLIP_BUF;                  // (no barrier here: the readers of the previous pass use the other buffer)
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const unsigned l = rowof(i);
-            *reinterpret_cast<double2*>(lds + (l << 4)) = in1[i];
-            if (ORDER == 2) *reinterpret_cast<double2*>(lds + (l << 4) + 32768) = in2s[i];
+            la[i] ^= FLIP_BUF;
+            *reinterpret_cast<double2*>(lds + boff + (l << 4)) = in1[i];
+            if (ORDER == 2) *reinterpret_cast<double2*>(lds + boff + (l << 4) + 32768) = in2s[i];
             o1[i] = make_double2(0.0, 0.0);
             if (!keep) o2[i] = make_double2(0.0, 0.0);
         }
@@ -404,6 +412,18 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
             } else {
                 if (im) block(std::true_type(), std::integral_constant<int, 0>());
                 else block(std::false_type(), std::integral_constant<int, 0>());
+            }
+        };
+            if constexpr (RPT == 4) {
+                if (fi == 0) planes(std::integral_constant<int, 0>());
+                else if (fi == 1) planes(std::integral_constant<int, 1>());
+                else if (fi == 2) planes(std::integral_constant<int, 2>());
+                else planes(std::integral_constant<int, 3>());
+            } else if constexpr (RPT == 2) {
+                if (fi) planes(std::integral_constant<int, 1>());
+                else planes(std::integral_constant<int, 0>());
+            } else {
+                planes(std::integral_constant<int, 0>());
             }
         };
         const bool xc = exch && !dead && !(a.ablate & 8);
