@@ -414,18 +414,6 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
                 else block(std::false_type(), std::integral_constant<int, 0>());
             }
         };
-            if constexpr (RPT == 4) {
-                if (fi == 0) planes(std::integral_constant<int, 0>());
-                else if (fi == 1) planes(std::integral_constant<int, 1>());
-                else if (fi == 2) planes(std::integral_constant<int, 2>());
-                else planes(std::integral_constant<int, 3>());
-            } else if constexpr (RPT == 2) {
-                if (fi) planes(std::integral_constant<int, 1>());
-                else planes(std::integral_constant<int, 0>());
-            } else {
-                planes(std::integral_constant<int, 0>());
-            }
-        };
         const bool xc = exch && !dead && !(a.ablate & 8);
         const int ft0 = (int)((unsigned)lane_i32(meta_l, n_loc < n_all ? n_loc : 0) & (unsigned)(TH - 1));
         const int pw0 = wave ^ (ft0 >> 6);
