@@ -18,7 +18,7 @@
 //   * the few slots that cross the halves read their operands STRAIGHT from the partner's payload (ONE set of 16-byte loads
 //     into registers for all crossing slots whose flips share their thread bits): the partner's half is never staged in LDS --
 //     one barrier and (RPT x ORDER) ds_write_b128 per thread and pass less, and the workgroup holds only its own half in LDS
-//     (64 KB at n = 4096);
+//     (64 KB at n = 4096 -- twice: consecutive passes alternate between two operand buffers, see the kernel);
 //   * the slot loops are bound by their VECTOR instructions, not by the LDS (ablations in profiles/r05_cfg5_duo.md), so a
 //     slot carries as few as possible: its flip mask through ONE v_readlane_b32 from a lane-held copy (lane j: slot j; at
 //     most 64 slots), its two coefficients through ONE 16-byte scalar load (constant address space) from a table a small
