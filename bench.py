@@ -791,6 +791,32 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
                         "cus_busy = instances x workgroups per instance (one workgroup per CU: LDS); frac_of_the_busy_cus "
                         "prices the same bytes against those CUs only.  Vector fp64, no MFMA: the operators have at most "
                         "19 non-zeros per row"}
+            if parts == 2 and form == 3:
+                # where a term of the default kernel goes: the same launch with its exchange switched off (ablate 1) and with the
+                # exchange AND every operator slot switched off (ablate 13: staging, barrier, series arithmetic) -- results wrong,
+                # kernel time only; the LDS rate of the slot loops alone follows from their difference
+                cross = ctx.counters("sweep_cross")
+                local_slots = int(cross["ms"] - cross["launches"])
+                dec = {}
+                for tag, bits in (("without_exchange", 1), ("skeleton", 13)):
+                    with ctx.options(ablate=bits):
+                        run()
+                        csa = profile_pass(ctx, run, ("rk4_resident",))
+                    dec[tag] = csa["rk4_resident"]["ms"] * 1e3 / max(terms, 1)
+                run()       # (a complete solve again before anything else is timed)
+                us_term = k_ms * 1e3 / max(terms, 1)
+                slot_us = max(dec["without_exchange"] - dec["skeleton"], 1e-9)
+                local_bytes_term = count * 2 * local_slots * n * 2 * 16
+                out["roofline"]["term_decomposition"] = {
+                    "us_per_term": {"complete": round(us_term, 2), "without_exchange": round(dec["without_exchange"], 2),
+                                    "skeleton": round(dec["skeleton"], 2)},
+                    "local_slot_loops_us": round(slot_us, 2), "exchange_and_crossing_slots_us": round(us_term - dec["without_exchange"], 2),
+                    "local_slots": local_slots,
+                    "lds_gbs_inside_the_slot_loops": round(local_bytes_term / (slot_us * 1e-6) / 1e9, 1),
+                    "frac_inside_the_slot_loops": round(local_bytes_term / (slot_us * 1e-6) / 1e9 / LDS_PEAK_GBS, 4),
+                    "note": "ablation launches of the same kernel in this run (ctx option ablate: 1 = no exchange, 13 = no exchange and no "
+                            "operator slots); frac above divides ALL gathered bytes by the whole term, this one the local slots' bytes by "
+                            "the time the slot loops take (without_exchange - skeleton)"}
             if parts == 2 and form == 3:     # the two-workgroup kernel WITH operator elements beside it (ell_sweep_flip = 0)
                 with ctx.options(ell_sweep_flip=0):
                     ys3, dev3, wall3, cs3 = measure(True)
