@@ -6,6 +6,9 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("MIDYN_LIB_AB"):      # A/B of two builds: another libmidyn.so for this process
+    import qiskit_dynamics_amd._lib as _l
+    _l.LIB_PATH = os.environ["MIDYN_LIB_AB"]
 import bench  # noqa: E402
 import qiskit_dynamics_amd as qd  # noqa: E402
 from qiskit_dynamics_amd import workloads  # noqa: E402
