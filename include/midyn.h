@@ -59,6 +59,9 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         (work-list kernels; the skipped products are exact zeros)
  *   chebyshev [1]         expm action, Magnus order 1, nearly skew-Hermitian generator: Chebyshev series instead of
  *                         the scaled Taylor series when shorter (2: always, 0: never)
+ *   cheb_tail [1]         where that Chebyshev series ends: 1 = where the dropped terms of a step sum to less than 2^-53 (the
+ *                         unit-roundoff backward error the Taylor schemes and scipy.linalg.expm are built for), 0 = every
+ *                         Bessel coefficient >= 1e-18 is kept (rounds 2-5: one or two terms more per step)
  *   sparse_bm [0]         row-panel height of the sparse MFMA route: 0 by list density, or 16 | 32 | 64 | 128
  *   krylov [1]            one column, Magnus order 1: Arnoldi instead of the scaled Taylor series when the
  *                         series is long enough to pay for it (2: always, 0: never)
