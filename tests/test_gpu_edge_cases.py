@@ -286,3 +286,51 @@ def test_results_in_pinned_arrays_survive_later_solves(qd):
     assert not np.shares_memory(a, c)
     assert np.array_equal(a, keep)
     assert np.array_equal(solve(1), keep)
+
+
+@pytest.mark.parametrize("n,magn", [(200, 9.0), (128, 2.0)])
+def test_chebyshev_series_ends_at_the_unit_roundoff(qd, n, magn):
+    """Option cheb_tail (csrc/midyn_action.inc, cheb_plan): the Chebyshev series of the expm action ends where the dropped terms
+    of a step sum to less than 2^-53 (default) instead of keeping every Bessel coefficient >= 1e-18 (cheb_tail = 0, rounds 2-5).
+    The default must take FEWER products, agree with the old rule to a few ulps per step, and both must agree with the dense
+    expm route and with the oracle's scipy.linalg.expm steps (solvers/fixed_step_solvers.py:80-108) at the solve tolerance."""
+    from oracle import dynamics_oracle as orc
+
+    ctx = qd.default_context()
+    rng = np.random.default_rng(7 * n)
+
+    def crand_(*shape):
+        return rng.uniform(-1, 1, shape) + 1j * rng.uniform(-1, 1, shape)
+
+    evals = rng.uniform(-magn, magn, n) * 20.0
+    q_, _ = np.linalg.qr(crand_(n, n))
+    h_static = (q_ * evals) @ q_.conj().T
+    h_static = (h_static + h_static.conj().T) / 2
+    a_ = crand_(n, n)
+    h_ops = np.array([(a_ + a_.conj().T) / 2 * 0.3])
+    solver = qd.Solver(static_hamiltonian=h_static, hamiltonian_operators=h_ops)
+    sig = [qd.Signal(lambda t: 0.5 * np.cos(t) + 0j, 1.0, 0.2)]
+    y0 = crand_(n)
+    y0 /= np.linalg.norm(y0)
+    kw = dict(t_span=[0.0, 0.2], y0=y0, signals=sig, method="scipy_expm", max_dt=0.05)
+    res, products = {}, {}
+    for tag, opts in (("roundoff", dict(cheb_tail=1, chebyshev=2)), ("every_coefficient", dict(cheb_tail=0, chebyshev=2)),
+                      ("dense", dict(expm_action=0))):
+        with ctx.options(profile=1, **opts):
+            ctx.reset_counters()
+            res[tag] = np.asarray(solver.solve(**kw).y)
+            products[tag] = ctx.counters("rhs_stream")["launches"]
+    assert ctx.get_option("cheb_tail") == 1                       # (the default, restored)
+    assert 0 < products["roundoff"] < products["every_coefficient"], products
+    assert products["every_coefficient"] - products["roundoff"] <= 4 * 4, products      # a term or two per step, four steps
+    assert np.abs(res["roundoff"] - res["every_coefficient"]).max() < 2e-15
+    assert np.abs(res["roundoff"] - res["dense"]).max() < 1e-11
+    g = -1j * h_static
+    ops = -1j * h_ops
+
+    def gen(t):
+        return g + np.real(0.5 * np.cos(t) * np.exp(1j * (2 * np.pi * 1.0 * t + 0.2))) * ops[0]
+
+    _, yo = orc.expm_solve(gen, [0.0, 0.2], y0, 0.05)
+    assert np.abs(res["roundoff"] - yo).max() < 1e-9
+    assert abs(np.linalg.norm(res["roundoff"][-1]) - 1.0) < 1e-13
