@@ -20,7 +20,13 @@ The only collective of the path is ONE RCCL broadcast of the packed operator sta
 HBM; K steps enqueued on the library's HIP stream, bracketed by barrier + device synchronisation and by a HIP-event
 pair on that stream; MAX over ranks.  Rank 0 prints ONE JSON line.
 
-Objects on the line besides the contract fields:
+OUTPUT.  The LAST (and only) stdout line is a COMPACT object, below 6 KB (the driver keeps 8 018 characters of stdout):
+the contract fields, `roofline`, `cpu_baseline`, `cfg3_three_numbers` and one {value, unit, frac, bound} object per other
+configuration / SURVEY section 8 row (cfg2, cfg4, cfg5, sharded_cfg5, dense_expm, f2, f3, f4, projected_strong_scaling) --
+tools/bench_legs/compact.py.  The FULL result (every object described below, notes, A/B legs, term decompositions) goes to
+`bench_detail.json` beside this script (and to gpurun_out/ when that directory exists) and to stderr.
+
+Objects of the full result besides the contract fields:
   roofline                    dominant kernel of `value` (fp64-MFMA batched RHS contraction): `achieved` = EXECUTED
                               MFMA flops / launch time, `frac` = achieved / 78.6 TFLOP/s (a hardware fraction, <= 1);
                               the SURVEY 8(d) "useful" figure is kept as `useful_tflops`
@@ -49,6 +55,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+from tools.bench_legs.compact import emit  # noqa: E402  (the one stdout line: compact object; details -> bench_detail.json)
 
 N_QUBITS = 10
 N_DRIVES = 8
@@ -1878,8 +1886,9 @@ def main():
                 "what": "same sweep with Python-callable Gaussian envelopes: coefficient table evaluated on the host",
                 "solve_s": round(t_solve, 2), "rhs_evals_per_s_end_to_end": round(b_loc * 4000 / t_solve, 1),
                 "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(yf, axis=1) - 1.0)))}
-    if rank == 0:
-        print(json.dumps(out), file=json_out, flush=True)
+    # the driver keeps 8 018 characters of stdout: the LAST line is the compact object (contract fields, roofline, cpu_baseline,
+    # one {value, frac} per other configuration); everything above goes to bench_detail.json and stderr
+    emit(out, json_out, ROOT, rank)
     D.close()
 
 

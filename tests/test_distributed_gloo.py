@@ -127,6 +127,15 @@ def test_bench_spawns_its_own_ranks_and_refuses_mismatched_worlds():
                        text=True, timeout=240)
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert out["scaling"] == "weak" and out["instances_total"] == 200 and out["shard_rank0"] == [0, 100]
+    # N = 1 and N = 8 (the driver's scaling run launches 1 / 2 / 4 / 8): one line each, LAST on stdout, far below the 8 018
+    # characters of stdout the driver keeps (the real line is covered in test_host_logic.py)
+    for n_ranks in (1, 8):
+        p = subprocess.run([sys.executable, bench, "--gpus", str(n_ranks)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout + p.stderr
+        last = p.stdout.strip().splitlines()[-1]
+        assert len(last) < 6144
+        out = json.loads(last)
+        assert out["n_gpus"] == n_ranks and out["instances_total"] == 4096 and out["shard_rank0"] == [0, 4096 // n_ranks]
     # a launcher-provided world that disagrees with --gpus is an error, not a smaller job
     env_bad = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, bench, "--gpus", "8"], env=env_bad, capture_output=True, text=True, timeout=60)

@@ -646,6 +646,40 @@ def test_bench_two_ranks_share_one_gpu():
     assert out["config"]["global_instances"] == 4096 and out["config"]["instances_per_gpu"] == 2048
     assert out["max_norm_deviation"] < 1e-10 and out["value"] > 1e5
     assert out["roofline"]["frac"] <= 1.0
+    assert len(lines[0]) < 6144                      # the N > 1 line too fits the driver's stdout tail
+
+
+def test_bench_line_of_a_real_run_fits_the_drivers_stdout_tail():
+    """`python bench.py` at N = 1 with its legs on (cfg 2, cfg 4, cfg 5, CPU baseline; the SURVEY-8 rows and A/B variants off to
+    keep the test short): the LAST stdout line is the compact object -- below 6 KB of the 8 018 characters the driver keeps
+    (VERDICT round 5 item 1), with the contract fields, roofline and cpu_baseline -- and bench_detail.json beside the script
+    holds the full result it was reduced from."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k_, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--repeats", "1",
+                        "--no-rows", "--no-variants", "--no-end-to-end"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 6144, (len(lines), len(lines[-1]))
+    c = json.loads(lines[0])
+    assert {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline", "cfg2", "cfg4", "cfg5", "detail"} <= set(c)
+    assert c["n_gpus"] == 1 and c["steps"] == 4 and c["dtype"] == "f64" and c["vs_baseline"] is None
+    assert {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "executed_flops_per_launch",
+            "frac_survey_8d"} <= set(c["roofline"])
+    assert 0.3 < c["roofline"]["frac"] <= 1.0 and c["roofline"]["kernel"].startswith("rhs_combine_kernel<0, 2, 0>")
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] > 0
+    assert c["value"] == pytest.approx(4096 * 4 * 1e3 / c["ms_per_step"], rel=1e-3)
+    with open(os.path.join(root, c["detail"])) as f:
+        full = json.load(f)
+    assert full["value"] == c["value"] and "note" in full["roofline"] and "term_decomposition" in full["cfg5"]["roofline"]
 
 
 def test_bench_two_ranks_share_one_gpu_with_the_sharded_cfg5_leg():

@@ -548,3 +548,55 @@ def test_result_arrays_in_pinned_blocks_ownership(monkeypatch):
     assert rt.freed == [addr]
     del b
     gc.collect()
+
+
+def test_bench_line_is_compact_and_complete():
+    """bench.py's ONE stdout line (tools/bench_legs/compact.py): the driver keeps 8 018 characters of stdout, so the line
+    must stay below 6 KB whatever the legs put into the full result (round 5's 31 KB line was not parsed).  Inputs: the full
+    result dicts of rounds 4 and 5 as committed under profiles/, and the round-5 one with every string blown up."""
+    import io
+    import json
+
+    from tools.bench_legs import compact
+
+    need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "detail"}
+    for name in ("r04_bench.json", "r05_bench_last.json"):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            full = json.load(f)
+        line = json.dumps(compact.compact_line(full), separators=(",", ":"))
+        assert len(line) < compact.MAX_LINE_BYTES, (name, len(line))
+        c = json.loads(line)
+        assert need <= set(c), need - set(c)
+        assert c["value"] == full["value"] and c["ms_per_step"] == full["ms_per_step"] and c["dtype"] == "f64"
+        assert set(compact.ROOFLINE_KEYS) <= set(c["roofline"]) and c["roofline"]["bound"] == "mfma"
+        assert c["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4)
+        assert c["roofline"]["executed_flops_per_launch"] == pytest.approx(full["roofline"]["executed_mfma_flops_per_launch"], rel=1e-4)
+        assert {"value", "unit", "cores", "kind"} <= set(c["cpu_baseline"])
+        assert {"workload", "instances_per_gpu", "global_instances"} <= set(c["config"])
+        assert "NaN" not in line and "Infinity" not in line
+    for key in ("cfg2", "cfg4", "cfg5", "dense_expm", "f2", "f3", "f4", "cfg3_three_numbers", "projected_strong_scaling"):
+        assert key in c, key                                   # (the round-5 dict has every leg)
+    assert c["cfg5"]["frac"] == full["cfg5"]["roofline"]["frac"] and c["f4"]["magnus"]["value"] == full["perturbative"]["magnus"]["solve_s"]
+
+    def blow_up(o):
+        if isinstance(o, dict):
+            return {k: blow_up(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [blow_up(v) for v in o] * 3
+        return o * 40 if isinstance(o, str) else o
+
+    big = blow_up(full)
+    big["cfg4"] = {"error": "x" * 5000}
+    big["max_norm_deviation"] = float("nan")
+    out = io.StringIO()
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        line = compact.emit(big, out, tmp)
+        with open(os.path.join(tmp, compact.DETAIL_NAME)) as f:
+            assert json.load(f)["roofline"]["note"] == big["roofline"]["note"]      # nothing is lost: the detail file has it all
+    assert out.getvalue() == line + "\n" and len(line) < compact.MAX_LINE_BYTES
+    c = json.loads(line)
+    assert need <= set(c) and c["max_norm_deviation"] is None and len(c["cfg4"]["error"]) <= 120
+    assert "NaN" not in line

@@ -8,6 +8,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench.json 2> $O/bench.err
+cp $R/bench_detail.json $O/bench_detail.json     # the full result the compact stdout line (bench.json) was reduced from
 # (the traced command times the same 40 steps behind the same 16 warm-up steps as the default run: the first dozen launches
 # of the dominant kernel run 10-20 % slower while the clocks settle, and a 10-step region would be mostly that)
 B="python $R/bench.py --steps 40 --warmup 16 --repeats 1 --no-cpu-baseline --no-end-to-end --no-projection"
