@@ -702,10 +702,14 @@ def test_bench_two_ranks_share_one_gpu_with_the_sharded_cfg5_leg():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2
-    leg = out["sharded_cfg5"]
+    assert len(lines[0]) < 6144
+    assert "error" not in out["sharded_cfg5"] and out["sharded_cfg5"]["instances_per_gpu"] == 512     # (the compact line)
+    with open(os.path.join(root, out["detail"])) as f:      # the full result of the same run
+        leg = json.load(f)["sharded_cfg5"]
     assert "error" not in leg, leg
     assert leg["instances_total"] == 1024 and leg["instances_per_gpu"] == 512 and leg["n_gpus"] == 2
     assert leg["max_norm_deviation_rank0"] < 1e-10 and leg["instance_steps_per_s"] > 1e4
+    assert out["sharded_cfg5"]["value"] == pytest.approx(leg["instance_steps_per_s"], rel=1e-3)
 
 
 def test_c_program_drives_the_hot_path_through_the_c_abi(tmp_path):
