@@ -154,6 +154,48 @@ def test_cfg5_shard_vs_oracle(qd, route):
         assert_close(res[b].y[-1], y, SOLVE_TOL)
 
 
+def test_cfg5_two_full_size_steps_vs_the_oracles_magnus2_and_scipy_expm(qd):
+    """BASELINE cfg 5 at full size against the REAL algorithm: the 128-instance shard on the product's
+    default route (ONE launch of ell_flip_duo_kernel<2, 2, 1024>, asserted through the counters) over t_span = [2.25, 2.75] --
+    two steps of max_dt = 0.25 in the middle of the pulse -- and instance 63 against
+    oracle.solve_generator_model(..., "scipy_expm", magnus_order=2): the oracle's dense generators G(t1), G(t2) (n = 4096),
+    oracle.magnus_terms (h (G1 + G2) / 2 + sqrt(3)/12 h^2 [G2, G1], two dense n^3 products) and scipy.linalg.expm of the 4096 x 4096
+    Omega, as the reference does it (solvers/fixed_step_solvers.py:80-108, 345-363) -- no test-local series, no sparse copy.
+    About 25 s of CPU.  Tolerance 1e-9 (SOLVE_TOL)."""
+    from oracle import dynamics_oracle as orc
+    from qiskit_dynamics_amd import workloads
+
+    ctx = qd.default_context()
+    cfg = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
+    frame = np.diag(cfg["h_d"]).real.copy()
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=frame)
+    nb, n, pick = 128, 4096, 63
+    sweeps = [_gauss_signals(qd, cfg, b, 8, 2.5) for b in range(nb)]
+    rng = np.random.default_rng(2026)
+    y0 = rng.normal(size=n) + 1j * rng.normal(size=n)
+    y0 /= np.linalg.norm(y0)
+    t_span = [2.25, 2.75]
+    gave_up_before = ctx.counters("resident_fallbacks")["launches"]
+    res = _profiled(ctx, lambda: solver.solve(t_span=t_span, y0=y0, signals=sweeps, method="scipy_expm", max_dt=0.25,
+                                              magnus_order=2))
+    assert ctx.counters("rk4_resident")["launches"] == 1
+    split = ctx.counters("sweep_split")
+    assert (int(split["launches"]), int(split["ms"])) == (2, 3), f"not ell_flip_duo_kernel: {split}"
+    assert ctx.counters("resident_fallbacks")["launches"] == gave_up_before
+    assert all(r.nfev == 2 * 2 for r in res)
+    finals = np.stack([r.y[-1] for r in res])
+    assert np.max(np.abs(np.linalg.norm(finals, axis=1) - 1.0)) < 1e-12
+    assert np.max(np.abs(finals[pick] - y0)) > 5e-4          # (the pulse is on: the state moves, by ~10 % of an entry)
+
+    a_d, a, d, basis = orc.hamiltonian_model_build(cfg["h_d"], cfg["ops"], frame)
+    assert basis is None
+    sig = sweeps[pick]
+    _, ys = orc.solve_generator_model(a_d, a, d, None, lambda t: np.array([np.real(s_(t)) for s_ in sig]), t_span, y0,
+                                      method="scipy_expm", max_dt=0.25, magnus_order=2)
+    assert_close(res[pick].y[-1], ys[-1], SOLVE_TOL)
+    assert np.max(np.abs(res[pick].y[-1] - ys[-1])) < 1e-11      # (what two steps actually differ by is far below the bound)
+
+
 @pytest.mark.parametrize("frame", ["no_frame", "diag_frame"])
 def test_cfg4_default_route_all_steps_vs_oracle(qd, frame):
     """BASELINE cfg 4 exactly as bench.py's cfg4 leg times it: 6 qubits, N = 4096 superoperators built
