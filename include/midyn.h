@@ -59,6 +59,8 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         (work-list kernels; the skipped products are exact zeros)
  *   chebyshev [1]         expm action, Magnus order 1, nearly skew-Hermitian generator: Chebyshev series instead of
  *                         the scaled Taylor series when shorter (2: always, 0: never)
+ *   expm_direct_out [1]   midyn_expm_solve / midyn_expm_plan_run on the one-launch sweep route: saved states written by the kernel
+ *                         straight into a device-writable (pinned) result block of the caller; 0: device block + copy
  *   cheb_tail [1]         where that Chebyshev series ends: 1 = where the dropped terms of a step sum to less than 2^-53 (the
  *                         unit-roundoff backward error the Taylor schemes and scipy.linalg.expm are built for), 0 = every
  *                         Bessel coefficient >= 1e-18 is kept (rounds 2-5: one or two terms more per step)
@@ -291,6 +293,26 @@ int midyn_rk4_plan_create(midyn_stack* stack, int B, int m, int R, const double*
 int midyn_rk4_plan_run(midyn_rk4_plan* plan, int step_begin, int step_end);
 int midyn_rk4_plan_fetch(midyn_rk4_plan* plan, midyn_complex* Y_out);
 int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
+
+/* ---- device-resident Magnus/expm solve of a parameter scan (solvers/fixed_step_solvers.py:80-108, 345-363, 406-459) ----
+ * A scan re-solves the SAME model on the SAME time grid with new signal parameters (solvers/solver_classes.py:556-590).
+ * midyn_expm_plan_create keeps what those solves share on the device: the frame-phase table of `times`, the step tables, y0, the
+ * result block and the exchange slots of the one-launch sweep kernels (arguments as midyn_expm_solve, without S).
+ * midyn_expm_plan_run(plan, S, Y_direct) uploads the coefficient table S[B][R][k] (host or device pointer), chooses the series of
+ * every step from the norm bounds of THIS table, and launches; it returns when the launch is queued.  Y_direct (optional,
+ * [B][P][n][m]): when it is device-writable host memory (hipHostMalloc / hipHostRegister) the kernel writes the saved states
+ * straight into it (ctx option expm_direct_out [1]); otherwise they stay on the device until the fetch.
+ * midyn_expm_plan_fetch(plan, Y_out) waits for the launch and delivers [B][P][n][m] (slot 0 = y0); with Y_out == the Y_direct
+ * of the run nothing is copied.  A plan can run any number of times.  Solves that the one-launch sweep kernels do not take
+ * (dense stacks, matrix states, magnus_order 3) are run by midyn_expm_solve itself inside midyn_expm_plan_run: same results,
+ * no saving.  midyn_expm_solve on the sweep route is create + run + fetch + destroy of this plan. */
+typedef struct midyn_expm_plan midyn_expm_plan;
+int midyn_expm_plan_create(midyn_stack* stack, int B, int m, int R, const double* times, int nsteps,
+                           const int* step_rows, const double* step_h, const int* step_save, int P,
+                           int magnus_order, const midyn_complex* y0, int y0_shared, midyn_expm_plan** out);
+int midyn_expm_plan_run(midyn_expm_plan* plan, const double* S, midyn_complex* Y_direct);
+int midyn_expm_plan_fetch(midyn_expm_plan* plan, midyn_complex* Y_out);
+int midyn_expm_plan_destroy(midyn_expm_plan* plan);
 
 /* ---- counters ----------------------------------------------------------------------------------
  * Kernel-time accounting measured with HIP events on the ctx stream.

@@ -5,7 +5,7 @@ build, the ctypes binding of libmidyn.so (HIP kernels for gfx950) and the fixed-
 Importing the package does not touch the GPU; the first model or context does, and it raises
 ``HipLibraryError`` if libmidyn.so or a HIP device is missing (there is no CPU fallback).
 """
-from ._lib import DynamicsError, HipLibraryError, Context, Stack, Rk4Plan, default_context
+from ._lib import DynamicsError, HipLibraryError, Context, Stack, Rk4Plan, ExpmPlan, default_context
 from .signals import Signal, DiscreteSignal, SignalSum, DiscreteSignalSum, SignalList
 from .rotating_frame import RotatingFrame
 from .models import GeneratorModel, HamiltonianModel, LindbladModel
@@ -13,7 +13,7 @@ from .solvers import Solver, solve_lmde, solve_ode
 from .perturbative import DysonSolver, MagnusSolver, ExpansionModel
 
 __all__ = [
-    "DynamicsError", "HipLibraryError", "Context", "Stack", "Rk4Plan", "default_context",
+    "DynamicsError", "HipLibraryError", "Context", "Stack", "Rk4Plan", "ExpmPlan", "default_context",
     "Signal", "DiscreteSignal", "SignalSum", "DiscreteSignalSum", "SignalList", "RotatingFrame",
     "GeneratorModel", "HamiltonianModel", "LindbladModel", "Solver", "solve_lmde", "solve_ode",
     "DysonSolver", "MagnusSolver", "ExpansionModel",

@@ -22,7 +22,8 @@ ABI_SYMBOLS = [
     "midyn_stack_adopt", "midyn_stack_antiherm_defect",
     "midyn_stack_destroy", "midyn_stack_info", "midyn_stack_segment_modes", "midyn_eval_generator", "midyn_eval_rhs",
     "midyn_rk4_solve", "midyn_expm", "midyn_expm_solve", "midyn_zgemm", "midyn_rk4_plan_create",
-    "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_get_counters",
+    "midyn_rk4_plan_run", "midyn_rk4_plan_fetch", "midyn_rk4_plan_destroy", "midyn_expm_plan_create", "midyn_expm_plan_run",
+    "midyn_expm_plan_fetch", "midyn_expm_plan_destroy", "midyn_get_counters",
     "midyn_reset_counters", "midyn_microbench", "midyn_lindblad_create", "midyn_lindblad_destroy",
     "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve", "midyn_sigtable_create", "midyn_sigtable_data",
     "midyn_sigtable_fetch", "midyn_sigtable_destroy", "midyn_parallel_solve", "midyn_expansion_create",
@@ -153,6 +154,10 @@ def load():
         lib.midyn_rk4_plan_run.argtypes = [_vp, _ci, _ci]
         lib.midyn_rk4_plan_fetch.argtypes = [_vp, _vp]
         lib.midyn_rk4_plan_destroy.argtypes = [_vp]
+        lib.midyn_expm_plan_create.argtypes = [_vp, _ci, _ci, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _ci, _vp, _ci, ctypes.POINTER(_vp)]
+        lib.midyn_expm_plan_run.argtypes = [_vp, _vp, _vp]
+        lib.midyn_expm_plan_fetch.argtypes = [_vp, _vp]
+        lib.midyn_expm_plan_destroy.argtypes = [_vp]
         lib.midyn_get_counters.argtypes = [_vp, ctypes.c_char_p, P(_cd)]
         lib.midyn_reset_counters.argtypes = [_vp]
         lib.midyn_microbench.argtypes = [_vp, ctypes.c_char_p, P(_cd)]
@@ -808,6 +813,67 @@ class Rk4Plan:
         if (getattr(self, "handle", None) is not None and self.handle and self.stack.handle
                 and self.stack.ctx.handle):
             self.stack.ctx.lib.midyn_rk4_plan_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+
+class ExpmPlan:
+    """Device-resident state of a fixed-step Magnus / scipy_expm solve that is repeated with new signal parameters
+    (midyn_expm_plan_*): the frame-phase table, step tables, y0, result block and exchange slots are made once;
+    ``solve(table)`` uploads a coefficient table and runs; ``run(table)`` / ``fetch()`` split it (run returns when the
+    launch is queued)."""
+
+    def __init__(self, stack: Stack, times, step_rows, step_h, step_save, n_save, magnus_order, y0, batch, y0_shared):
+        self.stack = stack
+        ctx = stack.ctx
+        times = f64(times)
+        r = times.shape[0]
+        step_rows = i32(step_rows).reshape(-1, 3)
+        step_h = f64(step_h)
+        step_save = i32(step_save)
+        nsteps = step_rows.shape[0]
+        y0 = stack._rows_in(c128(y0), -2)      # (n, m) or (B, n, m): rows into the internal order
+        self.m = y0.shape[-1]
+        self.batch, self.r, self.n_save = batch, r, int(n_save)
+        self._out = None
+        h = _vp()
+        ctx.check(ctx.lib.midyn_expm_plan_create(
+            stack.handle, batch, self.m, r, _ptr(times), nsteps, _ptr(step_rows), _ptr(step_h), _ptr(step_save),
+            self.n_save, int(magnus_order), _ptr(y0), int(bool(y0_shared)), ctypes.byref(h)))
+        self.handle = h
+
+    def run(self, table):
+        if self.stack.k > 0:
+            if not isinstance(table, SignalTable):
+                table = f64(table)
+            if table.shape != (self.batch, self.r, self.stack.k):
+                raise DynamicsError(f"coefficient table must be (B,R,k)={(self.batch, self.r, self.stack.k)}, got {table.shape}")
+        else:
+            table = None
+        self._out = result_array((self.batch, self.n_save, self.stack.n, self.m))
+        self.stack.ctx.check(self.stack.ctx.lib.midyn_expm_plan_run(self.handle, _ptr(table), _ptr(self._out)))
+
+    def fetch(self):
+        if self._out is None:
+            raise DynamicsError("ExpmPlan.fetch before run")
+        out, self._out = self._out, None
+        self.stack.ctx.check(self.stack.ctx.lib.midyn_expm_plan_fetch(self.handle, _ptr(out)))
+        return self.stack._rows_out(out, 2)
+
+    def solve(self, table):
+        self.run(table)
+        return self.fetch()
+
+    def close(self):
+        # the plan points into its stack and context: only destroy it while both are alive
+        if (getattr(self, "handle", None) is not None and self.handle and self.stack.handle
+                and self.stack.ctx.handle):
+            self.stack.ctx.lib.midyn_expm_plan_destroy(self.handle)
         self.handle = None
 
     def __del__(self):

@@ -37,6 +37,7 @@ using namespace midyn;
 #include "midyn_eval.inc"
 #include "midyn_rk4.inc"
 #include "midyn_expm.inc"
+#include "midyn_sweep_plan.inc"
 #include "midyn_action.inc"
 #include "midyn_parallel.inc"
 #include "midyn_expansion.inc"

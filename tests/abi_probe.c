@@ -38,7 +38,8 @@ int main(int argc, char** argv) {
     CHECK(midyn_stack_segment_modes); CHECK(midyn_eval_generator); CHECK(midyn_eval_rhs);
     CHECK(midyn_rk4_solve); CHECK(midyn_expm); CHECK(midyn_expm_solve); CHECK(midyn_zgemm);
     CHECK(midyn_rk4_plan_create); CHECK(midyn_rk4_plan_run); CHECK(midyn_rk4_plan_fetch);
-    CHECK(midyn_rk4_plan_destroy); CHECK(midyn_get_counters); CHECK(midyn_reset_counters);
+    CHECK(midyn_rk4_plan_destroy); CHECK(midyn_expm_plan_create); CHECK(midyn_expm_plan_run); CHECK(midyn_expm_plan_fetch);
+    CHECK(midyn_expm_plan_destroy); CHECK(midyn_get_counters); CHECK(midyn_reset_counters);
     CHECK(midyn_microbench); CHECK(midyn_lindblad_create); CHECK(midyn_lindblad_destroy);
     CHECK(midyn_lindblad_rhs); CHECK(midyn_lindblad_rk4_solve);
     CHECK(midyn_stack_create_lindblad); CHECK(midyn_stack_antiherm_defect); CHECK(midyn_sigtable_create);

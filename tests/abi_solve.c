@@ -34,6 +34,11 @@ static int (*p_midyn_rk4_solve)(midyn_stack*, int, int, int, const double*, cons
                                 const int*, int, const midyn_complex*, int, midyn_complex*);
 static int (*p_midyn_expm_solve)(midyn_stack*, int, int, int, const double*, const double*, int, const int*, const double*,
                                  const int*, int, int, const midyn_complex*, int, midyn_complex*);
+static int (*p_midyn_expm_plan_create)(midyn_stack*, int, int, int, const double*, int, const int*, const double*, const int*, int,
+                                       int, const midyn_complex*, int, midyn_expm_plan**);
+static int (*p_midyn_expm_plan_run)(midyn_expm_plan*, const double*, midyn_complex*);
+static int (*p_midyn_expm_plan_fetch)(midyn_expm_plan*, midyn_complex*);
+static int (*p_midyn_expm_plan_destroy)(midyn_expm_plan*);
 static int (*p_midyn_comm_get_unique_id)(void*);
 static int (*p_midyn_comm_init_rank)(midyn_ctx*, int, int, const void*, void**);
 static int (*p_midyn_comm_destroy)(midyn_ctx*, void*);
@@ -68,6 +73,7 @@ int main(int argc, char** argv) {
     LOAD(midyn_stack_destroy) LOAD(midyn_eval_rhs) LOAD(midyn_rk4_solve) LOAD(midyn_expm_solve)
     LOAD(midyn_comm_get_unique_id) LOAD(midyn_comm_init_rank) LOAD(midyn_comm_destroy) LOAD(midyn_stack_broadcast)
     LOAD(midyn_stack_broadcast_from) LOAD(midyn_stack_create_empty)
+    LOAD(midyn_expm_plan_create) LOAD(midyn_expm_plan_run) LOAD(midyn_expm_plan_fetch) LOAD(midyn_expm_plan_destroy)
 
     midyn_ctx* ctx = NULL;
     CHECK(NULL, p_midyn_ctx_create(0, &ctx));
@@ -162,6 +168,21 @@ int main(int argc, char** argv) {
         const midyn_complex* yb = Y + ((size_t)b * 2 + 1) * N;
         worst_expm = fmax(worst_expm, fmax(cabs(yb[0] - cos(theta)), cabs(yb[1] + I * sin(theta))));
     }
+    /* the same solve through the plan object (made once, run twice with different tables): the second run must equal
+     * midyn_expm_solve of that table bit for bit, and the first the solve above */
+    midyn_expm_plan* plan = NULL;
+    midyn_complex* Yp = malloc(sizeof(midyn_complex) * B * 2 * N);
+    midyn_complex* Yq = malloc(sizeof(midyn_complex) * B * 2 * N);
+    CHECK(ctx, p_midyn_expm_plan_create(stack, B, 1, RE, te, ESTEPS, rows_e, hse, save_e, 2, 2, y0, 1, &plan));
+    CHECK(ctx, p_midyn_expm_plan_run(plan, Se, NULL));
+    CHECK(ctx, p_midyn_expm_plan_fetch(plan, Yp));
+    if (memcmp(Yp, Y, sizeof(midyn_complex) * B * 2 * N) != 0) return 14;
+    for (int i = 0; i < B * RE; ++i) Se[i] *= 0.5;
+    CHECK(ctx, p_midyn_expm_plan_run(plan, Se, NULL));
+    CHECK(ctx, p_midyn_expm_plan_fetch(plan, Yp));
+    CHECK(ctx, p_midyn_expm_solve(stack, B, 1, RE, te, Se, ESTEPS, rows_e, hse, save_e, 2, 2, y0, 1, Yq));
+    if (memcmp(Yp, Yq, sizeof(midyn_complex) * B * 2 * N) != 0) return 15;
+    CHECK(ctx, p_midyn_expm_plan_destroy(plan));
     if (comm) CHECK(ctx, p_midyn_comm_destroy(ctx, comm));
     CHECK(ctx, p_midyn_stack_destroy(stack));
     CHECK(ctx, p_midyn_ctx_destroy(ctx));

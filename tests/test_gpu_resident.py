@@ -903,3 +903,64 @@ def test_one_launch_kernels_fall_back_when_a_wait_gives_up(qd, route):
         _, ref = orc.solve_generator_model(a_d, a, d, basis, lambda tt: np.array([np.real(s(tt)) for s in sweeps[0]]),
                                            t_span, y0, method, kw["max_dt"], magnus_order=kw.get("magnus_order", 1))
         assert_close(runs["gives_up"][0], ref[-1], SOLVE_TOL)
+
+
+@pytest.mark.parametrize("nq,count,order", [(10, 64, 2), (12, 16, 2), (10, 300, 1), (5, 7, 2)])
+def test_expm_plan_equals_expm_solve(qd, nq, count, order):
+    """midyn_expm_plan_* (csrc/midyn_sweep_plan.inc): a plan made ONCE for a model + time grid and run with several coefficient
+    tables gives, for each table, exactly what midyn_expm_solve gives for it (the solve IS create + run + fetch + destroy on
+    the sweep route) -- bit for bit, with the saved states written by the kernel straight into the pinned result block and with
+    the device block + copy (option expm_direct_out = 0), for the two-workgroup flip kernel (10 and 12 qubits, 64 / 16
+    instances), the one-workgroup kernel (300 instances) and a small dense model the sweep kernels do not take (5 qubits: the
+    plan runs midyn_expm_solve itself).  Reference: solvers/fixed_step_solvers.py:80-108 called once per parameter set
+    (solver_classes.py:556-590)."""
+    from qiskit_dynamics_amd import workloads as W
+    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+
+    ctx = qd.default_context()
+    cfg = W.schrodinger_config(n_qubits=nq, n_drives=min(8, nq), t_final=2.0, max_dt=0.25)
+    k = min(8, nq)
+    fr = RotatingFrame(np.diag(cfg["h_d"]).real.copy())
+    stack = qd.Stack(ctx, -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag)
+    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(order))
+    rng = np.random.default_rng(nq * 100 + count)
+    n = 2**nq
+    y0 = (rng.normal(size=n) + 1j * rng.normal(size=n)).reshape(-1, 1)
+    y0 /= np.linalg.norm(y0)
+
+    def table(scale, first):
+        amps = np.array([W.sweep_parameters(first + b, k)[0] for b in range(count)]) * scale
+        phs = np.array([W.sweep_parameters(first + b, k)[1] for b in range(count)])
+        return W.gaussian_coefficient_table(sched.times, amps, phs, cfg["carrier"][:k], 2.0)
+
+    tables = [table(1.0, 0), table(2.5, 1000), table(0.1, 5)]       # (different norm bounds -> different series per run)
+    want = [stack.expm_solve(sched.times, t, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, order, y0, count, True)
+            for t in tables]
+    assert np.max(np.abs(want[0] - want[1])) > 1e-3
+    ctx.reset_counters()
+    with ctx.options(profile=1):
+        stack.expm_solve(sched.times, tables[0], sched.step_rows, sched.step_h, sched.step_save, sched.n_save, order, y0, count, True)
+        on_sweep = ctx.counters("rk4_resident")["launches"] == 1
+        split = ctx.counters("sweep_split")
+    assert on_sweep == (nq >= 10)
+    if nq >= 10:
+        assert int(split["launches"]) == (2 if count <= 128 else 1), split
+    plan = qd.ExpmPlan(stack, sched.times, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, order, y0, count, True)
+    for direct in (1, 0):
+        with ctx.options(expm_direct_out=direct):
+            for t, w in zip(tables, want):
+                got = plan.solve(t)
+                assert got.shape == w.shape and np.array_equal(got, w), (direct, np.max(np.abs(got - w)))
+            # run without fetch, then run again: the first launch is waited for, the second is what fetch returns
+            plan.run(tables[1])
+            plan.run(tables[2])
+            assert np.array_equal(plan.fetch(), want[2])
+            assert np.array_equal(stack.expm_solve(sched.times, tables[1], sched.step_rows, sched.step_h, sched.step_save,
+                                                   sched.n_save, order, y0, count, True), want[1])
+    with pytest.raises(qd.DynamicsError):
+        plan.run(tables[0][:, :-1])
+    with pytest.raises(qd.DynamicsError):
+        plan.fetch()
+    plan.close()
+    assert np.max(np.abs(np.linalg.norm(want[1][:, -1, :, 0], axis=1) - 1.0)) < 1e-11

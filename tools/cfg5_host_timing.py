@@ -27,3 +27,17 @@ print("--- after the 1024-instance solve", file=sys.stderr, flush=True)
 for i in range(4):
     t0 = time.perf_counter(); ys = run(); t1 = time.perf_counter()
     print("solve wall %.1f us" % ((t1 - t0) * 1e6), ys.shape, file=sys.stderr, flush=True)
+# ... and through the plan object (midyn_expm_plan_*): tables, buffers and the result block's route made once
+print("--- plan object: create once, then run + fetch per solve", file=sys.stderr, flush=True)
+t0 = time.perf_counter()
+plan = qd.ExpmPlan(stack, sched.times, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2, y0, count, True)
+print("plan create %.1f us" % ((time.perf_counter() - t0) * 1e6), file=sys.stderr, flush=True)
+for direct in (1, 0):
+    with ctx.options(expm_direct_out=direct):
+        for i in range(5):
+            t0 = time.perf_counter(); ctx.timer_start(); plan.run(table); t1 = time.perf_counter(); ys2 = plan.fetch(); ev = ctx.timer_stop(); t2 = time.perf_counter()
+            print("direct_out=%d  plan run %.1f us  fetch %.1f us  total %.1f us  (stream %.1f us)  equal %s" % (
+                direct, (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t2 - t0) * 1e6, ev * 1e3, np.array_equal(ys2, ys)), file=sys.stderr, flush=True)
+        for i in range(3):
+            t0 = time.perf_counter(); ys3 = run(); t1 = time.perf_counter()
+            print("direct_out=%d  one-shot solve wall %.1f us" % (direct, (t1 - t0) * 1e6), file=sys.stderr, flush=True)
