@@ -731,6 +731,31 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
            "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(ys[:, -1, :, 0], axis=1) - 1.0))),
            "note": "solve_s = midyn_expm_solve wall clock: coefficient table H2D, 20 device steps, results D2H "
                    "(%.0f MB over PCIe); stream_ms = HIP events around the same call" % (ys.nbytes / 1e6)}
+    # the same solve repeated through a plan object (midyn_expm_plan_*: model + time grid made once, one coefficient table per run):
+    # what a parameter scan or an optimiser loop pays per solve
+    try:
+        plan = qd.ExpmPlan(stack, sched.times, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2, y0, count, True)
+        for _ in range(3):
+            yp = plan.solve(table)
+        ctx.synchronize()
+        best_p = None
+        for _ in range(5):
+            t0_ = time.perf_counter()
+            plan.run(table)
+            t1_ = time.perf_counter()
+            yp = plan.fetch()
+            t2_ = time.perf_counter()
+            if best_p is None or t2_ - t0_ < best_p[0]:
+                best_p = (t2_ - t0_, t1_ - t0_)
+        plan.close()
+        out["plan"] = {"solve_s": round(best_p[0], 5), "ms_per_step": round(best_p[0] / n_steps * 1e3, 4),
+                       "run_call_ms": round(best_p[1] * 1e3, 4), "equal_to_the_one_shot_solve": bool(np.array_equal(yp, ys)),
+                       "instance_steps_per_s": round(count * n_steps / best_p[0], 1),
+                       "what": "midyn_expm_plan_run + _fetch of a plan made once (frame phases, step tables, y0, exchange slots, result "
+                               "block on the device; per run: table upload, norm bounds, series, launch; saved states written by the kernel "
+                               "straight into the pinned result block)"}
+    except Exception as exc:  # pylint: disable=broad-except
+        out["plan"] = {"error": repr(exc)}
     if with_profile:
         took_sweep = cs["rk4_resident"]["launches"] > 0
         out["launches_per_step"] = {c: round(v["launches"] / n_steps, 2) for c, v in cs.items() if v["launches"]}
@@ -789,11 +814,18 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
                 "avg_launch_ms": round(k_ms / max(cs["rk4_resident"]["launches"], 1), 4),
                 "series_terms_per_instance": terms, "operator_slots_per_row": slots,
                 "us_per_term": round(k_ms * 1e3 / max(terms, 1), 2),
+                "host_side_ms_one_shot": round(wall * 1e3 - k_ms / max(cs["rk4_resident"]["launches"], 1), 4),
+                "host_side_ms_plan": (round(out["plan"]["solve_s"] * 1e3 - k_ms / max(cs["rk4_resident"]["launches"], 1), 4)
+                                      if "solve_s" in out.get("plan", {}) else None),
                 "executed_gflops_per_launch": round(flops / 1e9, 2),
                 "executed_tflops": round(flops / (k_ms * 1e-3) / 1e12, 3),
                 "operator_element_bytes": elem_bytes,
                 "l2_operator_bytes_per_launch": l2_bytes,
                 "l2_operator_gbs": round(l2_bytes / (k_ms * 1e-3) / 1e9, 1),
+                "bound_note": "round 6 (profiles/r06_cfg5_pipeline.md): neither the LDS nor the fp64 pipe is the bound -- with four waves per "
+                              "SIMD (1024 threads and 128 KB of LDS per workgroup: one workgroup per CU) the kernel is bound by the "
+                              "instructions its waves issue (a slot: 23 instructions around 4 gathers and 8 multiply-adds); a loop that "
+                              "hides the LDS round trip with 4 more instructions per slot measured 1.4 us per term slower",
                 "note": "achieved = bytes gathered from LDS (16 B per operator slot, row and operand vector) / kernel "
                         "time; peak = 256 B per clock and CU (ds_read_b128, MI355X_MICROARCH.md) x 256 CUs x 2.4 GHz; "
                         "cus_busy = instances x workgroups per instance (one workgroup per CU: LDS); frac_of_the_busy_cus "
@@ -1829,11 +1861,19 @@ def main():
                     "max_norm_deviation_rank0": full["max_norm_deviation"], "stack_broadcast": bcast5}
                 if world == 1 and "projected_strong_scaling" in out:
                     proj5 = {}
+                    proj5p = {}
+                    plan_full = full.get("plan", {}).get("solve_s")
                     for n_r in (2, 4, 8):
                         sh = leg_cfg5(qd, ctx, workloads, stack5, cfg5, 0, CFG5_SWEEP // n_r, with_profile=False)
                         proj5[str(n_r)] = {"instances_per_gpu": CFG5_SWEEP // n_r, "solve_s": sh["solve_s"],
                                            "efficiency": round(solve5 / (n_r * sh["solve_s"]), 4)}
+                        plan_sh = sh.get("plan", {}).get("solve_s")
+                        if plan_full and plan_sh:
+                            proj5p[str(n_r)] = {"instances_per_gpu": CFG5_SWEEP // n_r, "solve_s": plan_sh,
+                                                "efficiency": round(plan_full / (n_r * plan_sh), 4)}
                     out["projected_strong_scaling"]["cfg5"] = proj5
+                    if proj5p:      # repeated solves through midyn_expm_plan_* (tables and buffers made once per model + time grid)
+                        out["projected_strong_scaling"]["cfg5_plan"] = proj5p
         except Exception as exc:  # pylint: disable=broad-except
             if rank == 0:
                 out["sharded_cfg5"] = {"error": repr(exc)}

@@ -301,7 +301,8 @@ int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
  * midyn_expm_plan_run(plan, S, Y_direct) uploads the coefficient table S[B][R][k] (host or device pointer), chooses the series of
  * every step from the norm bounds of THIS table, and launches; it returns when the launch is queued.  Y_direct (optional,
  * [B][P][n][m]): when it is device-writable host memory (hipHostMalloc / hipHostRegister) the kernel writes the saved states
- * straight into it (ctx option expm_direct_out [1]); otherwise they stay on the device until the fetch.
+ * straight into it (ctx option expm_direct_out [1]); otherwise they stay on the device until the fetch.  A block the plan has
+ * accepted once must stay pinned for as long as it is handed to this plan (the query is made once per block).
  * midyn_expm_plan_fetch(plan, Y_out) waits for the launch and delivers [B][P][n][m] (slot 0 = y0); with Y_out == the Y_direct
  * of the run nothing is copied.  A plan can run any number of times.  Solves that the one-launch sweep kernels do not take
  * (dense stacks, matrix states, magnus_order 3) are run by midyn_expm_solve itself inside midyn_expm_plan_run: same results,

@@ -100,6 +100,8 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
     // 10.9 us term on the cfg 5 shard, tools/bench_cfg5_variants.py no_barrier1).  Safe with one barrier: a wave that writes
     // buffer p & 1 for pass p + 2 has passed the barrier of pass p + 1, which every wave reaches after its gathers of pass p.
     extern __shared__ __attribute__((aligned(16))) double2 flip_lds[];
+    // (round 6: a software-pipelined slot loop was built, measured slower and removed -- profiles/r06_cfg5_pipeline.md)
+    constexpr bool SMEM = MIDYN_FLIP_SMEM != 0;
     constexpr unsigned FLIP_BUF = ORDER == 2 ? 65536u : 32768u;
     const int tid = threadIdx.x, np = a.n_pad;
     const unsigned unp = (unsigned)np;
@@ -120,7 +122,6 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
     const int lane = tid & 63;
     const int meta_l = lane < n_all ? a.meta[lane] : 0;      // lane j: flip mask | plane of slot j
     const int xm_l = (meta_l & 0x7fffffff) << 4;             // lane j: flip mask of slot j as an LDS byte offset
-    double wa_l = 0.0, wb_l = 0.0;                            // lane j: the two coefficients of slot j as this pass uses them
     auto lane_i32 = [](const int v, const int j) { return __builtin_amdgcn_readlane(v, j); };
     auto lane_f64 = [](const double v, const int j) {
         const long long q = __double_as_longlong(v);
@@ -150,6 +151,24 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
             }
         }
     };
+    const double p2 = 0.14433756729740643;   // sqrt(3) / 12
+    // a wave-uniform double into a pair of SCALAR registers (the per-step and per-term factors of the series are computed by
+    // vector instructions and would otherwise each hold two vector registers through the passes -- round 6: with the pipeline's
+    // operand sets in flight the compiler spilled them to scratch, a load + vmcnt(0) per term)
+    auto uni = [](const double v) {
+        const long long q = __double_as_longlong(v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(q >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    double2 pw[RPT], acc[RPT], cur[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const unsigned r = row0 + rowof(i);
+        // (an unconditional load of a valid row and a select: a branch around the load kept its 64-bit address alive -- in scratch)
+        const double2 yv = a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + (r < (unsigned)a.n ? r : 0u)];
+        acc[i] = (r < (unsigned)a.n) ? yv : make_double2(0.0, 0.0);
+        cur[i] = pw[i] = make_double2(0.0, 0.0);
+    }
     const bool exch = !(a.ablate & 1) && n_all > n_loc;     // (no crossing slot: the halves are independent problems)
     bool one_l2 = false;
     if (exch) {      // do the partners share an XCD (one L2)?  Each publishes its XCC id + 1 once and reads the other's.
@@ -159,14 +178,6 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
         if (tid == 0) __hip_atomic_store(my_flags + 16, (int)xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int theirs = wait_word(partner_flags + 16, 1);
         one_l2 = !dead && theirs == (int)xcc + 1 && !(a.ablate & 2);
-    }
-    const double p2 = 0.14433756729740643;   // sqrt(3) / 12
-    double2 pw[RPT], acc[RPT], cur[RPT];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-        const unsigned r = row0 + rowof(i);
-        acc[i] = (r < (unsigned)a.n) ? a.y0[(a.y0_shared ? 0 : (size_t)b * a.n) + r] : make_double2(0.0, 0.0);
-        cur[i] = pw[i] = make_double2(0.0, 0.0);
     }
     // the local slots in four parts when there is an exchange (see above): part p = slots [cut[p], cut[p + 1]).  The exchange needs
     // most of a pass from the stores to the last operand in a register (acknowledgement, flag, flag seen, 64 KB of loads per
@@ -213,23 +224,16 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
     // flip mask, which the gathers need FIRST, stays a v_readlane.  (Measured, cfg 5 shard, the slot loops alone: with the
     // gathers removed they still took 6.0 of their 6.7 us per term -- eight multiply-adds, five v_readlane and two XORs per slot
     // are the bound, not the LDS; the scale of the second sum went into the staged operand for the same reason.)
-    bool pass_swapped = false;
+    // (Round 6: no "swapped" coefficient sets any more -- the second pass of a term hands its operands over in the order of the
+    // coefficient sets instead, see the term loop: slot coefficient a always meets the operand in the X1 buffer.)
     const MIDYN_CONST_AS flip_d2* ccab = nullptr;     // the coefficient table of this (instance, step)
     auto coef_a = [&](const int j) {
-#if MIDYN_FLIP_SMEM
-        const flip_d2 cc = ccab[j];
-        return pass_swapped ? cc.y : cc.x;
-#else
-        return lane_f64(wa_l, j);
-#endif
+        if constexpr (SMEM) return (double)ccab[j].x;
+        else return lane_f64(cx_l, j);
     };
     auto coef_b = [&](const int j) {
-#if MIDYN_FLIP_SMEM
-        const flip_d2 cc = ccab[j];
-        return pass_swapped ? cc.x : cc.y;
-#else
-        return lane_f64(wb_l, j);
-#endif
+        if constexpr (SMEM) return (double)ccab[j].y;
+        else return lane_f64(cy_l, j);
     };
     // LDS byte address of this thread's rows as an INTEGER in the LDS address space: (la ^ flip) is then the operand's address with
     // no addition of the (link-time) base of the dynamic LDS per gather -- two of a slot's thirteen vector instructions.  XOR and
@@ -281,19 +285,17 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
     // One exchange round and the pass it feeds.  in1 / in2: this thread's rows of the operand vectors as the operators see
     // them (X1 / X2 forms).  nv = 1: one vector travels (in1) and the X2 form of the partner's rows is dtab o in1 (dtab: the
     // frame phase between the Gauss points of this step; use_dp false: none); nv = 2: both forms travel.
-    // keep: o2 continues from its start value (its sum scaled by scale2); else both sums start at zero.
-    auto exchange_and_pass = [&](const double2 (&in1)[RPT], const double2 (&in2)[RPT], const int nv, const double2* dtab,
-                                 const bool use_dp, const bool swapped, const bool keep, const double scale2,
+    // o1 = sum over the slots of (coefficient a) x (in1 operand), o2 = of (coefficient b) x (in2 operand).
+    // keep: o1 continues from its start value and its sum is scaled by scale1; else both sums start at zero.
+    auto exchange_and_pass = [&](const double2 (&in1u)[RPT], const double2 (&in2)[RPT], const int nv, const double2* dtab,
+                                 const bool use_dp, const bool keep, const double scale1,
                                  double2 (&o1)[RPT], double2 (&o2)[RPT]) {
         const int slot = ORDER == 2 ? (nv == 2 ? 1 : 0) : (rr & 1);      // payload slot(s) of this round
-        // (the scale of the second sum is applied to its OPERAND -- staged and published scaled -- not to every slot's coefficient)
-        const double sc2 = keep ? scale2 : 1.0;
-        pass_swapped = swapped;
-        wa_l = swapped ? cy_l : cx_l;
-        wb_l = swapped ? cx_l : cy_l;
-        double2 in2s[RPT];
+        // (the scale of the kept sum is applied to its OPERAND -- staged and published scaled -- not to every slot's coefficient)
+        double2 in1[RPT];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) in2s[i] = keep ? make_double2(sc2 * in2[i].x, sc2 * in2[i].y) : in2[i];
+        for (int i = 0; i < RPT; ++i) in1[i] = keep ? make_double2(scale1 * in1u[i].x, scale1 * in1u[i].y) : in1u[i];
+        const double2 (&in2s)[RPT] = in2;
         if (exch) {                        // the rows leave first: nothing below needs them before the partner does
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
@@ -317,8 +319,8 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
             la[i] ^= FLIP_BUF;
             *reinterpret_cast<double2*>(lds + boff + (l << 4)) = in1[i];
             if (ORDER == 2) *reinterpret_cast<double2*>(lds + boff + (l << 4) + 32768) = in2s[i];
-            o1[i] = make_double2(0.0, 0.0);
-            if (!keep) o2[i] = make_double2(0.0, 0.0);
+            if (!keep) o1[i] = make_double2(0.0, 0.0);
+            o2[i] = make_double2(0.0, 0.0);
         }
         __syncthreads();
         ++rr;
@@ -469,50 +471,79 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
     };
     for (int st = 0; st < a.nsteps; ++st) {
         const int r0 = a.rows[3 * st];
-        const double h = a.hs[st];
+        const double h = uni(a.hs[st]);
         ccab = (const MIDYN_CONST_AS flip_d2*)(a.cab + ((size_t)b * a.nsteps + st) * a.wsp);
-        if (!MIDYN_FLIP_SMEM && lane < n_all) {
-            const flip_d2 cc = a.cab[((size_t)b * a.nsteps + st) * a.wsp + lane];
+        if (!SMEM && lane < n_all) {
+            // (scalar base of this (instance, step) + a 32-bit lane offset the optimiser cannot hoist: otherwise the per-thread 64-bit
+            // address a.cab + lane lives in a vector register pair through the whole kernel)
+            unsigned lo = (unsigned)lane << 4;
+            asm volatile("" : "+v"(lo));
+            const char* const cbase = reinterpret_cast<const char*>(a.cab + ((size_t)b * a.nsteps + st) * a.wsp);
+            const flip_d2 cc = *reinterpret_cast<const flip_d2*>(cbase + lo);
             cx_l = cc.x;
             cy_l = cc.y;
         }
-        const double2* const E0 = a.E ? a.E + (size_t)r0 * np : nullptr;
+        // (the two table rows of this step as SCALAR pointers the optimiser cannot look through: with the thread's offset added
+        // outside the step loop their 64-bit per-thread addresses lived in vector registers for the whole kernel -- one in scratch)
+        auto uni_ptr = [](const double2* q) {
+            const unsigned long long v = (unsigned long long)q;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+            return (const double2*)(((unsigned long long)hi << 32) | lo);
+        };
+        const double2* const E0 = uni_ptr(a.E ? a.E + (size_t)r0 * np + row0 : nullptr);
         const bool framed2 = a.E && ORDER == 2;
         // the frame phase between the two Gauss points of this step for this thread's rows
         const double2* const dtab = framed2 ? a.Dt + (size_t)st * np : nullptr;
+        const double2* const dtab_own = uni_ptr(framed2 ? dtab + row0 : nullptr);
         double2 dmr[RPT];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) dmr[i] = framed2 ? AT16(dtab + row0, i) : make_double2(1.0, 0.0);
+        for (int i = 0; i < RPT; ++i) dmr[i] = framed2 ? AT16(dtab_own, i) : make_double2(1.0, 0.0);
         const int Ks = a.ser_K[st], reps = a.ser_reps[st];
         const bool cheb = Ks > 0;
         const int K = cheb ? Ks : -Ks;
-        const double par = a.ser_par[st];
+        double p2s = p2;                       // (sqrt(3) / 12 in a scalar pair, made here: as a vector-register constant hoisted
+        asm volatile("" : "+s"(p2s));          // out of the step loop it was spilled to scratch)
+        const double par = uni(a.ser_par[st]);
+        // Chebyshev: the factor of a term is 1 / par (first term) or 2 / par -- ONE division per step (2 x (1 / par) == 2 / par bit
+        // for bit), and the products with the step size that the terms need, all as scalars
+        const double f_1 = uni(1.0 / par), f_2 = uni(2.0 * f_1);
+        const double ca_1 = uni((ORDER == 2 ? 0.5 * h : h) * f_1), ca_2 = uni((ORDER == 2 ? 0.5 * h : h) * f_2);
+        const double cb_1 = uni(p2s * h * h * f_1), cb_2 = uni(p2s * h * h * f_2);
         const double* coef = a.coef + (size_t)st * a.stride;
         const int slot = a.save ? a.save[st] : -1;
         for (int rep = 0; rep < reps; ++rep) {
-            const double c0 = cheb ? coef[0] : 1.0;
+            const double c0 = uni(cheb ? coef[0] : 1.0);
             // start of a series: phi_0 = the accumulated result (into the frame picture of the first Gauss point at the
             // first repetition: y~ = E(t1) o y)
 #pragma unroll
             for (int i = 0; i < RPT; ++i) {
                 double2 v = acc[i];
-                if (rep == 0 && a.E) v = cmul(AT16(E0 + row0, i), v);
+                if (rep == 0 && a.E) v = cmul(AT16(E0, i), v);
                 cur[i] = v;
                 acc[i] = make_double2(c0 * v.x, c0 * v.y);
                 pw[i] = make_double2(0.0, 0.0);      // Chebyshev: phi_{j-2};  Taylor: nothing
             }
             for (int j = 1; j <= K; ++j) {
-                const double f = cheb ? (j == 1 ? 1.0 : 2.0) / par : 1.0 / (par * (double)j);
+                // (Chebyshev: 1 / par or 2 / par -- ONE division per step, inv_par; 2 x (1 / par) == 2 / par bit for bit)
+                double ca, cb;
+                if (cheb) {
+                    ca = j == 1 ? ca_1 : ca_2;
+                    cb = j == 1 ? cb_1 : cb_2;
+                } else {
+                    const double f = 1.0 / (par * (double)j);
+                    ca = uni((ORDER == 2 ? 0.5 * h : h) * f);
+                    cb = uni(p2s * h * h * f);
+                }
                 double2 o1[RPT], o2[RPT], in2[RPT];
                 if (ORDER == 2) {
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) in2[i] = framed2 ? cmul(dmr[i], cur[i]) : cur[i];
                 }
                 // o1 = C(t1) v~, o2 = C(t2) (D v~)
-                exchange_and_pass(cur, ORDER == 2 ? in2 : cur, 1, dtab, framed2, false, false, 1.0, o1, o2);
+                exchange_and_pass(cur, ORDER == 2 ? in2 : cur, 1, dtab, framed2, false, 1.0, o1, o2);
                 double2 w[RPT];
                 if (ORDER == 2) {
-                    const double ca = 0.5 * h * f, cb = p2 * h * h * f;
+
                     double2 du1[RPT], u2[RPT], m0[RPT];
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
@@ -529,20 +560,20 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
                     }
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) o2[i] = m0[i];
-                    exchange_and_pass(du1, u2, 2, dtab, false, true, true, cb, o1, o2);     // o1 = C(t2) (D u1), o2 = -m + cb C(t1) u2
+                    // (coefficient set a = C(t1) meets the first operand, b = C(t2) the second: u2 goes first, into the kept sum)
+                    exchange_and_pass(u2, du1, 2, dtab, false, true, cb, o2, o1);           // o2 = -m + cb C(t1) u2, o1 = C(t2) (D u1)
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) {
                         const double2 v1 = framed2 ? cmul_conj_a(dmr[i], o1[i]) : o1[i];
                         w[i] = make_double2(cb * v1.x - o2[i].x, cb * v1.y - o2[i].y);
                     }
                 } else {
-                    const double ca = h * f;
 #pragma unroll
                     for (int i = 0; i < RPT; ++i) w[i] = cfma_r(ca, o1[i], pw[i]);
                 }
                 // end of the term: w joins the result and is the next term's input; the old phi_{j-1} is the next phi_{j-2}
                 const bool last = j == K;
-                const double cj = cheb ? 2.0 * coef[j] : 1.0;
+                const double cj = uni(cheb ? 2.0 * coef[j] : 1.0);
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) {
                     const unsigned r = row0 + rowof(i);
@@ -551,7 +582,7 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
                         pw[i] = cheb ? cur[i] : make_double2(0.0, 0.0);
                         cur[i] = w[i];
                     } else if (rep + 1 == reps) {    // out of the frame picture; saved states
-                        if (a.E) ac = cmul_conj_a(AT16(E0 + row0, i), ac);
+                        if (a.E) ac = cmul_conj_a(AT16(E0, i), ac);
                         if (slot >= 0 && r < (unsigned)a.n) a.out[((size_t)b * a.P + slot) * a.n + r] = ac;
                     }
                     acc[i] = ac;

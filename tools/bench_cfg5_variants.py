@@ -33,6 +33,7 @@ def run():
 # 512 crossing operands waited for and unpacked, one add instead of the multiply-adds
 variants = [("flip", {}), ("no_apply", dict(ablate=64)), ("no_poll", dict(ablate=32)), ("wait_only", dict(ablate=512)), ("no_crossing", dict(ablate=8)),
             ("no_exchange", dict(ablate=1)), ("nothing", dict(ablate=13)), ("write_through", dict(ablate=2)),
+            ("no_local", dict(ablate=4)),
             ("with_elements", dict(ell_sweep_flip=0)), ("one_workgroup", dict(ell_sweep_duo=0)), ("one_workgroup_with_elements", dict(ell_sweep_duo=0, ell_sweep_flip=0))]
 if len(sys.argv) > 1:
     variants = [v for v in variants if v[0] in sys.argv[1:]]
