@@ -66,6 +66,7 @@ struct FlipDuoArgs {
     int* flags;                 // [B][2][DUO_FLAG_WORDS]
     int* err;
     unsigned spin_limit;
+    int protocol;               // ctx option exchange_protocol: 1 = payload written through (sc1) and agent-scope flags on one XCD too
     int part_major;
     int ablate;                 // profiling only (results wrong): 1 no exchange, 2 write-through stores on one XCD too, 4 no local slots,
                                 // 8 no crossing slots (their waits and loads included)
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(TH) void ell_flip_duo_kernel(const FlipDuoArgs a) {
         xcc &= 15u;
         if (tid == 0) __hip_atomic_store(my_flags + 16, (int)xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int theirs = wait_word(partner_flags + 16, 1);
-        one_l2 = !dead && theirs == (int)xcc + 1 && !(a.ablate & 2);
+        one_l2 = !dead && theirs == (int)xcc + 1 && !(a.ablate & 2) && !a.protocol;
     }
     // the local slots in four parts when there is an exchange (see above): part p = slots [cut[p], cut[p + 1]).  The exchange needs
     // most of a pass from the stores to the last operand in a register (acknowledgement, flag, flag seen, 64 KB of loads per

@@ -83,6 +83,7 @@ struct ResidentArgs {
     double2* out;             // [P][n] saved states or nullptr
     int* err;                 // set when a wait gave up (results invalid: the host re-runs the range on the per-launch route)
     unsigned spin_limit;      // polls after which a wait gives up
+    int protocol;             // ctx option exchange_protocol: 0 = the measured default, 1 = the conforming forms (see midyn_core.inc)
     int exchange_only;        // measurement only (ctx option resident_exchange_only): every round publishes and polls as
                               // usual but skips the row's arithmetic -- the store -> poll floor of this launch geometry
 };
@@ -216,7 +217,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                     unsigned long long f[NPW];
 #pragma unroll
                     for (int i = 0; i < NPW; ++i)
-                        if (i < npw) f[i] = __hip_atomic_load(cur + (word_of[i] >= 0 ? word_of[i] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (i < npw) f[i] = a.protocol ? __hip_atomic_load(cur + (word_of[i] >= 0 ? word_of[i] : 0), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                                                       : __hip_atomic_load(cur + (word_of[i] >= 0 ? word_of[i] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bool pending = false;
 #pragma unroll
                     for (int i = 0; i < NPW; ++i)
@@ -323,7 +325,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (compiler: no ring store moves above the wait)
                 const int row_wg = blockIdx.x * WAVES;
                 unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row_wg + lane;
-                __hip_atomic_store(z, (unsigned long long)__double_as_longlong(reinterpret_cast<const double*>(pubs[rr & 1])[lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (exchange_protocol 1: the data word is a RELEASE store -- the re-arming store of the round before is ordered in front of
+                // it by the memory model, not only by the wait above -- and the polls are ACQUIRE loads)
+                if (a.protocol) __hip_atomic_store(z, (unsigned long long)__double_as_longlong(reinterpret_cast<const double*>(pubs[rr & 1])[lane]), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_store(z, (unsigned long long)__double_as_longlong(reinterpret_cast<const double*>(pubs[rr & 1])[lane]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned long long* zr = ring + (size_t)b_rearm * 2 * n_pad + 2 * row_wg + lane;
                 __hip_atomic_store(zr, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -334,7 +339,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void rk4_resident_kernel(const Resid
                 __builtin_amdgcn_s_waitcnt(0);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (compiler: no ring store moves above the wait)
                 unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row + lane;
-                __hip_atomic_store(z, (unsigned long long)__double_as_longlong(lane ? pub.y : pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.protocol) __hip_atomic_store(z, (unsigned long long)__double_as_longlong(lane ? pub.y : pub.x), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_store(z, (unsigned long long)__double_as_longlong(lane ? pub.y : pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // re-arm this row's words of the buffer read LAST round: having read this round from all my neighbours
                 // proves that every reader of those words has moved on (see the header)
                 unsigned long long* zr = ring + (size_t)b_rearm * 2 * n_pad + 2 * row + lane;
@@ -387,6 +393,7 @@ struct EllArgs {
     double2* out;             // [P][n] or nullptr
     int* err;
     unsigned spin_limit;      // polls after which a wait gives up
+    int protocol;             // ctx option exchange_protocol: 0 = the measured default, 1 = the conforming forms (see midyn_core.inc)
     // MODE 1: per step K > 0 terms of the Chebyshev series (or -K = the Taylor degree), the repetitions, h / rho (or
     // h / scaling) and the Bessel coefficients J_0..J_K
     const int* cheb_K;
@@ -507,7 +514,8 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
             unsigned long long f[NPW];
 #pragma unroll
             for (int i = 0; i < NPW; ++i)
-                if (i < npw) f[i] = __hip_atomic_load(cur + (word_of[i] >= 0 ? word_of[i] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i < npw) f[i] = a.protocol ? __hip_atomic_load(cur + (word_of[i] >= 0 ? word_of[i] : 0), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                                               : __hip_atomic_load(cur + (word_of[i] >= 0 ? word_of[i] : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool pending = false;
 #pragma unroll
             for (int i = 0; i < NPW; ++i)
@@ -576,8 +584,13 @@ __global__ __launch_bounds__(64 * ELL_WAVES, 1) void ell_resident_kernel(const E
             __builtin_amdgcn_s_waitcnt(0);
             __atomic_signal_fence(__ATOMIC_SEQ_CST);   // (compiler: no ring store moves above the wait)
             unsigned long long* z = ring + (size_t)b_nxt * 2 * n_pad + 2 * row;
-            __hip_atomic_store(z, (unsigned long long)__double_as_longlong(pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(z + 1, (unsigned long long)__double_as_longlong(pub.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.protocol) {       // (exchange_protocol 1: RELEASE stores / ACQUIRE polls, see rk4_resident_kernel)
+                __hip_atomic_store(z, (unsigned long long)__double_as_longlong(pub.x), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(z + 1, (unsigned long long)__double_as_longlong(pub.y), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(z, (unsigned long long)__double_as_longlong(pub.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(z + 1, (unsigned long long)__double_as_longlong(pub.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             unsigned long long* zr = ring + (size_t)b_rearm * 2 * n_pad + 2 * row;
             __hip_atomic_store(zr, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(zr + 1, RESIDENT_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1166,6 +1179,7 @@ struct SweepDuoArgs {
     int* flags;                 // [B][2 halves][DUO_FLAG_WORDS]: [0, 16) round number per wave, [16] XCC id + 1; all zero at launch
     int* err;
     unsigned spin_limit;        // polls after which a wait gives up
+    int protocol;             // ctx option exchange_protocol: 0 = the measured default, 1 = the conforming forms (see midyn_core.inc)
     int part_major;             // 1: blocks [p B, (p + 1) B) hold half p of every instance (B a multiple of 8: the partners of an
                                 // instance on one XCD under the observed b % 8 dispatch -- a speed matter only)
     int ablate;                 // profiling only (results wrong): 1 no exchange at all, 2 write-through stores on one XCD too,
@@ -1233,7 +1247,7 @@ __global__ __launch_bounds__(TH) void ell_sweep_duo_kernel(const SweepDuoArgs da
         xcc &= 15u;
         if (tid == 0) __hip_atomic_store(my_flags + 16, (int)xcc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int theirs = wait_word(partner_flags + 16, 1);
-        one_l2 = !dead && theirs == (int)xcc + 1 && !(da.ablate & 2);
+        one_l2 = !dead && theirs == (int)xcc + 1 && !(da.ablate & 2) && !da.protocol;    // (protocol 1: sc1 stores AND sc1 loads always)
     }
     const double p2 = 0.14433756729740643;   // sqrt(3) / 12
     double2 pw[SWEEP_RPT], acc[SWEEP_RPT], cur[SWEEP_RPT];
