@@ -334,3 +334,59 @@ def test_chebyshev_series_ends_at_the_unit_roundoff(qd, n, magn):
     _, yo = orc.expm_solve(gen, [0.0, 0.2], y0, 0.05)
     assert np.abs(res["roundoff"] - yo).max() < 1e-9
     assert abs(np.linalg.norm(res["roundoff"][-1]) - 1.0) < 1e-13
+
+
+def test_exchange_protocol_option_is_bit_identical(qd):
+    """ctx option exchange_protocol (profiles/r06_exchange_protocol.md): 1 selects the conforming hand-off forms -- RELEASE publishes /
+    ACQUIRE polls in rk4_resident_kernel (one trajectory, RK4) and ell_resident_kernel (vectorised Lindblad, scipy_expm), sc1 payload
+    stores + agent-scope flags also between two workgroups that share an L2 in ell_flip_duo_kernel (the path partners on different
+    XCDs always take; here forced, with 13 and 16 instances: instance-major and part-major workgroup order).  Same kernels, same
+    arithmetic: the results are bit-identical, the one-launch kernels ran (counters) and no wait gave up."""
+    from qiskit_dynamics_amd import workloads as W
+    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+
+    ctx = qd.default_context()
+    assert ctx.get_option("exchange_protocol") == 0
+    gave_up = ctx.counters("resident_fallbacks")["launches"]
+    # one trajectory, n = 1024: rk4_resident_kernel
+    cfg = W.schrodinger_config(t_final=0.3, max_dt=0.005)
+    amps, phases = W.sweep_parameters(1, len(cfg["ops"]))
+    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 0.15) ** 2) / 0.02), nu, ph) for a, nu, ph in zip(amps, cfg["carrier"], phases)]
+    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"], rotating_frame=cfg["h_d"])
+    # vectorised Lindbladian, N = 4096: ell_resident_kernel
+    cl = W.lindblad_config(t_final=0.5)
+    lm = qd.LindbladModel(static_hamiltonian=cl["h_d"], hamiltonian_operators=cl["ops"],
+                          hamiltonian_signals=[qd.Signal(1.0, nu) for nu in cl["carrier"]],
+                          static_dissipators=cl["static_dissipators"], vectorized=True)
+    rho0 = cl["rho0"].flatten(order="F")
+    # flip-structured stack, n = 1024, Magnus 2: ell_flip_duo_kernel
+    c5 = W.schrodinger_config(n_qubits=10, n_drives=8, t_final=1.0, max_dt=0.25)
+    fr = RotatingFrame(np.diag(c5["h_d"]).real.copy())
+    stack = qd.Stack(ctx, -1j * c5["ops"], -1j * c5["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag)
+    sched = FixedStepSchedule(c5["t_span"], None, c5["max_dt"], _magnus_points(2))
+    y5 = c5["y0"].reshape(-1, 1)
+    got = {}
+    for proto in (0, 1):
+        with ctx.options(exchange_protocol=proto, profile=1):
+            ctx.reset_counters()
+            a = solver.solve(t_span=[0.0, 0.3], y0=cfg["y0"], signals=sigs, method="RK4", max_dt=0.005).y[-1]
+            assert ctx.counters("rk4_resident")["launches"] >= 1
+            ctx.reset_counters()
+            b = qd.solve_lmde(lm, [0.0, 0.5], rho0, method="scipy_expm", max_dt=0.05).y[-1]
+            assert ctx.counters("rk4_resident")["launches"] >= 1
+            c = []
+            for count in (13, 16):
+                amps_ = np.array([W.sweep_parameters(i, 8)[0] for i in range(count)])
+                phs_ = np.array([W.sweep_parameters(i, 8)[1] for i in range(count)])
+                table = W.gaussian_coefficient_table(sched.times, amps_, phs_, c5["carrier"], 1.0)
+                ctx.reset_counters()
+                c.append(stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2, y5, count, True))
+                split = ctx.counters("sweep_split")
+                assert (int(split["launches"]), int(split["ms"])) == (2, 3), split        # two workgroups per instance, flip masks
+        got[proto] = (a, b, c[0], c[1])
+    for x0, x1 in zip(got[0], got[1]):
+        assert np.array_equal(x0, x1)
+    assert abs(np.linalg.norm(got[0][0]) - 1.0) < 1e-10 and np.max(np.abs(np.linalg.norm(got[0][3][:, -1, :, 0], axis=1) - 1.0)) < 1e-12
+    assert ctx.counters("resident_fallbacks")["launches"] == gave_up
+    assert ctx.get_option("exchange_protocol") == 0
