@@ -57,16 +57,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from tools.bench_legs.compact import emit  # noqa: E402  (the one stdout line: compact object; details -> bench_detail.json)
+from tools.bench_legs.common import (ALL_CLASSES, CFG5_SWEEP, FP64_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, LDS_PEAK_GBS, MAX_DT, N_DRIVES,  # noqa: E402,F401
+                                     N_QUBITS, SWEEP, T_FINAL, build_diag_frame_stack, build_frame_basis_stack, build_model_stack,
+                                     measured_traffic, profile_pass, sweep_table)
+from tools.bench_legs.cfg4 import leg_cfg4, leg_cfg4_diag_frame  # noqa: E402
+from tools.bench_legs.cfg5 import leg_cfg5  # noqa: E402
+from tools.bench_legs.cpu import leg_cpu_baseline, leg_cpu_configs  # noqa: E402
+from tools.bench_legs.rows import leg_dense_expm, leg_lindblad_rk4, leg_parallel_in_time, leg_perturbative  # noqa: E402
+from tools.bench_legs.sweeps import leg_diag_frame_sweep, leg_small_sweeps  # noqa: E402
 
-N_QUBITS = 10
-N_DRIVES = 8
-T_FINAL = 5.0
-MAX_DT = 0.005
-SWEEP = 4096                   # BASELINE.json: 4096-parameter batch
-CFG5_SWEEP = 1024              # BASELINE.json configs[4]: 1024-parameter sweep
-FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor FP64 matrix peak (SURVEY.md 8(d) / BASELINE.md 3)
-LDS_PEAK_GBS = 256.0 * 256 * 2.4      # ds_read_b64/b128: 256 B per clock and CU (MI355X_MICROARCH.md, LDS), 256 CUs, 2.4 GHz
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
 # -----------------------------------------------------------------------------------------------------------------
@@ -116,73 +115,6 @@ def spawn_ranks(n_ranks: int, argv) -> int:
                     procs[q].terminate()
         time.sleep(0.05)
     return rc
-
-
-# -----------------------------------------------------------------------------------------------------------------
-# helpers
-# -----------------------------------------------------------------------------------------------------------------
-def measured_traffic(kernel_prefix):
-    """(HBM bytes per dispatch, source) of the newest committed rocprofv3 PMC summary (profiles/*.traffic.json:
-    FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, separate --pmc passes), or (None, None).  bench.py cannot collect
-    PMC counters itself; the profile run is tools/profile_round.sh."""
-    import glob
-
-    best = (None, None)
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*.traffic.json"))):
-        try:
-            data = json.load(open(path))
-        except (OSError, ValueError):
-            continue
-        for name, t in data.get("kernels", {}).items():
-            if name.startswith(kernel_prefix) and "fetch_bytes" in t:
-                best = (round(t["fetch_bytes"] + t.get("write_bytes", 0.0)), f"{os.path.basename(path)}: {name}")
-    return best
-
-
-def build_frame_basis_stack(cfg):
-    """Host model build (a3/a4) WITHOUT grouping symmetry sectors: -iH, eigh of the frame, U^dagger . U in the
-    reference's ascending-eigenvalue order (the exact zeros of a symmetric model are scattered: dense kernels).
-    Used by tools/ for dense-kernel measurements."""
-    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
-
-    frame = RotatingFrame(cfg["h_d"])
-    static = frame.operator_into_frame_basis(-1j * cfg["h_d"]) - np.diag(frame.frame_diag)
-    ops = frame.operator_into_frame_basis(-1j * cfg["ops"])
-    return ops, static, frame.frame_diag_imag
-
-
-def build_model_stack(cfg):
-    """The stack exactly as HamiltonianModel uploads it (models.py): frame-basis vectors grouped by the symmetry
-    sectors of the frame operator (rotating_frame._eigh_by_sectors), so that exactly-zero operator blocks are
-    contiguous.  Returns (ops, static, frame_im, perm): internal position i holds the reference's index perm[i]."""
-    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
-
-    frame = RotatingFrame(cfg["h_d"])
-    static = frame.generator_minus_frame_in_basis(-1j * cfg["h_d"])     # U^+ (G - F) U: exactly zero here (frame = H_d)
-    ops = frame.operator_into_frame_basis(-1j * cfg["ops"])
-    fim = frame.frame_diag_imag
-    labels = frame.sector_labels
-    if labels is None:
-        return ops, static, fim, None
-    perm = np.argsort(labels, kind="stable")
-    take = lambda x: np.ascontiguousarray(np.take(np.take(x, perm, axis=-2), perm, axis=-1))  # noqa: E731
-    return take(ops), take(static), np.ascontiguousarray(fim[perm]), perm
-
-
-def build_diag_frame_stack(cfg):
-    """cfg 5: diagonal rotating frame diag(H_d) (1-D frame, no eigh): operators stay in the computational basis."""
-    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
-
-    fr = RotatingFrame(np.diag(cfg["h_d"]).real.copy())
-    return -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag, None
-
-
-def sweep_table(workloads, times, first, count, k, carrier, t_final):
-    amps = np.empty((count, k))
-    phs = np.empty((count, k))
-    for b in range(count):
-        amps[b], phs[b] = workloads.sweep_parameters(first + b, k)
-    return workloads.gaussian_coefficient_table(times, amps, phs, carrier, t_final), amps, phs
 
 
 class Dist:
@@ -380,898 +312,6 @@ def run_stub(args, D, json_out):
                           "scaling": "weak" if args.weak else "strong", "shard_rank0": [lo, hi],
                           "elapsed_max_s": round(elapsed, 4)}), file=json_out, flush=True)
     D.close()
-
-
-# -----------------------------------------------------------------------------------------------------------------
-# legs
-# -----------------------------------------------------------------------------------------------------------------
-def profile_pass(ctx, fn, classes):
-    ctx.reset_counters()
-    ctx.set_option("profile", 1)
-    try:
-        fn()
-        ctx.synchronize()
-        return {c: ctx.counters(c) for c in classes}
-    finally:
-        ctx.set_option("profile", 0)
-
-
-ALL_CLASSES = ("rhs_stream", "rhs_gemm", "zgemm", "gen_eval", "elementwise", "rhs_blocks", "rhs_blocks_gemm", "rk4_resident")
-
-
-def leg_diag_frame_sweep(qd, ctx, workloads, instances=4096, steps=40):
-    """The headline model set up in the DIAGONAL frame diag(H_d) instead of the full frame H_d (the same physics: results agree
-    out of the frame; a choice the reference leaves to the user, models/rotating_frame.py): the operators stay in the computational
-    basis -- ~20 non-zeros per row, every ELL slot one signed magnitude and one flip mask -- and the RK4 sweep is ONE launch of
-    ell_sweep_rk4_kernel<1, 1024, 3> (no operator elements, csrc/midyn_flip.h / midyn_resident.h).  Kernel time from the library's
-    HIP-event counters; the same kernel with 4-byte elements (option ell_sweep_flip = 0) and the work-list route beside it."""
-    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
-    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _rk4_points
-
-    cfg = workloads.schrodinger_config()
-    frame = RotatingFrame(np.diag(cfg["h_d"]).real.copy())
-    stack = qd.Stack(ctx, -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(frame.frame_diag), frame.frame_diag_imag)
-    sched = FixedStepSchedule(cfg["t_span"], None, 0.005, _rk4_points)
-    rows = sched.step_rows[:steps]
-    nr = int(rows.max()) + 1
-    k = cfg["ops"].shape[0]
-    pars = [workloads.sweep_parameters(b, k) for b in range(instances)]
-    table = workloads.gaussian_coefficient_table(sched.times[:nr], np.array([p[0] for p in pars]), np.array([p[1] for p in pars]),
-                                                 cfg["carrier"], 5.0)
-    y0 = cfg["y0"].reshape(-1, 1)
-    save = np.full(steps, -1, dtype=np.int32)
-    save[-1] = 1
-
-    def run():
-        return stack.rk4_solve(sched.times[:nr], table, rows, sched.step_h[:steps], save, 2, y0, instances, True)
-
-    best, out_y = {}, {}
-    for rnd in range(3):                       # interleaved, minimum per element form
-        for flag in (1, 0):
-            with ctx.options(ell_sweep_flip=flag, profile=1):
-                ctx.reset_counters()
-                ys = run()
-                ms = ctx.counters("rk4_resident")["ms"]
-                form = int(ctx.counters("sweep_split")["ms"])
-            best[form] = min(best.get(form, 1e9), ms)
-            out_y[form] = ys
-    with ctx.options(ell_sweep=0):
-        t0 = time.perf_counter()
-        ref = run()
-        wall_lists = time.perf_counter() - t0
-    form = max(best)
-    evals = 4.0 * instances * steps
-    out = {"workload": "the headline model (10 qubits, n = 1024, 8 drives) in the diagonal frame diag(H_d), %d instances x %d RK4 "
-                       "steps in ONE launch, inputs resident" % (instances, steps),
-           "kernel": "ell_sweep_rk4_kernel<1, 1024, %d>" % form, "element_form": form,
-           "rhs_evals_per_s_in_the_kernel": round(evals / (best[form] * 1e-3)),
-           "kernel_ms_per_step": round(best[form] / steps, 4),
-           "with_4_byte_elements_rhs_evals_per_s": round(evals / (best[min(best)] * 1e-3)) if len(best) > 1 else None,
-           "work_list_route_rhs_evals_per_s_wall": round(evals / wall_lists),
-           "max_abs_difference_to_the_work_list_route": float(np.max(np.abs(out_y[form] - ref))),
-           "max_abs_difference_between_the_element_forms": float(np.max(np.abs(out_y[form] - out_y[min(best)]))),
-           "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(out_y[form][:, -1, :, 0], axis=1) - 1.0))),
-           "note": "NOT the headline number: `value` is measured in the full frame H_d of BASELINE's configuration (dense frame-basis "
-                   "operators, MFMA combine + apply).  This key shows what the same physics costs when the user keeps the operators "
-                   "sparse; parity: tests/test_gpu_resident.py (element forms, random flip masks) and tools/fuzz_solver.py --pauli"}
-    return out
-
-
-def leg_small_sweeps(qd, workloads, instances=4096, steps=200):
-    """Sweeps of SMALL systems through the product Solver (list mode): chains of three-level transmons in the frame of their
-    static Hamiltonian, DiscreteSignal pulses with carriers -- the sizes pulse-level simulations have.  us per RK4 stage over
-    the device part of the solve on the one-launch kernel (csrc/midyn_combine_sweep.h) and with a launch per stage."""
-    out = {}
-    dt = 0.005
-    t_final = dt * steps
-    rng = np.random.default_rng(7)
-    for levels, sites in ((3, 3), (3, 4)):
-        h_d, ops, freqs = workloads.transmon_chain(levels, sites)
-        n = h_d.shape[0]
-        solver = qd.Solver(static_hamiltonian=h_d, hamiltonian_operators=ops, rotating_frame=h_d)
-        ctx = solver.model._ctx
-        n_smp = max(4, int(round(t_final / 0.05)))
-        lists = [[qd.DiscreteSignal(t_final / n_smp, rng.uniform(0.2, 1.0) * np.hanning(n_smp + 2)[1:-1], carrier_freq=f,
-                                    phase=rng.uniform(0, 2 * np.pi)) for f in freqs] for _ in range(instances)]
-        y0 = np.zeros(n, dtype=complex)
-        y0[0] = 1.0
-
-        def best(reps=3):
-            devs, calls = [], []
-            for _ in range(reps + 1):           # (the first one builds layouts / warms up)
-                t0 = time.perf_counter()
-                res = solver.solve(t_span=[0.0, t_final], y0=y0, signals=lists, method="RK4", max_dt=dt)
-                calls.append(time.perf_counter() - t0)
-                devs.append(res[0].wall_s)
-            return min(devs[1:]), min(calls[1:]), res
-
-        dev1, call1, res = best()
-        ctx.set_option("combine_sweep", 0)
-        try:
-            dev0, call0, ref = best()
-        finally:
-            ctx.set_option("combine_sweep", 1)
-        # the same sweep with scipy_expm (Magnus order 1, same steps): the expm action, one launch / a launch per product
-        e_steps = steps
-        expm = {}
-        for key, opt in (("one_launch", 1), ("launch_per_product", 0)):
-            ctx.set_option("combine_sweep", opt)
-            try:
-                devs = []
-                for _ in range(3):
-                    r_e = solver.solve(t_span=[0.0, t_final], y0=y0, signals=lists, method="scipy_expm", max_dt=dt)
-                    devs.append(r_e[0].wall_s)
-            finally:
-                ctx.set_option("combine_sweep", 1)
-            expm["us_per_step_" + key] = round(min(devs[1:]) / e_steps * 1e6, 2)
-        expm["max_abs_difference_to_the_rk4_result_midpoint_magnus_vs_rk4"] = float(max(np.max(np.abs(a_.y[-1] - b_.y[-1])) for a_, b_ in zip(res[::257], r_e[::257])))
-        evals = instances * 4 * steps
-        out[f"{sites}_transmons_n{n}"] = {
-            "scipy_expm_magnus1": expm,
-            "instances": instances, "steps": steps, "operators": len(ops),
-            "us_per_stage_one_launch": round(dev1 / (4 * steps) * 1e6, 2),
-            "us_per_stage_launch_per_stage": round(dev0 / (4 * steps) * 1e6, 2),
-            "rhs_evals_per_s_device": round(evals / dev1, 1), "rhs_evals_per_s_whole_call": round(evals / call1, 1),
-            "max_abs_difference_between_the_routes": float(max(np.max(np.abs(a_.y[-1] - b_.y[-1])) for a_, b_ in
-                                                               zip(res[::257], ref[::257]))),
-            "max_norm_deviation": float(max(abs(np.linalg.norm(r.y[-1]) - 1.0) for r in res[::257]))}
-    out["note"] = ("whole RK4 / scipy_expm solve of the sweep in ONE launch, 16 instances per workgroup, state in registers, stage "
-                   "input in LDS (combine_sweep_kernel); device part = midyn_rk4_solve / midyn_expm_solve incl. PCIe, plan set-up "
-                   "and (expm) the host-side choice of the series of every step; DESIGN 4.16")
-    return out
-
-
-def leg_cfg4_diag_frame(qd, ctx, workloads):
-    """cfg 4's "second run" of SURVEY 8(d): the same Lindbladian in the diagonal rotating frame diag(H_d), the same 100
-    steps through the product's default route (pinned to the oracle at this shape by
-    tests/test_gpu_production_shapes.py::test_cfg4_default_route_all_steps_vs_oracle[diag_frame])."""
-    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
-
-    cfg = workloads.lindblad_config()
-    frame = np.diag(cfg["h_d"]).real.copy()
-    t0 = time.perf_counter()
-    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
-                       static_dissipators=cfg["static_dissipators"], rotating_frame=frame, vectorized=True)
-    build_s = time.perf_counter() - t0
-    stack = solver.model.stack
-    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(1))
-    table, _, _ = sweep_table(workloads, sched.times, 0, 1, 6, cfg["carrier"], cfg["t_final"])
-    y0 = cfg["rho0"].flatten(order="F").reshape(-1, 1)
-
-    def run():
-        return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 1,
-                                y0, 1, True)
-
-    run()
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    ys = run()
-    dev_ms = ctx.timer_stop()
-    wall = time.perf_counter() - t0
-    cs = profile_pass(ctx, run, ALL_CLASSES)
-    n_steps = len(sched.step_h)
-    rho = ys[0, -1, :, 0].reshape(64, 64, order="F")
-    out = {"workload": "cfg4, second run of SURVEY 8(d): the same model in the diagonal rotating frame diag(H_d)",
-           "steps": n_steps, "solve_s": round(wall, 4), "ms_per_step": round(wall / n_steps * 1e3, 4),
-           "stream_ms_per_step": round(dev_ms / n_steps, 4), "model_build_s": round(build_s, 2),
-           "route": "ell_resident_kernel<1>: the whole solve in ONE launch" if cs["rk4_resident"]["launches"] == 1
-                    else "one launch per product",
-           "launches": {c: int(v["launches"]) for c, v in cs.items() if v["launches"]},
-           "trace_deviation": float(abs(np.trace(rho) - 1.0)), "hermiticity": float(np.linalg.norm(rho - rho.conj().T))}
-    del solver
-    return out
-
-
-def leg_cfg4(qd, ctx, workloads):
-    """cfg 4: 6-qubit vectorised Lindbladian (N = 4096 superoperators built on the device), 4 static dissipators,
-    scipy_expm magnus_order 1, max_dt 0.05, T = 5 -> 100 steps, one trajectory ("replicas only")."""
-    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
-
-    cfg = workloads.lindblad_config()
-    t0 = time.perf_counter()
-    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
-                       static_dissipators=cfg["static_dissipators"], vectorized=True)
-    build_s = time.perf_counter() - t0
-    stack = solver.model.stack
-    n_big = stack.n
-    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(1))
-    table, _, _ = sweep_table(workloads, sched.times, 0, 1, 6, cfg["carrier"], cfg["t_final"])
-    y0 = cfg["rho0"].flatten(order="F").reshape(-1, 1)
-
-    def run():
-        return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 1,
-                                y0, 1, True)
-
-    def measure(resident):
-        ctx.set_option("resident_rk4", 1 if resident else 0)
-        try:
-            run()                           # warm (lazy block lists, norms, allocations)
-            ctx.synchronize()
-            t0_ = time.perf_counter()
-            ctx.timer_start()
-            ys_ = run()
-            dev_ = ctx.timer_stop()
-            wall_ = time.perf_counter() - t0_
-            cs_ = profile_pass(ctx, run, ALL_CLASSES)
-        finally:
-            ctx.set_option("resident_rk4", 1)
-        return ys_, dev_, wall_, cs_
-
-    ys_res, dev_res, wall_res, cs_res = measure(True)       # the product's default route
-    ys, dev_ms, wall, cs = measure(False)                   # one launch per product (work-list streaming kernel)
-    took_resident = cs_res["rk4_resident"]["launches"] > 0
-    rho = ys_res[0, -1, :, 0].reshape(64, 64, order="F")
-    n_steps = len(sched.step_h)
-    blk = stack.block_info()
-    dom = max(cs, key=lambda c: cs[c]["ms"])
-    launches = cs[dom]["launches"]
-    avg_ms = cs[dom]["ms"] / max(launches, 1)
-    k_h, s_sq = 6, 0
-    products = launches / n_steps if dom == "rhs_blocks" else None
-    out = {"workload": "cfg4: 6-qubit vectorised LindbladModel (N=4096 superoperator), 4 static dissipators, no frame, "
-                       "scipy_expm magnus_order=1, max_dt=0.05, 100 steps, 1 trajectory",
-           "steps": n_steps, "solve_s": round(wall_res, 4), "ms_per_step": round(wall_res / n_steps * 1e3, 4),
-           "stream_ms_per_step": round(dev_res / n_steps, 4), "model_build_s": round(build_s, 2),
-           "route": ("ell_resident_kernel<1>: the whole solve in ONE launch, operator elements in registers (one lane "
-                     "per row), one exchange round per series term") if took_resident else "one launch per product",
-           "us_per_product": round(dev_res / n_steps / products * 1e3, 3) if products else None,
-           "products_per_step": round(products, 2) if products else None,
-           "bound": "exchange latency (store -> poll across XCDs per term)" if took_resident else "launch latency",
-           "trace_deviation": float(abs(np.trace(rho) - 1.0)),
-           "hermiticity": float(np.linalg.norm(rho - rho.conj().T)),
-           "max_abs_difference_between_the_routes": float(np.max(np.abs(ys_res - ys))),
-           "per_launch_route": {
-               "solve_s": round(wall, 4), "ms_per_step": round(wall / n_steps * 1e3, 4),
-               "stream_ms_per_step": round(dev_ms / n_steps, 4),
-               "launches_per_step": {c: round(v["launches"] / n_steps, 2) for c, v in cs.items() if v["launches"]},
-               "kernel_ms_per_step": {c: round(v["ms"] / n_steps, 4) for c, v in cs.items() if v["launches"]}}}
-    if dom == "rhs_blocks" and blk["state"] == 1:
-        # one product G.v on the work lists: every listed 16x16 block (4 KiB) is read once, plus state in / out
-        bytes_launch = blk["nonzero_blocks"] * 16 * 16 * 16 + 2 * 16 * n_big
-        gbs = bytes_launch / (avg_ms * 1e-3) / 1e9
-        out["roofline"] = {
-            "route": "per-launch route (option resident_rk4=0)",
-            "kernel": "rhs_blocks_kernel<1> (expm action: one product G.v per launch over the non-zero 16x16 blocks)",
-            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic("rhs_blocks_kernel<1>")[0],
-            "traffic_source": measured_traffic("rhs_blocks_kernel<1>")[1], "avg_launch_ms": round(avg_ms, 5),
-            "launches_timed": int(launches), "executed_bytes_per_launch": bytes_launch,
-            "nonzero_blocks": blk["nonzero_blocks"], "block_density": round(blk["block_density"], 5),
-            "products_per_step": round(launches / n_steps, 2),
-            "note": "executed bytes of the block work lists; the kernel is a latency chain of a few dozen blocks per "
-                    "row group, not a bandwidth problem (DESIGN 4.12)",
-            "dense_form_price": {
-                "labelled": "SURVEY 8(d) cfg 4 prices the reference's dense algorithm, which is NOT executed here",
-                "assembly_bytes_per_step": 16 * (k_h + 1) * n_big * n_big,
-                "expm_flops_per_step": 8.0 * n_big**3 * (7.33 + s_sq),
-                "mfma_ceiling_ms_per_step": round(8.0 * n_big**3 * 7.33 / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 1),
-                "measured_ms_per_step": round(wall_res / n_steps * 1e3, 4)}}
-    else:
-        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 5)}
-    del solver
-    return out
-
-
-def cfg5_roofline(ctx, stack, cs, n_cols, n, n_steps, wall, n_inst):
-    """Roofline object of a cfg-5 style solve whose dominant kernel is the sparse MFMA work-list contraction."""
-    dom = max(cs, key=lambda c: cs[c]["ms"])
-    launches = cs[dom]["launches"]
-    avg_ms = cs[dom]["ms"] / max(launches, 1)
-    if dom != "rhs_blocks_gemm":
-        return {"kernel": dom, "bound": "mfma", "achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 5)}
-    tile = ctx.counters("sparse_tile")
-    lst = ctx.counters("sparse_list")
-    bm, bn = int(tile["launches"]), int(tile["ms"])
-    listed, splits = lst["launches"], int(lst["ms"])
-    per_launch = max(1, int(ctx.counters("sparse_pair")["launches"]))   # 2: two independent products share a launch
-    cols_pad = -(-n_cols // bn) * bn
-    modes = [m for m in stack.segment_modes if m != 3]
-    real_flops_per_mac = 4 if all(m in (1, 2) for m in modes) else 8
-    # every listed (BM x 16) tile times all columns, for each contraction of the launch
-    flops_launch = per_launch * listed * bm * 16 * cols_pad * real_flops_per_mac
-    tf = flops_launch / (avg_ms * 1e-3) / 1e12
-    return {
-        "kernel": f"zgemm_seg_kernel<{bm},{bn},...,SPARSE> (batched contraction over the tile work lists, fp64 MFMA)",
-        "bound": "mfma", "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
-        "launches_timed": int(launches), "executed_mfma_flops_per_launch": flops_launch,
-        "listed_tiles": int(listed), "tile": [bm, bn], "splits": splits, "columns": n_cols,
-        "contractions_per_launch": per_launch, "contractions_per_step": round(per_launch * launches / n_steps, 2),
-        "note": "executed flops = listed (panel, K tile, operator) tiles x BM x 16 x columns x 4 real flops per complex "
-                "MAC (single-plane operators); short panels are latency-bound (DESIGN 4.12, section 8)",
-        "dense_form_price": {
-            "labelled": "SURVEY 8(d) cfg 5 prices the reference's dense algorithm (2 commutator zgemms + expm per "
-                        "instance-step), which is NOT executed here: the expm ACTION needs no n^3 work",
-            "flops_per_instance_step": 8.0 * n**3 * (2 + 7.33),
-            "mfma_ceiling_ms_per_instance_step": round(8.0 * n**3 * 9.33 / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 1),
-            "measured_ms_per_instance_step": round(wall / n_steps / n_inst * 1e3, 5)}}
-
-
-def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
-    """cfg 5: 12-qubit (n = 4096) Schrodinger sweep in the diagonal frame, scipy_expm magnus_order 2, max_dt 0.25,
-    T = 5 -> 20 steps; instances [first, first + count)."""
-    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
-
-    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(2))
-    table, _, _ = sweep_table(workloads, sched.times, first, count, 8, cfg["carrier"], cfg["t_final"])
-    y0 = cfg["y0"].reshape(-1, 1)
-
-    def run():
-        return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2,
-                                y0, count, True)
-
-    def measure(sweep_kernel, duo=1):
-        with ctx.options(ell_sweep=1 if sweep_kernel else 0, ell_sweep_duo=duo):
-            # (three untimed solves first: the sweep kernel's first launches after a lighter leg run ~10 % slower while the clocks
-            # settle -- tools/bench_cfg5_variants.py -- and the binding's pinned result blocks of this size exist afterwards)
-            for _ in range(3 if sweep_kernel else 1):
-                run()
-            ctx.synchronize()
-            best = None
-            for _ in range(5 if sweep_kernel else 1):       # (best of five: a 2.5 ms solve next to 8 MB of PCIe)
-                t0_ = time.perf_counter()
-                ctx.timer_start()
-                ys_ = run()
-                dev_ = ctx.timer_stop()
-                wall_ = time.perf_counter() - t0_
-                if best is None or wall_ < best[2]:
-                    best = (ys_, dev_, wall_)
-            cs_ = profile_pass(ctx, run, ALL_CLASSES) if with_profile else None
-        return best[0], best[1], best[2], cs_
-
-    ys, dev_ms, wall, cs = measure(True)            # the product's default route
-    n_steps = len(sched.step_h)
-    out = {"instances": count, "steps": n_steps, "solve_s": round(wall, 4),
-           "ms_per_step": round(wall / n_steps * 1e3, 4), "stream_ms_per_step": round(dev_ms / n_steps, 4),
-           "us_per_instance_step": round(wall / n_steps / count * 1e6, 3),
-           "instance_steps_per_s": round(count * n_steps / wall, 1),
-           "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(ys[:, -1, :, 0], axis=1) - 1.0))),
-           "note": "solve_s = midyn_expm_solve wall clock: coefficient table H2D, 20 device steps, results D2H "
-                   "(%.0f MB over PCIe); stream_ms = HIP events around the same call" % (ys.nbytes / 1e6)}
-    # the same solve repeated through a plan object (midyn_expm_plan_*: model + time grid made once, one coefficient table per run):
-    # what a parameter scan or an optimiser loop pays per solve
-    try:
-        plan = qd.ExpmPlan(stack, sched.times, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2, y0, count, True)
-        for _ in range(3):
-            yp = plan.solve(table)
-        ctx.synchronize()
-        best_p = None
-        for _ in range(5):
-            t0_ = time.perf_counter()
-            plan.run(table)
-            t1_ = time.perf_counter()
-            yp = plan.fetch()
-            t2_ = time.perf_counter()
-            if best_p is None or t2_ - t0_ < best_p[0]:
-                best_p = (t2_ - t0_, t1_ - t0_)
-        plan.close()
-        out["plan"] = {"solve_s": round(best_p[0], 5), "ms_per_step": round(best_p[0] / n_steps * 1e3, 4),
-                       "run_call_ms": round(best_p[1] * 1e3, 4), "equal_to_the_one_shot_solve": bool(np.array_equal(yp, ys)),
-                       "instance_steps_per_s": round(count * n_steps / best_p[0], 1),
-                       "what": "midyn_expm_plan_run + _fetch of a plan made once (frame phases, step tables, y0, exchange slots, result "
-                               "block on the device; per run: table upload, norm bounds, series, launch; saved states written by the kernel "
-                               "straight into the pinned result block)"}
-    except Exception as exc:  # pylint: disable=broad-except
-        out["plan"] = {"error": repr(exc)}
-    if with_profile:
-        took_sweep = cs["rk4_resident"]["launches"] > 0
-        out["launches_per_step"] = {c: round(v["launches"] / n_steps, 2) for c, v in cs.items() if v["launches"]}
-        out["kernel_ms_per_step"] = {c: round(v["ms"] / n_steps, 4) for c, v in cs.items() if v["launches"]}
-        if took_sweep:
-            ser = ctx.counters("sweep_series")
-            terms, slots = ser["launches"], int(ser["ms"])
-            k_ms = cs["rk4_resident"]["ms"]
-            n = stack.n
-            # per term and instance: 2 passes over the operator slots of every row; a pass gathers 2 complex numbers
-            # from LDS and does 2 real x complex multiply-adds per slot and reads one operator element from L2
-            form = int(ctx.counters("sweep_split")["ms"])          # 0 general (12 B elements), 1 packed, 2 direct (4 B)
-            elem_bytes = {0: 12, 1: 4, 2: 4, 3: 0}[form]
-            flops = terms * count * 2 * slots * n * 2 * 4
-            lds_bytes = terms * count * 2 * slots * n * 2 * 16
-            l2_bytes = terms * count * 2 * slots * n * elem_bytes
-            parts = int(ctx.counters("sweep_split")["launches"])   # workgroups per instance
-            busy = min(count * parts, 256)
-            form_name = {0: "general: 4 B column + 8 B value", 1: "packed: column | sign, one magnitude per slot",
-                         2: "direct: LDS address of the operand, one signed magnitude per slot",
-                         3: "none: one signed magnitude and one flip mask per slot, column = row ^ flip"}[form]
-            if parts == 2 and form == 3:
-                cross = ctx.counters("sweep_cross")
-                kname = "ell_flip_duo_kernel<2, 2, 1024>"
-                out["route"] = ("%s: ONE launch, TWO workgroups (1024 threads, half of the rows each) per instance through all steps; "
-                                "NO operator elements are read (every slot of this stack has one signed magnitude and one flip mask: "
-                                "the LDS address of an operand is the thread's own address XOR a per-slot constant; coefficients and "
-                                "flip masks through v_readlane from lane-held copies); each workgroup stages ITS half of an operand "
-                                "vector in LDS and applies the %d of %d slots that stay inside the half; the %d slots that reach across "
-                                "read their operands straight from the partner's payload (one set of 16-byte sc1 loads shared by the "
-                                "slots, issued inside the slot loop after half of the local slots, per-wave round flags; payload in the "
-                                "L2 the partners share -- plain stores -- or written through on different XCDs); series vectors in registers"
-                                % (kname, int(cross["ms"] - cross["launches"]), int(cross["ms"]), int(cross["launches"])))
-            elif parts == 2:
-                cross = ctx.counters("sweep_cross")
-                kname = "ell_sweep_duo_kernel<2, 2, 1024, %d>" % form
-                out["route"] = ("%s: ONE launch, TWO workgroups (1024 threads, half of the rows each) per instance through all "
-                                "steps; each stages its half of an operand vector in LDS and applies the %d of %d operator slots "
-                                "that stay inside the half while the partner's half arrives (per-wave round flags; payload slots in "
-                                "device memory that stay in the L2 the partners share -- plain stores, sc1 loads -- or are written "
-                                "through when they sit on different XCDs), then the %d slots that reach across; operator elements "
-                                "(%s) from L2; series vectors in registers"
-                                % (kname, int(cross["ms"] - cross["launches"]), int(cross["ms"]), int(cross["launches"]), form_name))
-            else:
-                kname = "ell_sweep_kernel<2, 4, 1024, %d>" % form
-                out["route"] = ("%s: ONE launch, one workgroup (1024 threads) per instance through "
-                                "all steps; staged vectors in LDS, operator elements (%s) from L2, series vectors the passes "
-                                "do not touch in a per-instance stash" % (kname, form_name))
-            out["workgroups_per_instance"] = parts
-            out["roofline"] = {
-                "kernel": kname, "bound": "lds",
-                "achieved": round(lds_bytes / (k_ms * 1e-3) / 1e9, 1),
-                "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s",
-                "frac": round(lds_bytes / (k_ms * 1e-3) / 1e9 / LDS_PEAK_GBS, 4), "traffic": None,
-                "cus_busy": busy, "frac_of_the_busy_cus": round(lds_bytes / (k_ms * 1e-3) / 1e9 / (LDS_PEAK_GBS * busy / 256), 4),
-                "avg_launch_ms": round(k_ms / max(cs["rk4_resident"]["launches"], 1), 4),
-                "series_terms_per_instance": terms, "operator_slots_per_row": slots,
-                "us_per_term": round(k_ms * 1e3 / max(terms, 1), 2),
-                "host_side_ms_one_shot": round(wall * 1e3 - k_ms / max(cs["rk4_resident"]["launches"], 1), 4),
-                "host_side_ms_plan": (round(out["plan"]["solve_s"] * 1e3 - k_ms / max(cs["rk4_resident"]["launches"], 1), 4)
-                                      if "solve_s" in out.get("plan", {}) else None),
-                "executed_gflops_per_launch": round(flops / 1e9, 2),
-                "executed_tflops": round(flops / (k_ms * 1e-3) / 1e12, 3),
-                "operator_element_bytes": elem_bytes,
-                "l2_operator_bytes_per_launch": l2_bytes,
-                "l2_operator_gbs": round(l2_bytes / (k_ms * 1e-3) / 1e9, 1),
-                "bound_note": "round 6 (profiles/r06_cfg5_pipeline.md): neither the LDS nor the fp64 pipe is the bound -- with four waves per "
-                              "SIMD (1024 threads and 128 KB of LDS per workgroup: one workgroup per CU) the kernel is bound by the "
-                              "instructions its waves issue (a slot: 23 instructions around 4 gathers and 8 multiply-adds); a loop that "
-                              "hides the LDS round trip with 4 more instructions per slot measured 1.4 us per term slower",
-                "note": "achieved = bytes gathered from LDS (16 B per operator slot, row and operand vector) / kernel "
-                        "time; peak = 256 B per clock and CU (ds_read_b128, MI355X_MICROARCH.md) x 256 CUs x 2.4 GHz; "
-                        "cus_busy = instances x workgroups per instance (one workgroup per CU: LDS); frac_of_the_busy_cus "
-                        "prices the same bytes against those CUs only.  Vector fp64, no MFMA: the operators have at most "
-                        "19 non-zeros per row"}
-            if parts == 2 and form == 3:
-                # where a term of the default kernel goes: the same launch with its exchange switched off (ablate 1) and with the
-                # exchange AND every operator slot switched off (ablate 13: staging, barrier, series arithmetic) -- results wrong,
-                # kernel time only; the LDS rate of the slot loops alone follows from their difference
-                cross = ctx.counters("sweep_cross")
-                local_slots = int(cross["ms"] - cross["launches"])
-                dec = {}
-                for tag, bits in (("without_exchange", 1), ("skeleton", 13)):
-                    with ctx.options(ablate=bits):
-                        run()
-                        csa = profile_pass(ctx, run, ("rk4_resident",))
-                    dec[tag] = csa["rk4_resident"]["ms"] * 1e3 / max(terms, 1)
-                run()       # (a complete solve again before anything else is timed)
-                us_term = k_ms * 1e3 / max(terms, 1)
-                slot_us = max(dec["without_exchange"] - dec["skeleton"], 1e-9)
-                local_bytes_term = count * 2 * local_slots * n * 2 * 16
-                out["roofline"]["term_decomposition"] = {
-                    "us_per_term": {"complete": round(us_term, 2), "without_exchange": round(dec["without_exchange"], 2),
-                                    "skeleton": round(dec["skeleton"], 2)},
-                    "local_slot_loops_us": round(slot_us, 2), "exchange_and_crossing_slots_us": round(us_term - dec["without_exchange"], 2),
-                    "local_slots": local_slots,
-                    "lds_gbs_inside_the_slot_loops": round(local_bytes_term / (slot_us * 1e-6) / 1e9, 1),
-                    "frac_inside_the_slot_loops": round(local_bytes_term / (slot_us * 1e-6) / 1e9 / LDS_PEAK_GBS, 4),
-                    "note": "ablation launches of the same kernel in this run (ctx option ablate: 1 = no exchange, 13 = no exchange and no "
-                            "operator slots); frac above divides ALL gathered bytes by the whole term, this one the local slots' bytes by "
-                            "the time the slot loops take (without_exchange - skeleton)"}
-            if parts == 2 and form == 3:     # the two-workgroup kernel WITH operator elements beside it (ell_sweep_flip = 0)
-                with ctx.options(ell_sweep_flip=0):
-                    ys3, dev3, wall3, cs3 = measure(True)
-                out["two_workgroups_with_elements_route"] = {
-                    "kernel": "ell_sweep_duo_kernel<2, 2, 1024, 2>", "solve_s": round(wall3, 4),
-                    "ms_per_step": round(wall3 / n_steps * 1e3, 4), "kernel_ms_per_step": round(cs3["rk4_resident"]["ms"] / n_steps, 4),
-                    "us_per_term": round(cs3["rk4_resident"]["ms"] * 1e3 / max(terms, 1), 2), "cus_busy": busy,
-                    "max_abs_difference_to_the_default_route": float(np.max(np.abs(ys - ys3)))}
-            if parts == 2:     # round 3's kernel beside it: one workgroup per instance (what a shard of more than 128 instances runs)
-                ys1, dev1, wall1, cs1 = measure(True, duo=0)
-                out["one_workgroup_per_instance_route"] = {
-                    "kernel": "ell_sweep_kernel<2, 4, 1024, %d>" % form, "solve_s": round(wall1, 4),
-                    "ms_per_step": round(wall1 / n_steps * 1e3, 4), "stream_ms_per_step": round(dev1 / n_steps, 4),
-                    "kernel_ms_per_step": round(cs1["rk4_resident"]["ms"] / n_steps, 4),
-                    "us_per_term": round(cs1["rk4_resident"]["ms"] * 1e3 / max(terms, 1), 2), "cus_busy": min(count, 256),
-                    "max_abs_difference_to_the_default_route": float(np.max(np.abs(ys - ys1)))}
-        else:
-            out["roofline"] = cfg5_roofline(ctx, stack, cs, count, stack.n, n_steps, wall, count)
-        if took_sweep:     # the work-list MFMA route beside it
-            ys2, dev2, wall2, cs2 = measure(False)
-            out["max_abs_difference_between_the_routes"] = float(np.max(np.abs(ys - ys2)))
-            out["mfma_work_list_route"] = {
-                "solve_s": round(wall2, 4), "ms_per_step": round(wall2 / n_steps * 1e3, 4),
-                "stream_ms_per_step": round(dev2 / n_steps, 4),
-                "launches_per_step": {c: round(v["launches"] / n_steps, 2) for c, v in cs2.items() if v["launches"]},
-                "kernel_ms_per_step": {c: round(v["ms"] / n_steps, 4) for c, v in cs2.items() if v["launches"]},
-                "roofline": cfg5_roofline(ctx, stack, cs2, count, stack.n, n_steps, wall2, count)}
-    return out
-
-
-def leg_cpu_baseline(workloads, cfg, static, ops, frame_im, amps, phs):
-    from oracle import dynamics_oracle as orc
-    from threadpoolctl import threadpool_info, threadpool_limits
-
-    a_d, a = static, ops
-    d = 1j * frame_im
-    best = None
-    for threads in sorted({8, 32, os.cpu_count() or 8}):      # short probe: which BLAS width is fastest here
-        if threads > (os.cpu_count() or 8):
-            continue
-        with threadpool_limits(limits=threads):
-            t0c = time.perf_counter()
-
-            def rhs(t, y):
-                c = workloads.gaussian_coefficient_table(np.array([t]), amps[0], phs[0], cfg["carrier"], T_FINAL)[0]
-                return orc.generator_rhs(a_d, a, c, d, None, t, y)
-
-            orc.rk4_solve(rhs, [0.0, 10 * MAX_DT], cfg["y0"], MAX_DT)
-            rate = 40 / (time.perf_counter() - t0c)
-        if best is None or rate > best[0]:
-            best = (rate, threads)
-    threads = best[1]
-    n_inst = 4
-    n_steps = int(min(200, max(20, best[0] * 15 / (4 * n_inst))))   # ~15 s of CPU work
-    with threadpool_limits(limits=threads):
-        t0c = time.perf_counter()
-        for b in range(n_inst):
-            def rhs(t, y, b=b):
-                c = workloads.gaussian_coefficient_table(np.array([t]), amps[b], phs[b], cfg["carrier"], T_FINAL)[0]
-                return orc.generator_rhs(a_d, a, c, d, None, t, y)
-
-            orc.rk4_solve(rhs, [0.0, n_steps * MAX_DT], cfg["y0"], MAX_DT)
-        cpu_s = time.perf_counter() - t0c
-    best = (n_inst * n_steps * 4 / cpu_s, threads, cpu_s)
-    return {
-        "value": round(best[0], 1), "unit": "RHS evals/s", "cores": best[1], "kind": "port",
-        "cores_for_blas3": min(os.cpu_count() or 8, 64),
-        "sample": f"{n_inst} instances x {n_steps} RK4 steps ({n_inst * n_steps * 4} RHS evals) of the same "
-                  f"model with the NumPy oracle (tensordot + matvec); best of BLAS thread counts 8/32/all on a "
-                  f"{os.cpu_count()}-CPU host: {best[1]} threads, {best[2]:.1f} s",
-        "host": {"cpu_count": os.cpu_count(), "numpy": np.__version__,
-                 "blas": [f"{i.get('internal_api')} {i.get('version')} ({i.get('threading_layer') or i.get('user_api')})"
-                          for i in threadpool_info()],
-                 "OPENBLAS_NUM_THREADS": os.environ.get("OPENBLAS_NUM_THREADS")}}
-
-
-def leg_cpu_configs(workloads, threads, want4=True, want5=True):
-    """CPU baselines of cfg 4 / cfg 5 beside the device numbers: ONE step of the reference's algorithm
-    (solvers/fixed_step_solvers.py:80-108,321-363: dense generator(s) by tensordot, Magnus term, scipy.linalg.expm, one
-    matrix-vector product) with the NumPy oracle on this host -- exactly linear in steps (and instances)."""
-    import scipy.linalg
-    import scipy.sparse as sp
-    from oracle import dynamics_oracle as orc
-    from threadpoolctl import threadpool_limits
-
-    out = {}
-    with threadpool_limits(limits=threads):
-        if want4:
-            cfg = workloads.lindblad_config()
-            n = cfg["h_d"].shape[0]
-            eye = sp.identity(n, format="csr")
-
-            def vcomm(a):        # -i (I (x) A - A^T (x) I), oracle.vec_commutator built sparse (set-up only, not timed)
-                a = sp.csr_matrix(a)
-                return (-1j * (sp.kron(eye, a) - sp.kron(a.T, eye))).toarray()
-
-            def vdiss(l):        # conj(L) (x) L - (I (x) L^+L + (L^+L)^T (x) I) / 2, oracle.vec_dissipator
-                l = sp.csr_matrix(l)
-                ldl = l.conj().T @ l
-                return (sp.kron(l.conj(), l) - 0.5 * (sp.kron(eye, ldl) + sp.kron(ldl.T, eye))).toarray()
-
-            s_d = vcomm(cfg["h_d"]) + sum(vdiss(l) for l in cfg["static_dissipators"])
-            s_ops = np.stack([vcomm(o) for o in cfg["ops"]])
-            amps, phases = workloads.sweep_parameters(0, len(cfg["ops"]))
-            h, t0 = cfg["max_dt"], cfg["t_final"] / 2
-
-            def gen(t):
-                c = workloads.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], cfg["t_final"])[0]
-                return orc.generator_evaluate(s_d, s_ops, c, None, None, t)
-
-            y = cfg["rho0"].flatten(order="F")
-            t1 = time.perf_counter()
-            omega = orc.magnus_terms(gen, t0, h, 1)
-            t2 = time.perf_counter()
-            prop = scipy.linalg.expm(omega)
-            t3 = time.perf_counter()
-            y = prop @ y
-            t4 = time.perf_counter()
-            out["cfg4"] = {"value": round(1.0 / (t4 - t1), 4), "unit": "steps/s", "s_per_step": round(t4 - t1, 2), "cores": threads,
-                           "kind": "port", "sample": "1 scipy_expm step (Magnus order 1) of the N = 4096 superoperator model "
-                           "with the NumPy oracle: generator by tensordot over the dense (7, 4096, 4096) stack %.1f s, "
-                           "scipy.linalg.expm %.1f s, matvec %.3f s; 100 steps per solve" % (t2 - t1, t3 - t2, t4 - t3),
-                           "trace_after_the_step": float(abs(np.trace(y.reshape(n, n, order="F"))))}
-            del s_d, s_ops, prop, omega
-        if want5:
-            cfg = workloads.schrodinger_config(n_qubits=12, n_drives=8, t_final=5.0, max_dt=0.25)
-            ops, static, fim, _ = build_diag_frame_stack(cfg)
-            d = 1j * fim
-            amps, phases = workloads.sweep_parameters(0, 8)
-
-            def gen5(t):
-                c = workloads.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], cfg["t_final"])[0]
-                return orc.generator_evaluate(static, ops, c, d, None, t)
-
-            t1 = time.perf_counter()
-            omega = orc.magnus_terms(gen5, 2.5, cfg["max_dt"], 2)
-            t2 = time.perf_counter()
-            prop = scipy.linalg.expm(omega)
-            t3 = time.perf_counter()
-            y = prop @ cfg["y0"]
-            t4 = time.perf_counter()
-            out["cfg5"] = {"value": round(1.0 / (t4 - t1), 4), "unit": "instance-steps/s", "s_per_instance_step": round(t4 - t1, 2),
-                           "cores": threads, "kind": "port",
-                           "sample": "1 instance x 1 scipy_expm step (Magnus order 2) of the n = 4096 model with the NumPy "
-                                     "oracle: two dense generators + commutator %.1f s, scipy.linalg.expm %.1f s, matvec "
-                                     "%.3f s; 1024 instances x 20 steps per sweep" % (t2 - t1, t3 - t2, t4 - t3),
-                           "norm_after_the_step": float(np.linalg.norm(y))}
-    return out
-
-
-# -----------------------------------------------------------------------------------------------------------------
-def _mfma_roofline(kernel, flops, kernel_ms, note, **extra):
-    tf = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    return {"kernel": kernel, "bound": "mfma", "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "executed_flops": flops, "kernel_ms": round(kernel_ms, 4),
-            "traffic": None, "note": note, **extra}
-
-
-ZGEMM_NOTE = ("achieved = real flops the zgemm_seg_kernel launches EXECUTE (library counter flops:zgemm: M N K per launch x 6 "
-              "with three real products per complex product (3M, the solver pipelines' mode) or 8 with four) / the HIP-event "
-              "time of the same launches (counter class zgemm, profile on); elementwise passes (lincomb, norms) are listed "
-              "beside it, not counted as flops")
-
-
-def leg_dense_expm(qd, ctx):
-    """Row a11: the dense matrix exponential `midyn_expm` (scaling and squaring of a Taylor polynomial on the MFMA zgemm;
-    the reference calls scipy.linalg.expm, solvers/fixed_step_solvers.py:22,104) at the sizes BASELINE names: n = 1024 and
-    n = 4096, complex128, anti-Hermitian matrices of 1-norm 5 (a Magnus step of cfg 4 has 2.7) -- wall clock of the call
-    (PCIe both ways included), kernel time and executed flops from the library's counters, scipy on this host beside it."""
-    import scipy.linalg
-    from threadpoolctl import threadpool_limits
-
-    out = {}
-    rng = np.random.default_rng(11)
-    for n in (1024, 4096):
-        a = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
-        a = a - a.conj().T
-        a *= 5.0 / np.abs(a).sum(axis=0).max()
-        ctx.expm(a)                                           # warm-up: workspace, clocks
-        t0 = time.perf_counter()
-        e, info = ctx.expm(a, return_info=True)
-        wall = time.perf_counter() - t0
-        ctx.reset_counters()
-        ctx.set_option("profile", 1)
-        try:
-            ctx.expm(a)
-            ctx.synchronize()
-            cz, ce = ctx.counters("zgemm"), ctx.counters("elementwise")
-            flops = ctx.executed_flops("zgemm")
-        finally:
-            ctx.set_option("profile", 0)
-        threads = min(os.cpu_count() or 8, 64)
-        with threadpool_limits(limits=threads):
-            t0 = time.perf_counter()
-            ref = scipy.linalg.expm(a)
-            cpu_s = time.perf_counter() - t0
-        err = float(np.abs(e - ref).sum(axis=0).max() / np.abs(ref).sum(axis=0).max())
-        unit = float(np.abs(e.conj().T @ e - np.eye(n)).max()) if n <= 1024 else None
-        products = int(cz["launches"])
-        out[f"n{n}"] = {
-            "workload": f"expm of one {n} x {n} complex128 anti-Hermitian matrix, ||A||_1 = 5",
-            "wall_s_host_to_host": round(wall, 4), "kernel_ms": round(cz["ms"] + ce["ms"], 3), "matrix_products": products,
-            "squarings": int(info[0][0]), "elementwise_ms": round(ce["ms"], 3),
-            "expm_per_s_kernels": round(1e3 / (cz["ms"] + ce["ms"]), 2),
-            "rel_1norm_error_vs_scipy": err, "unitarity_defect": unit,
-            "roofline": _mfma_roofline("zgemm_seg_kernel<64, 64, 2, 2, 16, 4> (3M dense complex product)", flops, cz["ms"],
-                                       ZGEMM_NOTE, launches=products),
-            "cpu_baseline": {"value": round(1.0 / cpu_s, 4), "unit": "expm/s", "s_per_expm": round(cpu_s, 3), "cores": threads,
-                             "kind": "reference", "sample": f"scipy.linalg.expm (what the reference calls) of the same matrix "
-                                                            f"on this host, {threads} BLAS threads: {cpu_s:.2f} s"},
-            "pcie_note": "wall_s_host_to_host includes 2 x 16 n^2 bytes over PCIe and the host-side padding copy; "
-                         "inside midyn_expm_solve the matrices never leave the device"}
-    return out
-
-
-def leg_lindblad_rk4(qd, ctx, workloads, n_qubits=10, instances=64, steps=5):
-    """Row f2: NON-vectorised Lindblad RK4 (LindbladCollection.evaluate_rhs, models/operator_collections.py:451-567:
-    (A + B) rho + rho (A - B) + sum gamma L rho L^+ with n x n products, no n^2 x n^2 superoperator) -- the 10-qubit chain
-    (n = 1024) with 4 static dissipators in the frame of its static Hamiltonian, a sweep of density-matrix trajectories
-    through the product Solver (list mode)."""
-    from oracle import dynamics_oracle as orc
-    from threadpoolctl import threadpool_limits
-
-    cfg = workloads.lindblad_config(n_qubits=n_qubits, n_drives=8, n_diss=4, gamma=1e-3, t_final=5.0, max_dt=0.005)
-    n = cfg["h_d"].shape[0]
-    t0 = time.perf_counter()
-    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
-                       static_dissipators=cfg["static_dissipators"], rotating_frame=cfg["h_d"], vectorized=False)
-    build_s = time.perf_counter() - t0
-    sweeps = []
-    for b in range(instances):
-        amps, phases = workloads.sweep_parameters(b, 8)
-        sweeps.append([qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph)
-                       for a, nu, ph in zip(amps, cfg["carrier"], phases)])
-    t_span = [2.4, 2.4 + steps * cfg["max_dt"]]
-    solver.solve(t_span=[2.4, 2.4 + cfg["max_dt"]], y0=cfg["rho0"], signals=sweeps[:2], method="RK4", max_dt=cfg["max_dt"])
-    t0 = time.perf_counter()
-    res = solver.solve(t_span=t_span, y0=cfg["rho0"], signals=sweeps, method="RK4", max_dt=cfg["max_dt"])
-    wall = time.perf_counter() - t0
-    dev_s = res[0].wall_s
-    ctx.reset_counters()
-    ctx.set_option("profile", 1)
-    try:
-        solver.solve(t_span=[2.4, 2.4 + cfg["max_dt"]], y0=cfg["rho0"], signals=sweeps[:4], method="RK4", max_dt=cfg["max_dt"])
-        ctx.synchronize()
-        cz, cg, ce = ctx.counters("zgemm"), ctx.counters("gen_eval"), ctx.counters("elementwise")
-        flops = ctx.executed_flops("zgemm")
-    finally:
-        ctx.set_option("profile", 0)
-    evals = instances * 4 * steps
-    rho = res[-1].y[-1]
-    # CPU: the oracle's matrix-form RHS (lindblad_rhs) of the same model in the same frame, one instance, a few evaluations
-    h_d, h_ops, n_static, l_ops, d, basis = orc.lindblad_model_build(cfg["h_d"], cfg["ops"], cfg["static_dissipators"], None,
-                                                                      cfg["h_d"])
-    amps, phases = workloads.sweep_parameters(0, 8)
-    rho_f = basis.conj().T @ cfg["rho0"] @ basis
-    threads = min(os.cpu_count() or 8, 64)
-    n_cpu = 4
-    with threadpool_limits(limits=threads):
-        t0 = time.perf_counter()
-        for i in range(n_cpu):
-            t = 2.4 + 0.0025 * i
-            c = workloads.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], cfg["t_final"])[0]
-            orc.lindblad_rhs(h_d, h_ops, n_static, l_ops, c, None, d, t, rho_f)
-        cpu_s = (time.perf_counter() - t0) / n_cpu
-    return {
-        "workload": f"{n_qubits}-qubit (n = {n}) Lindblad master equation, 8 drives, 4 static sigma^- dissipators, frame of H_d, "
-                    f"vectorized=False, RK4 max_dt 0.005: {instances} density-matrix trajectories x {steps} steps",
-        "rhs_evals_per_s": round(evals / dev_s, 2), "ms_per_instance_evaluation": round(dev_s / evals * 1e3, 4),
-        "solve_s_device_call": round(dev_s, 3), "solve_s_whole_call": round(wall, 3), "model_build_s": round(build_s, 2),
-        "trace_deviation": float(abs(np.trace(rho) - 1.0)), "hermiticity": float(np.linalg.norm(rho - rho.conj().T)),
-        "kernel_ms_per_evaluation": {"zgemm": round(cz["ms"] / 16, 4), "gen_eval": round(cg["ms"] / 16, 4),
-                                     "elementwise": round(ce["ms"] / 16, 4)},
-        "products_per_evaluation": round(cz["launches"] / 16, 2),
-        "roofline": _mfma_roofline("zgemm_seg_kernel (n x n products of the non-vectorised Lindblad right-hand side)", flops,
-                                   cz["ms"], ZGEMM_NOTE + "; profiled pass: 4 instances x 1 step = 16 evaluations",
-                                   launches=int(cz["launches"])),
-        "cpu_baseline": {"value": round(1.0 / cpu_s, 3), "unit": "RHS evals/s", "cores": threads, "kind": "port",
-                         "sample": f"{n_cpu} evaluations of oracle.lindblad_rhs (the reference's matrix form, NumPy matmul) of the "
-                                   f"same model on this host, {threads} BLAS threads: {cpu_s * 1e3:.1f} ms each"}}
-
-
-def leg_parallel_in_time(qd, ctx, workloads, n_qubits=4, steps=1000):
-    """Row f3: parallel-in-time propagation (fixed_step_lmde_solver_parallel_template_jax, solvers/fixed_step_solvers.py:
-    524-613): all step propagators by batched launches, then a binary-tree product.  cfg 4's model class -- the vectorised
-    Lindbladian of the qubit chain with sigma^- dissipators, scipy_expm Magnus order 1 -- at 4 qubits (N = 256), 1000 steps.
-    (At cfg 4's own N = 4096 the 1000 step propagators are 268 GB: that size keeps the sequential expm action.)"""
-    import scipy.linalg
-    from oracle import dynamics_oracle as orc
-    from threadpoolctl import threadpool_limits
-
-    cfg = workloads.lindblad_config(n_qubits=n_qubits, n_drives=n_qubits, n_diss=min(4, n_qubits), gamma=1e-3, t_final=5.0,
-                                    max_dt=5.0 / steps)
-    n = cfg["h_d"].shape[0]
-    solver = qd.Solver(static_hamiltonian=cfg["h_d"], hamiltonian_operators=cfg["ops"],
-                       static_dissipators=cfg["static_dissipators"], vectorized=True)
-    amps, phases = workloads.sweep_parameters(0, n_qubits)
-    sigs = [qd.Signal(lambda t, a=a: a * np.exp(-((t - 2.5) ** 2) / 2.0), nu, ph) for a, nu, ph in zip(amps, cfg["carrier"], phases)]
-
-    y0_vec = cfg["rho0"].flatten(order="F")      # (a vectorised model takes the column-stacked density matrix)
-
-    def solve(method):
-        best, r_ = 1e9, None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            r_ = solver.solve(t_span=cfg["t_span"], y0=y0_vec, signals=sigs, method=method, max_dt=cfg["max_dt"])
-            best = min(best, time.perf_counter() - t0)
-        return best, r_
-
-    t_par, r_par = solve("hip_expm_parallel")
-    t_seq, r_seq = solve("scipy_expm")
-    ctx.reset_counters()
-    ctx.set_option("profile", 1)
-    try:
-        solver.solve(t_span=cfg["t_span"], y0=y0_vec, signals=sigs, method="hip_expm_parallel", max_dt=cfg["max_dt"])
-        ctx.synchronize()
-        cz, cg, ce = ctx.counters("zgemm"), ctx.counters("gen_eval"), ctx.counters("elementwise")
-        flops = ctx.executed_flops("zgemm")
-    finally:
-        ctx.set_option("profile", 0)
-    # CPU: the reference's sequential loop (generator by tensordot, scipy.linalg.expm, matvec) on the superoperators, 20 steps
-    s_d, s_ops = orc.vectorized_lindblad_stack(cfg["h_d"], cfg["ops"], cfg["static_dissipators"], None)
-    threads = 8
-    n_cpu = 20
-
-    def gen(t):
-        c = workloads.gaussian_coefficient_table(np.array([t]), amps, phases, cfg["carrier"], cfg["t_final"])[0]
-        return orc.generator_evaluate(s_d, s_ops, c, None, None, t)
-
-    with threadpool_limits(limits=threads):
-        t0 = time.perf_counter()
-        y = cfg["rho0"].flatten(order="F")
-        for i in range(n_cpu):
-            y = scipy.linalg.expm(orc.magnus_terms(gen, 2.4 + i * cfg["max_dt"], cfg["max_dt"], 1)) @ y
-        cpu_s = (time.perf_counter() - t0) / n_cpu
-    rho = r_par.y[-1].reshape(n, n, order="F")
-    return {
-        "workload": f"{n_qubits}-qubit vectorised Lindbladian (N = {n * n}), {n_qubits} drives, {len(cfg['static_dissipators'])} "
-                    f"dissipators, no frame, scipy_expm magnus_order 1, {steps} steps, ONE trajectory",
-        "steps_per_s_parallel_in_time": round(steps / t_par, 1), "solve_s_parallel_in_time": round(t_par, 4),
-        "solve_s_sequential_device_route": round(t_seq, 4), "route": getattr(r_par, "route", None),
-        "max_abs_difference_between_the_routes": float(np.max(np.abs(r_par.y[-1] - r_seq.y[-1]))),
-        "trace_deviation": float(abs(np.trace(rho) - 1.0)),
-        "kernel_ms": {"zgemm": round(cz["ms"], 3), "gen_eval": round(cg["ms"], 3), "elementwise": round(ce["ms"], 3)},
-        "roofline": _mfma_roofline("zgemm_seg_kernel (batched N x N products: Taylor blocks and squarings of every step's expm, "
-                                   "then the tree of step propagators)", flops, cz["ms"], ZGEMM_NOTE, launches=int(cz["launches"])),
-        "cpu_baseline": {"value": round(1.0 / cpu_s, 2), "unit": "steps/s", "cores": threads, "kind": "port",
-                         "sample": f"{n_cpu} steps of the reference's sequential loop with the NumPy oracle (tensordot generator, "
-                                   f"scipy.linalg.expm, matvec) on the N = {n * n} superoperators, {threads} BLAS threads: "
-                                   f"{cpu_s * 1e3:.1f} ms per step"}}
-
-
-def leg_perturbative(qd, ctx):
-    """Row f4: MagnusSolver / DysonSolver (solvers/perturbative_solvers/magnus_solver.py:107-129, perturbation/
-    array_polynomial.py:524-544) on the two-transmon model of the reference's own test (dim 25, two drives; tests/
-    bench_perturbative_vs_oracle.py holds the same model): 1000 steps of dt = 0.01, y0 = identity."""
-    from oracle import dynamics_oracle as orc
-
-    w_c, w_t = 2 * np.pi * 5.033, 2 * np.pi * 4.067
-    alpha_c, alpha_t, jc = 2 * np.pi * (-0.33534), 2 * np.pi * (-0.33834), 2 * np.pi * 0.002
-    dim = 5
-    a = np.diag(np.sqrt(np.arange(1, dim)), 1)
-    num = np.diag(np.arange(dim)).astype(float)
-    i1, i2 = np.eye(dim), np.eye(dim**2)
-    a0, a1 = np.kron(a, i1), np.kron(i1, a)
-    n0, n1 = np.kron(num, i1), np.kron(i1, num)
-    h0 = w_c * n0 + 0.5 * alpha_c * n0 @ (n0 - i2) + w_t * n1 + 0.5 * alpha_t * n1 @ (n1 - i2) + jc * (a0 @ a1.T + a0.T @ a1)
-    hdc, hdt = 2 * np.pi * (a0 + a0.T), 2 * np.pi * (a1 + a1.T)
-    sig_w = 0.399128 / 0.2
-    gauss = qd.Signal(lambda t: np.exp(-((t - 3.5 * sig_w) ** 2) / (2 * sig_w**2)), carrier_freq=5.0)
-    dt, n_steps = 0.01, 1000
-    y0 = np.eye(dim**2, dtype=complex)
-    out = {}
-    for name, cls, order in (("magnus", qd.MagnusSolver, 3), ("dyson", qd.DysonSolver, 4)):
-        t0 = time.perf_counter()
-        sol = cls(operators=[-1j * hdc, -1j * hdt], rotating_frame=-1j * h0, dt=dt, carrier_freqs=[5.0, 5.0],
-                  chebyshev_orders=[1, 1], expansion_order=order, integration_method="DOP853", atol=1e-10, rtol=1e-10)
-        build_s = time.perf_counter() - t0
-        sol.solve(t0=0.0, n_steps=64, y0=y0, signals=[gauss, gauss])
-        best = 1e9
-        for _ in range(3):
-            t0 = time.perf_counter()
-            yf = sol.solve(t0=0.0, n_steps=n_steps, y0=y0, signals=[gauss, gauss]).y[-1]
-            best = min(best, time.perf_counter() - t0)
-        ctx.reset_counters()
-        ctx.set_option("profile", 1)
-        try:
-            sol.solve(t0=0.0, n_steps=n_steps, y0=y0, signals=[gauss, gauss])
-            ctx.synchronize()
-            cz, ce = ctx.counters("zgemm"), ctx.counters("elementwise")
-            flops = ctx.executed_flops("zgemm")
-        finally:
-            ctx.set_option("profile", 0)
-        m = sol.model
-        coeffs = m.approximate_signals([gauss, gauss], 0.0, n_steps)
-        labels = np.array([list(lab) + [-1] * (order - len(lab)) for lab in m.monomial_labels])
-        d, basis = orc.frame_setup(-1j * h0)
-        n_cpu = 50
-        t0 = time.perf_counter()
-        orc.perturbative_solve(name, m.array_coefficients, labels, m.Udt, d, basis, coeffs[:, :n_cpu], y0, 0.0, n_cpu, dt)
-        cpu_s = (time.perf_counter() - t0) / n_cpu
-        out[name] = {
-            "workload": f"{cls.__name__} expansion_order {order}, two 5-level transmons (dim 25), {len(m.monomial_labels)} expansion "
-                        f"terms, {n_steps} steps of dt {dt}, y0 = identity",
-            "steps_per_s": round(n_steps / best, 1), "solve_s": round(best, 5), "model_build_s": round(build_s, 2),
-            "unitarity_defect": float(np.abs(yf.conj().T @ yf - np.eye(dim**2)).max()),
-            "kernel_ms": {"zgemm": round(cz["ms"], 3), "elementwise": round(ce["ms"], 3)},
-            "roofline": _mfma_roofline("zgemm_seg_kernel (the polynomial of all steps as ONE product mono[T][M] x terms[M][n_pad^2], "
-                                       "batched expm and Udt products, tree of step maps)", flops, cz["ms"],
-                                       ZGEMM_NOTE + "; dim 25 pads to 64: the launches are latency-bound at this size, the "
-                                       "roofline fraction says so", launches=int(cz["launches"])),
-            "cpu_baseline": {"value": round(1.0 / cpu_s, 1), "unit": "steps/s", "cores": 1, "kind": "port",
-                             "sample": f"{n_cpu} steps of oracle.perturbative_solve (the reference's per-step loop: array polynomial by "
-                                       f"tensordot, scipy.linalg.expm, matmul) on this host: {cpu_s * 1e3:.2f} ms per step"}}
-    return out
 
 
 def main():

@@ -1,0 +1,242 @@
+"""bench.py legs: BASELINE cfg 5 (12-qubit Magnus-2 sweep, diagonal frame): the shard / full sweep solve with its rooflines."""
+import os
+import time
+
+import numpy as np
+
+from .common import (ALL_CLASSES, CFG5_SWEEP, FP64_MFMA_PEAK_TFLOPS, HBM_PEAK_GBS, LDS_PEAK_GBS, MAX_DT, N_DRIVES, N_QUBITS, ROOT, SWEEP,  # noqa: F401
+                     T_FINAL, ZGEMM_NOTE, _mfma_roofline, build_diag_frame_stack, build_frame_basis_stack, build_model_stack,
+                     measured_traffic, profile_pass, sweep_table)
+
+
+def cfg5_roofline(ctx, stack, cs, n_cols, n, n_steps, wall, n_inst):
+    """Roofline object of a cfg-5 style solve whose dominant kernel is the sparse MFMA work-list contraction."""
+    dom = max(cs, key=lambda c: cs[c]["ms"])
+    launches = cs[dom]["launches"]
+    avg_ms = cs[dom]["ms"] / max(launches, 1)
+    if dom != "rhs_blocks_gemm":
+        return {"kernel": dom, "bound": "mfma", "achieved": None, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 5)}
+    tile = ctx.counters("sparse_tile")
+    lst = ctx.counters("sparse_list")
+    bm, bn = int(tile["launches"]), int(tile["ms"])
+    listed, splits = lst["launches"], int(lst["ms"])
+    per_launch = max(1, int(ctx.counters("sparse_pair")["launches"]))   # 2: two independent products share a launch
+    cols_pad = -(-n_cols // bn) * bn
+    modes = [m for m in stack.segment_modes if m != 3]
+    real_flops_per_mac = 4 if all(m in (1, 2) for m in modes) else 8
+    # every listed (BM x 16) tile times all columns, for each contraction of the launch
+    flops_launch = per_launch * listed * bm * 16 * cols_pad * real_flops_per_mac
+    tf = flops_launch / (avg_ms * 1e-3) / 1e12
+    return {
+        "kernel": f"zgemm_seg_kernel<{bm},{bn},...,SPARSE> (batched contraction over the tile work lists, fp64 MFMA)",
+        "bound": "mfma", "achieved": round(tf, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+        "launches_timed": int(launches), "executed_mfma_flops_per_launch": flops_launch,
+        "listed_tiles": int(listed), "tile": [bm, bn], "splits": splits, "columns": n_cols,
+        "contractions_per_launch": per_launch, "contractions_per_step": round(per_launch * launches / n_steps, 2),
+        "note": "executed flops = listed (panel, K tile, operator) tiles x BM x 16 x columns x 4 real flops per complex "
+                "MAC (single-plane operators); short panels are latency-bound (DESIGN 4.12, section 8)",
+        "dense_form_price": {
+            "labelled": "SURVEY 8(d) cfg 5 prices the reference's dense algorithm (2 commutator zgemms + expm per "
+                        "instance-step), which is NOT executed here: the expm ACTION needs no n^3 work",
+            "flops_per_instance_step": 8.0 * n**3 * (2 + 7.33),
+            "mfma_ceiling_ms_per_instance_step": round(8.0 * n**3 * 9.33 / (FP64_MFMA_PEAK_TFLOPS * 1e12) * 1e3, 1),
+            "measured_ms_per_instance_step": round(wall / n_steps / n_inst * 1e3, 5)}}
+
+
+def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
+    """cfg 5: 12-qubit (n = 4096) Schrodinger sweep in the diagonal frame, scipy_expm magnus_order 2, max_dt 0.25,
+    T = 5 -> 20 steps; instances [first, first + count)."""
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+
+    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(2))
+    table, _, _ = sweep_table(workloads, sched.times, first, count, 8, cfg["carrier"], cfg["t_final"])
+    y0 = cfg["y0"].reshape(-1, 1)
+
+    def run():
+        return stack.expm_solve(sched.times, table, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2,
+                                y0, count, True)
+
+    def measure(sweep_kernel, duo=1):
+        with ctx.options(ell_sweep=1 if sweep_kernel else 0, ell_sweep_duo=duo):
+            # (three untimed solves first: the sweep kernel's first launches after a lighter leg run ~10 % slower while the clocks
+            # settle -- tools/bench_cfg5_variants.py -- and the binding's pinned result blocks of this size exist afterwards)
+            for _ in range(3 if sweep_kernel else 1):
+                run()
+            ctx.synchronize()
+            best = None
+            for _ in range(5 if sweep_kernel else 1):       # (best of five: a 2.5 ms solve next to 8 MB of PCIe)
+                t0_ = time.perf_counter()
+                ctx.timer_start()
+                ys_ = run()
+                dev_ = ctx.timer_stop()
+                wall_ = time.perf_counter() - t0_
+                if best is None or wall_ < best[2]:
+                    best = (ys_, dev_, wall_)
+            cs_ = profile_pass(ctx, run, ALL_CLASSES) if with_profile else None
+        return best[0], best[1], best[2], cs_
+
+    ys, dev_ms, wall, cs = measure(True)            # the product's default route
+    n_steps = len(sched.step_h)
+    out = {"instances": count, "steps": n_steps, "solve_s": round(wall, 4),
+           "ms_per_step": round(wall / n_steps * 1e3, 4), "stream_ms_per_step": round(dev_ms / n_steps, 4),
+           "us_per_instance_step": round(wall / n_steps / count * 1e6, 3),
+           "instance_steps_per_s": round(count * n_steps / wall, 1),
+           "max_norm_deviation": float(np.max(np.abs(np.linalg.norm(ys[:, -1, :, 0], axis=1) - 1.0))),
+           "note": "solve_s = midyn_expm_solve wall clock: coefficient table H2D, 20 device steps, results D2H "
+                   "(%.0f MB over PCIe); stream_ms = HIP events around the same call" % (ys.nbytes / 1e6)}
+    # the same solve repeated through a plan object (midyn_expm_plan_*: model + time grid made once, one coefficient table per run):
+    # what a parameter scan or an optimiser loop pays per solve
+    try:
+        plan = qd.ExpmPlan(stack, sched.times, sched.step_rows, sched.step_h, sched.step_save, sched.n_save, 2, y0, count, True)
+        for _ in range(3):
+            yp = plan.solve(table)
+        ctx.synchronize()
+        best_p = None
+        for _ in range(5):
+            t0_ = time.perf_counter()
+            plan.run(table)
+            t1_ = time.perf_counter()
+            yp = plan.fetch()
+            t2_ = time.perf_counter()
+            if best_p is None or t2_ - t0_ < best_p[0]:
+                best_p = (t2_ - t0_, t1_ - t0_)
+        plan.close()
+        out["plan"] = {"solve_s": round(best_p[0], 5), "ms_per_step": round(best_p[0] / n_steps * 1e3, 4),
+                       "run_call_ms": round(best_p[1] * 1e3, 4), "equal_to_the_one_shot_solve": bool(np.array_equal(yp, ys)),
+                       "instance_steps_per_s": round(count * n_steps / best_p[0], 1),
+                       "what": "midyn_expm_plan_run + _fetch of a plan made once (frame phases, step tables, y0, exchange slots, result "
+                               "block on the device; per run: table upload, norm bounds, series, launch; saved states written by the kernel "
+                               "straight into the pinned result block)"}
+    except Exception as exc:  # pylint: disable=broad-except
+        out["plan"] = {"error": repr(exc)}
+    if with_profile:
+        took_sweep = cs["rk4_resident"]["launches"] > 0
+        out["launches_per_step"] = {c: round(v["launches"] / n_steps, 2) for c, v in cs.items() if v["launches"]}
+        out["kernel_ms_per_step"] = {c: round(v["ms"] / n_steps, 4) for c, v in cs.items() if v["launches"]}
+        if took_sweep:
+            ser = ctx.counters("sweep_series")
+            terms, slots = ser["launches"], int(ser["ms"])
+            k_ms = cs["rk4_resident"]["ms"]
+            n = stack.n
+            # per term and instance: 2 passes over the operator slots of every row; a pass gathers 2 complex numbers
+            # from LDS and does 2 real x complex multiply-adds per slot and reads one operator element from L2
+            form = int(ctx.counters("sweep_split")["ms"])          # 0 general (12 B elements), 1 packed, 2 direct (4 B)
+            elem_bytes = {0: 12, 1: 4, 2: 4, 3: 0}[form]
+            flops = terms * count * 2 * slots * n * 2 * 4
+            lds_bytes = terms * count * 2 * slots * n * 2 * 16
+            l2_bytes = terms * count * 2 * slots * n * elem_bytes
+            parts = int(ctx.counters("sweep_split")["launches"])   # workgroups per instance
+            busy = min(count * parts, 256)
+            form_name = {0: "general: 4 B column + 8 B value", 1: "packed: column | sign, one magnitude per slot",
+                         2: "direct: LDS address of the operand, one signed magnitude per slot",
+                         3: "none: one signed magnitude and one flip mask per slot, column = row ^ flip"}[form]
+            if parts == 2 and form == 3:
+                cross = ctx.counters("sweep_cross")
+                kname = "ell_flip_duo_kernel<2, 2, 1024>"
+                out["route"] = ("%s: ONE launch, TWO workgroups (1024 threads, half of the rows each) per instance through all steps; "
+                                "NO operator elements are read (every slot of this stack has one signed magnitude and one flip mask: "
+                                "the LDS address of an operand is the thread's own address XOR a per-slot constant; coefficients and "
+                                "flip masks through v_readlane from lane-held copies); each workgroup stages ITS half of an operand "
+                                "vector in LDS and applies the %d of %d slots that stay inside the half; the %d slots that reach across "
+                                "read their operands straight from the partner's payload (one set of 16-byte sc1 loads shared by the "
+                                "slots, issued inside the slot loop after half of the local slots, per-wave round flags; payload in the "
+                                "L2 the partners share -- plain stores -- or written through on different XCDs); series vectors in registers"
+                                % (kname, int(cross["ms"] - cross["launches"]), int(cross["ms"]), int(cross["launches"])))
+            elif parts == 2:
+                cross = ctx.counters("sweep_cross")
+                kname = "ell_sweep_duo_kernel<2, 2, 1024, %d>" % form
+                out["route"] = ("%s: ONE launch, TWO workgroups (1024 threads, half of the rows each) per instance through all "
+                                "steps; each stages its half of an operand vector in LDS and applies the %d of %d operator slots "
+                                "that stay inside the half while the partner's half arrives (per-wave round flags; payload slots in "
+                                "device memory that stay in the L2 the partners share -- plain stores, sc1 loads -- or are written "
+                                "through when they sit on different XCDs), then the %d slots that reach across; operator elements "
+                                "(%s) from L2; series vectors in registers"
+                                % (kname, int(cross["ms"] - cross["launches"]), int(cross["ms"]), int(cross["launches"]), form_name))
+            else:
+                kname = "ell_sweep_kernel<2, 4, 1024, %d>" % form
+                out["route"] = ("%s: ONE launch, one workgroup (1024 threads) per instance through "
+                                "all steps; staged vectors in LDS, operator elements (%s) from L2, series vectors the passes "
+                                "do not touch in a per-instance stash" % (kname, form_name))
+            out["workgroups_per_instance"] = parts
+            out["roofline"] = {
+                "kernel": kname, "bound": "lds",
+                "achieved": round(lds_bytes / (k_ms * 1e-3) / 1e9, 1),
+                "peak": round(LDS_PEAK_GBS, 1), "unit": "GB/s",
+                "frac": round(lds_bytes / (k_ms * 1e-3) / 1e9 / LDS_PEAK_GBS, 4), "traffic": None,
+                "cus_busy": busy, "frac_of_the_busy_cus": round(lds_bytes / (k_ms * 1e-3) / 1e9 / (LDS_PEAK_GBS * busy / 256), 4),
+                "avg_launch_ms": round(k_ms / max(cs["rk4_resident"]["launches"], 1), 4),
+                "series_terms_per_instance": terms, "operator_slots_per_row": slots,
+                "us_per_term": round(k_ms * 1e3 / max(terms, 1), 2),
+                "host_side_ms_one_shot": round(wall * 1e3 - k_ms / max(cs["rk4_resident"]["launches"], 1), 4),
+                "host_side_ms_plan": (round(out["plan"]["solve_s"] * 1e3 - k_ms / max(cs["rk4_resident"]["launches"], 1), 4)
+                                      if "solve_s" in out.get("plan", {}) else None),
+                "executed_gflops_per_launch": round(flops / 1e9, 2),
+                "executed_tflops": round(flops / (k_ms * 1e-3) / 1e12, 3),
+                "operator_element_bytes": elem_bytes,
+                "l2_operator_bytes_per_launch": l2_bytes,
+                "l2_operator_gbs": round(l2_bytes / (k_ms * 1e-3) / 1e9, 1),
+                "bound_note": "round 6 (profiles/r06_cfg5_pipeline.md): neither the LDS nor the fp64 pipe is the bound -- with four waves per "
+                              "SIMD (1024 threads and 128 KB of LDS per workgroup: one workgroup per CU) the kernel is bound by the "
+                              "instructions its waves issue (a slot: 23 instructions around 4 gathers and 8 multiply-adds); a loop that "
+                              "hides the LDS round trip with 4 more instructions per slot measured 1.4 us per term slower",
+                "note": "achieved = bytes gathered from LDS (16 B per operator slot, row and operand vector) / kernel "
+                        "time; peak = 256 B per clock and CU (ds_read_b128, MI355X_MICROARCH.md) x 256 CUs x 2.4 GHz; "
+                        "cus_busy = instances x workgroups per instance (one workgroup per CU: LDS); frac_of_the_busy_cus "
+                        "prices the same bytes against those CUs only.  Vector fp64, no MFMA: the operators have at most "
+                        "19 non-zeros per row"}
+            if parts == 2 and form == 3:
+                # where a term of the default kernel goes: the same launch with its exchange switched off (ablate 1) and with the
+                # exchange AND every operator slot switched off (ablate 13: staging, barrier, series arithmetic) -- results wrong,
+                # kernel time only; the LDS rate of the slot loops alone follows from their difference
+                cross = ctx.counters("sweep_cross")
+                local_slots = int(cross["ms"] - cross["launches"])
+                dec = {}
+                for tag, bits in (("without_exchange", 1), ("skeleton", 13)):
+                    with ctx.options(ablate=bits):
+                        run()
+                        csa = profile_pass(ctx, run, ("rk4_resident",))
+                    dec[tag] = csa["rk4_resident"]["ms"] * 1e3 / max(terms, 1)
+                run()       # (a complete solve again before anything else is timed)
+                us_term = k_ms * 1e3 / max(terms, 1)
+                slot_us = max(dec["without_exchange"] - dec["skeleton"], 1e-9)
+                local_bytes_term = count * 2 * local_slots * n * 2 * 16
+                out["roofline"]["term_decomposition"] = {
+                    "us_per_term": {"complete": round(us_term, 2), "without_exchange": round(dec["without_exchange"], 2),
+                                    "skeleton": round(dec["skeleton"], 2)},
+                    "local_slot_loops_us": round(slot_us, 2), "exchange_and_crossing_slots_us": round(us_term - dec["without_exchange"], 2),
+                    "local_slots": local_slots,
+                    "lds_gbs_inside_the_slot_loops": round(local_bytes_term / (slot_us * 1e-6) / 1e9, 1),
+                    "frac_inside_the_slot_loops": round(local_bytes_term / (slot_us * 1e-6) / 1e9 / LDS_PEAK_GBS, 4),
+                    "note": "ablation launches of the same kernel in this run (ctx option ablate: 1 = no exchange, 13 = no exchange and no "
+                            "operator slots); frac above divides ALL gathered bytes by the whole term, this one the local slots' bytes by "
+                            "the time the slot loops take (without_exchange - skeleton)"}
+            if parts == 2 and form == 3:     # the two-workgroup kernel WITH operator elements beside it (ell_sweep_flip = 0)
+                with ctx.options(ell_sweep_flip=0):
+                    ys3, dev3, wall3, cs3 = measure(True)
+                out["two_workgroups_with_elements_route"] = {
+                    "kernel": "ell_sweep_duo_kernel<2, 2, 1024, 2>", "solve_s": round(wall3, 4),
+                    "ms_per_step": round(wall3 / n_steps * 1e3, 4), "kernel_ms_per_step": round(cs3["rk4_resident"]["ms"] / n_steps, 4),
+                    "us_per_term": round(cs3["rk4_resident"]["ms"] * 1e3 / max(terms, 1), 2), "cus_busy": busy,
+                    "max_abs_difference_to_the_default_route": float(np.max(np.abs(ys - ys3)))}
+            if parts == 2:     # round 3's kernel beside it: one workgroup per instance (what a shard of more than 128 instances runs)
+                ys1, dev1, wall1, cs1 = measure(True, duo=0)
+                out["one_workgroup_per_instance_route"] = {
+                    "kernel": "ell_sweep_kernel<2, 4, 1024, %d>" % form, "solve_s": round(wall1, 4),
+                    "ms_per_step": round(wall1 / n_steps * 1e3, 4), "stream_ms_per_step": round(dev1 / n_steps, 4),
+                    "kernel_ms_per_step": round(cs1["rk4_resident"]["ms"] / n_steps, 4),
+                    "us_per_term": round(cs1["rk4_resident"]["ms"] * 1e3 / max(terms, 1), 2), "cus_busy": min(count, 256),
+                    "max_abs_difference_to_the_default_route": float(np.max(np.abs(ys - ys1)))}
+        else:
+            out["roofline"] = cfg5_roofline(ctx, stack, cs, count, stack.n, n_steps, wall, count)
+        if took_sweep:     # the work-list MFMA route beside it
+            ys2, dev2, wall2, cs2 = measure(False)
+            out["max_abs_difference_between_the_routes"] = float(np.max(np.abs(ys - ys2)))
+            out["mfma_work_list_route"] = {
+                "solve_s": round(wall2, 4), "ms_per_step": round(wall2 / n_steps * 1e3, 4),
+                "stream_ms_per_step": round(dev2 / n_steps, 4),
+                "launches_per_step": {c: round(v["launches"] / n_steps, 2) for c, v in cs2.items() if v["launches"]},
+                "kernel_ms_per_step": {c: round(v["ms"] / n_steps, 4) for c, v in cs2.items() if v["launches"]},
+                "roofline": cfg5_roofline(ctx, stack, cs2, count, stack.n, n_steps, wall2, count)}
+    return out
