@@ -201,7 +201,8 @@ int midyn_sigtable_destroy(midyn_sigtable* tab);
  * into one batched contraction).  The caller evaluates the signals on the host into the table
  * S[B][R][k] (signals/signals.py:792-803) at the R distinct times `times[R]`; step s uses table
  * rows step_rows[s][0..2] = (t, t+h/2, t+h) and step size step_h[s]; after step s the state is
- * stored in output slot step_save[s] when that is >= 0.  Slot 0 always receives y0.
+ * stored in output slot step_save[s] when that is >= 1 (negative: not saved).  Slot 0 always receives y0: step_save[s] == 0
+ * is refused by the one-launch sweep route of midyn_expm_solve / midyn_expm_plan_* and should not be used on any route.
  * y0 is [B][n][m], or [n][m] when y0_shared != 0; Y_out is [B][P][n][m]. */
 int midyn_rk4_solve(midyn_stack* stack, int B, int m, int R, const double* times, const double* S,
                     int nsteps, const int* step_rows, const double* step_h, const int* step_save,

@@ -199,9 +199,13 @@ def load():
 _PINNED_MIN_BYTES = 1 << 20        # below: the copy is latency, not bandwidth
 _PINNED_MAX_BYTES = 256 << 20      # above: page-locking that much for as long as the caller keeps the result is not ours to decide
 _PINNED_CACHE_MAX = 1 << 30
+_PINNED_LIVE_MAX = int(os.environ.get("MIDYN_PINNED_BUDGET_MB", "2048")) << 20   # page-locked bytes in the hands of callers at most: beyond, np.empty
 _pinned_cache = {}          # nbytes -> [pointers]
 _pinned_cached_bytes = 0
-_pinned_lock = threading.Lock()
+_pinned_live_bytes = 0
+# RLock: _PinnedBlock.__del__ can run inside a garbage collection that starts while this thread holds the lock;
+# the finalizer itself allocates nothing under it (the per-size lists are made in result_array)
+_pinned_lock = threading.RLock()
 _hiprt = None
 
 
@@ -226,11 +230,13 @@ class _PinnedBlock:
         self.ptr, self.nbytes = ptr, nbytes
 
     def __del__(self):
-        global _pinned_cached_bytes
+        global _pinned_cached_bytes, _pinned_live_bytes
         try:
             with _pinned_lock:
-                if _pinned_cached_bytes + self.nbytes <= _PINNED_CACHE_MAX:
-                    _pinned_cache.setdefault(self.nbytes, []).append(self.ptr)
+                _pinned_live_bytes -= self.nbytes
+                blocks = _pinned_cache.get(self.nbytes)         # (made by result_array before the block existed)
+                if blocks is not None and _pinned_cached_bytes + self.nbytes <= _PINNED_CACHE_MAX:
+                    blocks.append(self.ptr)
                     _pinned_cached_bytes += self.nbytes
                     return
             _hip_runtime().hipHostFree(_vp(self.ptr))
@@ -240,7 +246,7 @@ class _PinnedBlock:
 
 def result_array(shape, dtype=np.complex128):
     """An uninitialised C-contiguous array for results the device writes: pinned host memory when large."""
-    global _pinned_cached_bytes
+    global _pinned_cached_bytes, _pinned_live_bytes
     dtype = np.dtype(dtype)
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     if (nbytes < _PINNED_MIN_BYTES or nbytes > _PINNED_MAX_BYTES or os.environ.get("MIDYN_PINNED_RESULTS", "1") == "0"
@@ -248,21 +254,39 @@ def result_array(shape, dtype=np.complex128):
         return np.empty(shape, dtype=dtype)
     ptr = None
     with _pinned_lock:
-        blocks = _pinned_cache.get(nbytes)
+        # a scan that KEEPS its results must not page-lock the host: past the budget, results are ordinary arrays
+        if _pinned_live_bytes + nbytes > _PINNED_LIVE_MAX:
+            return np.empty(shape, dtype=dtype)
+        _pinned_live_bytes += nbytes
+        blocks = _pinned_cache.setdefault(nbytes, [])
         if blocks:
             ptr = blocks.pop()
             _pinned_cached_bytes -= nbytes
     if ptr is None:
         p = _vp()
         try:
-            if _hip_runtime().hipHostMalloc(ctypes.byref(p), nbytes, 0) != 0 or not p.value:
-                return np.empty(shape, dtype=dtype)
+            ok = _hip_runtime().hipHostMalloc(ctypes.byref(p), nbytes, 0) == 0 and bool(p.value)
         except (OSError, AttributeError):
+            ok = False
+        if not ok:
+            with _pinned_lock:
+                _pinned_live_bytes -= nbytes
             return np.empty(shape, dtype=dtype)
         ptr = p.value
     buf = (ctypes.c_char * nbytes).from_address(ptr)
     buf._midyn_block = _PinnedBlock(ptr, nbytes)      # lives exactly as long as the buffer every view of the array refers to
     return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+def is_pinned(a) -> bool:
+    """Does this array live in one of result_array's pinned blocks (device-writable host memory)?"""
+    for _ in range(8):
+        if a is None:
+            return False
+        if getattr(a, "_midyn_block", None) is not None:
+            return True
+        a = getattr(a, "base", None) if isinstance(a, np.ndarray) else getattr(a, "obj", None) if isinstance(a, memoryview) else None
+    return False
 
 
 def _ptr(a):
@@ -856,7 +880,8 @@ class ExpmPlan:
         else:
             table = None
         self._out = result_array((self.batch, self.n_save, self.stack.n, self.m))
-        self.stack.ctx.check(self.stack.ctx.lib.midyn_expm_plan_run(self.handle, _ptr(table), _ptr(self._out)))
+        # (only a block of OUR pinned cache is offered for direct writes: the plan remembers accepted blocks by address)
+        self.stack.ctx.check(self.stack.ctx.lib.midyn_expm_plan_run(self.handle, _ptr(table), _ptr(self._out) if is_pinned(self._out) else None))
 
     def fetch(self):
         if self._out is None:

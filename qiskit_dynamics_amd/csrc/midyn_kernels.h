@@ -2731,6 +2731,7 @@ MIDYN_GLOBAL __launch_bounds__(256) void stream_read_kernel(const double2* src, 
     MIDYN_FOR_PLANE_MODE(X, 128, 128, 2, 4, 16) MIDYN_FOR_PLANE_MODE(X, 64, 64, 2, 2, 16) MIDYN_FOR_PLANE_MODE(X, 32, 128, 1, 4, 16) \
     MIDYN_FOR_PLANE_MODE(X, 32, 64, 1, 2, 16) MIDYN_FOR_PLANE_MODE(X, 16, 128, 1, 4, 16) MIDYN_FOR_PLANE_MODE(X, 16, 64, 1, 2, 16)
 #define MIDYN_GEMM_TILES(X) MIDYN_GEMM_PAIR_TILES(X)     // (the 128 x 64 x 8 two-per-CU tile of round 2's A/B is no longer built: nothing selects it)
+#define MIDYN_GEMM_DENSE_TILES(X) MIDYN_FOR_PLANE_MODE(X, 128, 128, 2, 4, 16) MIDYN_FOR_PLANE_MODE(X, 64, 64, 2, 2, 16)   // (dense: no panel tiles)
 #ifdef MIDYN_TU_GEMM_DENSE
 #define MIDYN_GEMM_DENSE_EXTERN
 #else
@@ -2748,7 +2749,7 @@ MIDYN_GLOBAL __launch_bounds__(256) void stream_read_kernel(const double2* src, 
 #endif
 #define MIDYN_X(BM_, BN_, WM_, WN_, BK_, MODE_) \
     MIDYN_GEMM_DENSE_EXTERN template __global__ void zgemm_seg_kernel<BM_, BN_, WM_, WN_, BK_, MODE_, 2, false>(GemmArgs);
-MIDYN_GEMM_TILES(MIDYN_X)
+MIDYN_GEMM_DENSE_TILES(MIDYN_X)
 MIDYN_X(64, 64, 2, 2, 16, 4)      // 3M: three accumulator sets fit the registers on the 64 x 64 tile only
 #undef MIDYN_X
 #define MIDYN_X(BM_, BN_, WM_, WN_, BK_, MODE_) \
