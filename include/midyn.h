@@ -59,6 +59,8 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         (work-list kernels; the skipped products are exact zeros)
  *   chebyshev [1]         expm action, Magnus order 1, nearly skew-Hermitian generator: Chebyshev series instead of
  *                         the scaled Taylor series when shorter (2: always, 0: never)
+ *   expansion_pack [1]    midyn_expansion_solve with n <= 32: two step matrices share one padded 64 x 64 block (block diagonal), so the
+ *                         batched expm / tree run on half as many padded matrices; 0: one step per block
  *   exchange_protocol [0] hand-offs between the workgroups of a one-launch kernel: 0 = the measured default, 1 = the conforming forms of
  *                         MI355X_MICROARCH.md (release / acquire, sc1 stores and loads everywhere); same results bit for bit
  *   expm_direct_out [1]   midyn_expm_solve / midyn_expm_plan_run on the one-launch sweep route: saved states written by the kernel

@@ -1862,6 +1862,42 @@ MIDYN_GLOBAL __launch_bounds__(256) void mono_operand_kernel(const double* mono,
     }
 }
 
+// The same operand for TWO steps per row (midyn_expansion: blockdiag packing, n <= 32): row t = (instance b, i < ns) holds the monomials
+// of step i in columns [0, Mc) and those of step i + ns in [Mc, 2 Mc) (Mc = M + constant); mono is [instances][2 ns][M].
+MIDYN_GLOBAL __launch_bounds__(256) void mono_operand2_kernel(const double* mono, int nb, int M, int has_const, int T, int K2, int ns,
+                                                            double2* A) {
+    const size_t total = (size_t)T * K2;
+    const int Mc = M + has_const;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int t = (int)(idx / K2);
+        const int j = (int)(idx - (size_t)t * K2);
+        double v = 0.0;
+        if (t < nb && j < 2 * Mc) {
+            const int b = t / ns, i = t % ns, hi = j >= Mc ? 1 : 0, jj = j - hi * Mc;
+            if (jj < M) v = mono[((size_t)b * 2 * ns + (size_t)hi * ns + i) * M + jj];
+            else v = 1.0;
+        }
+        A[idx] = make_double2(v, 0.0);
+    }
+}
+
+// rows [0, blk) of every column -> rows [blk, 2 blk) (dir > 0) or back (dir < 0); the rows left behind are zeroed
+MIDYN_GLOBAL __launch_bounds__(256) void expansion_shift_kernel(double2* Y, int ldy, int cols, int blk, int dir) {
+    const size_t total = (size_t)blk * cols;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int r = (int)(idx / cols), c = (int)(idx - (size_t)r * cols);
+        double2* lo = Y + (size_t)r * ldy + c;
+        double2* hi = Y + (size_t)(r + blk) * ldy + c;
+        if (dir > 0) {
+            *hi = *lo;
+            *lo = make_double2(0.0, 0.0);
+        } else {
+            *lo = *hi;
+            *hi = make_double2(0.0, 0.0);
+        }
+    }
+}
+
 // Host batch layout [B][n][m] (or shared [n][m]) -> device column block [n_pad][ld]; also writes the
 // pre-phased copy yin = E o y.  Padding rows/cols are zeroed by the caller (memset).
 MIDYN_GLOBAL __launch_bounds__(256) void scatter_state_kernel(const double2* src, int shared, int B, int n,

@@ -2450,3 +2450,37 @@ def test_adaptive_scipy_methods_golden(qd, golden):
                   rtol=1e-10)
     assert len(res) == 2
     assert_close(res[1].y, g["r7_DOP853_y"], 5e-8)
+
+
+@pytest.mark.parametrize("kind", ["dyson", "magnus"])
+def test_expansion_two_steps_per_padded_block(qd, golden, kind):
+    """midyn_expansion_solve with n <= 32 (round 6, ctx option expansion_pack): the step matrices of steps i and i + nsteps / 2 share ONE
+    padded 64 x 64 block (block diagonal: products and exponentials never mix the blocks), the batched expm / Udt products / tree run
+    on half as many padded matrices, and an instance's product is (lower block) . (upper block).  Same results as one step per block
+    (1e-12; the blocks' exponentials may take a different scaling than each alone) for an even number of steps -- packed, asserted
+    through the counter -- and identical for an odd number (not packed); list mode with two instances included.  Reference:
+    solvers/perturbative_solvers/perturbative_solver.py:172-219, array_polynomial.py:524-544."""
+    g = golden("perturbative")
+    ctx = qd.default_context()
+    cls = qd.DysonSolver if kind == "dyson" else qd.MagnusSolver
+    sol = cls(operators=g["t3_ops"], rotating_frame=g["t3_frame"], dt=0.02, carrier_freqs=[4.9, 0.0],
+              chebyshev_orders=[1, 0], expansion_order=2, expansion_labels=[[0, 0, 1], [0, 1, 4]],
+              include_imag=[True, False], integration_method="DOP853", atol=1e-12, rtol=1e-12)
+    sig_a = qd.Signal(lambda t: 0.8 * np.exp(-((t - 1.0) ** 2) / 0.5) * np.exp(0.3j * t), carrier_freq=4.9, phase=0.2)
+    sig_b = qd.Signal(lambda t: 0.4 * np.cos(0.7 * t) + 0j, carrier_freq=0.0)
+    sig_c = qd.Signal(lambda t: 0.5 * np.exp(-((t - 0.7) ** 2) / 0.3) + 0j, carrier_freq=4.95, phase=-0.4)
+    for n_steps, want in ((60, 2), (2, 2), (61, 1), (1, 1), (334, 2)):
+        res = {}
+        for pack in (1, 0):
+            with ctx.options(expansion_pack=pack):
+                r = sol.solve(t0=0.1, n_steps=n_steps, y0=[np.eye(3, dtype=complex), g["t3_y0"]], signals=[[sig_a, sig_b], [sig_c, sig_b]])
+                per_block = int(ctx.counters("expansion_pack")["launches"])
+            assert per_block == (want if pack else 1), (n_steps, pack, per_block)
+            res[pack] = [x.y[-1] for x in r]
+        for a, b in zip(res[1], res[0]):
+            assert a.shape == b.shape
+            if want == 1:
+                assert np.array_equal(a, b)
+            else:
+                assert_close(a, b, 1e-12)
+    assert_close(res[1][0], sol.solve(t0=0.1, n_steps=334, y0=np.eye(3, dtype=complex), signals=[sig_a, sig_b]).y[-1], 1e-12)

@@ -236,8 +236,16 @@ def leg_perturbative(qd, ctx):
             ctx.synchronize()
             cz, ce = ctx.counters("zgemm"), ctx.counters("elementwise")
             flops = ctx.executed_flops("zgemm")
+            per_block = int(ctx.counters("expansion_pack")["launches"])
         finally:
             ctx.set_option("profile", 0)
+        with ctx.options(expansion_pack=0):          # one step per padded block (rounds 1-5), beside it
+            y_one = sol.solve(t0=0.0, n_steps=n_steps, y0=y0, signals=[gauss, gauss]).y[-1]
+            best_one = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                sol.solve(t0=0.0, n_steps=n_steps, y0=y0, signals=[gauss, gauss])
+                best_one = min(best_one, time.perf_counter() - t0)
         m = sol.model
         coeffs = m.approximate_signals([gauss, gauss], 0.0, n_steps)
         labels = np.array([list(lab) + [-1] * (order - len(lab)) for lab in m.monomial_labels])
@@ -252,10 +260,16 @@ def leg_perturbative(qd, ctx):
             "steps_per_s": round(n_steps / best, 1), "solve_s": round(best, 5), "model_build_s": round(build_s, 2),
             "unitarity_defect": float(np.abs(yf.conj().T @ yf - np.eye(dim**2)).max()),
             "kernel_ms": {"zgemm": round(cz["ms"], 3), "elementwise": round(ce["ms"], 3)},
+            "steps_per_padded_block": per_block,
+            "one_step_per_block": {"solve_s": round(best_one, 5), "max_abs_difference": float(np.max(np.abs(y_one - yf)))},
             "roofline": _mfma_roofline("zgemm_seg_kernel (the polynomial of all steps as ONE product mono[T][M] x terms[M][n_pad^2], "
                                        "batched expm and Udt products, tree of step maps)", flops, cz["ms"],
                                        ZGEMM_NOTE + "; dim 25 pads to 64: the launches are latency-bound at this size, the "
-                                       "roofline fraction says so", launches=int(cz["launches"])),
+                                       "roofline fraction says so", launches=int(cz["launches"]),
+                                       # the cubic part (expm, Udt and tree products) of the EXECUTED flops that is not padding:
+                                       # blocks of 64 / steps_per_padded_block rows hold 25 x 25 matrices
+                                       frac_unpadded=round(flops / (cz["ms"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS
+                                                           * per_block * (dim**2 / 64.0) ** 3, 4) if cz["ms"] > 0 else None),
             "cpu_baseline": {"value": round(1.0 / cpu_s, 1), "unit": "steps/s", "cores": 1, "kind": "port",
                              "sample": f"{n_cpu} steps of oracle.perturbative_solve (the reference's per-step loop: array polynomial by "
                                        f"tensordot, scipy.linalg.expm, matmul) on this host: {cpu_s * 1e3:.2f} ms per step"}}
