@@ -260,6 +260,15 @@ int midyn_expansion_create(midyn_ctx* ctx, int n, int M, const midyn_complex* te
 int midyn_expansion_destroy(midyn_expansion* exp);
 int midyn_expansion_solve(midyn_expansion* exp, int B, int nsteps, const double* mono, int m,
                           const midyn_complex* y0, int y0_shared, midyn_complex* Y_out);
+/* The monomials on the device as well (the first half of ArrayPolynomial.__call__: perturbation/array_polynomial.py:524-528 with
+ * :547-601): midyn_expansion_set_monomials hands over the multiset labels of the M terms once -- labels[M][order], row I = the indices
+ * (< n_vars) of the coefficients whose product is monomial I, -1 behind the last one -- and midyn_expansion_solve_coeffs takes
+ * coeffs[B][n_vars][nsteps], the Chebyshev coefficients of every step (expansion_model.py:410-551), instead of the (nsteps x M) table:
+ * 32 KB instead of 0.3-0.5 MB per 1000-step solve cross the bus, nothing but the signal evaluation is left on the host.  The products are
+ * associated as the host's table does (c[l0] * (c[l1] * ...)): both entry points give the same bits. */
+int midyn_expansion_set_monomials(midyn_expansion* exp, int n_vars, int order, const int* labels);
+int midyn_expansion_solve_coeffs(midyn_expansion* exp, int B, int nsteps, const double* coeffs, int m,
+                                 const midyn_complex* y0, int y0_shared, midyn_complex* Y_out);
 
 /* ---- non-vectorised Lindblad RHS -------------------------------------
  * LindbladCollection.evaluate_rhs (models/operator_collections.py:451-567) with n x n zgemms:

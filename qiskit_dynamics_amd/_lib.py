@@ -27,7 +27,8 @@ ABI_SYMBOLS = [
     "midyn_reset_counters", "midyn_microbench", "midyn_lindblad_create", "midyn_lindblad_destroy",
     "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve", "midyn_sigtable_create", "midyn_sigtable_data",
     "midyn_sigtable_fetch", "midyn_sigtable_destroy", "midyn_parallel_solve", "midyn_expansion_create",
-    "midyn_expansion_destroy", "midyn_expansion_solve", "midyn_ctx_timer", "midyn_stack_block_info",
+    "midyn_expansion_destroy", "midyn_expansion_solve", "midyn_expansion_set_monomials", "midyn_expansion_solve_coeffs",
+    "midyn_ctx_timer", "midyn_stack_block_info",
     "midyn_comm_get_unique_id", "midyn_comm_init_rank", "midyn_comm_destroy", "midyn_comm_count", "midyn_stack_create_empty",
     "midyn_stack_broadcast", "midyn_stack_broadcast_from",
 ]
@@ -170,6 +171,8 @@ def load():
         lib.midyn_expansion_create.argtypes = [_vp, _ci, _ci, _vp, _vp, _vp, _ci, P(_vp)]
         lib.midyn_expansion_destroy.argtypes = [_vp]
         lib.midyn_expansion_solve.argtypes = [_vp, _ci, _ci, _vp, _ci, _vp, _ci, _vp]
+        lib.midyn_expansion_set_monomials.argtypes = [_vp, _ci, _ci, _vp]
+        lib.midyn_expansion_solve_coeffs.argtypes = [_vp, _ci, _ci, _vp, _ci, _vp, _ci, _vp]
         lib.midyn_sigtable_create.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, P(_vp)]
         lib.midyn_sigtable_data.argtypes = [_vp, P(_vp), _vp]
         lib.midyn_sigtable_fetch.argtypes = [_vp, _vp]
@@ -793,6 +796,31 @@ class Expansion:
         out = np.empty((batch, self.n, m), dtype=np.complex128)
         self.ctx.check(self.ctx.lib.midyn_expansion_solve(self.handle, int(batch), int(mono.shape[1]), _ptr(mono),
                                                           int(m), _ptr(y0), int(bool(y0_shared)), _ptr(out)))
+        return out
+
+    def set_monomials(self, n_vars, labels):
+        """labels: the M index multisets of the terms (tuples of coefficient indices < n_vars); afterwards ``solve_coeffs`` takes the
+        Chebyshev coefficients themselves and the monomial table is formed on the device."""
+        if len(labels) != self.n_terms or any(len(lab) == 0 for lab in labels):
+            raise DynamicsError(f"one non-empty label per expansion term ({self.n_terms}) is required")
+        order = max(len(lab) for lab in labels)
+        tab = np.full((self.n_terms, order), -1, dtype=np.int32)
+        for i, lab in enumerate(labels):
+            tab[i, : len(lab)] = lab
+        self.ctx.check(self.ctx.lib.midyn_expansion_set_monomials(self.handle, int(n_vars), int(order), _ptr(tab)))
+        self.n_vars = int(n_vars)
+
+    def solve_coeffs(self, coeffs, y0, batch, y0_shared):
+        """coeffs (B, n_vars, nsteps) real; y0 (n, m) if shared else (B, n, m) -> final states (B, n, m)."""
+        coeffs = f64(coeffs)
+        if coeffs.ndim != 3 or coeffs.shape[0] != batch or coeffs.shape[1] != getattr(self, "n_vars", -1):
+            raise DynamicsError(f"coefficient table must be (B, n_vars, nsteps) = ({batch}, {getattr(self, 'n_vars', '?')}, *); "
+                                "call set_monomials first")
+        y0 = c128(y0)
+        m = y0.shape[-1]
+        out = np.empty((batch, self.n, m), dtype=np.complex128)
+        self.ctx.check(self.ctx.lib.midyn_expansion_solve_coeffs(self.handle, int(batch), int(coeffs.shape[2]), _ptr(coeffs),
+                                                                 int(m), _ptr(y0), int(bool(y0_shared)), _ptr(out)))
         return out
 
     def close(self):

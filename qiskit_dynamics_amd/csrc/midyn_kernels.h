@@ -1881,6 +1881,38 @@ MIDYN_GLOBAL __launch_bounds__(256) void mono_operand2_kernel(const double* mono
     }
 }
 
+// The operand built from the Chebyshev COEFFICIENTS of the steps (midyn_expansion_solve_coeffs): c is [instances][n_vars][nsteps], labels
+// [M][order] (-1 behind a label's last index); monomial I of a step = c[lab[0]] * (c[lab[1]] * (... c[lab[last]])) -- the association of
+// perturbative.compute_monomials, so the table equals the host's bit for bit.  Row t of the chunk is table row row0 + t = (instance b,
+// i < ns); pack: columns [0, Mc) belong to step i, [Mc, 2 Mc) to step i + ns (two steps per padded block), else columns [0, Mc) to step i.
+MIDYN_GLOBAL __launch_bounds__(256) void mono_operand_labels_kernel(const double* __restrict__ c, const int* __restrict__ labels, int order,
+                                                                  int n_vars, int nsteps, long long row0, int nb, int M, int has_const, int T,
+                                                                  int K, int ns, int pack, double2* A) {
+    const size_t total = (size_t)T * K;
+    const int Mc = M + has_const;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int t = (int)(idx / K);
+        const int j = (int)(idx - (size_t)t * K);
+        double v = 0.0;
+        if (t < nb && j < (pack ? 2 * Mc : Mc)) {
+            const long long r = row0 + t;
+            const long long b = r / ns;
+            const int hi = pack && j >= Mc ? 1 : 0, jj = j - hi * Mc;
+            if (jj < M) {
+                const double* cb = c + (size_t)b * n_vars * nsteps + (size_t)(r - b * ns) + (size_t)hi * ns;
+                const int* lab = labels + (size_t)jj * order;
+                int k = order - 1;
+                while (k > 0 && lab[k] < 0) --k;
+                v = cb[(size_t)lab[k] * nsteps];
+                for (--k; k >= 0; --k) v = cb[(size_t)lab[k] * nsteps] * v;
+            } else {
+                v = 1.0;
+            }
+        }
+        A[idx] = make_double2(v, 0.0);
+    }
+}
+
 // rows [0, blk) of every column -> rows [blk, 2 blk) (dir > 0) or back (dir < 0); the rows left behind are zeroed
 MIDYN_GLOBAL __launch_bounds__(256) void expansion_shift_kernel(double2* Y, int ldy, int cols, int blk, int dir) {
     const size_t total = (size_t)blk * cols;

@@ -12,9 +12,10 @@ Split of the work
     frame basis with SciPy's ``solve_ivp``; Magnus terms follow from the series logarithm.  This is
     an own formulation (the reference: ``perturbation/solve_lmde_perturbation.py`` +
     ``perturbation/dyson_magnus.py``); its results are checked against the reference's terms.
-  * every solve (the hot step): monomials of the Chebyshev coefficients on the host (a few real
-    products per step), then ``midyn_expansion_solve`` on the device -- one GEMM evaluates the
-    polynomial for all steps, batched expm (Magnus), tree product of the step propagators.
+  * every solve (the hot step): the Chebyshev coefficients of the envelopes on the host (the signals are
+    Python callables), then ``midyn_expansion_solve_coeffs`` on the device -- monomials of the
+    coefficients, one GEMM that evaluates the polynomial for all steps, batched expm (Magnus), tree
+    product of the step propagators.
 """
 from __future__ import annotations
 
@@ -35,14 +36,37 @@ from .signals import Signal, SignalList
 # -------------------------------------------------------------------------------------------------
 # Chebyshev approximation of signal envelopes (expansion_model.py:410-551)
 # -------------------------------------------------------------------------------------------------
+_DCT_CACHE = {}
+
+
 def _construct_dct(degree: int, dt: float):
-    order = degree + 1
-    xcheb = chebpts1(order)
-    shifted = 0.5 * (dt * xcheb + dt)
-    mat = chebvander(xcheb, degree).T
-    mat[0] /= order
-    mat[1:] /= 0.5 * order
-    return mat, shifted
+    key = (int(degree), float(dt))
+    hit = _DCT_CACHE.get(key)
+    if hit is None:
+        order = degree + 1
+        xcheb = chebpts1(order)
+        shifted = 0.5 * (dt * xcheb + dt)
+        mat = chebvander(xcheb, degree).T
+        mat[0] /= order
+        mat[1:] /= 0.5 * order
+        if len(_DCT_CACHE) > 64:
+            _DCT_CACHE.clear()
+        hit = _DCT_CACHE[key] = (mat, shifted)
+    return hit
+
+
+def _envelope_in_reference_frame(signal: Signal, reference_freq: float, x_vals: np.ndarray) -> np.ndarray:
+    """``signal.complex_value(x) * exp(-i 2 pi reference_freq x)``.  For a plain carrier signal the two phase factors are ONE
+    factor ``exp(i (2 pi (nu - reference_freq) x + phase))`` -- and no factor at all when the expansion's reference frequency IS the
+    signal's carrier (the usual case: expansion_model.py's ``carrier_freqs``); that halves the host time of a solve's signal
+    evaluation and drops the rounding of two cancelling 2 pi nu x arguments."""
+    if type(signal).complex_value is Signal.complex_value and np.ndim(signal.carrier_freq) == 0 and np.ndim(signal.phase) == 0:
+        env = signal.envelope(x_vals)
+        dnu, ph = float(signal.carrier_freq) - float(reference_freq), float(signal.phase)
+        if dnu == 0.0 and ph == 0.0:
+            return np.asarray(env, dtype=complex)
+        return env * np.exp(1j * (2 * np.pi * dnu * x_vals + ph))
+    return signal.complex_value(x_vals) * np.exp(-1j * 2 * np.pi * reference_freq * x_vals)
 
 
 def signal_envelope_dct(signal: Signal, reference_freq: float, degree: int, t0: float, dt: float,
@@ -50,21 +74,24 @@ def signal_envelope_dct(signal: Signal, reference_freq: float, degree: int, t0: 
     """(degree+1, n_intervals) complex Chebyshev coefficients of the envelope of ``signal`` relative
     to ``reference_freq`` on consecutive intervals of length ``dt`` starting at ``t0``."""
     t_vals = t0 + np.arange(n_intervals) * dt
-    phase_arg = -1j * 2 * np.pi * reference_freq
-    final_phase_shift = np.exp(-phase_arg * t_vals)
+    final_phase_shift = np.exp((1j * 2 * np.pi * reference_freq) * t_vals)
     mat, xcheb = _construct_dct(degree, dt)
     x_vals = np.add.outer(xcheb, t_vals)
-    shifted = signal.complex_value(x_vals) * np.exp(phase_arg * x_vals)
+    shifted = _envelope_in_reference_frame(signal, reference_freq, x_vals)
     return (mat @ shifted) * np.expand_dims(final_phase_shift, axis=0)
 
 
 def signal_list_envelope_dct(signals, reference_freqs, degrees, t0, dt, n_intervals, include_imag=None):
-    """Real coefficient rows for all signals: real parts, then imaginary parts where included."""
+    """Real coefficient rows for all signals: real parts, then imaginary parts where included.  The SAME signal object with the
+    same reference frequency and degree (two drives that share one pulse) is evaluated once."""
     if include_imag is None:
         include_imag = [True] * len(signals)
-    rows = []
+    rows, seen = [], {}
     for sig, freq, deg, inc in zip(signals, reference_freqs, degrees, include_imag):
-        c = signal_envelope_dct(sig, freq, deg, t0, dt, n_intervals)
+        key = (id(sig), float(freq), int(deg))
+        c = seen.get(key)
+        if c is None:
+            c = seen[key] = signal_envelope_dct(sig, freq, deg, t0, dt, n_intervals)
         rows.append(c.real)
         if inc:
             rows.append(c.imag)
@@ -318,7 +345,7 @@ class ExpansionModel:
             raise DynamicsError("evaluate() is available for the Dyson expansion; the Magnus step is "
                                 "Udt expm(polynomial) and is applied by MagnusSolver.solve.")
         n = self._terms.shape[-1]
-        return self.device().solve(self.monomial_table(coeffs)[None], np.eye(n, dtype=complex), 1, True)[0]
+        return self.device().solve_coeffs(coeffs[None], np.eye(n, dtype=complex), 1, True)[0]
 
     def device(self) -> "_lib.Expansion":
         if self._device is None:
@@ -326,6 +353,7 @@ class ExpansionModel:
             magnus = self._expansion_method == "magnus"
             self._device = _lib.Expansion(ctx, self._terms, constant_term=self._constant_term,
                                           post=self._Udt if magnus else None, use_expm=magnus)
+            self._device.set_monomials(self._n_perturbations, self._labels)
         return self._device
 
 
@@ -399,14 +427,15 @@ class _PerturbativeSolver:
             groups.setdefault((int(nss[i]), y.shape), []).append(i)
         ident = np.eye(n, dtype=complex)
         for (steps, shape), idxs in groups.items():
-            mono = np.empty((len(idxs), steps, len(model.monomial_labels)), dtype=np.float64)
+            dev = model.device()
+            coeffs = np.empty((len(idxs), dev.n_vars, steps), dtype=np.float64)
             ys = []
             for j, i in enumerate(idxs):
-                coeffs = model.approximate_signals(sgs[i], t0s[i], steps)
-                mono[j] = compute_monomials(model.monomial_labels, coeffs).T
+                # (the monomials of the coefficients are formed on the device: midyn_expansion_solve_coeffs)
+                coeffs[j] = model.approximate_signals(sgs[i], t0s[i], steps)
                 u0 = np.asarray(frame.state_out_of_frame(t0s[i], ident))
                 ys.append((u0 @ np.asarray(y0s[i], dtype=complex)).reshape(n, -1))
-            finals = model.device().solve(mono, np.stack(ys), len(idxs), False)
+            finals = dev.solve_coeffs(coeffs, np.stack(ys), len(idxs), False)
             for j, i in enumerate(idxs):
                 uf = np.asarray(frame.state_into_frame(t0s[i] + steps * model.dt, ident))
                 yf = (uf @ finals[j]).reshape(shape)

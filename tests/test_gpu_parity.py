@@ -2485,3 +2485,45 @@ def test_expansion_two_steps_per_padded_block(qd, golden, kind):
             else:
                 assert_close(a, b, 1e-12)
     assert_close(res[1][0], sol.solve(t0=0.1, n_steps=334, y0=np.eye(3, dtype=complex), signals=[sig_a, sig_b]).y[-1], 1e-12)
+
+
+@pytest.mark.parametrize("kind", ["dyson", "magnus"])
+def test_expansion_coefficients_on_the_device_equal_the_monomial_table(qd, golden, kind):
+    """midyn_expansion_solve_coeffs (round 6): the monomials c^I of the Chebyshev coefficients are formed on the device from the
+    multiset labels (midyn_expansion_set_monomials) -- the first half of ArrayPolynomial.__call__ (perturbation/array_polynomial.py:
+    524-528, :547-601) -- instead of arriving as a (nsteps x M) table.  Same bits as midyn_expansion_solve on the host's table
+    (perturbative.compute_monomials associates the products the same way), for packed and unpacked blocks, several instances, a
+    repeated shape (the offset tables of the last shape stay on the device) and changing shapes in between; the value of the table
+    itself against the oracle's monomials."""
+    from oracle import dynamics_oracle as orc
+
+    g = golden("perturbative")
+    ctx = qd.default_context()
+    cls = qd.DysonSolver if kind == "dyson" else qd.MagnusSolver
+    sol = cls(operators=g["t3_ops"], rotating_frame=g["t3_frame"], dt=0.02, carrier_freqs=[4.9, 0.0],
+              chebyshev_orders=[1, 0], expansion_order=3, expansion_labels=[[0, 0, 1, 4]],
+              include_imag=[True, False], integration_method="DOP853", atol=1e-10, rtol=1e-10)
+    m = sol.model
+    dev = m.device()
+    sig_a = qd.Signal(lambda t: 0.8 * np.exp(-((t - 1.0) ** 2) / 0.5) * np.exp(0.3j * t), carrier_freq=4.9, phase=0.2)
+    sig_b = qd.Signal(lambda t: 0.4 * np.cos(0.7 * t) + 0j, carrier_freq=0.0)
+    sig_c = qd.Signal(lambda t: 0.5 * np.exp(-((t - 0.7) ** 2) / 0.3) + 0j, carrier_freq=4.95, phase=-0.4)
+    rng = np.random.default_rng(5)
+    y_shared = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))
+    for n_steps in (60, 60, 61, 60, 2, 1, 334, 334):
+        cs = np.stack([m.approximate_signals(sg, 0.1, n_steps) for sg in ([sig_a, sig_b], [sig_c, sig_b], [sig_a, sig_c])])
+        mono = np.stack([m.monomial_table(c) for c in cs])
+        labels = np.array([list(lab) + [-1] * (4 - len(lab)) for lab in m.monomial_labels])
+        assert_close(mono[1].T, orc.monomials(labels, cs[1]), 1e-15)          # (left-to-right products there: last-bit differences)
+        ys = np.stack([np.eye(3, dtype=complex), 1j * y_shared.T, y_shared])
+        for shared in (False, True):
+            y0 = y_shared if shared else ys
+            a = dev.solve_coeffs(cs, y0, 3, shared)
+            b = dev.solve(mono, y0, 3, shared)
+            assert np.array_equal(a, b), (n_steps, shared, float(np.max(np.abs(a - b))))
+            assert np.array_equal(a, dev.solve_coeffs(cs, y0, 3, shared))
+    with pytest.raises(qd.DynamicsError):
+        dev.solve_coeffs(cs[:, :-1], ys, 3, False)
+    with pytest.raises(qd.DynamicsError):
+        dev.set_monomials(2, m.monomial_labels)          # an index >= n_vars
+    dev.set_monomials(cs.shape[1], m.monomial_labels)
