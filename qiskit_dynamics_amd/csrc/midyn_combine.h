@@ -241,19 +241,29 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // (the lane number again, from the execution mask count: the main loop uses all 256 registers, and a value of the prologue
+    //  that is only needed down here would be parked in scratch around it -- tests/test_codeobj.py refuses that)
+    int lane_t;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+    const int lb_t = lane_t & 15, lq_t = lane_t >> 4;
     if (a.splits > 1) {
-        // partial sums through LDS as a tree: in the round of half h = splits / 2, splits / 4, .., 1 wave sp + h hands its
-        // accumulators to wave sp and leaves (fixed order: bit-reproducible; splits / 2 slots per pair -- 8 waves on one pair
-        // fit 128 KB with 64 instances per wave)
+        // Partial sums through LDS by recursive HALVING (round 6; rounds 2-5: a tree that ended in ONE wave, which then ran the
+        // fused epilogue of the whole 32 x (16 NG) tile alone while the other waves of the workgroup had left -- on the shards of
+        // a strong-scaling run, where every workgroup splits one list, that tail was the epilogue's whole cost with nothing to
+        // hide it behind).  The tile of a pair is RT x NG sub-tiles of 16 rows x 16 instances.  In every phase a wave and its
+        // partner (sp ^ h, h = n / 2, n / 4, ..) keep one half of what they still hold each, hand the other half over and
+        // add what they receive: first the halves in t (rows), then in g; after log2(n) phases every wave holds the complete sums
+        // of 1 / n of the tile and runs the epilogue on that.  The pairs (w, w ^ 4), then (.., w ^ 2), then (.., w ^ 1) are
+        // the tree's, and a + b = b + a bit for bit: the sums equal the tree's.  A wave writes what it hands over where it has
+        // just READ (only it read there): ONE barrier per phase, (splits / 2) x NV x 64 doubles per pair as before.
         constexpr int NV = RT * NG * 8;     // doubles per lane
-        double* lds = reinterpret_cast<double*>(smem_raw);
-        const unsigned red = (unsigned)(wv * (a.splits >> 1)) * (NV * 64) + lane;   // this pair's slots (32-bit LDS offsets)
-        // one round; a wave that has handed its sums over stays for the remaining barriers (every wave of the workgroup
-        // reaches every __syncthreads(): nothing here relies on how the hardware counts waves that have ended)
-        bool alive = true;                  // wave-uniform (sp is)
-        auto round = [&](int h) {
-            if (alive && sp >= h) {
-                double* mine = lds + (red + (unsigned)(sp - h) * (NV * 64));
+        double* const lds = reinterpret_cast<double*>(smem_raw) + (size_t)(wv * (a.splits >> 1)) * (NV * 64) + lane_t;
+        int n = a.splits;                   // waves of the pair that still hold sums
+        unsigned stride = (unsigned)(NV / 2) * 64;       // slot stride of the first halving phase
+        if (RT * NG < n) {
+            // (NG = 2, eight waves: four sub-tiles only -- waves 4..7 hand everything to 0..3 first and wait at the barriers below)
+            if (sp >= 4) {
+                double* mine = lds + (unsigned)(sp - 4) * (NV * 64);
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -265,9 +275,8 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a) {
                         }
             }
             __syncthreads();
-            if (sp >= h) alive = false;
-            if (alive) {
-                const double* theirs = lds + (red + (unsigned)sp * (NV * 64));
+            if (sp < 4) {
+                const double* theirs = lds + (unsigned)sp * (NV * 64);
 #pragma unroll
                 for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -278,19 +287,136 @@ __device__ __forceinline__ void combine_body(const CombineArgs& a) {
                             oim[t][g][r] += theirs[((t * NG + g) * 8 + 4 + r) * 64];
                         }
             }
-        };
-        if (a.splits >= 8) {
-            round(4);
-            __syncthreads();                // (the slots are written again in the next round)
+            n = 4;
+            stride = (unsigned)NV * 64;
         }
-        if (a.splits >= 4) {
-            round(2);
+        const bool holds = sp < n;          // wave-uniform
+        // where this wave reads in the coming phase (= where its partner writes): phase 1: the partner's slot; later: see above
+        int h = n >> 1;
+        unsigned wr_at = (unsigned)sp * stride, rd_at = (unsigned)(sp ^ h) * stride;
+        // ---- rows: keep t = (sp & h ? 1 : 0)
+        const bool hi_t = (sp & h) != 0;
+        if (holds) {
+            if (hi_t) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const d4 xr = ore[0][g], xi = oim[0][g];
+                    ore[0][g] = ore[1][g];
+                    oim[0][g] = oim[1][g];
+                    ore[1][g] = xr;
+                    oim[1][g] = xi;
+                }
+            }
+            double* mine = lds + wr_at;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mine[(g * 8 + r) * 64] = ore[1][g][r];
+                    mine[(g * 8 + 4 + r) * 64] = oim[1][g][r];
+                }
+        }
+        __syncthreads();
+        if (holds) {
+            const double* theirs = lds + rd_at;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ore[0][g][r] += theirs[(g * 8 + r) * 64];
+                    oim[0][g][r] += theirs[(g * 8 + 4 + r) * 64];
+                }
+        }
+        const int row_t = rg * CMB_ROWS + lq_t + (hi_t ? 16 : 0);
+        int col_g = col0 + lb_t, kept = NG;                // first column and number of the sub-tiles this wave still holds (ore[0][0 .. kept))
+        if (n >= 4) {
+            // ---- instance groups, upper / lower half (NG = 4: two phases; NG = 2: one)
+            h >>= 1;
+            wr_at = rd_at;                                     // (this wave's last read)
+            rd_at = (unsigned)((sp ^ h) ^ (n >> 1)) * stride;  // (the partner's last read)
+            const bool hi_g = (sp & h) != 0;
+            constexpr int GH = NG / 2;
+            if (holds) {
+                if (hi_g) {
+#pragma unroll
+                    for (int g = 0; g < GH; ++g) {
+                        const d4 xr = ore[0][g], xi = oim[0][g];
+                        ore[0][g] = ore[0][GH + g];
+                        oim[0][g] = oim[0][GH + g];
+                        ore[0][GH + g] = xr;
+                        oim[0][GH + g] = xi;
+                    }
+                }
+                double* mine = lds + wr_at;
+#pragma unroll
+                for (int g = 0; g < GH; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        mine[(g * 8 + r) * 64] = ore[0][GH + g][r];
+                        mine[(g * 8 + 4 + r) * 64] = oim[0][GH + g][r];
+                    }
+            }
             __syncthreads();
+            if (holds) {
+                const double* theirs = lds + rd_at;
+#pragma unroll
+                for (int g = 0; g < GH; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ore[0][g][r] += theirs[(g * 8 + r) * 64];
+                        oim[0][g][r] += theirs[(g * 8 + 4 + r) * 64];
+                    }
+            }
+            col_g += hi_g ? 16 * GH : 0;
+            kept = GH;
+            if constexpr (NG == 4) {
+                if (n >= 8) {
+                    // ---- eight waves: the last halving, g = 0 / 1 of the kept pair
+                    const int h1 = h >> 1;
+                    wr_at = rd_at;
+                    rd_at = (unsigned)(((sp ^ h1) ^ h) ^ (n >> 1)) * stride;
+                    const bool hi_l = (sp & h1) != 0;
+                    if (hi_l) {
+                        const d4 xr = ore[0][0], xi = oim[0][0];
+                        ore[0][0] = ore[0][1];
+                        oim[0][0] = oim[0][1];
+                        ore[0][1] = xr;
+                        oim[0][1] = xi;
+                    }
+                    double* mine = lds + wr_at;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        mine[r * 64] = ore[0][1][r];
+                        mine[(4 + r) * 64] = oim[0][1][r];
+                    }
+                    __syncthreads();
+                    const double* theirs = lds + rd_at;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ore[0][0][r] += theirs[r * 64];
+                        oim[0][0][r] += theirs[(4 + r) * 64];
+                    }
+                    col_g += hi_l ? 16 : 0;
+                    kept = 1;
+                }
+            }
         }
-        round(1);
-        if (!alive) return;
+        if (!holds) return;
+        // the fused epilogue on the kept sub-tiles, one 16 x 16 sub-tile per trip (ONE copy of the epilogue's code: the sub-tiles
+        // move down through ore[0][0]; the whole tile took four trips on one wave before)
+#pragma clang loop unroll(disable)
+        for (int q = 0; q < kept; ++q) {
+            const d4 fre[1][1] = {{ore[0][0]}}, fim[1][1] = {{oim[0][0]}};
+            store_tile<1, 1>(a.epi, row_t, col_g + 16 * q, fre, fim);
+#pragma unroll
+            for (int g = 0; g + 1 < NG; ++g) {
+                ore[0][g] = ore[0][g + 1];
+                oim[0][g] = oim[0][g + 1];
+            }
+        }
+        return;
     }
-    store_tile<RT, NG>(a.epi, rg * CMB_ROWS + lq, col0 + lb, ore, oim);
+    store_tile<RT, NG>(a.epi, rg * CMB_ROWS + lq_t, col0 + lb_t, ore, oim);
 }
 
 template <int NRE4, int NIM4, int STAT>
