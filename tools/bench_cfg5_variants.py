@@ -34,6 +34,10 @@ def run():
 variants = [("flip", {}), ("no_apply", dict(ablate=64)), ("no_poll", dict(ablate=32)), ("wait_only", dict(ablate=512)), ("no_crossing", dict(ablate=8)),
             ("no_exchange", dict(ablate=1)), ("nothing", dict(ablate=13)), ("write_through", dict(ablate=2)),
             ("no_local", dict(ablate=4)),
+            # the kernel with its saved states written to DEVICE memory (option expm_direct_out = 0: the library then copies them to the
+            # host) instead of straight into the pinned result block over the bus -- what the kernel alone costs per term
+            ("device_out", dict(expm_direct_out=0)), ("device_out_no_exchange", dict(expm_direct_out=0, ablate=1)),
+            ("device_out_nothing", dict(expm_direct_out=0, ablate=13)),
             ("with_elements", dict(ell_sweep_flip=0)), ("one_workgroup", dict(ell_sweep_duo=0)), ("one_workgroup_with_elements", dict(ell_sweep_duo=0, ell_sweep_flip=0))]
 if len(sys.argv) > 1:
     variants = [v for v in variants if v[0] in sys.argv[1:]]

@@ -198,6 +198,19 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
                         run()
                         csa = profile_pass(ctx, run, ("rk4_resident",))
                     dec[tag] = csa["rk4_resident"]["ms"] * 1e3 / max(terms, 1)
+                # ... and with the saved states written to DEVICE memory (option expm_direct_out = 0; the library then copies them to the
+                # host): by default the kernel's last term stores them straight into the pinned result block, 8.4 MB over the bus at
+                # its end -- kernel time that is the download of the result, not work on a term
+                with ctx.options(expm_direct_out=0):
+                    run()
+                    csd = profile_pass(ctx, run, ("rk4_resident",))
+                k_dev_ms = csd["rk4_resident"]["ms"]
+                out["roofline"]["us_per_term_device_out"] = round(k_dev_ms * 1e3 / max(terms, 1), 2)
+                out["roofline"]["result_writeout_ms_per_launch"] = round((k_ms - k_dev_ms) / max(cs["rk4_resident"]["launches"], 1), 4)
+                out["roofline"]["us_per_term_note"] = (
+                    "us_per_term = the DEFAULT launch / terms: its last term writes the saved states (%.1f MB) straight into the pinned result "
+                    "block over the bus (no download afterwards); us_per_term_device_out = the same kernel writing them to device memory "
+                    "(expm_direct_out = 0): what the terms themselves cost" % (count * n * 16 * max(1, int(sched.n_save)) / 1e6))
                 run()       # (a complete solve again before anything else is timed)
                 us_term = k_ms * 1e3 / max(terms, 1)
                 slot_us = max(dec["without_exchange"] - dec["skeleton"], 1e-9)
