@@ -39,6 +39,12 @@ static int (*p_midyn_expm_plan_create)(midyn_stack*, int, int, int, const double
 static int (*p_midyn_expm_plan_run)(midyn_expm_plan*, const double*, midyn_complex*);
 static int (*p_midyn_expm_plan_fetch)(midyn_expm_plan*, midyn_complex*);
 static int (*p_midyn_expm_plan_destroy)(midyn_expm_plan*);
+static int (*p_midyn_expansion_create)(midyn_ctx*, int, int, const midyn_complex*, const midyn_complex*, const midyn_complex*, int,
+                                       midyn_expansion**);
+static int (*p_midyn_expansion_destroy)(midyn_expansion*);
+static int (*p_midyn_expansion_solve)(midyn_expansion*, int, int, const double*, int, const midyn_complex*, int, midyn_complex*);
+static int (*p_midyn_expansion_set_monomials)(midyn_expansion*, int, int, const int*);
+static int (*p_midyn_expansion_solve_coeffs)(midyn_expansion*, int, int, const double*, int, const midyn_complex*, int, midyn_complex*);
 static int (*p_midyn_comm_get_unique_id)(void*);
 static int (*p_midyn_comm_init_rank)(midyn_ctx*, int, int, const void*, void**);
 static int (*p_midyn_comm_destroy)(midyn_ctx*, void*);
@@ -74,6 +80,8 @@ int main(int argc, char** argv) {
     LOAD(midyn_comm_get_unique_id) LOAD(midyn_comm_init_rank) LOAD(midyn_comm_destroy) LOAD(midyn_stack_broadcast)
     LOAD(midyn_stack_broadcast_from) LOAD(midyn_stack_create_empty)
     LOAD(midyn_expm_plan_create) LOAD(midyn_expm_plan_run) LOAD(midyn_expm_plan_fetch) LOAD(midyn_expm_plan_destroy)
+    LOAD(midyn_expansion_create) LOAD(midyn_expansion_destroy) LOAD(midyn_expansion_solve) LOAD(midyn_expansion_set_monomials)
+    LOAD(midyn_expansion_solve_coeffs)
 
     midyn_ctx* ctx = NULL;
     CHECK(NULL, p_midyn_ctx_create(0, &ctx));
@@ -183,6 +191,53 @@ int main(int argc, char** argv) {
     CHECK(ctx, p_midyn_expm_solve(stack, B, 1, RE, te, Se, ESTEPS, rows_e, hse, save_e, 2, 2, y0, 1, Yq));
     if (memcmp(Yp, Yq, sizeof(midyn_complex) * B * 2 * N) != 0) return 15;
     CHECK(ctx, p_midyn_expm_plan_destroy(plan));
+    /* row f4: the array polynomial of a Dyson-type step, X_k = 1 + c0 A0 + c1 A1 + c0 c1 A01 (three terms, two coefficients), 6 steps,
+     * two instances -- through the monomial table (midyn_expansion_solve) and through the coefficients + labels
+     * (midyn_expansion_set_monomials / midyn_expansion_solve_coeffs): same bits, and the host's own product of the step matrices */
+    {
+        enum { XM = 3, XT = 6, XB = 2, XV = 2 };
+        const midyn_complex terms[XM * N * N] = {0.0, -0.3 * I, -0.3 * I, 0.0, 0.2, 0.0, 0.0, -0.2, 0.05 * I, 0.01, -0.01, 0.02 * I};
+        const midyn_complex ident[N * N] = {1.0, 0.0, 0.0, 1.0};
+        const int labels[XM * 2] = {0, -1, 1, -1, 0, 1};
+        double coeffs[XB * XV * XT], mono[XB * XT * XM];
+        for (int b = 0; b < XB; ++b)
+            for (int k = 0; k < XT; ++k) {
+                const double c0 = 0.1 * (k + 1) * (b + 1), c1 = 0.3 - 0.05 * k + 0.02 * b;
+                coeffs[(b * XV + 0) * XT + k] = c0;
+                coeffs[(b * XV + 1) * XT + k] = c1;
+                mono[(b * XT + k) * XM + 0] = c0;
+                mono[(b * XT + k) * XM + 1] = c1;
+                mono[(b * XT + k) * XM + 2] = c0 * c1;
+            }
+        midyn_expansion* ex = NULL;
+        midyn_complex Ya[XB * N * N], Yb[XB * N * N];
+        CHECK(ctx, p_midyn_expansion_create(ctx, N, XM, terms, ident, NULL, 0, &ex));
+        CHECK(ctx, p_midyn_expansion_solve(ex, XB, XT, mono, N, ident, 1, Ya));
+        CHECK(ctx, p_midyn_expansion_set_monomials(ex, XV, 2, labels));
+        CHECK(ctx, p_midyn_expansion_solve_coeffs(ex, XB, XT, coeffs, N, ident, 1, Yb));
+        if (memcmp(Ya, Yb, sizeof(Ya)) != 0) return 16;
+        CHECK(ctx, p_midyn_expansion_solve_coeffs(ex, XB, XT, coeffs, N, ident, 1, Yb));     /* (the kept offset tables) */
+        if (memcmp(Ya, Yb, sizeof(Ya)) != 0) return 17;
+        for (int b = 0; b < XB; ++b) {
+            midyn_complex P[N * N] = {1.0, 0.0, 0.0, 1.0};
+            for (int k = 0; k < XT; ++k) {
+                midyn_complex X[N * N], Q[N * N];
+                for (int e = 0; e < N * N; ++e) {
+                    X[e] = ident[e];
+                    for (int i = 0; i < XM; ++i) X[e] += mono[(b * XT + k) * XM + i] * terms[i * N * N + e];
+                }
+                for (int r = 0; r < N; ++r)
+                    for (int c = 0; c < N; ++c) {
+                        Q[r * N + c] = 0.0;
+                        for (int q = 0; q < N; ++q) Q[r * N + c] += X[r * N + q] * P[q * N + c];
+                    }
+                memcpy(P, Q, sizeof(P));
+            }
+            for (int e = 0; e < N * N; ++e)
+                if (cabs(P[e] - Ya[b * N * N + e]) > 1e-13) return 18;
+        }
+        CHECK(ctx, p_midyn_expansion_destroy(ex));
+    }
     if (comm) CHECK(ctx, p_midyn_comm_destroy(ctx, comm));
     CHECK(ctx, p_midyn_stack_destroy(stack));
     CHECK(ctx, p_midyn_ctx_destroy(ctx));

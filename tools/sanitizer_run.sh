@@ -32,6 +32,10 @@ cp $R/build/asan/libmidyn_asan.so $R/qiskit_dynamics_amd/libmidyn.so
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 ( cd $R && LD_PRELOAD=$RT MIDYN_HIP_RUNTIME=system timeout 1500 python -m pytest tests/test_gpu_edge_cases.py tests/test_gpu_combine.py tests/test_gpu_resident.py \
     -m gpu -q -x -p no:cacheprovider > $O/pytest_asan.log 2>&1 ; echo "pytest exit $?" >> $O/pytest_asan.log )
+# (round 6: the expansion entry points -- pinned staging block, kept offset tables, coefficient path -- and the expm plan object)
+( cd $R && LD_PRELOAD=$RT MIDYN_HIP_RUNTIME=system timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -p no:cacheprovider \
+    -k "expansion or perturbative or dyson or magnus_solver" > $O/pytest_asan_expansion.log 2>&1 ; echo "pytest exit $?" >> $O/pytest_asan_expansion.log )
 cp /tmp/libmidyn_plain.so $R/qiskit_dynamics_amd/libmidyn.so
 tail -5 $O/pytest_asan.log
-grep -c "ERROR: AddressSanitizer\|runtime error:" $O/abi_solve.log $O/pytest_asan.log
+tail -5 $O/pytest_asan_expansion.log
+grep -c "ERROR: AddressSanitizer\|runtime error:" $O/abi_solve.log $O/pytest_asan.log $O/pytest_asan_expansion.log
