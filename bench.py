@@ -896,7 +896,7 @@ def main():
                     "workload": "cfg5: 12-qubit (n=4096) Schrodinger sweep, 1024 instances in total, Magnus-2 expm, "
                                 "20 steps, sharded 1024/N per GPU (strong scaling)",
                     "instances_total": CFG5_SWEEP, "instances_per_gpu": hi5 - lo5, "n_gpus": world,
-                    "solve_s_max_over_ranks": round(solve5, 4),
+                    "solve_s_max_over_ranks": round(solve5, 6),
                     "instance_steps_per_s": round(CFG5_SWEEP * full["steps"] / solve5, 1),
                     "max_norm_deviation_rank0": full["max_norm_deviation"], "stack_broadcast": bcast5}
                 if world == 1 and "projected_strong_scaling" in out:

@@ -63,6 +63,11 @@ const char* midyn_last_error(midyn_ctx* ctx);
  *                         batched expm / tree run on half as many padded matrices; 0: one step per block
  *   exchange_protocol [0] hand-offs between the workgroups of a one-launch kernel: 0 = the measured default, 1 = the conforming forms of
  *                         MI355X_MICROARCH.md (release / acquire, sc1 stores and loads everywhere); same results bit for bit
+ *   expm_plan_cache [1]   one-shot midyn_expm_solve on the one-launch sweep route keeps its plan (frame phases, step tables, y0, exchange
+ *                         slots, result block) in the stack: the next call with the same shapes, time grid, step tables and initial
+ *                         states (compared byte for byte; per-instance y0 up to 1 MB) only uploads its coefficient table -- a scan
+ *                         through the one-shot entry point costs what midyn_expm_plan_run + _fetch cost.  Any midyn_ctx_set_option
+ *                         call, a different solve, a received stack or midyn_stack_destroy retires the plan.  0: made per call
  *   expm_direct_out [1]   midyn_expm_solve / midyn_expm_plan_run on the one-launch sweep route: saved states written by the kernel
  *                         straight into a device-writable (pinned) result block of the caller; 0: device block + copy
  *   cheb_tail [1]         where that Chebyshev series ends: 1 = where the dropped terms of a step sum to less than 2^-53 (the
@@ -307,6 +312,15 @@ int midyn_rk4_plan_create(midyn_stack* stack, int B, int m, int R, const double*
 int midyn_rk4_plan_run(midyn_rk4_plan* plan, int step_begin, int step_end);
 int midyn_rk4_plan_fetch(midyn_rk4_plan* plan, midyn_complex* Y_out);
 int midyn_rk4_plan_destroy(midyn_rk4_plan* plan);
+
+/* ---- result blocks the device writes directly -------------------------------------------------------------------------------------
+ * midyn_host_alloc returns page-locked host memory that the GPU can write (hipHostMalloc); midyn_host_free gives it back.  The
+ * one-launch sweep kernels store their saved states straight into a result block (Y_out of midyn_expm_solve, Y_direct of
+ * midyn_expm_plan_run) when it is such memory -- no device copy, no download.  A block from midyn_host_alloc is recognised by its
+ * address (a table inside the library); any other pointer is examined with hipPointerGetAttributes at every call (60-80 us), and
+ * ordinary pageable memory simply takes the device block + copy.  The Python binding's result arrays (>= 1 MB) come from here. */
+int midyn_host_alloc(size_t bytes, void** out);
+int midyn_host_free(void* ptr);
 
 /* ---- device-resident Magnus/expm solve of a parameter scan (solvers/fixed_step_solvers.py:80-108, 345-363, 406-459) ----
  * A scan re-solves the SAME model on the SAME time grid with new signal parameters (solvers/solver_classes.py:556-590).

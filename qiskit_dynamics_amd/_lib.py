@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "midyn_reset_counters", "midyn_microbench", "midyn_lindblad_create", "midyn_lindblad_destroy",
     "midyn_lindblad_rhs", "midyn_lindblad_rk4_solve", "midyn_sigtable_create", "midyn_sigtable_data",
     "midyn_sigtable_fetch", "midyn_sigtable_destroy", "midyn_parallel_solve", "midyn_expansion_create",
-    "midyn_expansion_destroy", "midyn_expansion_solve", "midyn_expansion_set_monomials", "midyn_expansion_solve_coeffs",
+    "midyn_expansion_destroy", "midyn_expansion_solve", "midyn_expansion_set_monomials", "midyn_expansion_solve_coeffs", "midyn_host_alloc", "midyn_host_free",
     "midyn_ctx_timer", "midyn_stack_block_info",
     "midyn_comm_get_unique_id", "midyn_comm_init_rank", "midyn_comm_destroy", "midyn_comm_count", "midyn_stack_create_empty",
     "midyn_stack_broadcast", "midyn_stack_broadcast_from",
@@ -171,6 +171,8 @@ def load():
         lib.midyn_expansion_create.argtypes = [_vp, _ci, _ci, _vp, _vp, _vp, _ci, P(_vp)]
         lib.midyn_expansion_destroy.argtypes = [_vp]
         lib.midyn_expansion_solve.argtypes = [_vp, _ci, _ci, _vp, _ci, _vp, _ci, _vp]
+        lib.midyn_host_alloc.argtypes = [ctypes.c_size_t, P(_vp)]
+        lib.midyn_host_free.argtypes = [_vp]
         lib.midyn_expansion_set_monomials.argtypes = [_vp, _ci, _ci, _vp]
         lib.midyn_expansion_solve_coeffs.argtypes = [_vp, _ci, _ci, _vp, _ci, _vp, _ci, _vp]
         lib.midyn_sigtable_create.argtypes = [_vp, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, P(_vp)]
@@ -212,15 +214,25 @@ _pinned_lock = threading.RLock()
 _hiprt = None
 
 
+class _LibraryHostBlocks:
+    """Page-locked blocks through the library (``midyn_host_alloc`` / ``midyn_host_free``, include/midyn.h): the library then
+    knows a result array by its address and hands the device address to the kernels that write results directly, without asking
+    the HIP runtime about the pointer at every solve (60-80 us).  Method names: those of the runtime calls behind them."""
+
+    def __init__(self):
+        self.lib = load()
+
+    def hipHostMalloc(self, pp, nbytes, flags):  # pylint: disable=invalid-name,unused-argument
+        return self.lib.midyn_host_alloc(nbytes, pp)
+
+    def hipHostFree(self, p):  # pylint: disable=invalid-name
+        return self.lib.midyn_host_free(p)
+
+
 def _hip_runtime():
     global _hiprt
     if _hiprt is None:
-        rt = ctypes.CDLL(HIP_RUNTIME)          # (already loaded RTLD_GLOBAL by _preload_hip_runtime: the same instance)
-        rt.hipHostMalloc.argtypes = [ctypes.POINTER(_vp), ctypes.c_size_t, ctypes.c_uint]
-        rt.hipHostMalloc.restype = _ci
-        rt.hipHostFree.argtypes = [_vp]
-        rt.hipHostFree.restype = _ci
-        _hiprt = rt
+        _hiprt = _LibraryHostBlocks()
     return _hiprt
 
 
@@ -269,7 +281,7 @@ def result_array(shape, dtype=np.complex128):
         p = _vp()
         try:
             ok = _hip_runtime().hipHostMalloc(ctypes.byref(p), nbytes, 0) == 0 and bool(p.value)
-        except (OSError, AttributeError):
+        except (OSError, AttributeError, HipLibraryError):
             ok = False
         if not ok:
             with _pinned_lock:

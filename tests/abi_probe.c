@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     CHECK(midyn_stack_create_lindblad); CHECK(midyn_stack_antiherm_defect); CHECK(midyn_sigtable_create);
     CHECK(midyn_sigtable_data); CHECK(midyn_sigtable_fetch); CHECK(midyn_sigtable_destroy);
     CHECK(midyn_parallel_solve); CHECK(midyn_expansion_create); CHECK(midyn_expansion_destroy);
-    CHECK(midyn_expansion_solve); CHECK(midyn_expansion_set_monomials); CHECK(midyn_expansion_solve_coeffs);
+    CHECK(midyn_expansion_solve); CHECK(midyn_expansion_set_monomials); CHECK(midyn_expansion_solve_coeffs); CHECK(midyn_host_alloc); CHECK(midyn_host_free);
     CHECK(midyn_ctx_timer); CHECK(midyn_stack_block_info);
     /* multi-GPU: the RCCL broadcast of the stack (librccl itself is only resolved at first use) */
     CHECK(midyn_comm_get_unique_id); CHECK(midyn_comm_init_rank); CHECK(midyn_comm_destroy); CHECK(midyn_comm_count);

@@ -964,3 +964,83 @@ def test_expm_plan_equals_expm_solve(qd, nq, count, order):
         plan.fetch()
     plan.close()
     assert np.max(np.abs(np.linalg.norm(want[1][:, -1, :, 0], axis=1) - 1.0)) < 1e-11
+
+
+def test_one_shot_expm_solve_keeps_its_plan_in_the_stack(qd):
+    """ctx option expm_plan_cache (round 6): the one-shot midyn_expm_solve on the sweep route keeps its plan -- frame phases, step
+    tables, y0, exchange slots, result block -- in the stack, and the next call with the same shapes, time grid, step tables and
+    initial states only uploads its coefficient table (the scan of solver_classes.py:556-590 through the one-shot entry point).
+    Asserted: hit / miss by the counter; bit-equal results with the cache on and off for changing tables; a changed y0, time grid,
+    instance count or ANY option change retires the plan; pageable and pinned result blocks in turn (the plan forgets the blocks
+    it was shown: the one-shot caller promised nothing about them); a stack destroyed with a plan inside."""
+    from qiskit_dynamics_amd import _lib
+    from qiskit_dynamics_amd import workloads as W
+    from qiskit_dynamics_amd.rotating_frame import RotatingFrame
+    from qiskit_dynamics_amd.solvers import FixedStepSchedule, _magnus_points
+
+    ctx = qd.default_context()
+    nq, count, order = 10, 64, 2
+    cfg = W.schrodinger_config(n_qubits=nq, n_drives=8, t_final=2.0, max_dt=0.25)
+    fr = RotatingFrame(np.diag(cfg["h_d"]).real.copy())
+    stack = qd.Stack(ctx, -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag)
+    sched = FixedStepSchedule(cfg["t_span"], None, cfg["max_dt"], _magnus_points(order))
+    sched2 = FixedStepSchedule([0.0, 1.5], None, cfg["max_dt"], _magnus_points(order))
+    rng = np.random.default_rng(77)
+    n = 2**nq
+    y0 = (rng.normal(size=n) + 1j * rng.normal(size=n)).reshape(-1, 1)
+    y0 /= np.linalg.norm(y0)
+    y0b = y0[::-1].copy()
+
+    def table(sc, scale, first, cnt=count):
+        amps = np.array([W.sweep_parameters(first + b, 8)[0] for b in range(cnt)]) * scale
+        phs = np.array([W.sweep_parameters(first + b, 8)[1] for b in range(cnt)])
+        return W.gaussian_coefficient_table(sc.times, amps, phs, cfg["carrier"][:8], 2.0)
+
+    def solve(sc, t, y, cnt=count):
+        r = stack.expm_solve(sc.times, t, sc.step_rows, sc.step_h, sc.step_save, sc.n_save, order, y, cnt, True)
+        return r, int(ctx.counters("expm_plan_cache")["launches"])
+
+    tabs = [table(sched, 1.0, 0), table(sched, 2.5, 1000), table(sched, 0.1, 5)]
+    with ctx.options(expm_plan_cache=0):
+        want = [solve(sched, t, y0) for t in tabs]
+        assert all(h == 0 for _, h in want)
+        want_b = solve(sched, tabs[1], y0b)[0]
+        want_2 = solve(sched2, table(sched2, 1.0, 0), y0)[0]
+        want_half = solve(sched, tabs[0][: count // 2], y0, count // 2)[0]
+    want = [w for w, _ in want]
+    # (the option change above retired whatever was cached: the first call makes a plan, the following ones find it)
+    hits = []
+    for i in (0, 1, 2, 1, 0):
+        got, h = solve(sched, tabs[i], y0)
+        assert np.array_equal(got, want[i]), i
+        hits.append(h)
+    assert hits == [0, 1, 1, 1, 1], hits
+    got, h = solve(sched, tabs[1], y0b)                       # other initial states: a new plan
+    assert h == 0 and np.array_equal(got, want_b)
+    got, h = solve(sched, tabs[1], y0b)
+    assert h == 1 and np.array_equal(got, want_b)
+    got, h = solve(sched2, table(sched2, 1.0, 0), y0)         # other time grid
+    assert h == 0 and np.array_equal(got, want_2)
+    got, h = solve(sched, tabs[0][: count // 2], y0, count // 2)      # other instance count
+    assert h == 0 and np.array_equal(got, want_half)
+    got, h = solve(sched, tabs[0][: count // 2], y0, count // 2)
+    assert h == 1 and np.array_equal(got, want_half)
+    with ctx.options(expm_direct_out=0):                     # an option change retires the plan; so does changing it back
+        got, h = solve(sched, tabs[0][: count // 2], y0, count // 2)
+        assert h == 0 and np.array_equal(got, want_half)
+    got, h = solve(sched, tabs[0][: count // 2], y0, count // 2)
+    assert h == 0 and np.array_equal(got, want_half)
+    # result blocks: the binding hands out page-locked blocks of the library (>= 1 MB); a pageable block in between takes the
+    # device block + copy -- same bits, and nothing remembered about either
+    lib, args = ctx.lib, stack._solve_args(sched.times, tabs[2], sched.step_rows, sched.step_h, sched.step_save, y0, count)
+    times, r, tab, rows, hs, save, nsteps, y = args
+    for kind in ("pageable", "pinned", "pageable"):
+        out = np.empty((count, sched.n_save, n, 1), dtype=complex) if kind == "pageable" else _lib.result_array((count, sched.n_save, n, 1))
+        assert _lib.is_pinned(out) == (kind == "pinned")
+        ctx.check(lib.midyn_expm_solve(stack.handle, count, 1, r, _lib._ptr(times), _lib._ptr(tab), nsteps, _lib._ptr(rows), _lib._ptr(hs),
+                                       _lib._ptr(save), sched.n_save, order, _lib._ptr(y), 1, _lib._ptr(out)))
+        assert np.array_equal(stack._rows_out(out, 2), want[2]), kind
+    stack.close()                                             # (with the plan inside)
+    stack2 = qd.Stack(ctx, -1j * cfg["ops"], -1j * cfg["h_d"] - np.diag(fr.frame_diag), fr.frame_diag_imag)
+    got = stack2.expm_solve(sched.times, tabs[0], sched.step_rows, sched.step_h, sched.step_save, sched.n_save, order, y0, count, True)
+    assert int(ctx.counters("expm_plan_cache")["launches"]) == 0 and np.array_equal(got, want[0])

@@ -79,7 +79,7 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
 
     ys, dev_ms, wall, cs = measure(True)            # the product's default route
     n_steps = len(sched.step_h)
-    out = {"instances": count, "steps": n_steps, "solve_s": round(wall, 4),
+    out = {"instances": count, "steps": n_steps, "solve_s": round(wall, 6),
            "ms_per_step": round(wall / n_steps * 1e3, 4), "stream_ms_per_step": round(dev_ms / n_steps, 4),
            "us_per_instance_step": round(wall / n_steps / count * 1e6, 3),
            "instance_steps_per_s": round(count * n_steps / wall, 1),
