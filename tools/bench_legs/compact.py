@@ -106,7 +106,8 @@ def compact_line(out, detail=DETAIL_NAME):
         c["cfg5"] = _pair(out["cfg5"], "ms_per_step", "ms per Magnus-2 step, 128-instance shard",
                           us_per_term=("roofline", "us_per_term"), us_per_term_device_out=("roofline", "us_per_term_device_out"),
                           us_per_instance_step="us_per_instance_step",
-                          solve_s="solve_s", kernel_ms=("roofline", "avg_launch_ms"), plan_solve_s=("plan", "solve_s"),
+                          solve_s="solve_s", first_call_s="solve_s_first_call_of_a_grid", kernel_ms=("roofline", "avg_launch_ms"),
+                          plan_solve_s=("plan", "solve_s"),
                           host_ms_one_shot=("roofline", "host_side_ms_one_shot"), host_ms_plan=("roofline", "host_side_ms_plan"))
         if c["cfg5"] is not None and "roofline" in out["cfg5"]:
             c["cfg5"]["kernel"] = _short(str(_get(out, "cfg5", "roofline", "kernel", default="")).split(" (")[0], 60)
