@@ -62,11 +62,13 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
         with ctx.options(ell_sweep=1 if sweep_kernel else 0, ell_sweep_duo=duo):
             # (three untimed solves first: the sweep kernel's first launches after a lighter leg run ~10 % slower while the clocks
             # settle -- tools/bench_cfg5_variants.py -- and the binding's pinned result blocks of this size exist afterwards)
-            for _ in range(3 if sweep_kernel else 1):
+            # (round 6: 25, not 3 -- 50 ms: after a light leg the first dozen 2 ms solves measured 10-13 % slower than the same call
+            # a few legs later, solve_s 1.94 against 1.71 ms in one run)
+            for _ in range(25 if sweep_kernel else 1):
                 run()
             ctx.synchronize()
             best = None
-            for _ in range(5 if sweep_kernel else 1):       # (best of five: a 2.5 ms solve next to 8 MB of PCIe)
+            for _ in range(7 if sweep_kernel else 1):       # (best of seven: a 2 ms solve next to 8 MB of PCIe)
                 t0_ = time.perf_counter()
                 ctx.timer_start()
                 ys_ = run()
@@ -89,17 +91,27 @@ def leg_cfg5(qd, ctx, workloads, stack, cfg, first, count, with_profile=True):
                    "result block) in the stack and finds it again at a call with the same time grid and y0 (ctx option expm_plan_cache): "
                    "solve_s_first_call_of_a_grid has the same call making that plan; stream_ms = HIP events around the call"
                    % (ys.nbytes / 1e6)}
-    try:        # the same one-shot call when nothing is kept between calls (every call of a new time grid or y0)
-        with ctx.options(expm_plan_cache=0):
-            run()
-            ctx.synchronize()
-            cold = None
-            for _ in range(5):
+    try:        # the same one-shot call when nothing is kept between calls (every call of a new time grid or y0) -- INTERLEAVED with
+        # calls that find the plan (solves of 2 ms drift by several per cent with what ran just before them)
+        kept = cold = None
+        for _ in range(5):
+            with ctx.options(expm_plan_cache=1):
+                run()                   # (the option change retired the plan: this call makes it)
+                ctx.synchronize()
+                t0_ = time.perf_counter()
+                run()
+                dt_ = time.perf_counter() - t0_
+                kept = dt_ if kept is None else min(kept, dt_)
+            with ctx.options(expm_plan_cache=0):
+                run()
+                ctx.synchronize()
                 t0_ = time.perf_counter()
                 run()
                 dt_ = time.perf_counter() - t0_
                 cold = dt_ if cold is None else min(cold, dt_)
         out["solve_s_first_call_of_a_grid"] = round(cold, 6)
+        out["one_shot_interleaved"] = {"plan_kept_s": round(kept, 6), "nothing_kept_s": round(cold, 6),
+                                       "what": "five alternating pairs of one-shot calls, best of each kind"}
     except Exception as exc:  # pylint: disable=broad-except
         out["solve_s_first_call_of_a_grid"] = repr(exc)
     # the same solve repeated through a plan object (midyn_expm_plan_*: model + time grid made once, one coefficient table per run):
